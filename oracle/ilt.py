@@ -1,0 +1,193 @@
+"""Oracle: inverse Laplace transform reconstruction (stage a9 of SURVEY.md §8).
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.
+
+Restates ``torchlaplace.laplace_reconstruct`` as called from the reference at
+``w_nl.py:137-144`` (and ``w_latent_ode.py:88-94``).  The package itself is an
+un-vendored, unpinned PyPI dependency (``requirements.txt:17``) that is absent
+here, so this file follows the published algorithm:
+
+* query points + Fourier-series ILT: Neural Laplace paper (arXiv 2206.04843),
+  eq. for the Riemann-sphere maps ``u``/``v`` and the Fourier ILT;
+* de Hoog-Knight-Stokes: mpmath 1.3.0 ``calculus/inverselaplace.py:426-432``
+  (abscissa) and ``:476-531`` (QD table, continued fraction, remainder).
+
+**Parity unpinned vs upstream torchlaplace**: the defaults ``alpha``, ``tol``,
+``scale`` and the rep-func input order ``[theta_s | phi_s | p]`` are recalled,
+not verifiable offline.  They are parameters here and in the
+HIP path, with the same defaults on both sides.
+"""
+
+import math
+
+import torch
+
+# recalled torchlaplace defaults
+ILT_DEFAULTS = {
+    "fourier": dict(alpha=1.0e-3, scale=2.0),
+    "dehoog": dict(alpha=1.0e-10, scale=2.0),
+}
+
+
+def ilt_options(algo, options=None):
+    """Resolve (alpha, tol, scale) for an algorithm; tol defaults to 10*alpha."""
+    if algo not in ILT_DEFAULTS:
+        raise ValueError(f"unsupported ilt_algorithm {algo!r} (oracle restates 'fourier' and 'dehoog')")
+    o = dict(ILT_DEFAULTS[algo])
+    if options:
+        o.update(options)
+    if o.get("tol") is None:
+        o["tol"] = 10.0 * o["alpha"]
+    return o["alpha"], o["tol"], o["scale"]
+
+
+def query_points(t, S, alpha, tol, scale):
+    """s_k(t) = gamma + i*pi*k/T,  T = scale*t,  gamma = alpha - ln(tol)/(scale*T).
+
+    t: (...,) float64 -> (s_real (...,S), s_imag (...,S), T (...,), gamma (...,))
+    (mpmath inverselaplace.py:426-432; shared by Fourier and de Hoog.)
+    """
+    t = t.to(torch.float64)
+    T = scale * t
+    gamma = alpha - math.log(tol) / (scale * T)
+    k = torch.arange(S, dtype=torch.float64)
+    s_real = gamma.unsqueeze(-1).expand(*t.shape, S).clone()
+    s_imag = math.pi * k / T.unsqueeze(-1)
+    return s_real, s_imag, T, gamma
+
+
+def complex_to_sphere(s_real, s_imag):
+    """Riemann-sphere projection u: theta = atan2(Im, Re), phi = asin((|s|^2-1)/(|s|^2+1))."""
+    a2 = s_real * s_real + s_imag * s_imag
+    theta = torch.atan2(s_imag, s_real)
+    phi = torch.asin((a2 - 1.0) / (a2 + 1.0))
+    return theta, phi
+
+
+def sphere_to_complex(theta, phi):
+    """Inverse map v: F = tan(phi/2 + pi/4) * (cos theta + i sin theta)."""
+    r = torch.tan(phi / 2.0 + math.pi / 4.0)
+    return r * torch.cos(theta), r * torch.sin(theta)
+
+
+def fourier_line_integrate(f_real, f_imag, t, T, gamma):
+    """x(t) = e^{gamma t}/T * [ Re F_0 / 2 + sum_{k>=1} Re(F_k e^{i pi k t/T}) ].
+
+    f_*: (..., S) with leading dims broadcastable against t's (...); returns (...)
+    """
+    S = f_real.shape[-1]
+    k = torch.arange(S, dtype=torch.float64)
+    ang = math.pi * k * (t / T).unsqueeze(-1)
+    re = f_real * torch.cos(ang) - f_imag * torch.sin(ang)
+    total = 0.5 * re[..., 0] + re[..., 1:].sum(-1)
+    return torch.exp(gamma * t) / T * total
+
+
+def _cdiv(ar, ai, br, bi):
+    den = br * br + bi * bi
+    return (ar * br + ai * bi) / den, (ai * br - ar * bi) / den
+
+
+def dehoog_line_integrate(f_real, f_imag, t, T, gamma):
+    """de Hoog-Knight-Stokes accelerated Fourier ILT (mpmath inverselaplace.py:476-531).
+
+    f_*: (..., S) with S = 2M+1; t, T, gamma broadcastable to (...); returns (...).
+    Uses torch complex128 for brevity; arithmetic order follows mpmath.
+    """
+    S = f_real.shape[-1]
+    if S % 2 != 1 or S < 3:
+        raise ValueError("de Hoog needs an odd number of terms 2M+1 >= 3")
+    M = (S - 1) // 2
+    fp = torch.complex(f_real, f_imag)
+    lead = fp.shape[:-1]
+    e = torch.zeros(*lead, S, M + 1, dtype=torch.complex128)
+    q = torch.zeros(*lead, 2 * M, M, dtype=torch.complex128)
+    q[..., 0, 0] = fp[..., 1] / (fp[..., 0] / 2.0)
+    for i in range(1, 2 * M):
+        q[..., i, 0] = fp[..., i + 1] / fp[..., i]
+    for r in range(1, M + 1):
+        mr = 2 * (M - r) + 1
+        e[..., 0:mr, r] = q[..., 1 : mr + 1, r - 1] - q[..., 0:mr, r - 1] + e[..., 1 : mr + 1, r - 1]
+        if r != M:
+            rq = r + 1
+            mrq = 2 * (M - rq) + 1 + 2
+            for i in range(mrq):
+                q[..., i, rq - 1] = q[..., i + 1, rq - 2] * e[..., i + 1, rq - 1] / e[..., i, rq - 1]
+    d = torch.zeros(*lead, S, dtype=torch.complex128)
+    d[..., 0] = fp[..., 0] / 2.0
+    for r in range(1, M + 1):
+        d[..., 2 * r - 1] = -q[..., 0, r - 1]
+        d[..., 2 * r] = -e[..., 0, r]
+    ang = math.pi * (t / T)
+    z = torch.complex(torch.cos(ang), torch.sin(ang))
+    A_prev = torch.zeros(lead, dtype=torch.complex128)
+    A_cur = d[..., 0].clone()
+    B_prev = torch.ones(lead, dtype=torch.complex128)
+    B_cur = torch.ones(lead, dtype=torch.complex128)
+    for i in range(1, 2 * M):
+        A_next = A_cur + d[..., i] * A_prev * z
+        B_next = B_cur + d[..., i] * B_prev * z
+        A_prev, A_cur = A_cur, A_next
+        B_prev, B_cur = B_cur, B_next
+    brem = (1.0 + (d[..., 2 * M - 1] - d[..., 2 * M]) * z) / 2.0
+    rem = brem * (torch.sqrt(1.0 + d[..., 2 * M] * z / brem) - 1.0)
+    A_np = A_cur + rem * A_prev
+    B_np = B_cur + rem * B_prev
+    return torch.exp(gamma * t) / T * (A_np / B_np).real
+
+
+LINE_INTEGRATE = {"fourier": fourier_line_integrate, "dehoog": dehoog_line_integrate}
+
+
+def ilt_from_sphere(theta, phi, t, algo="fourier", options=None):
+    """theta, phi: (N, d, S) rep-func outputs; t: (N,) -> x (N, d)."""
+    alpha, tol, scale = ilt_options(algo, options)
+    t = t.to(torch.float64)
+    T = scale * t
+    gamma = alpha - math.log(tol) / (scale * T)
+    fr, fi = sphere_to_complex(theta, phi)
+    return LINE_INTEGRATE[algo](fr, fi, t.unsqueeze(-1), T.unsqueeze(-1), gamma.unsqueeze(-1))
+
+
+def rep_func_inputs(p, t, S, algo="fourier", options=None):
+    """Rows ``[theta_s(0..S-1) | phi_s(0..S-1) | p]`` fed to the representation MLP.
+
+    p: (B, P); t: (B, Tt) or (Tt,) -> (B, Tt, 2S+P), t2 (B, Tt)
+    """
+    alpha, tol, scale = ilt_options(algo, options)
+    B = p.shape[0]
+    t = t.to(torch.float64)
+    if t.dim() == 0:
+        t = t.view(1)
+    t2 = t.view(1, -1).expand(B, -1) if t.dim() == 1 else t
+    sr, si, _, _ = query_points(t2, S, alpha, tol, scale)
+    th_s, ph_s = complex_to_sphere(sr, si)
+    Tt = t2.shape[1]
+    inp = torch.cat((th_s, ph_s, p.view(B, 1, -1).expand(B, Tt, p.shape[1])), dim=-1)
+    return inp, t2
+
+
+def laplace_reconstruct(
+    laplace_rep_func,
+    p,
+    t,
+    recon_dim=None,
+    ilt_algorithm="fourier",
+    ilt_reconstruction_terms=33,
+    options=None,
+):
+    """Oracle for ``torchlaplace.laplace_reconstruct`` (call sites w_nl.py:137-144).
+
+    laplace_rep_func: callable((B, Tt, 2S+P)) -> (theta, phi) each (B*Tt, d, S)
+    p: (B, P) ; t: (B, Tt) or (Tt,)  ->  (B, Tt, d)
+    """
+    S = ilt_reconstruction_terms
+    if recon_dim is None:
+        recon_dim = p.shape[1]
+    inp, t2 = rep_func_inputs(p, t, S, ilt_algorithm, options)
+    B, Tt = t2.shape
+    theta, phi = laplace_rep_func(inp)
+    theta = theta.reshape(B * Tt, recon_dim, S)
+    phi = phi.reshape(B * Tt, recon_dim, S)
+    x = ilt_from_sphere(theta, phi, t2.reshape(-1), ilt_algorithm, options)
+    return x.view(B, Tt, recon_dim)

@@ -1,0 +1,211 @@
+"""Oracle: Neural Laplace dynamics model (stages a5-a8 of SURVEY.md §8).
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.
+
+Restates ``w_nl.py``:
+* ``ReverseGRUEncoder``           w_nl.py:14-29   (explicit PyTorch GRU gate equations)
+* ``LaplaceRepresentationFunc``   w_nl.py:32-63
+* ``NeuralLaplaceModel.forward``  w_nl.py:117-145
+and the harness dynamics closure ``mppi_with_model.py:103-122``
+(``state + model(state, window, ts_pred)``).
+
+Weights travel as a plain ``dict`` with the reference's ``state_dict`` keys
+(``action_encoder.gru.weight_ih_l0`` ..., ``laplace_rep_func.linear_tanh_stack.{0,2,4}.*``,
+buffers ``state_mean/state_std/action_mean/action_std/dt``), all float64.
+"""
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ilt
+
+# train_utils.py:187-200 -- per-env normalisation constants (mean is 0 everywhere)
+ENV_STATS = {
+    "oderl-cartpole": dict(
+        d=5, nu=1, act_high=3.0, state_std=[2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048]
+    ),
+    "oderl-pendulum": dict(d=3, nu=1, act_high=2.0, state_std=[0.70634571, 0.70784512, 2.89072771]),
+    "oderl-acrobot": dict(
+        d=6, nu=2, act_high=5.0, state_std=[0.70711024, 0.70710328, 0.7072186, 0.7069949, 2.88642115, 2.88627309]
+    ),
+}
+
+
+# "Trained-like" taming of the synthetic weights.  With the raw constructor init the random
+# model is chaotic: |dx| ~ 10-70 per step and a 1e-10 state perturbation grows to O(1e3) by
+# T=40 (1-ulp differences between aten::gru and the explicit GRU equations reach 2e-8 after
+# only 8 steps), so no two float64 implementations can agree at BASELINE horizons.  Shifting
+# the phi rows of the last rep-func bias by -3 puts F(s) near the sphere's south pole
+# (|F| ~ 4e-3, as a trained model predicting small state differences would), which makes the
+# rollout neutrally stable (1e-10 -> 1.6e-10 at T=40) with a non-degenerate cost spread.
+PHI_BIAS_SHIFT = -3.0
+
+
+def tame_(sd, d, S, shift=PHI_BIAS_SHIFT):
+    sd["laplace_rep_func.linear_tanh_stack.4.bias"][d * S :] += shift
+    return sd
+
+
+def make_synthetic_state_dict(
+    seed=0, d=5, nu=1, h=128, S=17, state_std=None, action_std=None, dt=0.05, encode_obs_time=False, tame=False
+):
+    """Seeded synthetic weights of the reference architecture (no checkpoints ship: SURVEY F8).
+
+    Builds the torch modules in the reference constructor's order (GRU, head Linear +
+    xavier, then the three rep-func Linears + xavier: w_nl.py:21-23, 40-50) so that under
+    the same ``torch.manual_seed`` the values equal the reference constructor's.
+    """
+    g = h // 2
+    P = d + 2
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    gru = nn.GRU(nu + (1 if encode_obs_time else 0), g, 2, batch_first=True)
+    lin_out = nn.Linear(g, 2)
+    nn.init.xavier_uniform_(lin_out.weight)
+    l0, l2, l4 = nn.Linear(2 * S + P, h), nn.Linear(h, h), nn.Linear(h, 2 * d * S)
+    for m in (l0, l2, l4):
+        nn.init.xavier_uniform_(m.weight)
+    torch.random.set_rng_state(gen_state)
+    sd = {}
+    for k, v in gru.state_dict().items():
+        sd[f"action_encoder.gru.{k}"] = v
+    sd["action_encoder.linear_out.weight"] = lin_out.weight
+    sd["action_encoder.linear_out.bias"] = lin_out.bias
+    for idx, m in ((0, l0), (2, l2), (4, l4)):
+        sd[f"laplace_rep_func.linear_tanh_stack.{idx}.weight"] = m.weight
+        sd[f"laplace_rep_func.linear_tanh_stack.{idx}.bias"] = m.bias
+    sd = {k: v.detach().to(torch.float64).clone() for k, v in sd.items()}
+    sd["state_mean"] = torch.zeros(d, dtype=torch.float64)
+    sd["state_std"] = torch.tensor(state_std if state_std is not None else [1.0] * d, dtype=torch.float64)
+    sd["action_mean"] = torch.zeros(nu, dtype=torch.float64)
+    sd["action_std"] = torch.tensor(action_std if action_std is not None else [1.0], dtype=torch.float64)
+    # w_nl.py:115 registers torch.tensor(dt) = FLOAT32; model.double() (mppi_with_model.py:101)
+    # then widens it, so the time normaliser is float32(0.05) = 0.05000000074505806.
+    sd["dt"] = torch.tensor(dt, dtype=torch.float32).to(torch.float64)
+    if tame:
+        tame_(sd, d, S)
+    return sd
+
+
+def gru_encoder(sd, window):
+    """ReverseGRUEncoder.forward (w_nl.py:25-29) with explicit gate equations.
+
+    window: (N, L, in) already normalised -> (N, 2).
+    PyTorch GRU: r=sig(W_ir x+b_ir+W_hr h+b_hr), z=sig(W_iz x+b_iz+W_hz h+b_hz),
+    n=tanh(W_in x+b_in+r*(W_hn h+b_hn)), h'=(1-z)*n+z*h; gates stacked [r;z;n].
+    """
+    x = torch.flip(window, (1,))
+    N, L, _ = x.shape
+    pre = "action_encoder.gru."
+    g = sd[pre + "weight_hh_l0"].shape[1]
+    seq = x
+    for layer in (0, 1):
+        Wi, Wh = sd[pre + f"weight_ih_l{layer}"], sd[pre + f"weight_hh_l{layer}"]
+        bi, bh = sd[pre + f"bias_ih_l{layer}"], sd[pre + f"bias_hh_l{layer}"]
+        hcur = torch.zeros(N, g, dtype=torch.float64)
+        outs = []
+        for s in range(L):
+            gi = seq[:, s] @ Wi.T + bi
+            gh = hcur @ Wh.T + bh
+            r = torch.sigmoid(gi[:, :g] + gh[:, :g])
+            z = torch.sigmoid(gi[:, g : 2 * g] + gh[:, g : 2 * g])
+            n = torch.tanh(gi[:, 2 * g :] + r * gh[:, 2 * g :])
+            hcur = (1.0 - z) * n + z * hcur
+            outs.append(hcur)
+        seq = torch.stack(outs, dim=1)
+    return seq[:, -1] @ sd["action_encoder.linear_out.weight"].T + sd["action_encoder.linear_out.bias"]
+
+
+def rep_func(sd, inp, d, S):
+    """LaplaceRepresentationFunc.forward (w_nl.py:55-63): -> theta, phi each (N, d, S)."""
+    pre = "laplace_rep_func.linear_tanh_stack."
+    x = inp.reshape(-1, inp.shape[-1])
+    x = torch.tanh(x @ sd[pre + "0.weight"].T + sd[pre + "0.bias"])
+    x = torch.tanh(x @ sd[pre + "2.weight"].T + sd[pre + "2.bias"])
+    out = (x @ sd[pre + "4.weight"].T + sd[pre + "4.bias"]).view(-1, 2 * d, S)
+    theta = torch.tanh(out[:, :d, :]) * math.pi
+    # phi_scale = pi ; tanh*phi_scale/2 - pi/2 + phi_scale/2 (w_nl.py:52-62)
+    phi = torch.tanh(out[:, d:, :]) * math.pi / 2.0 - math.pi / 2.0 + math.pi / 2.0
+    return theta, phi
+
+
+def nl_forward(
+    sd, obs, window, ts_pred, S=17, ilt_algorithm="fourier", normalize=True, normalize_time=True, ilt_options=None
+):
+    """NeuralLaplaceModel.forward (w_nl.py:117-145): predicted state difference (N, d)."""
+    d = obs.shape[-1]
+    if normalize:
+        o = (obs - sd["state_mean"]) / sd["state_std"]
+        a = (window - sd["action_mean"]) / sd["action_std"]
+        if normalize_time:
+            ts_pred = ts_pred / (sd["dt"] * 8.0)
+    else:
+        o = obs
+        a = window / 3.0
+    if a.dim() == 2:
+        a = a.unsqueeze(1)
+    p_action = gru_encoder(sd, a)
+    p = torch.cat((o, p_action), dim=1)
+    out = ilt.laplace_reconstruct(
+        lambda i: rep_func(sd, i, d, S),
+        p,
+        ts_pred,
+        recon_dim=d,
+        ilt_algorithm=ilt_algorithm,
+        ilt_reconstruction_terms=S,
+        options=ilt_options,
+    )
+    return torch.squeeze(out)
+
+
+def nl_dynamics(sd, ts_pred, **kw):
+    """Harness closure mppi_with_model.py:103-122: state + model(state, window, ts_pred)."""
+
+    def dynamics(state, window):
+        return state + nl_forward(sd, state, window, ts_pred[: state.shape[0]], **kw).view(state.shape)
+
+    return dynamics
+
+
+class TorchGRUModel:
+    """Same computation with ``torch.nn.GRU`` (aten::gru), i.e. the reference's op sequence.
+
+    Used (a) to cross-check ``gru_encoder`` and (b) as the timed ``cpu_baseline`` in
+    ``bench.py`` so the CPU number reflects what the reference actually executes
+    (w_nl.py:21,28 -> aten::gru; SURVEY §6: ~83 % of CPU time).
+    """
+
+    def __init__(self, sd, nu, encode_obs_time=False):
+        g = sd["action_encoder.gru.weight_hh_l0"].shape[1]
+        self.gru = nn.GRU(nu + (1 if encode_obs_time else 0), g, 2, batch_first=True).double()
+        self.gru.load_state_dict({k.split("gru.")[1]: v for k, v in sd.items() if ".gru." in k})
+        self.sd = sd
+
+    @torch.no_grad()
+    def encode(self, window):
+        out, _ = self.gru(torch.flip(window, (1,)))
+        return out[:, -1, :] @ self.sd["action_encoder.linear_out.weight"].T + self.sd["action_encoder.linear_out.bias"]
+
+    @torch.no_grad()
+    def forward(self, obs, window, ts_pred, S=17, ilt_algorithm="fourier"):
+        sd = self.sd
+        d = obs.shape[-1]
+        o = (obs - sd["state_mean"]) / sd["state_std"]
+        a = (window - sd["action_mean"]) / sd["action_std"]
+        t = ts_pred / (sd["dt"] * 8.0)
+        p = torch.cat((o, self.encode(a)), dim=1)
+        out = ilt.laplace_reconstruct(
+            lambda i: rep_func(sd, i, d, S), p, t, recon_dim=d, ilt_algorithm=ilt_algorithm, ilt_reconstruction_terms=S
+        )
+        return torch.squeeze(out)
+
+
+def state_dict_to_numpy(sd):
+    return {k: np.asarray(v.detach().cpu().numpy(), dtype=np.float64) for k, v in sd.items()}
+
+
+def state_dict_from_numpy(npz):
+    return {k: torch.as_tensor(np.asarray(npz[k]), dtype=torch.float64) for k in npz.keys()}

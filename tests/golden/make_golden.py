@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are
+data (inputs + expected outputs), never reference source.  Re-run:
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  g1_mppi_<env>_d<delay>.npz  reference MPPIDelay + reference oracle.*_dynamics_dt_delay +
+                              reference env reward methods           (pins a1-a4, a10-a12)
+  g2_stages_<env>.npz         reference ReverseGRUEncoder / LaplaceRepresentationFunc I/O
+                              (pins a7, a8 against real nn.GRU / the real module)
+  g3_nl_<env>.npz             reference NeuralLaplaceModel.forward + reference MPPIDelay.command
+                              with NL dynamics; ONLY laplace_reconstruct is the build's
+                              restatement (torchlaplace is absent: parity unpinned for a9)
+  g4_ilt_known.npz            analytic Laplace pairs + mpmath.invertlaplace(method='dehoog')
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import envs as oenvs  # noqa: E402
+from oracle import ilt as oilt  # noqa: E402
+from oracle import nl_model as onl  # noqa: E402
+
+
+def install_stubs():
+    """Minimal stand-ins so the reference modules import without gym/torchdiffeq/torchlaplace."""
+    tl = types.ModuleType("torchlaplace")
+    tl.laplace_reconstruct = oilt.laplace_reconstruct  # the ONLY non-reference arithmetic in G3
+    sys.modules["torchlaplace"] = tl
+
+    gym = types.ModuleType("gym")
+
+    class Env:
+        pass
+
+    gym.Env = Env
+    spaces = types.ModuleType("gym.spaces")
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape if shape else np.shape(low)).copy()
+            self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape if shape else np.shape(high)).copy()
+            self.shape = self.low.shape
+
+    spaces.Box = Box
+    gym.spaces = spaces
+    gutils = types.ModuleType("gym.utils")
+    seeding = types.ModuleType("gym.utils.seeding")
+    seeding.np_random = lambda seed=None: (np.random.RandomState(seed), seed)
+    gutils.seeding = seeding
+    gym.utils = gutils
+    sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.utils": gutils, "gym.utils.seeding": seeding})
+    tde = types.ModuleType("torchdiffeq")
+    tde.odeint = None
+    sys.modules["torchdiffeq"] = tde
+    pk = types.ModuleType("TorchDiffEqPack")
+    pko = types.ModuleType("TorchDiffEqPack.odesolver")
+    pko.odesolve = None
+    pk.odesolver = pko
+    sys.modules.update({"TorchDiffEqPack": pk, "TorchDiffEqPack.odesolver": pko})
+
+
+def load_reference_modules():
+    """Import reference modules by file path so they do not clash with this repo's ``oracle`` package."""
+    import importlib.util
+
+    install_stubs()
+    sys.argv = [sys.argv[0]]
+    sys.path.insert(0, REF)
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    ref_oracle = load("ref_oracle", f"{REF}/oracle.py")
+    import config as ref_config  # noqa: F401
+    from planners.mppi_delay import MPPIDelay
+
+    w_nl = load("ref_w_nl", f"{REF}/w_nl.py")
+    from envs.oderl.envs import CTAcrobot, CTCartpole, CTPendulum
+
+    envs = {
+        "oderl-cartpole": lambda: CTCartpole(dt=0.05, obs_trans=True, device="cpu", solver="euler", friction=False),
+        "oderl-pendulum": lambda: CTPendulum(dt=0.05, obs_trans=True, device="cpu", solver="euler"),
+        "oderl-acrobot": lambda: CTAcrobot(dt=0.05, obs_trans=True, device="cpu", solver="euler"),
+    }
+    dyn = {
+        "oderl-cartpole": ref_oracle.cartpole_dynamics_dt_delay,
+        "oderl-pendulum": ref_oracle.pendulum_dynamics_dt_delay,
+        "oderl-acrobot": ref_oracle.acrobot_dynamics_dt_delay,
+    }
+    return MPPIDelay, w_nl, envs, dyn
+
+
+def noise_sigma(nu, sigma=1.0):
+    # mppi_with_model.py:66-70
+    g = sigma**2
+    return torch.ones((nu, nu), dtype=torch.double) * 0.5 * g + torch.eye(nu, dtype=torch.double) * (g - 0.5 * g)
+
+
+def np_(x):
+    return x.detach().cpu().numpy().astype(np.float64)
+
+
+def capture_command(mppi, state, action_buffer):
+    """Run reference command() while recording U_before and the raw noise draw."""
+    U_before = mppi.U.clone()
+    rng = torch.random.get_rng_state()
+    raw = mppi.noise_dist.sample((mppi.K, mppi.T))  # same draw command() will make
+    torch.random.set_rng_state(rng)
+    action = mppi.command(state, action_buffer)
+    return dict(
+        U_before=np_(U_before),
+        noise_raw=np_(raw),
+        action=np_(action),
+        U_after=np_(mppi.U),
+        cost_total=np_(mppi.cost_total),
+        omega=np_(mppi.omega),
+        noise=np_(mppi.noise),
+        perturbed_action=np_(mppi.perturbed_action),
+        states=np_(mppi.states),
+        actions=np_(mppi.actions),
+    )
+
+
+def make_g1(MPPIDelay, envs, dyn):
+    K, T, B = 64, 8, 4
+    for env_name, mk in envs.items():
+        env = mk()
+        nx, nu, A = oenvs.OBS_DIM[env_name], oenvs.ACT_DIM[env_name], oenvs.ACTION_HIGH[env_name]
+        assert float(env.action_space.high[0]) == A
+        ts_pred = torch.full((K, 1), 0.05, dtype=torch.double)
+
+        def running_cost(state, action, env=env):
+            return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+        for delay in range(4):
+            torch.manual_seed(100 + delay)
+            from functools import partial
+
+            dynamics = partial(dyn[env_name], ts=ts_pred, delay=delay, friction=False)
+            mppi = MPPIDelay(
+                dynamics,
+                running_cost,
+                nx,
+                noise_sigma(nu),
+                num_samples=K,
+                horizon=T,
+                device="cpu",
+                lambda_=1.0,
+                u_min=torch.tensor(-A),
+                u_max=torch.tensor(A),
+                u_scale=A,
+            )
+            state = oenvs.initial_state(env_name, seed=delay)
+            action_buffer = (torch.rand(B, nu, dtype=torch.double) - 0.5) * A
+            out = {}
+            # two consecutive commands: the second exercises the U shift of a non-trivial U
+            for step in range(2):
+                c = capture_command(mppi, state.numpy(), action_buffer)
+                for k, v in c.items():
+                    out[f"s{step}_{k}"] = v
+                out[f"s{step}_state"] = np_(state)
+                out[f"s{step}_action_buffer"] = np_(action_buffer)
+                state = mppi.states[0, 0].clone()  # any plausible next state
+                action_buffer = torch.roll(action_buffer, -1, dims=0)
+                action_buffer[-1] = torch.as_tensor(c["action"])
+            np.savez_compressed(
+                f"{HERE}/g1_mppi_{env_name.split('-')[1]}_d{delay}.npz",
+                K=K, T=T, B=B, delay=delay, nx=nx, nu=nu, A=A, **out,
+            )
+            print("g1", env_name, delay, "action", out["s1_action"])
+
+
+def build_ref_model(w_nl, env_name, seed, S=17, algo="fourier", h=128):
+    st = onl.ENV_STATS[env_name]
+    torch.manual_seed(seed)
+    model = w_nl.NeuralLaplaceModel(
+        st["d"],
+        st["nu"],
+        st["d"],
+        hidden_units=h,
+        s_recon_terms=S,
+        ilt_algorithm=algo,
+        encode_obs_time=False,
+        state_mean=np.zeros(st["d"]),
+        state_std=np.array(st["state_std"]),
+        action_mean=np.array([0] * st["nu"]),
+        action_std=np.array([st["act_high"] / 2.0]),
+        normalize=True,
+        normalize_time=True,
+    ).double()
+    return model
+
+
+def make_g2_g3(MPPIDelay, w_nl, envs):
+    for env_name, mk in envs.items():
+        short = env_name.split("-")[1]
+        st = onl.ENV_STATS[env_name]
+        d, nu, A = st["d"], st["nu"], st["act_high"]
+        S = 17
+        model = build_ref_model(w_nl, env_name, seed=0)
+        sd = {k: np_(v) for k, v in model.state_dict().items()}
+        # the oracle's synthetic-weight builder must reproduce the reference constructor's weights
+        mine = onl.make_synthetic_state_dict(
+            0, d, nu, 128, S, state_std=st["state_std"], action_std=[A / 2.0]
+        )
+        for k in sd:
+            assert np.array_equal(sd[k], np_(mine[k])), f"synthetic weights differ from reference ctor: {k}"
+        torch.manual_seed(7)
+        N, B = 48, 4
+        with torch.no_grad():
+            # ---- G2: stage I/O
+            win = torch.randn(N, B, nu, dtype=torch.double)
+            p_action = model.action_encoder(win)
+            rep_in = torch.randn(N, 2 * S + d + 2, dtype=torch.double)
+            theta, phi = model.laplace_rep_func(rep_in)
+            np.savez_compressed(
+                f"{HERE}/g2_stages_{short}.npz",
+                d=d, nu=nu, S=S, h=128,
+                gru_in=np_(win), gru_out=np_(p_action),
+                rep_in=np_(rep_in), rep_theta=np_(theta), rep_phi=np_(phi),
+                **{f"w::{k}": v for k, v in sd.items()},
+            )
+            # ---- G3: model forward + command with NL dynamics, on the "trained-like" tamed
+            # weights (oracle/nl_model.py PHI_BIAS_SHIFT: the raw random model is chaotic)
+            model.laplace_rep_func.linear_tanh_stack[4].bias[d * S :] += onl.PHI_BIAS_SHIFT
+            sd = {k: np_(v) for k, v in model.state_dict().items()}
+            obs = torch.randn(N, d, dtype=torch.double) * torch.tensor(st["state_std"])
+            window = (torch.rand(N, B, nu, dtype=torch.double) * 2 - 1) * A
+            ts = torch.full((N, 1), 0.05, dtype=torch.double)
+            fwd = model(obs, window, ts)
+            fwd33 = None
+            out = dict(fwd_obs=np_(obs), fwd_window=np_(window), fwd_ts=np_(ts), fwd_out=np_(fwd))
+            K, T = 64, 8
+            ts_pred = torch.full((K, 1), 0.05, dtype=torch.double)
+            env = mk()
+
+            def dynamics(state, perturbed_action):
+                return state + model(state, perturbed_action, ts_pred)
+
+            def running_cost(state, action, env=env):
+                return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+            torch.manual_seed(11)
+            mppi = MPPIDelay(
+                dynamics, running_cost, d, noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
+                lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+            )
+            state = oenvs.initial_state(env_name, seed=3)
+            action_buffer = torch.zeros(B, nu, dtype=torch.double)
+            for step in range(2):
+                c = capture_command(mppi, state.numpy(), action_buffer)
+                for k, v in c.items():
+                    out[f"s{step}_{k}"] = v
+                out[f"s{step}_state"] = np_(state)
+                out[f"s{step}_action_buffer"] = np_(action_buffer)
+                state = mppi.states[0, 0].clone()
+                action_buffer = torch.roll(action_buffer, -1, dims=0)
+                action_buffer[-1] = torch.as_tensor(c["action"])
+            # de Hoog / S=33 variant of the forward (cfg5)
+            model33 = build_ref_model(w_nl, env_name, seed=1, S=33, algo="dehoog")
+            fwd33 = model33(obs, window, ts)
+            sd33 = {k: np_(v) for k, v in model33.state_dict().items()}
+            np.savez_compressed(
+                f"{HERE}/g3_nl_{short}.npz",
+                d=d, nu=nu, S=S, h=128, K=K, T=T, B=B, A=A,
+                fwd33_out=np_(fwd33),
+                **out,
+                **{f"w::{k}": v for k, v in sd.items()},
+                **{f"w33::{k}": v for k, v in sd33.items()},
+            )
+            print("g3", env_name, "action", out["s1_action"], "fwd[0]", out["fwd_out"][0])
+
+
+def make_g4():
+    """ILT known answers: analytic pairs + mpmath de Hoog (degree 16 -> 33 terms)."""
+    import mpmath as mp
+
+    mp.mp.dps = 30
+    ts = [0.125, 0.5, 1.0, 2.5]
+    pairs = {
+        "exp_decay": (lambda s: 1 / (s + 1), lambda t: mp.e ** (-t)),
+        "cosine": (lambda s: s / (s * s + 4), lambda t: mp.cos(2 * t)),
+        "sine_damped": (lambda s: 3 / ((s + mp.mpf("0.5")) ** 2 + 9), lambda t: mp.e ** (-t / 2) * mp.sin(3 * t)),
+        "ramp": (lambda s: 1 / (s * s), lambda t: t),
+        "delayed_step": (lambda s: mp.e ** (-mp.mpf("0.3") * s) / s, lambda t: mp.mpf(1) if t > 0.3 else mp.mpf(0)),
+    }
+    out = {"ts": np.array(ts)}
+    for name, (F, f) in pairs.items():
+        out[f"{name}_exact"] = np.array([float(f(mp.mpf(t))) for t in ts])
+        out[f"{name}_mp_dehoog"] = np.array(
+            # same abscissa parameters as the restated torchlaplace defaults (alpha=1e-10, tol=1e-9)
+            [float(mp.invertlaplace(F, t, method="dehoog", degree=16, alpha=1e-10, tol=1e-9)) for t in ts]
+        )
+        # F sampled at the query points the oracle/HIP path use (both algorithms), so the
+        # device test needs no mpmath: (len(ts), S) real/imag
+        for algo, S in (("fourier", 17), ("fourier", 33), ("dehoog", 33), ("dehoog", 17)):
+            alpha, tol, scale = oilt.ilt_options(algo)
+            sr, si, _, _ = oilt.query_points(torch.tensor(ts), S, alpha, tol, scale)
+            vals = [[complex(F(mp.mpc(float(sr[i, k]), float(si[i, k])))) for k in range(S)] for i in range(len(ts))]
+            out[f"{name}_{algo}{S}_Fre"] = np.array([[v.real for v in row] for row in vals])
+            out[f"{name}_{algo}{S}_Fim"] = np.array([[v.imag for v in row] for row in vals])
+    np.savez_compressed(f"{HERE}/g4_ilt_known.npz", **out)
+    print("g4 done")
+
+
+def main():
+    MPPIDelay, w_nl, envs, dyn = load_reference_modules()
+    make_g1(MPPIDelay, envs, dyn)
+    make_g2_g3(MPPIDelay, w_nl, envs)
+    make_g4()
+
+
+if __name__ == "__main__":
+    main()
