@@ -1,0 +1,195 @@
+/*
+ * nlc.h -- C ABI of libnlc_hip.so: the MI355X (gfx950) planning hot path of Neural Laplace Control.
+ *
+ * The reference (samholt/NeuralLaplaceControl) is pure Python and has NO FFI layer; its boundary for
+ * this path is three Python call sites.  Each entry point below names the reference interface it
+ * replaces (file:line, relative to the reference tree).  The Python mirror of those interfaces
+ * (neurallaplacecontrol_amd/) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns an int status (NLC_OK = 0, negative = error); text via nlc_last_error().
+ *     No C++ exception crosses this boundary.
+ *   - "_dev" pointers are DEVICE pointers (HBM of the ctx's GPU; e.g. torch.Tensor.data_ptr()),
+ *     "_host" pointers are host pointers.  All payloads are float64, row-major, contiguous.
+ *   - the caller owns every pointer for the duration of the call only; the ctx copies what it keeps.
+ *   - kernels are enqueued on the stream given to nlc_set_stream() (default: the ctx's own stream).
+ *     Functions that return host data synchronise that stream before returning; the others are
+ *     asynchronous with respect to the host, ordered on the stream.
+ *   - a ctx is not thread-safe: one ctx per (process, device).  HIP is initialised lazily inside
+ *     nlc_create(), never at library load (spawn-safe, cf. run_exp_multi.py:145,207).
+ */
+#ifndef NLC_H_
+#define NLC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLC_ABI_VERSION 1
+
+#define NLC_OK 0
+#define NLC_ERR_BAD_ARG (-1)
+#define NLC_ERR_BAD_SHAPE (-2)
+#define NLC_ERR_HIP (-3)
+#define NLC_ERR_UNSUPPORTED (-4)
+#define NLC_ERR_STATE (-5)
+
+#define NLC_MAX_NU 2   /* action dims (cartpole/pendulum 1, acrobot 2) */
+#define NLC_MAX_NIN 3  /* GRU input dims = nu + encode_obs_time */
+#define NLC_MAX_D 8    /* observation dims (3..6 in the reference envs) */
+
+/* ILT algorithms (torchlaplace `ilt_algorithm`, call site w_nl.py:141) */
+#define NLC_ILT_FOURIER 0
+#define NLC_ILT_DEHOOG 1
+
+/* env running costs (mppi_with_model.py:145-171 -> ctcartpole.py:289-346, ctpendulum.py:139-155,
+ * ctacrobot.py:233-255) and oracle dynamics (oracle.py:11-224) */
+#define NLC_ENV_CARTPOLE 0
+#define NLC_ENV_PENDULUM 1
+#define NLC_ENV_ACROBOT 2
+
+/* rollout dynamics */
+#define NLC_DYN_NL 0     /* state + NeuralLaplaceModel(state, window, ts_pred)  (mppi_with_model.py:103-122) */
+#define NLC_DYN_ORACLE 1 /* oracle.{cartpole,pendulum,acrobot}_dynamics_dt_delay (mppi_with_model.py:129-143) */
+#define NLC_DYN_EXTERNAL 2 /* caller-supplied dynamics/cost callables: the caller runs the horizon loop
+                              (mppi_delay.py:271-296) itself between nlc_mppi_rollout and nlc_mppi_weights */
+
+typedef struct nlc_ctx nlc_ctx;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int nlc_abi_version(void);
+int nlc_create(int device, nlc_ctx** out);
+void nlc_destroy(nlc_ctx* ctx);
+const char* nlc_last_error(const nlc_ctx* ctx); /* ctx may be NULL: error of the last failed nlc_create */
+int nlc_set_stream(nlc_ctx* ctx, void* hip_stream); /* hipStream_t; NULL restores the ctx's own stream */
+int nlc_synchronize(nlc_ctx* ctx);
+/* device properties the bench reports next to its roofline numbers */
+int nlc_device_info(nlc_ctx* ctx, char* name, int name_len, int* num_cus, int* clock_mhz, double* hbm_gib);
+
+/* ---- ILT: torchlaplace.laplace_reconstruct (external; call sites w_nl.py:137-144,
+ *      w_latent_ode.py:88-94).  Parity unpinned vs upstream torchlaplace: alpha/tol/scale and the
+ *      [theta_s | phi_s | p] input order are the recalled defaults, exposed here as parameters. ---- */
+typedef struct {
+  int32_t algo;  /* NLC_ILT_* */
+  int32_t terms; /* S = ilt_reconstruction_terms (de Hoog: odd, 2M+1) */
+  double alpha;  /* fourier 1e-3, dehoog 1e-10 */
+  double tol;    /* 10*alpha */
+  double scale;  /* 2.0 */
+} nlc_ilt_desc;
+
+/* Contour evaluation + Riemann-sphere projection + concat: rows [theta_s(0..S-1) | phi_s(0..S-1) | p]
+ * for every (batch row b, time point j).  t_dev is (B*Tt) if t_batched else (Tt) shared by all rows.
+ * out_dev: (B, Tt, 2S+P). */
+int nlc_ilt_rep_inputs(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* p_dev, const double* t_dev,
+                       int t_batched, int64_t B, int64_t Tt, int P, double* out_dev);
+/* Sphere -> complex map and line integral: theta_dev, phi_dev (N, d, S) rep-func outputs, t_dev (N)
+ * -> x_dev (N, d).  HBM-bound streaming kernel for Fourier; algorithmic bytes (2dS+d)*8 per point. */
+int nlc_ilt_reconstruct(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* theta_dev, const double* phi_dev,
+                        const double* t_dev, int64_t N, int d, double* x_dev);
+
+/* ---- model: NeuralLaplaceModel (w_nl.py:66-145), ReverseGRUEncoder (:14-29),
+ *      LaplaceRepresentationFunc (:32-63) ------------------------------------------------------- */
+typedef struct {
+  int32_t d;   /* state_dim (obs dim) */
+  int32_t nin; /* GRU input dim = action_dim + encode_obs_time (w_nl.py:19-20) */
+  int32_t h;   /* hidden_units (GRU hidden = h/2, w_nl.py:92) */
+  nlc_ilt_desc ilt;
+  double time_div; /* ts_pred is divided by this: dt*8 if normalize&&normalize_time else 1 (w_nl.py:122) */
+  double state_mean[NLC_MAX_D], state_std[NLC_MAX_D];       /* identity (0,1) if !normalize */
+  double action_mean[NLC_MAX_NIN], action_std[NLC_MAX_NIN]; /* (0,3) if !normalize (w_nl.py:129) */
+} nlc_model_desc;
+
+/* weights_host: float64 blob, tensors in the reference's state_dict order:
+ *   gru.weight_ih_l0 (3g,nin) weight_hh_l0 (3g,g) bias_ih_l0 (3g) bias_hh_l0 (3g)
+ *   gru.weight_ih_l1 (3g,g)   weight_hh_l1 (3g,g) bias_ih_l1 (3g) bias_hh_l1 (3g)
+ *   linear_out.weight (2,g) linear_out.bias (2)
+ *   linear_tanh_stack.0.weight (h,2S+d+2) .0.bias (h) .2.weight (h,h) .2.bias (h)
+ *   .4.weight (2dS,h) .4.bias (2dS)
+ * n_doubles must equal nlc_model_blob_size(desc).  The ctx repacks them into MFMA fragment order. */
+int64_t nlc_model_blob_size(const nlc_model_desc* desc);
+int nlc_set_model(nlc_ctx* ctx, const nlc_model_desc* desc, const double* weights_host, int64_t n_doubles);
+/* ReverseGRUEncoder.forward on the model's normalised input: window_dev (N, B, nin) raw
+ * (un-normalised) actions, B = window length (action_buffer_size, config.py:58) -> out_dev (N, 2) */
+int nlc_gru_encode(nlc_ctx* ctx, const double* window_dev, int64_t N, int B, double* out_dev);
+/* NeuralLaplaceModel.forward: obs_dev (N,d), window_dev (N,B,nin), ts_dev (N) raw ts_pred
+ * -> out_dev (N,d) predicted state difference.  ws_dev: scratch of nlc_model_workspace_bytes(N). */
+int64_t nlc_model_workspace_bytes(nlc_ctx* ctx, int64_t N);
+int nlc_model_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev,
+                      int64_t N, int B, double* out_dev, void* ws_dev);
+
+/* ---- planner: MPPIDelay (planners/mppi_delay.py:54-381) ------------------------------------- */
+typedef struct {
+  int64_t K;        /* samples owned by THIS ctx (its shard of the population) */
+  int64_t K_global; /* whole population (== K on one GPU) */
+  int64_t k_offset; /* global index of this shard's first sample (Philox counters, sample_null_action) */
+  int32_t T;        /* horizon */
+  int32_t nu;       /* action dims */
+  int32_t d;        /* nx */
+  int32_t B;        /* rows of action_buffer */
+  double lambda_;
+  double u_scale;
+  int32_t has_bounds; /* u_min/u_max given (mppi_delay.py:143-153) */
+  double u_min[NLC_MAX_NU], u_max[NLC_MAX_NU];
+  double u_init[NLC_MAX_NU];
+  double noise_mu[NLC_MAX_NU];
+  double noise_sigma[NLC_MAX_NU * NLC_MAX_NU];     /* covariance, row-major nu x nu */
+  double noise_sigma_inv[NLC_MAX_NU * NLC_MAX_NU]; /* torch.inverse(noise_sigma) (:157) */
+  double noise_chol[NLC_MAX_NU * NLC_MAX_NU];      /* lower Cholesky factor (device RNG only) */
+  int32_t sample_null_action; /* :322-323 */
+  int32_t noise_abs_cost;     /* :329-330 */
+  int32_t u_per_command;      /* :217-220 */
+  int32_t dynamics;           /* NLC_DYN_* */
+  int32_t env;                /* NLC_ENV_* running cost (and oracle dynamics) */
+  int32_t delay;              /* oracle dynamics: action applied = window[-(delay+1)] */
+  int32_t friction;           /* oracle cartpole only */
+  double ts_pred;             /* raw dt handed to the dynamics (mppi_with_model.py:74) */
+} nlc_mppi_desc;
+
+/* caller-owned device buffers the kernels read/write (the Python mirror keeps them as the public
+ * attributes .noise .perturbed_action .states .actions .cost_total .cost_total_non_zero .omega) */
+typedef struct {
+  double* noise;      /* (K,T,nu) in: raw N(mu,Sigma) draw when rng == 0; out: bounded noise (:328) */
+  double* perturbed;  /* (K,T,nu) out: bounded perturbed action, normalised units (:325-326) */
+  double* states;     /* (K,T,d)  out, may be NULL */
+  double* actions;    /* (K,T,nu) out = perturbed (actions/u_scale, :340), may be NULL */
+  double* cost_total; /* (K) out */
+  double* cost_nz;    /* (K) out: exp(-(cost-beta)/lambda) */
+  double* omega;      /* (K) out: cost_nz/eta, may be NULL */
+  double* partials;   /* (2+T*nu) out: this shard's (beta_r, eta_r, S_r[t,j]) */
+  void* workspace;    /* nlc_mppi_workspace_bytes() bytes of scratch */
+} nlc_mppi_buffers;
+
+int nlc_mppi_configure(nlc_ctx* ctx, const nlc_mppi_desc* desc);
+int64_t nlc_mppi_workspace_bytes(nlc_ctx* ctx);
+int nlc_mppi_set_U(nlc_ctx* ctx, const double* U_host); /* (T,nu) control sequence, :161-164 */
+int nlc_mppi_get_U(nlc_ctx* ctx, double* U_host);
+/* Phase 1 of command(): shift U (:199-200), sample/perturb/bound (:319-335), hoisted GRU encode,
+ * T-step rollout + running cost (:232-313), perturbation cost (:343-344), and this shard's
+ * softmax partials (beta_r, eta_r, S_r) into buf->partials.
+ *   state_host: (d) or (K,d) if state_per_sample (:243-246); action_buffer_host: (B,nu).
+ *   rng: 0 = buf->noise holds the caller's raw draw; 1 = device Philox4x32-10(seed, counter). */
+int nlc_mppi_rollout(nlc_ctx* ctx, const double* state_host, int state_per_sample,
+                     const double* action_buffer_host, const nlc_mppi_buffers* buf, int rng, uint64_t seed,
+                     uint64_t counter);
+/* NLC_DYN_EXTERNAL only: nlc_mppi_rollout stops after the perturbation; once the caller has filled
+ * buf->cost_total (rollout cost + perturbation cost, :339-344) this computes the softmax partials. */
+int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
+/* Phase 2: merge G shard partials (gathered_dev: (G, 2+T*nu); pass buf->partials and G=1 on one GPU),
+ * omega, U[t] += sum_k omega_k noise[k,t] (:210-216) and return action = U[:u_per_command]*u_scale
+ * (:217-224) into action_host (u_per_command*nu).  Synchronises. */
+int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
+                    double* action_host);
+
+/* ---- in-library kernel timing (hipEvent pairs on the launch stream) ------------------------- */
+int nlc_profile_enable(nlc_ctx* ctx, int on);
+int nlc_profile_reset(nlc_ctx* ctx);
+int nlc_profile_count(nlc_ctx* ctx);
+int nlc_profile_read(nlc_ctx* ctx, int idx, char* name, int name_len, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLC_H_ */

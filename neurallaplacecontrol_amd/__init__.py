@@ -1,0 +1,31 @@
+"""neurallaplacecontrol_amd -- the Neural-Laplace-Control planning hot path on AMD MI355X (gfx950).
+
+Drop-in mirrors of the reference's Python interfaces for this path:
+
+    from neurallaplacecontrol_amd import MPPIDelay              # planners/mppi_delay.py:54
+    from neurallaplacecontrol_amd import NeuralLaplaceModel     # w_nl.py:66
+    from neurallaplacecontrol_amd import laplace_reconstruct    # torchlaplace (external)
+
+All arithmetic runs in hand-written HIP kernels behind the C ABI of ``libnlc_hip.so``
+(``include/nlc.h``); importing the package does not touch the GPU.  There is no CPU fallback.
+"""
+
+from .envs import EnvCost, NLDynamics, OracleDynamics, initial_state, noise_sigma  # noqa: F401
+from .laplace import ilt_reconstruct, laplace_reconstruct, rep_func_inputs  # noqa: F401
+from .nl_model import LaplaceRepresentationFunc, NeuralLaplaceModel, ReverseGRUEncoder  # noqa: F401
+from .planners.mppi_delay import MPPIDelay  # noqa: F401
+
+__all__ = [
+    "MPPIDelay",
+    "NeuralLaplaceModel",
+    "ReverseGRUEncoder",
+    "LaplaceRepresentationFunc",
+    "laplace_reconstruct",
+    "ilt_reconstruct",
+    "rep_func_inputs",
+    "NLDynamics",
+    "OracleDynamics",
+    "EnvCost",
+    "noise_sigma",
+    "initial_state",
+]

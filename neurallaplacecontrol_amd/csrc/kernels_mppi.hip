@@ -1,0 +1,346 @@
+// MPPI sampling, bounding, importance weighting and the oracle-dynamics rollout.
+//   MPPIDelay.command                 planners/mppi_delay.py:193-224
+//   MPPIDelay._compute_total_cost_batch  :315-345   (_bound_action :347-353)
+//   oracle.*_dynamics_dt_delay        oracle.py:11-224        (rollout with model_name == "oracle")
+// All of these are HBM-light streaming / reduction kernels over the (K, T, nu) noise tensor.
+#include "nlc_device.h"
+#include "nlc_kernels.h"
+
+namespace nlc {
+
+// ------------------------------------------------------------------ U <- roll(U, -1); U[-1] = u_init  (:199-200)
+__global__ void shift_U_kernel(const PerturbArgs a) {
+  const int n = a.T * a.nu;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int t = i / a.nu, j = i - t * a.nu;
+    a.U_new[i] = (t + 1 < a.T) ? a.U_old[i + a.nu] : a.u_init[j];
+  }
+}
+hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(shift_U_kernel, dim3(1), dim3(128), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ sample / perturb / bound (:319-328)
+// One thread per (k, t).  rng == 1 draws eps ~ N(mu, Sigma) on the device: Philox4x32-10 keyed by the
+// seed, counter (global sample index, t, command counter) -> the draw does not depend on the sharding.
+__global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
+  const int64_t total = a.K * a.T;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = idx / a.T;
+    const int t = (int)(idx - k * a.T);
+    const int64_t kg = a.k_offset + k;
+    double eps[NLC_MAX_NU];
+    if (a.rng) {
+      double z[NLC_MAX_NU];
+      static_assert(NLC_MAX_NU <= 2, "one Philox block yields two normals");
+      const u4 r = philox4x32_10(u4{(uint32_t)kg, (uint32_t)(kg >> 32), (uint32_t)t, (uint32_t)a.counter},
+                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32) ^ (uint32_t)(a.counter >> 32));
+      const double u1 = u53(r.x, r.y), u2 = u53(r.z, r.w);
+      const double rad = sqrt(-2.0 * log(u1));
+      double sn, cs;
+      m::sincos_bounded(2.0 * kPi * u2 - kPi, &sn, &cs);  // angle in (-pi, pi)
+      z[0] = rad * cs;
+      z[1] = rad * sn;
+      for (int i = 0; i < a.nu; ++i) {
+        double v = a.mu[i];
+        for (int j = 0; j <= i; ++j) v += a.chol[i * a.nu + j] * z[j];
+        eps[i] = v;
+      }
+    } else {
+      for (int i = 0; i < a.nu; ++i) eps[i] = a.noise[idx * a.nu + i];
+    }
+    const bool null_action = a.sample_null_action && (kg == a.K_global - 1);
+    for (int i = 0; i < a.nu; ++i) {
+      const double U = a.U_new[t * a.nu + i];
+      double V = U + eps[i];
+      if (null_action) V = 0.0;  // :322-323
+      double Vs = V * a.u_scale;
+      if (a.has_bounds) Vs = fmax(fmin(Vs, a.u_max[i]), a.u_min[i]);  // :351
+      V = Vs / a.u_scale;                                            // :326
+      a.perturbed[idx * a.nu + i] = V;
+      a.noise[idx * a.nu + i] = V - U;                               // :328
+      if (a.actions != nullptr) a.actions[idx * a.nu + i] = (a.u_scale * V) / a.u_scale;  // :255,340
+    }
+  }
+}
+hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s) {
+  const int64_t total = a.K * a.T;
+  if (total <= 0) return hipSuccess;
+  const int64_t want = (total + 255) / 256;
+  const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(perturb_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ importance weights (:210-216)
+__device__ __forceinline__ double wave_min(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// pass 1: per-block min of cost
+__global__ __launch_bounds__(256) void cost_min_kernel(const WeightArgs a) {
+  __shared__ double sm[4];
+  double v = INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.K; i += (int64_t)gridDim.x * 256)
+    v = fmin(v, a.cost[i]);
+  v = wave_min(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) a.block_min[blockIdx.x] = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
+}
+
+// pass 2: w_k = exp(-(c_k - beta)/lambda); per-block partial eta and S[t,j] = sum_k w_k eps[k,t,j].
+// A block owns kWeightBlockSamples consecutive samples; thread tj < T*nu walks them with coalesced
+// reads of eps[k, :, :] rows and the weights broadcast from LDS (wavefront-uniform).
+__global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a, int nmin) {
+  __shared__ double sw[kWeightBlockSamples];
+  __shared__ double sbeta;
+  __shared__ double sm[4];
+  double v = INFINITY;
+  for (int i = threadIdx.x; i < nmin; i += 256) v = fmin(v, a.block_min[i]);
+  v = wave_min(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sbeta = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
+  __syncthreads();
+  const double beta = sbeta;
+  const int64_t k0 = (int64_t)blockIdx.x * kWeightBlockSamples;
+  const int ns = (int)((a.K - k0 < kWeightBlockSamples) ? (a.K - k0) : kWeightBlockSamples);
+  const int TN = a.T * a.nu;
+  double wk = 0.0;
+  if ((int)threadIdx.x < ns) {
+    wk = exp(-(1.0 / a.lambda_) * (a.cost[k0 + threadIdx.x] - beta));  // _ensure_non_zero :12-13
+    a.cost_nz[k0 + threadIdx.x] = wk;
+    sw[threadIdx.x] = wk;
+  }
+  __syncthreads();
+  double* out = a.block_part + (int64_t)blockIdx.x * (1 + TN);
+  if (threadIdx.x < 64) {
+    const double e = wave_sum(wk);  // threads 0..63 hold all (<= 64) weights of the block
+    if (threadIdx.x == 0) {
+      out[0] = e;
+      if (blockIdx.x == 0) a.partials[0] = beta;
+    }
+  }
+  for (int tj = threadIdx.x; tj < TN; tj += 256) {
+    double acc = 0.0;
+    const double* np = a.noise + k0 * TN + tj;
+    for (int s = 0; s < ns; ++s) acc += sw[s] * np[(int64_t)s * TN];
+    out[1 + tj] = acc;
+  }
+}
+
+// pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r)
+__global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
+  const int TN = a.T * a.nu;
+  for (int i = threadIdx.x; i < 1 + TN; i += 256) {
+    double acc = 0.0;
+    for (int b = 0; b < a.nblk; ++b) acc += a.block_part[(int64_t)b * (1 + TN) + i];
+    a.partials[1 + i] = acc;
+  }
+}
+
+hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
+  const int nmin = (int)((a.K + 255) / 256 < 256 ? (a.K + 255) / 256 : 256);
+  hipLaunchKernelGGL(cost_min_kernel, dim3(nmin), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk), dim3(256), 0, s, a, nmin);
+  hipLaunchKernelGGL(weight_final_kernel, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ merge shard partials, update U (:213-224)
+// gathered[g] = (beta_g, eta_g, S_g[T*nu]).  beta = min beta_g, scale_g = exp(-(beta_g - beta)/lambda),
+// eta = sum scale_g eta_g, dU = sum scale_g S_g / eta   (SURVEY §8e).  Every rank runs this identically.
+__global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
+  __shared__ double s_scale_self, s_eta;
+  const int TN = a.T * a.nu;
+  const int W = 2 + TN;
+  double beta = INFINITY;
+  for (int g = 0; g < a.G; ++g) beta = fmin(beta, a.gathered[(int64_t)g * W]);
+  double eta = 0.0;
+  for (int g = 0; g < a.G; ++g)
+    eta += exp(-(a.gathered[(int64_t)g * W] - beta) / a.lambda_) * a.gathered[(int64_t)g * W + 1];
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < TN; i += 256) {
+      double acc = 0.0;
+      for (int g = 0; g < a.G; ++g)
+        acc += exp(-(a.gathered[(int64_t)g * W] - beta) / a.lambda_) * a.gathered[(int64_t)g * W + 2 + i];
+      const double u = a.U[i] + (1.0 / eta) * acc;  // omega = (1/eta) w, :214-216
+      a.U[i] = u;
+      if (i < a.u_per_command * a.nu) a.action[i] = u * a.u_scale;  // :217-224
+    }
+    if (threadIdx.x == 0) {
+      a.beta_eta[0] = beta;
+      a.beta_eta[1] = eta;
+    }
+  }
+  // omega / cost_total_non_zero relative to the GLOBAL beta
+  if (threadIdx.x == 0) {
+    s_scale_self = (a.G == 1) ? 1.0 : exp(-(a.gathered[(int64_t)a.rank * W] - beta) / a.lambda_);
+    s_eta = eta;
+  }
+  __syncthreads();
+  const double sc = s_scale_self, inv = 1.0 / s_eta;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.K; k += (int64_t)gridDim.x * 256) {
+    double w = a.cost_nz[k];
+    if (a.G != 1) {
+      w *= sc;
+      a.cost_nz[k] = w;
+    }
+    if (a.omega != nullptr) a.omega[k] = inv * w;
+  }
+}
+hipError_t launch_merge(const MergeArgs& a, hipStream_t s) {
+  const int64_t want = (a.K + 255) / 256;
+  const unsigned grid = (unsigned)(want < 1024 ? (want > 0 ? want : 1) : 1024);
+  hipLaunchKernelGGL(merge_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ oracle-dynamics rollout
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+__device__ __forceinline__ double trig2angle_o(double c, double s) {
+  const double C = c * c + s * s;
+  c = c / C;
+  s = s / C;
+  return atan2(s / C, c / C);
+}
+
+// running costs: same formulas as kernels_nl.hip (kept local: this TU has no MFMA code)
+__device__ __forceinline__ double running_cost_o(int env, const double* x, const double* u, int nu) {
+  double uu = 0.0;
+  for (int j = 0; j < nu; ++j) uu += u[j] * u[j];
+  if (env == NLC_ENV_CARTPOLE) {
+    const double e0 = x[0] + x[3] - 0.0, e1 = x[2] - 1.0;
+    const double sr = -(e0 * e0 + e1 * e1);
+    const double vr = -(x[1] * x[1]) - x[4] * x[4];
+    return -((sr + 0.01 * vr) + (-0.01 * uu));
+  } else if (env == NLC_ENV_PENDULUM) {
+    const double om = 1.0 - x[0];
+    const double sr = -(om * om + x[1] * x[1]);
+    const double vr = -(x[2] * x[2]);
+    return -((sr + 0.01 * vr) + (-0.01 * uu));
+  } else {
+    const double th1 = trig2angle_o(x[0], x[1]), th2 = trig2angle_o(x[2], x[3]);
+    const double vr = -(x[4] * x[4]) - x[5] * x[5];
+    const double p1x = -cos(th1), p1y = sin(th1);
+    const double p2x = p1x - cos(th1 + th2), p2y = p1y + sin(th1 + th2);
+    const double ex = p2x - 1.0 - 1.0;
+    const double sr = -(ex * ex) - p2y * p2y;
+    return -((sr + 1e-1 * vr) + (-1e-4 * uu));
+  }
+}
+
+// One Euler step of the closed-form dynamics on the trig observation (oracle.py:11-86, 89-174, 177-224)
+__device__ __forceinline__ void oracle_step(int env, double* x, const double* uraw, double ts, int friction) {
+  if (env == NLC_ENV_CARTPOLE) {
+    const double u = clampd(uraw[0], -3.0, 3.0);
+    double xx = x[0], xd = x[1], c = x[2], s = x[3], thd = x[4];
+    const double C = c * c + s * s;
+    c = c / C;
+    s = s / C;
+    const double th = atan2(s / C, c / C);
+    const double g = 9.8, fmag = 3.0, mc = 1.0, mp = 0.1, len = 1.0;
+    const double mt = mp + mc, pml = mp * len;
+    const double force = u * fmag;
+    double temp, thacc;
+    if (friction) {
+      const double sg = (xd > 0.0) ? 1.0 : ((xd < 0.0) ? -1.0 : 0.0);
+      temp = (force + pml * thd * thd * s - 5e-4 * sg) / mt;
+      thacc = (g * s - c * temp - 2e-6 * thd / pml) / (len * (4.0 / 3.0 - mp * c * c / mt));
+    } else {
+      temp = (force + pml * thd * thd * s) / mt;
+      thacc = (g * s - c * temp) / (len * (4.0 / 3.0 - mp * c * c / mt));
+    }
+    const double xacc = temp - pml * thacc * c / mt;
+    const double nthd = thd + thacc * ts, nth = th + thd * ts;
+    const double nxd = xd + xacc * ts, nx = xx + xd * ts;
+    x[0] = nx;
+    x[1] = nxd;
+    x[2] = cos(nth);
+    x[3] = sin(nth);
+    x[4] = nthd;
+  } else if (env == NLC_ENV_PENDULUM) {
+    const double u = clampd(uraw[0], -2.0, 2.0);
+    const double c = x[0], s = x[1], thd = x[2];
+    const double C = c * c + s * s;
+    const double th = atan2((s / C) / C, (c / C) / C);
+    const double nth = th + thd * ts;
+    const double nthd = thd + (-15.0 * sin(th + kPi) + 3.0 * u) * ts;  // -3g/(2l), 3/(m l^2)
+    x[0] = cos(nth);
+    x[1] = sin(nth);
+    x[2] = nthd;
+  } else {
+    const double u0 = clampd(uraw[0], -5.0, 5.0), u1 = clampd(uraw[1], -5.0, 5.0);
+    const double th1 = trig2angle_o(x[0], x[1]), th2 = trig2angle_o(x[2], x[3]);
+    const double d1v = x[4], d2v = x[5];
+    const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
+    const double c2 = cos(th2), s2 = sin(th2);
+    const double D1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
+    const double D2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+    const double phi2 = m2 * lc2 * g * cos(th1 + th2 - kPi / 2.0);
+    const double phi1 = -m2 * l1 * lc2 * (d2v * d2v) * s2 - 2 * m2 * l1 * lc2 * d2v * d1v * s2 +
+                        (m1 * lc1 + m2 * l1) * g * cos(th1 - kPi / 2) + phi2;
+    const double dd2 = (u0 + D2 / D1 * phi1 - m2 * l1 * lc2 * (d1v * d1v) * s2 - phi2) /
+                       (m2 * (lc2 * lc2) + I2 - (D2 * D2) / D1);
+    const double dd1 = -(u1 + D2 * dd2 + phi1) / D1;
+    const double nd1 = d1v + dd1 * ts, nd2 = d2v + dd2 * ts;
+    const double nth1 = th1 + d1v * ts, nth2 = th2 + d2v * ts;
+    x[0] = cos(nth1);
+    x[1] = sin(nth1);
+    x[2] = cos(nth2);
+    x[3] = sin(nth2);
+    x[4] = nd1;
+    x[5] = nd2;
+  }
+}
+
+__global__ __launch_bounds__(256) void oracle_rollout_kernel(const OracleRolloutArgs a) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.K) return;
+  double x[NLC_MAX_D];
+  const double* st = a.state0 + (a.state_per_sample ? k * a.d : 0);
+  for (int i = 0; i < a.d; ++i) x[i] = st[i];
+  double cost = 0.0, pcost = 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    // window (k,t) = hist[k][t : t+B]; applied action = window[-(delay+1)] = hist[k][t + B-1-delay]
+    double ud[NLC_MAX_NU], u[NLC_MAX_NU];
+    const int i = t + a.B - 1 - a.delay;
+    for (int j = 0; j < a.nu; ++j) {
+      ud[j] = (i < a.B - 1) ? a.abuf[(1 + i) * a.nu + j]
+                            : a.u_scale * a.perturbed[(k * a.T + (i - (a.B - 1))) * a.nu + j];
+      u[j] = a.u_scale * a.perturbed[(k * a.T + t) * a.nu + j];
+    }
+    oracle_step(a.env, x, ud, a.ts, a.friction);
+    if (a.states != nullptr)
+      for (int ii = 0; ii < a.d; ++ii) a.states[(k * a.T + t) * a.d + ii] = x[ii];
+    double pc = 0.0;
+    for (int j = 0; j < a.nu; ++j) {
+      double acj = 0.0;
+      for (int ii = 0; ii < a.nu; ++ii) {
+        double e = a.noise[(k * a.T + t) * a.nu + ii];
+        if (a.noise_abs_cost) e = fabs(e);
+        acj += (a.lambda_ * e) * a.sigma_inv[ii * a.nu + j];
+      }
+      pc += a.U[t * a.nu + j] * acj;
+    }
+    cost += running_cost_o(a.env, x, u, a.nu);
+    pcost += pc;
+  }
+  a.cost_total[k] = cost + pcost;
+}
+hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s) {
+  if (a.K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(oracle_rollout_kernel, dim3((unsigned)((a.K + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace nlc

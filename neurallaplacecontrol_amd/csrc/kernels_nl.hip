@@ -1,0 +1,279 @@
+// Representation MLP + sphere->complex + Fourier ILT + state update + running cost, fused.
+//   LaplaceRepresentationFunc.forward  w_nl.py:55-63
+//   torchlaplace.laplace_reconstruct   (external; call site w_nl.py:137-144)  -- Fourier ILT, scale == 2
+//   harness dynamics / running_cost    mppi_with_model.py:103-122, 145-171
+//   horizon loop                       planners/mppi_delay.py:271-296
+//
+// One wavefront owns 16 samples for the WHOLE horizon: state, hidden activations and the ILT partial sums
+// stay in MFMA accumulator layout (feature on rows/registers, sample on columns/lanes) across all T steps.
+// The only HBM traffic per (sample, step) is the GRU latent in (16 B), the action in (nu*8 B) and the
+// state out (d*8 B); the (2dS) theta/phi tensor of the reference (22 MB/step at cfg2) never exists.
+//
+// Layer-3 rows are permuted on the host into "slots": tile j, register r in {0,1} holds theta of ILT
+// element e = 4(2j+r)+q, register r+2 holds phi of the same element, so the sphere->complex map
+// F = tan(phi/2+pi/4) e^{i theta} is lane-local.  Elements are ordered even-k first, odd-k second, because
+// with scale == 2 the Fourier phase e^{i pi k t/T} is i^k: even-k terms need only cos(theta),
+// odd-k terms only sin(theta).  The sum over k is one more MFMA with a constant (dims x elements)
+// coefficient matrix; its output rows are the state dims, which is exactly the B-fragment layout of the
+// next step's layer-1 input, so x <- x + dx needs no lane movement either.
+//
+// Roofline: FP64 MFMA bound; per 16 samples and step (2 + h/4)*HT + (h/4)*nt3 + 2*nt3 MFMAs.
+#include "nlc_device.h"
+#include "nlc_kernels.h"
+
+namespace nlc {
+
+// ------------------------------------------------------------------ env running costs (a10)
+// cost = -(diff_obs_reward_(x, exp_reward=False) + diff_ac_reward_(u))   mppi_with_model.py:163-164
+__device__ __forceinline__ double trig2angle(double c, double s) {
+  // base_env.py:297-301: divide by C twice, then atan2
+  const double C = c * c + s * s;
+  c = c / C;
+  s = s / C;
+  return atan2(s / C, c / C);
+}
+
+__device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MAX_D], const double (&u)[NLC_MAX_NU],
+                                               int nu) {
+  double uu = 0.0;
+  for (int j = 0; j < nu; ++j) uu += u[j] * u[j];
+  if (env == NLC_ENV_CARTPOLE) {
+    // ctcartpole.py:303-339,345-346: ee = (x + sin_l, cos_l), goal (0, 1)
+    const double e0 = x[0] + x[3] - 0.0, e1 = x[2] - 1.0;
+    const double state_reward = -(e0 * e0 + e1 * e1);
+    const double vel_reward = -(x[1] * x[1]) - x[4] * x[4];
+    return -((state_reward + 0.01 * vel_reward) + (-0.01 * uu));
+  } else if (env == NLC_ENV_PENDULUM) {
+    // ctpendulum.py:139-155
+    const double om = 1.0 - x[0];
+    const double state_reward = -(om * om + x[1] * x[1]);
+    const double vel_reward = -(x[2] * x[2]);
+    return -((state_reward + 0.01 * vel_reward) + (-0.01 * uu));
+  } else {
+    // ctacrobot.py:233-255 (consts :110-111)
+    const double th1 = trig2angle(x[0], x[1]), th2 = trig2angle(x[2], x[3]);
+    const double vel_reward = -(x[4] * x[4]) - x[5] * x[5];
+    const double p1x = -cos(th1), p1y = sin(th1);
+    const double p2x = p1x - cos(th1 + th2), p2y = p1y + sin(th1 + th2);
+    const double ex = p2x - 1.0 - 1.0;
+    const double state_reward = -(ex * ex) - p2y * p2y;
+    return -((state_reward + 1e-1 * vel_reward) + (-1e-4 * uu));
+  }
+}
+
+// ------------------------------------------------------------------ one model evaluation
+// p0/p1: layer-1 latent B fragments (index 4s+q).  Returns acc_x: ILT sums, rows = dims (reg r -> dim q+4r).
+// GENERAL_T: sphere coordinates of the per-sample query points enter layer 1 through W1s.
+template <int HT, int NT3, bool GENERAL_T>
+__device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn) {
+  constexpr int KS = HT * 4;  // h / 4
+  v4d h1[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) h1[j] = load_bias_tile(n.b1, j, q);
+  if constexpr (GENERAL_T) {
+    // s_k = gamma + i pi k / T,  T = scale*t,  gamma = alpha - ln(tol)/(scale*T); theta_s = atan2(Im, Re),
+    // phi_s = asin((|s|^2-1)/(|s|^2+1)); input order [theta_s(0..S-1) | phi_s(0..S-1)]
+    const double Tt = n.scale * tn;
+    const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+    const int kss = (2 * n.S + 3) / 4;
+    gptr p = opaque(n.W1s);
+    for (int ks = 0; ks < kss; ++ks) {
+      const int i = 4 * ks + q;
+      double b = 0.0;
+      if (i < 2 * n.S) {
+        const int k = (i < n.S) ? i : i - n.S;
+        const double im = kPi * (double)k / Tt;
+        if (i < n.S) {
+          b = atan2(im, gamma);
+        } else {
+          const double a2 = gamma * gamma + im * im;
+          b = asin((a2 - 1.0) / (a2 + 1.0));
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < HT; ++m) h1[m] = mfma(p[m * 64 + lane], b, h1[m]);
+      p = opaque(p + HT * 64);
+    }
+  }
+  gemm_acc<HT, 2>(h1, n.W1p, lane, [&](int ks) { return ks == 0 ? p0 : p1; });
+#pragma unroll
+  for (int j = 0; j < HT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[j][r] = m::tanh_d(h1[j][r]);
+
+  v4d h2[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) h2[j] = load_bias_tile(n.b2, j, q);
+  gemm_acc<HT, KS>(h2, n.W2p, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
+#pragma unroll
+  for (int j = 0; j < HT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[j][r] = m::tanh_d(h2[j][r]);
+
+  v4d o[NT3];
+#pragma unroll
+  for (int j = 0; j < NT3; ++j) o[j] = load_bias_tile(n.b3p, j, q);
+  gemm_acc<NT3, KS>(o, n.W3p, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
+
+  // sphere -> complex, keep the component the Fourier phase i^k selects, then sum over k by MFMA
+  v4d ax[1];
+  ax[0] = splat(0.0);
+  gptr cp = opaque(n.Cp);
+#pragma unroll
+  for (int j = 0; j < NT3; ++j) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int g = 2 * j + r;
+      const double theta = m::tanh_d(o[j][r]) * kPi;                               // w_nl.py:59
+      const double phi = m::tanh_d(o[j][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
+      const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
+      double sn, cs;
+      m::sincos_bounded(theta, &sn, &cs);
+      const double trig = (g < n.n_even_groups) ? cs : sn;
+      ax[0] = mfma(cp[g * 64 + lane], rad * trig, ax[0]);
+    }
+  }
+  return ax[0];
+}
+
+// ------------------------------------------------------------------ T-step rollout (planner)
+template <int HT, int NT3>
+__global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool valid = k < a.K;
+  const int64_t kc = valid ? k : a.K - 1;
+  const int d = n.d;
+
+  // lane (q) owns latent indices i0 = q and i1 = 4 + q: state dims, then the two GRU latents
+  const int i0 = q, i1 = 4 + q;
+  double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
+  const double* st = a.state0 + (a.state_per_sample ? kc * d : 0);
+  if (i0 < d) {
+    x0 = st[i0];
+    m0 = n.state_mean[i0];
+    s0 = n.state_std[i0];
+  }
+  if (i1 < d) {
+    x1 = st[i1];
+    m1 = n.state_mean[i1];
+    s1 = n.state_std[i1];
+  }
+  // ILT prefactor e^{gamma t}/T: constant over the rollout (ts_pred is constant)
+  const double Tt = n.scale * a.tn;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double factor = exp(gamma * a.tn) / Tt;
+
+  double cost = 0.0, pcost = 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    const double* pa = a.pa + (kc * a.T + t) * 2;
+    const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+    const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+    const v4d ax = nl_eval<HT, NT3, false>(n, lane, q, p0, p1, a.tn);
+    // state + model(state, window, ts_pred)   (mppi_with_model.py:120-121)
+    if (i0 < d) x0 = x0 + factor * ax[0];
+    if (i1 < d) x1 = x1 + factor * ax[1];
+    if (valid && a.states != nullptr) {
+      double* so = a.states + (k * a.T + t) * d;
+      if (i0 < d) so[i0] = x0;
+      if (i1 < d) so[i1] = x1;
+    }
+    // gather the sample's full state into every lane of its column
+    double xs[NLC_MAX_D];
+#pragma unroll
+    for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+    double u[NLC_MAX_NU] = {0.0, 0.0};
+    double pc = 0.0;
+    for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(kc * a.T + t) * a.nu + j];
+    // perturbation cost sum_j U[t,j] * (lambda * eps @ Sigma^-1)[j]   (mppi_delay.py:335,343)
+    for (int j = 0; j < a.nu; ++j) {
+      double acj = 0.0;
+      for (int i = 0; i < a.nu; ++i) {
+        double e = a.noise[(kc * a.T + t) * a.nu + i];
+        if (a.noise_abs_cost) e = fabs(e);
+        acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+      }
+      pc += a.U[t * a.nu + j] * acj;
+    }
+    cost += running_cost(a.env, xs, u, a.nu);
+    pcost += pc;
+  }
+  if (valid && q == 0) a.cost_total[k] = cost + pcost;
+}
+
+// ------------------------------------------------------------------ single model forward, per-sample t
+template <int HT, int NT3>
+__global__ __launch_bounds__(256) void nl_forward_kernel(const ForwardArgs a) {
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool valid = k < a.N;
+  const int64_t kc = valid ? k : a.N - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  const double* ob = a.obs + kc * d;
+  const double* pa = a.pa + kc * 2;
+  const double p0 = (i0 < d) ? (ob[i0] - n.state_mean[i0]) / n.state_std[i0]
+                             : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+  const double p1 = (i1 < d) ? (ob[i1] - n.state_mean[i1]) / n.state_std[i1]
+                             : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+  const double tn = a.ts[kc] / n.time_div;  // w_nl.py:122
+  const v4d ax = nl_eval<HT, NT3, true>(n, lane, q, p0, p1, tn);
+  const double Tt = n.scale * tn;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double factor = exp(gamma * tn) / Tt;
+  if (valid) {
+    if (i0 < d) a.out[k * d + i0] = factor * ax[0];
+    if (i1 < d) a.out[k * d + i1] = factor * ax[1];
+  }
+}
+
+// instantiated layer-3 tile counts; other (d,S) round up to the next one (zero-padded tiles)
+#define NLC_FOR_NT3(X) X(7) X(9) X(11) X(13) X(17) X(21) X(25)
+
+int nl_pick_nt3(int need) {
+#define X(N) \
+  if (need <= N) return N;
+  NLC_FOR_NT3(X)
+#undef X
+  return -1;
+}
+
+hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s) {
+  if (a.K <= 0) return hipSuccess;
+  if (a.net.h != 128) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((a.K + 63) / 64);
+  switch (a.net.nt3) {
+#define X(N)                                                                          \
+  case N:                                                                             \
+    hipLaunchKernelGGL((nl_rollout_kernel<8, N>), dim3(grid), dim3(256), 0, s, a); \
+    break;
+    NLC_FOR_NT3(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s) {
+  if (a.N <= 0) return hipSuccess;
+  if (a.net.h != 128) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((a.N + 63) / 64);
+  switch (a.net.nt3) {
+#define X(N)                                                                          \
+  case N:                                                                             \
+    hipLaunchKernelGGL((nl_forward_kernel<8, N>), dim3(grid), dim3(256), 0, s, a); \
+    break;
+    NLC_FOR_NT3(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace nlc

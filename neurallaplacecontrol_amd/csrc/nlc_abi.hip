@@ -1,0 +1,894 @@
+// Host side of libnlc_hip.so: context, weight repacking into MFMA fragment order, launch sequencing.
+// See include/nlc.h for the contract of every entry point and the reference interface it replaces.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "nlc_kernels.h"
+
+namespace nlc {
+int nl_pick_nt3(int need);
+}
+
+using namespace nlc;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfEntry {
+  std::string name;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct DeviceArena {
+  double* base = nullptr;
+  size_t n = 0;
+  std::vector<double> host;
+  size_t push(const std::vector<double>& v) {
+    // 64-double (512 B) alignment so every fragment row starts on a cache line
+    const size_t off = (host.size() + 63) / 64 * 64;
+    host.resize(off);
+    host.insert(host.end(), v.begin(), v.end());
+    return off;
+  }
+};
+
+}  // namespace
+
+struct nlc_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // model
+  bool has_model = false;
+  nlc_model_desc md{};
+  int g = 0, S = 0, P = 0;
+  DeviceArena arena;
+  GruArgs gru{};   // weight pointers + normalisation filled in
+  NlNetArgs net{}; // general-t variant (b1 = raw bias)
+  std::vector<double> W1s_host, b1_host;  // for folding the constant sphere inputs at configure time
+
+  // planner
+  bool has_mppi = false;
+  nlc_mppi_desc pd{};
+  double* U[2] = {nullptr, nullptr};
+  int ucur = 0;
+  double* b1fold = nullptr;   // (h) device
+  double* small = nullptr;    // action (<= T*nu) + beta_eta (2)
+  double tn = 0.0;
+  int nblk = 0;
+
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+};
+
+namespace {
+
+int fail(nlc_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define NLC_HIP(c, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return fail((c), NLC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+#define NLC_GUARD_BEGIN try {
+#define NLC_GUARD_END(c)                                                       \
+  }                                                                            \
+  catch (const std::exception& e) {                                            \
+    return fail((c), NLC_ERR_STATE, std::string("exception: ") + e.what());    \
+  }                                                                            \
+  catch (...) {                                                                \
+    return fail((c), NLC_ERR_STATE, "unknown exception");                      \
+  }
+
+// ---- profiling: hipEvent pair around one launch, on the launch stream
+struct ProfScope {
+  nlc_ctx* c;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfEntry* entry = nullptr;
+  ProfScope(nlc_ctx* ctx, const char* name) : c(ctx) {
+    if (!c->profiling) return;
+    for (auto& p : c->prof)
+      if (p.name == name) entry = &p;
+    if (!entry) {
+      c->prof.push_back(ProfEntry{});
+      c->prof.back().name = name;
+      entry = &c->prof.back();
+    }
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, c->stream);
+  }
+  ~ProfScope() {
+    if (!entry) return;
+    hipEventRecord(e1, c->stream);
+    entry->pending.emplace_back(e0, e1);
+    entry->launches += 1;
+  }
+};
+
+void prof_flush(nlc_ctx* c) {
+  for (auto& p : c->prof) {
+    for (auto& ev : p.pending) {
+      hipEventSynchronize(ev.second);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev.first, ev.second);
+      p.total_ms += ms;
+      hipEventDestroy(ev.first);
+      hipEventDestroy(ev.second);
+    }
+    p.pending.clear();
+  }
+}
+
+// ---- MFMA A-fragment packing:  out[(ks*MT + mt)*64 + lane] = W[row(16 mt + (lane & 15))][4 ks + (lane >> 4)]
+// rowmap[i] = source row of packed row i (-1 = zero row); cols beyond K are zero.
+std::vector<double> pack_A(const double* W, int ldw, int K, const std::vector<int>& rowmap) {
+  const int MT = (int)(rowmap.size() + 15) / 16;
+  const int KS = (K + 3) / 4;
+  std::vector<double> out((size_t)KS * MT * 64, 0.0);
+  for (int ks = 0; ks < KS; ++ks)
+    for (int mt = 0; mt < MT; ++mt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int prow = 16 * mt + (lane & 15), col = 4 * ks + (lane >> 4);
+        if (prow >= (int)rowmap.size() || col >= K) continue;
+        const int src = rowmap[prow];
+        if (src < 0) continue;
+        out[((size_t)ks * MT + mt) * 64 + lane] = W[(size_t)src * ldw + col];
+      }
+  return out;
+}
+std::vector<int> identity_rows(int n) {
+  std::vector<int> r(n);
+  for (int i = 0; i < n; ++i) r[i] = i;
+  return r;
+}
+
+struct Blob {
+  const double* p;
+  int64_t left;
+  const double* take(int64_t n) {
+    if (n > left) throw std::runtime_error("weight blob too short");
+    const double* r = p;
+    p += n;
+    left -= n;
+    return r;
+  }
+};
+
+int64_t blob_size(const nlc_model_desc* d) {
+  const int64_t g = d->h / 2, S = d->ilt.terms, P = d->d + 2, h = d->h;
+  return 3 * g * d->nin + 3 * g * g + 6 * g + 3 * g * g + 3 * g * g + 6 * g + 2 * g + 2 + h * (2 * S + P) + h +
+         h * h + h + 2 * d->d * S * h + 2 * d->d * S;
+}
+
+void sphere_inputs(const nlc_ilt_desc& ilt, double tn, std::vector<double>& sph) {
+  // [theta_s(0..S-1) | phi_s(0..S-1)] of s_k = gamma + i pi k / T
+  const int S = ilt.terms;
+  sph.assign(2 * S, 0.0);
+  const double Tt = ilt.scale * tn;
+  const double gamma = ilt.alpha - std::log(ilt.tol) / (ilt.scale * Tt);
+  for (int k = 0; k < S; ++k) {
+    const double im = M_PI * (double)k / Tt;
+    sph[k] = std::atan2(im, gamma);
+    const double a2 = gamma * gamma + im * im;
+    sph[S + k] = std::asin((a2 - 1.0) / (a2 + 1.0));
+  }
+}
+
+}  // namespace
+
+// =================================================================================== context
+extern "C" int nlc_abi_version(void) { return NLC_ABI_VERSION; }
+
+extern "C" int nlc_create(int device, nlc_ctx** out) {
+  if (!out) {
+    g_create_error = "nlc_create: out is NULL";
+    return NLC_ERR_BAD_ARG;
+  }
+  *out = nullptr;
+  try {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+      return NLC_ERR_HIP;
+    }
+    if (device < 0 || device >= n) {
+      g_create_error = "device index out of range";
+      return NLC_ERR_BAD_ARG;
+    }
+    nlc_ctx* c = new nlc_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+      g_create_error = std::string("HIP init failed: ") + hipGetErrorString(e);
+      delete c;
+      return NLC_ERR_HIP;
+    }
+    if (std::string(c->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+      g_create_error = std::string("libnlc_hip is built for gfx950 only, device is ") + c->prop.gcnArchName;
+      hipStreamDestroy(c->own_stream);
+      delete c;
+      return NLC_ERR_UNSUPPORTED;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return NLC_OK;
+  } catch (...) {
+    g_create_error = "exception in nlc_create";
+    return NLC_ERR_STATE;
+  }
+}
+
+extern "C" void nlc_destroy(nlc_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  prof_flush(c);
+  if (c->arena.base) hipFree(c->arena.base);
+  for (int i = 0; i < 2; ++i)
+    if (c->U[i]) hipFree(c->U[i]);
+  if (c->b1fold) hipFree(c->b1fold);
+  if (c->small) hipFree(c->small);
+  hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" const char* nlc_last_error(const nlc_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int nlc_set_stream(nlc_ctx* c, void* s) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return NLC_OK;
+}
+
+extern "C" int nlc_synchronize(nlc_ctx* c) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  return NLC_OK;
+}
+
+extern "C" int nlc_device_info(nlc_ctx* c, char* name, int name_len, int* cus, int* mhz, double* gib) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (name && name_len > 0) {
+    std::snprintf(name, name_len, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+  }
+  if (cus) *cus = c->prop.multiProcessorCount;
+  if (mhz) *mhz = c->prop.clockRate / 1000;
+  if (gib) *gib = (double)c->prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0);
+  return NLC_OK;
+}
+
+// =================================================================================== ILT
+static int check_ilt(nlc_ctx* c, const nlc_ilt_desc* d) {
+  if (!d) return fail(c, NLC_ERR_BAD_ARG, "ilt desc is NULL");
+  if (d->terms < 1 || d->terms > kMaxTerms) return fail(c, NLC_ERR_BAD_SHAPE, "ilt terms out of range [1,129]");
+  if (!(d->tol > 0.0) || !(d->scale > 0.0)) return fail(c, NLC_ERR_BAD_ARG, "ilt tol/scale must be positive");
+  if (d->algo != NLC_ILT_FOURIER && d->algo != NLC_ILT_DEHOOG)
+    return fail(c, NLC_ERR_UNSUPPORTED, "ilt_algorithm: only 'fourier' and 'dehoog' are implemented");
+  return NLC_OK;
+}
+
+extern "C" int nlc_ilt_rep_inputs(nlc_ctx* c, const nlc_ilt_desc* d, const double* p, const double* t, int t_batched,
+                                  int64_t B, int64_t Tt, int P, double* out) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (int r = check_ilt(c, d)) return r;
+  if (B < 0 || Tt < 0 || P < 0) return fail(c, NLC_ERR_BAD_SHAPE, "negative shape");
+  if (B * Tt == 0) return NLC_OK;
+  if (!p || !t || !out) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  RepInArgs a{p, t, out, B, Tt, P, d->terms, t_batched, d->alpha, std::log(d->tol), d->scale};
+  ProfScope ps(c, "rep_inputs_kernel");
+  NLC_HIP(c, launch_rep_inputs(a, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const double* theta, const double* phi,
+                                   const double* t, int64_t N, int dd, double* x) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (int r = check_ilt(c, d)) return r;
+  if (N < 0 || dd < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or d");
+  if (N == 0) return NLC_OK;
+  if (!theta || !phi || !t || !x) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  IltArgs a{theta, phi, t, x, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, 0};
+  if (d->algo == NLC_ILT_FOURIER) {
+    ProfScope ps(c, "ilt_fourier_kernel");
+    NLC_HIP(c, launch_ilt_fourier(a, c->stream));
+  } else {
+    if (d->terms != 33 && d->terms != 17 && d->terms != 9)
+      return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
+    ProfScope ps(c, "ilt_dehoog_kernel");
+    NLC_HIP(c, launch_ilt_dehoog(a, c->stream));
+  }
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+// =================================================================================== model
+extern "C" int64_t nlc_model_blob_size(const nlc_model_desc* d) { return d ? blob_size(d) : -1; }
+
+extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* w, int64_t n) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
+  if (int r = check_ilt(c, &d->ilt)) return r;
+  if (d->h != 128) return fail(c, NLC_ERR_UNSUPPORTED, "hidden_units must be 128 (GRU hidden 64)");
+  if (d->d < 1 || d->d > 6) return fail(c, NLC_ERR_UNSUPPORTED, "state_dim must be in 1..6");
+  if (d->nin < 1 || d->nin > NLC_MAX_NIN) return fail(c, NLC_ERR_UNSUPPORTED, "GRU input dim must be in 1..3");
+  if (d->ilt.scale != 2.0) return fail(c, NLC_ERR_UNSUPPORTED, "fused model path needs ILT scale == 2");
+  if (n != blob_size(d)) return fail(c, NLC_ERR_BAD_SHAPE, "weight blob size mismatch");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const int g = d->h / 2, S = d->ilt.terms, P = d->d + 2, h = d->h, dd = d->d, nin = d->nin;
+  Blob b{w, n};
+  const double* Wih0 = b.take(3 * g * nin);
+  const double* Whh0 = b.take(3 * g * g);
+  const double* bih0 = b.take(3 * g);
+  const double* bhh0 = b.take(3 * g);
+  const double* Wih1 = b.take(3 * g * g);
+  const double* Whh1 = b.take(3 * g * g);
+  const double* bih1 = b.take(3 * g);
+  const double* bhh1 = b.take(3 * g);
+  const double* Wo = b.take(2 * g);
+  const double* bo = b.take(2);
+  const double* W1 = b.take((int64_t)h * (2 * S + P));
+  const double* b1 = b.take(h);
+  const double* W2 = b.take((int64_t)h * h);
+  const double* b2 = b.take(h);
+  const double* W3 = b.take((int64_t)2 * dd * S * h);
+  const double* b3 = b.take(2 * dd * S);
+
+  DeviceArena ar;
+  // ---- GRU: layer-0 input weights with the bias folded into input column 3 (x = [a_0..a_{nin-1}, 0.., 1])
+  std::vector<double> Wih0b((size_t)3 * g * 4, 0.0);
+  for (int r = 0; r < 3 * g; ++r) {
+    for (int j = 0; j < nin; ++j) Wih0b[(size_t)r * 4 + j] = Wih0[(size_t)r * nin + j];
+    Wih0b[(size_t)r * 4 + 3] = bih0[r] + (r < 2 * g ? bhh0[r] : 0.0);
+  }
+  const auto rows3g = identity_rows(3 * g);
+  const size_t o_Wih0 = ar.push(pack_A(Wih0b.data(), 4, 4, rows3g));
+  const size_t o_Whh0 = ar.push(pack_A(Whh0, g, g, rows3g));
+  const size_t o_Wih1 = ar.push(pack_A(Wih1, g, g, rows3g));
+  const size_t o_Whh1 = ar.push(pack_A(Whh1, g, g, rows3g));
+  const size_t o_Wo = ar.push(pack_A(Wo, g, g, identity_rows(2)));
+  std::vector<double> bhn0(bhh0 + 2 * g, bhh0 + 3 * g), brz1(2 * g), bin1(bih1 + 2 * g, bih1 + 3 * g),
+      bhn1(bhh1 + 2 * g, bhh1 + 3 * g);
+  for (int r = 0; r < 2 * g; ++r) brz1[r] = bih1[r] + bhh1[r];
+  const size_t o_bhn0 = ar.push(bhn0), o_brz1 = ar.push(brz1), o_bin1 = ar.push(bin1), o_bhn1 = ar.push(bhn1);
+
+  // ---- representation MLP
+  // layer 1 split: sphere-coordinate columns [0, 2S) and latent columns [2S, 2S+P)
+  std::vector<double> W1s((size_t)h * 2 * S), W1p((size_t)h * 8, 0.0);
+  for (int r = 0; r < h; ++r) {
+    for (int j = 0; j < 2 * S; ++j) W1s[(size_t)r * 2 * S + j] = W1[(size_t)r * (2 * S + P) + j];
+    for (int j = 0; j < P; ++j) W1p[(size_t)r * 8 + j] = W1[(size_t)r * (2 * S + P) + 2 * S + j];
+  }
+  const auto rowsh = identity_rows(h);
+  const size_t o_W1s = ar.push(pack_A(W1s.data(), 2 * S, 2 * S, rowsh));
+  const size_t o_W1p = ar.push(pack_A(W1p.data(), 8, 8, rowsh));
+  const size_t o_b1 = ar.push(std::vector<double>(b1, b1 + h));
+  const size_t o_W2 = ar.push(pack_A(W2, h, h, rowsh));
+  const size_t o_b2 = ar.push(std::vector<double>(b2, b2 + h));
+  // layer 3: slot layout.  Element list = even-k (c,k) pairs, padded to a multiple of 4, then odd-k pairs.
+  std::vector<std::pair<int, int>> elems;
+  for (int cc = 0; cc < dd; ++cc)
+    for (int k = 0; k < S; k += 2) elems.emplace_back(cc, k);
+  while (elems.size() % 4) elems.emplace_back(-1, -1);
+  const int n_even_groups = (int)elems.size() / 4;
+  for (int cc = 0; cc < dd; ++cc)
+    for (int k = 1; k < S; k += 2) elems.emplace_back(cc, k);
+  while (elems.size() % 4) elems.emplace_back(-1, -1);
+  const int groups = (int)elems.size() / 4;
+  const int nt3 = nl_pick_nt3((groups + 1) / 2);
+  if (nt3 < 0) return fail(c, NLC_ERR_UNSUPPORTED, "2*d*S too large for the fused kernel (max 25 output tiles)");
+  elems.resize((size_t)nt3 * 8, {-1, -1});
+  std::vector<int> rowmap3((size_t)nt3 * 16, -1);
+  std::vector<double> b3p((size_t)nt3 * 16, 0.0);
+  for (int j = 0; j < nt3; ++j)
+    for (int m = 0; m < 16; ++m) {
+      const int r = m >> 2, q = m & 3;
+      const int gi = 2 * j + (r & 1);
+      const auto el = elems[(size_t)4 * gi + q];
+      if (el.first < 0) continue;
+      const int src = (r < 2 ? 0 : dd * S) + el.first * S + el.second;
+      rowmap3[(size_t)16 * j + m] = src;
+      b3p[(size_t)16 * j + m] = b3[src];
+    }
+  const size_t o_W3 = ar.push(pack_A(W3, h, h, rowmap3));
+  const size_t o_b3 = ar.push(b3p);
+  // ILT coefficient matrix C[dim][element]: w_k * Re-part selector of i^k (k even: cos, +1/-1; k odd: sin, -1/+1)
+  std::vector<double> Cp((size_t)2 * nt3 * 64, 0.0);
+  for (int gi = 0; gi < 2 * nt3; ++gi)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = lane & 15, kk = lane >> 4;
+      const auto el = elems[(size_t)4 * gi + kk];
+      if (el.first != m) continue;
+      const int k = el.second;
+      const double wk = (k == 0) ? 0.5 : 1.0;
+      const double sgn = ((k & 3) == 0 || (k & 3) == 3) ? 1.0 : -1.0;
+      Cp[(size_t)gi * 64 + lane] = wk * sgn;
+    }
+  const size_t o_Cp = ar.push(Cp);
+
+  // ---- upload
+  double* base = nullptr;
+  NLC_HIP(c, hipMalloc((void**)&base, ar.host.size() * sizeof(double)));
+  hipError_t e = hipMemcpy(base, ar.host.data(), ar.host.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    hipFree(base);
+    return fail(c, NLC_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e));
+  }
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->arena.base) hipFree(c->arena.base);
+  c->arena = std::move(ar);
+  c->arena.base = base;
+  c->md = *d;
+  c->g = g;
+  c->S = S;
+  c->P = P;
+  c->W1s_host = std::move(W1s);
+  c->b1_host.assign(b1, b1 + h);
+
+  GruArgs& G = c->gru;
+  G = GruArgs{};
+  G.nin = nin;
+  for (int j = 0; j < nin; ++j) {
+    G.mean[j] = d->action_mean[j];
+    G.std[j] = d->action_std[j];
+  }
+  G.Wih0p = base + o_Wih0;
+  G.Whh0p = base + o_Whh0;
+  G.Wih1p = base + o_Wih1;
+  G.Whh1p = base + o_Whh1;
+  G.Wop = base + o_Wo;
+  G.bhn0 = base + o_bhn0;
+  G.brz1 = base + o_brz1;
+  G.bin1 = base + o_bin1;
+  G.bhn1 = base + o_bhn1;
+  G.bo[0] = bo[0];
+  G.bo[1] = bo[1];
+
+  NlNetArgs& N = c->net;
+  N = NlNetArgs{};
+  N.d = dd;
+  N.S = S;
+  N.h = h;
+  N.nt3 = nt3;
+  N.n_even_groups = n_even_groups;
+  N.W1p = base + o_W1p;
+  N.W1s = base + o_W1s;
+  N.b1 = base + o_b1;
+  N.W2p = base + o_W2;
+  N.b2 = base + o_b2;
+  N.W3p = base + o_W3;
+  N.b3p = base + o_b3;
+  N.Cp = base + o_Cp;
+  for (int i = 0; i < NLC_MAX_D; ++i) {
+    N.state_mean[i] = i < dd ? d->state_mean[i] : 0.0;
+    N.state_std[i] = i < dd ? d->state_std[i] : 1.0;
+  }
+  N.alpha = d->ilt.alpha;
+  N.log_tol = std::log(d->ilt.tol);
+  N.scale = d->ilt.scale;
+  N.time_div = d->time_div;
+  c->has_model = true;
+  c->has_mppi = false;  // a planner configured against the previous weights must be re-configured
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_gru_encode(nlc_ctx* c, const double* window, int64_t N, int B, double* out) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
+  if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
+  if (N == 0) return NLC_OK;
+  if (!window || !out) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  GruArgs a = c->gru;
+  a.mode = 0;
+  a.window = window;
+  a.N = N;
+  a.B = B;
+  a.out = out;
+  ProfScope ps(c, "gru_encode_kernel");
+  NLC_HIP(c, launch_gru_encode(a, c->g, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+extern "C" int64_t nlc_model_workspace_bytes(nlc_ctx* c, int64_t N) {
+  (void)c;
+  return N < 0 ? -1 : (N * 2 + 64) * (int64_t)sizeof(double);
+}
+
+extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* window, const double* ts, int64_t N,
+                                 int B, double* out, void* ws) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
+  if (c->md.ilt.algo != NLC_ILT_FOURIER)
+    return fail(c, NLC_ERR_UNSUPPORTED, "fused model forward implements ilt_algorithm='fourier' (use the staged path)");
+  if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
+  if (N == 0) return NLC_OK;
+  if (!obs || !window || !ts || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  double* pa = (double*)ws;
+  {
+    GruArgs a = c->gru;
+    a.mode = 0;
+    a.window = window;
+    a.N = N;
+    a.B = B;
+    a.out = pa;
+    ProfScope ps(c, "gru_encode_kernel");
+    NLC_HIP(c, launch_gru_encode(a, c->g, c->stream));
+  }
+  {
+    ForwardArgs f{};
+    f.net = c->net;
+    f.N = N;
+    f.obs = obs;
+    f.pa = pa;
+    f.ts = ts;
+    f.out = out;
+    ProfScope ps(c, "nl_forward_kernel");
+    NLC_HIP(c, launch_nl_forward(f, c->stream));
+  }
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+// =================================================================================== planner
+extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!d) return fail(c, NLC_ERR_BAD_ARG, "NULL desc");
+  if (d->K < 1 || d->T < 1 || d->K_global < d->K || d->k_offset < 0 || d->k_offset + d->K > d->K_global)
+    return fail(c, NLC_ERR_BAD_SHAPE, "bad K / K_global / k_offset / T");
+  if (d->nu < 1 || d->nu > NLC_MAX_NU) return fail(c, NLC_ERR_UNSUPPORTED, "nu must be 1 or 2");
+  if (d->d < 1 || d->d > NLC_MAX_D) return fail(c, NLC_ERR_BAD_SHAPE, "bad nx");
+  if (d->B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "action_buffer needs at least one row");
+  if (!(d->lambda_ > 0.0) || d->u_scale == 0.0) return fail(c, NLC_ERR_BAD_ARG, "lambda_ must be > 0, u_scale != 0");
+  if (d->u_per_command < 1 || d->u_per_command > d->T) return fail(c, NLC_ERR_BAD_ARG, "bad u_per_command");
+  if (d->env < 0 || d->env > 2) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
+  static const int env_d[3] = {5, 3, 6}, env_nu[3] = {1, 1, 2};
+  if (d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
+    return fail(c, NLC_ERR_BAD_SHAPE, "nx / nu do not match the env's trig observation");
+  if (d->dynamics == NLC_DYN_EXTERNAL) {
+    // the caller owns dynamics and cost
+  } else if (d->dynamics == NLC_DYN_NL) {
+    if (!c->has_model) return fail(c, NLC_ERR_STATE, "NL dynamics need nlc_set_model first");
+    if (c->md.d != d->d || c->md.nin != d->nu)
+      return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
+    if (c->md.ilt.algo != NLC_ILT_FOURIER)
+      return fail(c, NLC_ERR_UNSUPPORTED, "fused rollout implements ilt_algorithm='fourier'");
+  } else if (d->dynamics == NLC_DYN_ORACLE) {
+    if (d->delay < 0 || d->delay > d->B - 1)
+      return fail(c, NLC_ERR_BAD_ARG, "oracle dynamics: delay must be in [0, action_buffer_size-1]");
+  } else {
+    return fail(c, NLC_ERR_UNSUPPORTED, "unknown dynamics id");
+  }
+  NLC_HIP(c, hipSetDevice(c->device));
+  const size_t un = (size_t)d->T * d->nu;
+  for (int i = 0; i < 2; ++i) {
+    if (c->U[i]) hipFree(c->U[i]);
+    c->U[i] = nullptr;
+    NLC_HIP(c, hipMalloc((void**)&c->U[i], un * sizeof(double)));
+    NLC_HIP(c, hipMemset(c->U[i], 0, un * sizeof(double)));
+  }
+  c->ucur = 0;
+  if (c->small) hipFree(c->small);
+  c->small = nullptr;
+  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 2) * sizeof(double)));
+  c->pd = *d;
+  c->nblk = (int)((d->K + kWeightBlockSamples - 1) / kWeightBlockSamples);
+  if (d->dynamics == NLC_DYN_NL) {
+    // constant prediction time => the 2S sphere-coordinate inputs of layer 1 are constants: fold into the bias
+    c->tn = d->ts_pred / c->md.time_div;
+    std::vector<double> sph;
+    sphere_inputs(c->md.ilt, c->tn, sph);
+    const int h = c->md.h, S = c->S;
+    std::vector<double> bf(h);
+    for (int r = 0; r < h; ++r) {
+      double acc = c->b1_host[r];
+      for (int j = 0; j < 2 * S; ++j) acc += c->W1s_host[(size_t)r * 2 * S + j] * sph[j];
+      bf[r] = acc;
+    }
+    if (c->b1fold) hipFree(c->b1fold);
+    c->b1fold = nullptr;
+    NLC_HIP(c, hipMalloc((void**)&c->b1fold, h * sizeof(double)));
+    NLC_HIP(c, hipMemcpy(c->b1fold, bf.data(), h * sizeof(double), hipMemcpyHostToDevice));
+  }
+  c->has_mppi = true;
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+namespace {
+struct WsLayout {
+  size_t block_min, block_part, pa, state0, abuf, total;
+};
+WsLayout ws_layout(const nlc_ctx* c) {
+  const nlc_mppi_desc& d = c->pd;
+  WsLayout w{};
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    const size_t o = off;
+    off += (n + 63) / 64 * 64;
+    return o;
+  };
+  w.block_min = take(256);
+  w.block_part = take((size_t)c->nblk * (1 + (size_t)d.T * d.nu));
+  w.pa = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * d.T * 2 : 0);
+  w.state0 = take(d.dynamics == NLC_DYN_EXTERNAL ? 0 : (size_t)d.K * d.d);
+  w.abuf = take((size_t)d.B * d.nu);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
+  const nlc_mppi_desc& d = c->pd;
+  const WsLayout w = ws_layout(c);
+  double* ws = (double*)buf->workspace;
+  WeightArgs wa{};
+  wa.K = d.K;
+  wa.T = d.T;
+  wa.nu = d.nu;
+  wa.lambda_ = d.lambda_;
+  wa.cost = buf->cost_total;
+  wa.noise = buf->noise;
+  wa.cost_nz = buf->cost_nz;
+  wa.block_min = ws + w.block_min;
+  wa.block_part = ws + w.block_part;
+  wa.partials = buf->partials;
+  wa.nblk = c->nblk;
+  ProfScope ps(c, "weight_kernels");
+  NLC_HIP(c, launch_weights(wa, c->stream));
+  return NLC_OK;
+}
+
+extern "C" int64_t nlc_mppi_workspace_bytes(nlc_ctx* c) {
+  if (!c || !c->has_mppi) return -1;
+  return (int64_t)(ws_layout(c).total * sizeof(double));
+}
+
+extern "C" int nlc_mppi_set_U(nlc_ctx* c, const double* U) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
+  if (!U) return fail(c, NLC_ERR_BAD_ARG, "NULL U");
+  NLC_HIP(c, hipSetDevice(c->device));
+  NLC_HIP(c, hipMemcpyAsync(c->U[c->ucur], U, (size_t)c->pd.T * c->pd.nu * sizeof(double), hipMemcpyHostToDevice,
+                            c->stream));
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  return NLC_OK;
+}
+
+extern "C" int nlc_mppi_get_U(nlc_ctx* c, double* U) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
+  if (!U) return fail(c, NLC_ERR_BAD_ARG, "NULL U");
+  NLC_HIP(c, hipSetDevice(c->device));
+  NLC_HIP(c, hipMemcpyAsync(U, c->U[c->ucur], (size_t)c->pd.T * c->pd.nu * sizeof(double), hipMemcpyDeviceToHost,
+                            c->stream));
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  return NLC_OK;
+}
+
+extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_sample, const double* abuf_host,
+                                const nlc_mppi_buffers* buf, int rng, uint64_t seed, uint64_t counter) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
+  const nlc_mppi_desc& d = c->pd;
+  const bool external = d.dynamics == NLC_DYN_EXTERNAL;
+  if ((!external && (!state || !abuf_host)) || !buf) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
+  if (!buf->noise || !buf->perturbed || !buf->cost_total || !buf->cost_nz || !buf->partials || !buf->workspace)
+    return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const WsLayout w = ws_layout(c);
+  double* ws = (double*)buf->workspace;
+  double* state_dev = ws + w.state0;
+  double* abuf_dev = ws + w.abuf;
+  if (!external) {
+    NLC_HIP(c, hipMemcpyAsync(state_dev, state, (size_t)(state_per_sample ? d.K : 1) * d.d * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+    NLC_HIP(c, hipMemcpyAsync(abuf_dev, abuf_host, (size_t)d.B * d.nu * sizeof(double), hipMemcpyHostToDevice,
+                              c->stream));
+  }
+  PerturbArgs p{};
+  p.K = d.K;
+  p.K_global = d.K_global;
+  p.k_offset = d.k_offset;
+  p.T = d.T;
+  p.nu = d.nu;
+  p.U_old = c->U[c->ucur];
+  p.U_new = c->U[c->ucur ^ 1];
+  p.noise = buf->noise;
+  p.perturbed = buf->perturbed;
+  p.actions = buf->actions;
+  p.u_scale = d.u_scale;
+  p.has_bounds = d.has_bounds;
+  p.sample_null_action = d.sample_null_action;
+  p.rng = rng;
+  for (int i = 0; i < NLC_MAX_NU; ++i) {
+    p.u_min[i] = d.u_min[i];
+    p.u_max[i] = d.u_max[i];
+    p.u_init[i] = d.u_init[i];
+    p.mu[i] = d.noise_mu[i];
+  }
+  for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) p.chol[i] = d.noise_chol[i];
+  p.seed = seed;
+  p.counter = counter;
+  {
+    ProfScope ps(c, "shift_U_kernel");
+    NLC_HIP(c, launch_shift_U(p, c->stream));
+  }
+  c->ucur ^= 1;
+  {
+    ProfScope ps(c, "perturb_kernel");
+    NLC_HIP(c, launch_perturb(p, c->stream));
+  }
+  if (external) return NLC_OK;  // the caller runs the horizon loop, then nlc_mppi_weights
+  if (d.dynamics == NLC_DYN_NL) {
+    double* pa = ws + w.pa;
+    GruArgs g = c->gru;
+    g.mode = 1;
+    g.perturbed = buf->perturbed;
+    g.abuf = abuf_dev;
+    g.u_scale = d.u_scale;
+    g.T = d.T;
+    g.N = d.K * d.T;
+    g.B = d.B;
+    g.out = pa;
+    {
+      ProfScope ps(c, "gru_encode_kernel");
+      NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
+    }
+    RolloutArgs r{};
+    r.net = c->net;
+    r.net.b1 = c->b1fold;
+    r.K = d.K;
+    r.T = d.T;
+    r.nu = d.nu;
+    r.B = d.B;
+    r.env = d.env;
+    r.state_per_sample = state_per_sample;
+    r.state0 = state_dev;
+    r.pa = pa;
+    r.perturbed = buf->perturbed;
+    r.noise = buf->noise;
+    r.U = c->U[c->ucur];
+    for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) r.sigma_inv[i] = d.noise_sigma_inv[i];
+    r.lambda_ = d.lambda_;
+    r.u_scale = d.u_scale;
+    r.noise_abs_cost = d.noise_abs_cost;
+    r.tn = c->tn;
+    r.states = buf->states;
+    r.cost_total = buf->cost_total;
+    ProfScope ps(c, "nl_rollout_kernel");
+    NLC_HIP(c, launch_nl_rollout(r, c->stream));
+  } else {
+    OracleRolloutArgs r{};
+    r.K = d.K;
+    r.T = d.T;
+    r.nu = d.nu;
+    r.B = d.B;
+    r.d = d.d;
+    r.env = d.env;
+    r.delay = d.delay;
+    r.friction = d.friction;
+    r.state_per_sample = state_per_sample;
+    r.state0 = state_dev;
+    r.abuf = abuf_dev;
+    r.perturbed = buf->perturbed;
+    r.noise = buf->noise;
+    r.U = c->U[c->ucur];
+    for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) r.sigma_inv[i] = d.noise_sigma_inv[i];
+    r.lambda_ = d.lambda_;
+    r.u_scale = d.u_scale;
+    r.ts = d.ts_pred;
+    r.noise_abs_cost = d.noise_abs_cost;
+    r.states = buf->states;
+    r.cost_total = buf->cost_total;
+    ProfScope ps(c, "oracle_rollout_kernel");
+    NLC_HIP(c, launch_oracle_rollout(r, c->stream));
+  }
+  return run_weights(c, buf);
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_mppi_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
+  if (!buf || !buf->noise || !buf->cost_total || !buf->cost_nz || !buf->partials || !buf->workspace)
+    return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  return run_weights(c, buf);
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int rank, const nlc_mppi_buffers* buf,
+                               double* action_host) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
+  if (!gathered || !buf || !action_host || !buf->cost_nz) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
+  if (G < 1 || rank < 0 || rank >= G) return fail(c, NLC_ERR_BAD_ARG, "bad G / rank");
+  const nlc_mppi_desc& d = c->pd;
+  NLC_HIP(c, hipSetDevice(c->device));
+  MergeArgs m{};
+  m.K = d.K;
+  m.T = d.T;
+  m.nu = d.nu;
+  m.G = G;
+  m.rank = rank;
+  m.u_per_command = d.u_per_command;
+  m.lambda_ = d.lambda_;
+  m.u_scale = d.u_scale;
+  m.gathered = gathered;
+  m.U = c->U[c->ucur];
+  m.cost_nz = buf->cost_nz;
+  m.omega = buf->omega;
+  m.action = c->small;
+  m.beta_eta = c->small + (size_t)d.T * d.nu;
+  {
+    ProfScope ps(c, "merge_kernel");
+    NLC_HIP(c, launch_merge(m, c->stream));
+  }
+  NLC_HIP(c, hipMemcpyAsync(action_host, c->small, (size_t)d.u_per_command * d.nu * sizeof(double),
+                            hipMemcpyDeviceToHost, c->stream));
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+// =================================================================================== profiling
+extern "C" int nlc_profile_enable(nlc_ctx* c, int on) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (!on) prof_flush(c);
+  c->profiling = on != 0;
+  return NLC_OK;
+}
+extern "C" int nlc_profile_reset(nlc_ctx* c) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  prof_flush(c);
+  c->prof.clear();
+  return NLC_OK;
+}
+extern "C" int nlc_profile_count(nlc_ctx* c) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  return (int)c->prof.size();
+}
+extern "C" int nlc_profile_read(nlc_ctx* c, int idx, char* name, int name_len, double* total_ms, int64_t* launches) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (idx < 0 || idx >= (int)c->prof.size()) return fail(c, NLC_ERR_BAD_ARG, "profile index out of range");
+  prof_flush(c);
+  const ProfEntry& p = c->prof[idx];
+  if (name && name_len > 0) std::snprintf(name, name_len, "%s", p.name.c_str());
+  if (total_ms) *total_ms = p.total_ms;
+  if (launches) *launches = p.launches;
+  return NLC_OK;
+}

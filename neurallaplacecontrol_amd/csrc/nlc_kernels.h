@@ -1,0 +1,173 @@
+// Host-visible launch wrappers and argument blocks of the NLC kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nlc.h"
+
+namespace nlc {
+
+constexpr int kMaxTerms = 129;  // ILT terms the coefficient tables hold
+
+// ------------------------------------------------------------------ ILT (standalone, a9)
+struct IltArgs {
+  const double* theta;  // (N, d, S)
+  const double* phi;    // (N, d, S)
+  const double* t;      // (N)
+  double* x;            // (N, d)
+  int64_t N;
+  int d, S;
+  double alpha, log_tol, scale;
+  int rows;  // rows per block (set by the launcher)
+};
+hipError_t launch_ilt_fourier(const IltArgs& a, hipStream_t s);
+hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s);
+
+struct RepInArgs {
+  const double* p;  // (B, P)
+  const double* t;  // (B*Tt) or (Tt)
+  double* out;      // (B, Tt, 2S+P)
+  int64_t B, Tt;
+  int P, S, t_batched;
+  double alpha, log_tol, scale;
+};
+hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ GRU action encoder (a7)
+// Action source: either an explicit window tensor (N, B, nin), or the MPPI history
+// hist[k][i] = i < B-1 ? action_buffer[1+i] : u_scale * perturbed[k][i-(B-1)]  (mppi_delay.py:257-260),
+// window (k,t) = hist[k][t : t+B].
+struct GruArgs {
+  const double* window;     // mode 0
+  const double* perturbed;  // mode 1: (K, T, nu)
+  const double* abuf;       // mode 1: (B, nu) device copy of action_buffer
+  double u_scale;
+  int mode, T;
+  int64_t N;  // windows (mode 1: K*T)
+  int B, nin;
+  double mean[NLC_MAX_NIN], std[NLC_MAX_NIN];
+  // fragment-packed weights (device)
+  const double* Wih0p;  // [1][MT][64]   k = input dims, k == 3 carries the folded bias
+  const double* Whh0p;  // [KS][MT][64]
+  const double* Wih1p;  // [KS][MT][64]
+  const double* Whh1p;  // [KS][MT][64]
+  const double* Wop;    // [KS][1][64]   linear_out, rows 0..1
+  const double* bhn0;   // (g)   b_hn layer 0
+  const double* brz1;   // (2g)  b_ih + b_hh, gates r,z, layer 1
+  const double* bin1;   // (g)
+  const double* bhn1;   // (g)
+  double bo[2];
+  double* out;  // (N, 2)
+};
+hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s);
+
+// ------------------------------------------------------------------ representation MLP + ILT + rollout
+struct NlNetArgs {
+  int d, S, h, nt3;      // nt3 = layer-3 output tiles (theta/phi interleaved slot layout)
+  int n_even_groups;     // ILT groups (4 slots each) below this index hold even-k terms (cos), the rest odd-k (sin)
+  const double* W1p;     // [2][HT][64]        latent part of layer 1 (P <= 8 inputs)
+  const double* W1s;     // [KSS][HT][64]      sphere-coordinate part (general-t mode only)
+  const double* b1;      // (h)                ROLLOUT: bias with the constant sphere inputs folded in
+  const double* W2p;     // [h/4][HT][64]
+  const double* b2;      // (h)
+  const double* W3p;     // [h/4][nt3][64]     rows permuted into the slot layout
+  const double* b3p;     // (16*nt3)           same permutation
+  const double* Cp;      // [2*nt3][64]        ILT coefficient matrix fragments (rows = dims)
+  double state_mean[NLC_MAX_D], state_std[NLC_MAX_D];
+  double alpha, log_tol, scale, time_div;
+};
+
+struct RolloutArgs {
+  NlNetArgs net;
+  int64_t K;
+  int T, nu, B, env;
+  int state_per_sample;
+  const double* state0;     // (d) or (K,d) device
+  const double* pa;         // (K, T, 2) GRU latents
+  const double* perturbed;  // (K, T, nu)
+  const double* noise;      // (K, T, nu) bounded noise
+  const double* U;          // (T, nu)
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale;
+  int noise_abs_cost;
+  double tn;                // normalised prediction time (constant over the rollout)
+  double* states;           // (K, T, d) or NULL
+  double* cost_total;       // (K)
+};
+hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s);
+
+struct ForwardArgs {
+  NlNetArgs net;
+  int64_t N;
+  const double* obs;  // (N, d)
+  const double* pa;   // (N, 2)
+  const double* ts;   // (N) raw ts_pred
+  double* out;        // (N, d)
+};
+hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ oracle-dynamics rollout (§8f-1)
+struct OracleRolloutArgs {
+  int64_t K;
+  int T, nu, B, d, env, delay, friction;
+  int state_per_sample;
+  const double* state0;
+  const double* abuf;  // (B, nu)
+  const double* perturbed;
+  const double* noise;
+  const double* U;
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale, ts;
+  int noise_abs_cost;
+  double* states;
+  double* cost_total;
+};
+hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ MPPI sampling / weighting
+struct PerturbArgs {
+  int64_t K, K_global, k_offset;
+  int T, nu;
+  const double* U_old;  // (T, nu) before the shift
+  double* U_new;        // (T, nu) after roll(-1) + u_init
+  double* noise;        // in (rng==0) / out
+  double* perturbed;
+  double* actions;      // may be NULL
+  double u_scale;
+  int has_bounds, sample_null_action, rng;
+  double u_min[NLC_MAX_NU], u_max[NLC_MAX_NU], u_init[NLC_MAX_NU], mu[NLC_MAX_NU];
+  double chol[NLC_MAX_NU * NLC_MAX_NU];
+  uint64_t seed, counter;
+};
+hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s);
+hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s);
+
+struct WeightArgs {
+  int64_t K;
+  int T, nu;
+  double lambda_;
+  const double* cost;   // (K)
+  const double* noise;  // (K, T, nu)
+  double* cost_nz;      // (K)
+  double* block_min;    // (nblk)
+  double* block_part;   // (nblk, 1 + T*nu)
+  double* partials;     // (2 + T*nu)
+  int nblk;
+};
+constexpr int kWeightBlockSamples = 64;
+hipError_t launch_weights(const WeightArgs& a, hipStream_t s);
+
+struct MergeArgs {
+  int64_t K;
+  int T, nu, G, rank, u_per_command;
+  double lambda_, u_scale;
+  const double* gathered;  // (G, 2 + T*nu)
+  double* U;               // (T, nu) updated in place
+  double* cost_nz;         // (K) rescaled to the global beta
+  double* omega;           // (K) or NULL
+  double* action;          // (u_per_command * nu) device
+  double* beta_eta;        // (2) device: merged beta, eta
+};
+hipError_t launch_merge(const MergeArgs& a, hipStream_t s);
+
+}  // namespace nlc

@@ -1,0 +1,158 @@
+// Bounded-range FP64 elementary functions for the NLC kernels.
+//
+// The hot kernels evaluate ~2000 FP64 transcendentals per (sample, horizon step).  ocml's full-range
+// versions (Payne-Hanek reduction, denormal paths) are several hundred instructions each once inlined and
+// blow the unroll budget of the fused kernels, so the kernels use these instead: every argument here has
+// a known bounded range (tanh outputs scaled by pi, gate pre-activations, ...).  Accuracy target is a few
+// ulp; tests/test_math_host.py checks them against libm on dense grids (this header also compiles as
+// plain C++ for that purpose).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NLC_HD __host__ __device__ __forceinline__
+#else
+#define NLC_HD inline
+#endif
+
+namespace nlc {
+namespace m {
+
+NLC_HD double rcp_refined(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);  // v_rcp_f64
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / d;
+#endif
+}
+
+// n / d for finite, normal d well inside the exponent range (no scaling / fixup paths)
+NLC_HD double div_fast(double n, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = rcp_refined(d);
+  const double q = n * r;
+  return fma(fma(-d, q, n), r, q);
+#else
+  return n / d;
+#endif
+}
+
+// expm1(r) for |r| <= ln2/2: Taylor/Horner to r^13 (remainder < 5e-18 relative)
+NLC_HD double expm1_poly(double r) {
+  double p = 1.0 / 6227020800.0;  // 1/13!
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  return fma(p * r, r, r);
+}
+
+// y = n ln2 + r
+NLC_HD double exp_reduce(double y, int* n) {
+  const double kLog2e = 1.44269504088896338700e+00;
+  const double kLn2Hi = 6.93147180369123816490e-01;
+  const double kLn2Lo = 1.90821492927058770002e-10;
+  const double fn = rint(y * kLog2e);
+  double r = fma(-fn, kLn2Hi, y);
+  r = fma(-fn, kLn2Lo, r);
+  *n = (int)fn;
+  return r;
+}
+
+// exp(y) for y in [-745, 709]
+NLC_HD double exp_d(double y) {
+  y = fmin(fmax(y, -745.0), 709.0);
+  int n;
+  const double r = exp_reduce(y, &n);
+  return ldexp(1.0 + expm1_poly(r), n);
+}
+
+// expm1(y) for y <= 0
+NLC_HD double expm1_neg(double y) {
+  y = fmax(y, -745.0);
+  int n;
+  const double r = exp_reduce(y, &n);
+  const double p = expm1_poly(r);
+  // 2^n (1 + p) - 1 = 2^n p + (2^n - 1); exact-ish for n = 0, no cancellation for n <= -1
+  const double two_n = ldexp(1.0, n);
+  return fma(two_n, p, two_n - 1.0);
+}
+
+NLC_HD double sigmoid_d(double x) {
+  const double e = exp_d(-fabs(x));  // (0, 1]
+  const double inv = rcp_refined(1.0 + e);
+  return x >= 0.0 ? inv : e * inv;
+}
+
+NLC_HD double tanh_d(double x) {
+  const double a = fabs(x);
+  const double em = expm1_neg(-2.0 * a);  // e^{-2a} - 1 in (-1, 0]
+  double t = div_fast(-em, 2.0 + em);
+  t = a > 20.0 ? 1.0 : t;
+  return copysign(t, x);
+}
+
+// fdlibm __kernel_sin / __kernel_cos on |y| <= pi/4 (+ a few ulp)
+NLC_HD double sin_poly(double y) {
+  const double z = y * y;
+  double p = 1.58969099521155010221e-10;
+  p = fma(p, z, -2.50507602534068634195e-08);
+  p = fma(p, z, 2.75573137070700676789e-06);
+  p = fma(p, z, -1.98412698298579493134e-04);
+  p = fma(p, z, 8.33333333332248946124e-03);
+  p = fma(p, z, -1.66666666666666324348e-01);
+  return fma(y * z, p, y);
+}
+NLC_HD double cos_poly(double y) {
+  const double z = y * y;
+  double p = -1.13596475577881948265e-11;
+  p = fma(p, z, 2.08757232129817482790e-09);
+  p = fma(p, z, -2.75573143513906633035e-07);
+  p = fma(p, z, 2.48015872894767294178e-05);
+  p = fma(p, z, -1.38888888888741095749e-03);
+  p = fma(p, z, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  // 1 - z/2 + z^2 p with the rounding error of (1 - hz) folded back in (as fdlibm does)
+  return w + (((1.0 - w) - hz) + z * z * p);
+}
+
+constexpr double kPio2Hi = 1.57079632679489655800e+00;
+constexpr double kPio2Lo = 6.12323399573676603587e-17;
+
+// sin and cos of x, |x| <= ~2 pi (quadrant count small enough for a two-constant Cody-Waite step)
+NLC_HD void sincos_bounded(double x, double* s, double* c) {
+  const double fk = rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double y = fma(-fk, kPio2Hi, x);
+  y = fma(-fk, kPio2Lo, y);
+  const int k = (int)fk;
+  const double sy = sin_poly(y), cy = cos_poly(y);
+  const double ss = (k & 1) ? cy : sy;
+  const double cc = (k & 1) ? sy : cy;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
+
+// tan(x) for x in [0, pi/2]
+NLC_HD double tan_0_halfpi(double x) {
+  const bool hi = x > 0.78539816339744830962;
+  // b = pi/2 - x computed with the two-constant split
+  const double b = (kPio2Hi - x) + kPio2Lo;
+  const double y = hi ? b : x;
+  const double sy = sin_poly(y), cy = cos_poly(y);
+  return hi ? div_fast(cy, sy) : div_fast(sy, cy);
+}
+
+}  // namespace m
+}  // namespace nlc

@@ -1,0 +1,283 @@
+"""MI355X implementation behind ``neurallaplacecontrol_amd.w_nl`` -- drop-in for the reference's ``w_nl.py``: ``NeuralLaplaceModel`` / ``ReverseGRUEncoder`` /
+``LaplaceRepresentationFunc`` with the same constructor arguments, sub-module names and
+``state_dict`` keys (``action_encoder.gru.*``, ``action_encoder.linear_out.*``,
+``laplace_rep_func.linear_tanh_stack.{0,2,4}.*``, buffers ``state_mean state_std action_mean
+action_std dt``: reference ``w_nl.py:14-115``), so checkpoints written by the reference's
+``train_utils.py:442,490`` load unchanged.
+
+``NeuralLaplaceModel.forward`` (reference ``w_nl.py:117-145``) runs as two HIP launches behind
+``nlc_model_forward``: the GRU encoder on FP64 matrix cores, then representation MLP + sphere map +
+Fourier ILT fused (the (N, 2dS) theta/phi tensor never reaches HBM).  Inference only, float64 only
+(the reference harness calls ``model.double()`` under ``torch.no_grad()``:
+``mppi_with_model.py:101,319``).
+"""
+
+import copy
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .laplace import compute_device, laplace_reconstruct
+
+
+class ReverseGRUEncoder(nn.Module):
+    """Encodes an observed (action) trajectory, newest element first, into a latent vector (w_nl.py:14-29)."""
+
+    def __init__(self, dimension_in, latent_dim, hidden_units, encode_obs_time=True):
+        super().__init__()
+        self.encode_obs_time = encode_obs_time
+        if self.encode_obs_time:
+            dimension_in += 1
+        self.gru = nn.GRU(dimension_in, hidden_units, 2, batch_first=True)
+        self.linear_out = nn.Linear(hidden_units, latent_dim)
+        nn.init.xavier_uniform_(self.linear_out.weight)
+
+    def forward(self, observed_data):
+        # stand-alone use (outside NeuralLaplaceModel) goes through PyTorch-ROCm; the fused model path
+        # uses the HIP GRU kernel (NeuralLaplaceModel.encode_actions / forward)
+        out, _ = self.gru(torch.flip(observed_data, (1,)))
+        return self.linear_out(out[:, -1, :])
+
+
+class LaplaceRepresentationFunc(nn.Module):
+    """Sphere-surface model C^{b+k} -> C^{b x d} in Riemann-sphere coordinates (w_nl.py:32-63)."""
+
+    def __init__(self, s_dim, output_dim, latent_dim, hidden_units=64):
+        super().__init__()
+        self.s_dim = s_dim
+        self.output_dim = output_dim
+        self.latent_dim = latent_dim
+        self.linear_tanh_stack = nn.Sequential(
+            nn.Linear(s_dim * 2 + latent_dim, hidden_units),
+            nn.Tanh(),
+            nn.Linear(hidden_units, hidden_units),
+            nn.Tanh(),
+            nn.Linear(hidden_units, s_dim * 2 * output_dim),
+        )
+        for m in self.linear_tanh_stack.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+        self.phi_scale = torch.pi / 2.0 - -torch.pi / 2.0
+
+    def forward(self, i):
+        out = self.linear_tanh_stack(i.view(-1, self.s_dim * 2 + self.latent_dim)).view(
+            -1, 2 * self.output_dim, self.s_dim
+        )
+        theta = torch.tanh(out[:, : self.output_dim, :]) * torch.pi
+        phi = torch.tanh(out[:, self.output_dim :, :]) * self.phi_scale / 2.0 - torch.pi / 2.0 + self.phi_scale / 2.0
+        return theta, phi
+
+
+# state_dict order of the weight blob nlc_set_model expects (include/nlc.h)
+_BLOB_KEYS = [
+    "action_encoder.gru.weight_ih_l0",
+    "action_encoder.gru.weight_hh_l0",
+    "action_encoder.gru.bias_ih_l0",
+    "action_encoder.gru.bias_hh_l0",
+    "action_encoder.gru.weight_ih_l1",
+    "action_encoder.gru.weight_hh_l1",
+    "action_encoder.gru.bias_ih_l1",
+    "action_encoder.gru.bias_hh_l1",
+    "action_encoder.linear_out.weight",
+    "action_encoder.linear_out.bias",
+    "laplace_rep_func.linear_tanh_stack.0.weight",
+    "laplace_rep_func.linear_tanh_stack.0.bias",
+    "laplace_rep_func.linear_tanh_stack.2.weight",
+    "laplace_rep_func.linear_tanh_stack.2.bias",
+    "laplace_rep_func.linear_tanh_stack.4.weight",
+    "laplace_rep_func.linear_tanh_stack.4.bias",
+]
+
+
+def _cme_terms(s_recon_terms):
+    raise NotImplementedError("ilt_algorithm='cme' is not implemented on the HIP path (fourier, dehoog only)")
+
+
+class NeuralLaplaceModel(nn.Module):
+    def __init__(
+        self,
+        state_dim,
+        action_dim,
+        latent_dim,
+        hidden_units=64,
+        s_recon_terms=33,
+        ilt_algorithm="fourier",
+        encode_obs_time=False,
+        state_mean=None,
+        state_std=None,
+        action_mean=None,
+        action_std=None,
+        normalize=False,
+        normalize_time=False,
+        dt=0.05,
+    ):
+        super().__init__()
+        self.ilt_algorithm = ilt_algorithm
+        if ilt_algorithm == "cme":
+            s_recon_terms = _cme_terms(s_recon_terms)
+        action_encoder_latent_dim = 2
+        laplace_latent_dim = state_dim + action_encoder_latent_dim
+        self.latent_dim = latent_dim
+        self.action_dim = action_dim
+        self.hidden_units = hidden_units
+        self.action_encoder = ReverseGRUEncoder(
+            action_dim, action_encoder_latent_dim, hidden_units // 2, encode_obs_time=encode_obs_time
+        )
+        self.laplace_rep_func = LaplaceRepresentationFunc(
+            s_recon_terms, state_dim, laplace_latent_dim, hidden_units=hidden_units
+        )
+        self.encode_obs_time = encode_obs_time
+        self.output_dim = state_dim
+        self.normalize = normalize
+        self.normalize_time = normalize_time
+        self.s_recon_terms = s_recon_terms
+        self.ilt_options = None  # optional dict(alpha=, tol=, scale=) override of the torchlaplace defaults
+        # same dtypes as the reference (w_nl.py:111-115): torch.tensor(dt) is FLOAT32, so after .double()
+        # the time normaliser is float32(0.05) widened; action_mean built from np.array([0]*nu) is int64
+        self.register_buffer("state_mean", torch.tensor(state_mean))
+        self.register_buffer("state_std", torch.tensor(state_std))
+        self.register_buffer("action_mean", torch.tensor(action_mean))
+        self.register_buffer("action_std", torch.tensor(action_std))
+        self.register_buffer("dt", torch.tensor(dt))
+        self._ctx = None
+        self._uploaded_key = None
+        self._rep_dev = None  # (key, device copy of laplace_rep_func) for the staged path
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def _weights_key(self):
+        ts = [p for p in self.parameters()] + [b for b in self.buffers()]
+        return tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in ts) + (
+            self.normalize,
+            self.normalize_time,
+            self.ilt_algorithm,
+            repr(self.ilt_options),
+        )
+
+    def model_desc(self):
+        d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)
+        desc = _lib.ModelDesc()
+        desc.d, desc.nin, desc.h = d, nin, self.hidden_units
+        desc.ilt = _lib.ilt_desc(self.ilt_algorithm, self.s_recon_terms, self.ilt_options)
+        f64 = lambda t: t.detach().to("cpu", torch.float64).reshape(-1)  # noqa: E731
+        if self.normalize:
+            sm, ss = f64(self.state_mean), f64(self.state_std)
+            am = f64(self.action_mean).expand(nin) if self.action_mean.numel() == 1 else f64(self.action_mean)
+            a_s = f64(self.action_std).expand(nin) if self.action_std.numel() == 1 else f64(self.action_std)
+            if am.numel() != nin or a_s.numel() != nin or sm.numel() != d or ss.numel() != d:
+                raise ValueError("normalisation buffers do not broadcast against the model's input dims")
+            desc.time_div = float(f64(self.dt)[0] * 8.0) if self.normalize_time else 1.0
+        else:
+            sm, ss = torch.zeros(d, dtype=torch.float64), torch.ones(d, dtype=torch.float64)
+            am, a_s = torch.zeros(nin, dtype=torch.float64), torch.full((nin,), 3.0, dtype=torch.float64)
+            desc.time_div = 1.0
+        for i in range(d):
+            desc.state_mean[i], desc.state_std[i] = float(sm[i]), float(ss[i])
+        for i in range(nin):
+            desc.action_mean[i], desc.action_std[i] = float(am[i]), float(a_s[i])
+        return desc
+
+    def hip_ctx(self, device=None):
+        """The model's ``nlc_ctx`` with its current weights uploaded (re-packed when they change)."""
+        if any(p.dtype != torch.float64 for p in self.parameters()):
+            raise NotImplementedError(
+                "the HIP path computes in float64 only: call model.double() first (reference: mppi_with_model.py:101)"
+            )
+        dev = compute_device(next(self.parameters())) if device is None else torch.device(device)
+        if self._ctx is None or self._ctx.device_index != dev.index:
+            self._ctx = _lib.Ctx(dev.index)
+            self._uploaded_key = None
+        key = self._weights_key()
+        if key != self._uploaded_key:
+            sd = self.state_dict()
+            blob = torch.cat([sd[k].detach().to("cpu", torch.float64).reshape(-1) for k in _BLOB_KEYS]).contiguous()
+            desc = self.model_desc()
+            n = self._ctx.lib.nlc_model_blob_size(C.byref(desc))
+            if n != blob.numel():
+                raise ValueError(f"weight blob has {blob.numel()} doubles, library expects {n}")
+            self._ctx.check(self._ctx.lib.nlc_set_model(self._ctx.h, C.byref(desc), _lib.ptr(blob), blob.numel()))
+            self._uploaded_key = key
+        return self._ctx
+
+    @staticmethod
+    def _no_grad_only():
+        if torch.is_grad_enabled():
+            raise NotImplementedError(
+                "neurallaplacecontrol_amd.NeuralLaplaceModel is inference-only on the HIP path: "
+                "wrap the call in torch.no_grad() (as the reference harness does, mppi_with_model.py:319)"
+            )
+
+    def encode_actions(self, in_batch_action):
+        """HIP GRU encoder on raw (un-normalised) action windows (N, B, nin) -> (N, 2)  [stage a7]."""
+        self._no_grad_only()
+        dev = compute_device(in_batch_action, next(self.parameters()))
+        ctx = self.hip_ctx(dev)
+        win = in_batch_action.detach().to(dev, torch.float64).contiguous()
+        if win.dim() == 2:
+            win = win.unsqueeze(1)
+        N, B, nin = win.shape
+        out = torch.empty((N, 2), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            ctx.use_torch_stream()
+            ctx.check(ctx.lib.nlc_gru_encode(ctx.h, _lib.ptr(win), N, B, _lib.ptr(out)))
+        return out
+
+    def forward(self, in_batch_obs, in_batch_action, ts_pred):
+        self._no_grad_only()
+        out_device = in_batch_obs.device
+        dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
+        ctx = self.hip_ctx(dev)
+        obs = in_batch_obs.detach().to(dev, torch.float64).contiguous()
+        win = in_batch_action.detach().to(dev, torch.float64).contiguous()
+        if win.dim() == 2:
+            win = win.unsqueeze(1)
+        ts = torch.as_tensor(ts_pred).detach().to(dev, torch.float64)
+        N, d = obs.shape
+        fused = self.ilt_algorithm == "fourier" and ts.numel() == N
+        if fused:
+            out = torch.empty((N, d), dtype=torch.float64, device=dev)
+            ws = torch.empty(ctx.lib.nlc_model_workspace_bytes(ctx.h, N) // 8, dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                ctx.use_torch_stream()
+                ctx.check(
+                    ctx.lib.nlc_model_forward(
+                        ctx.h,
+                        _lib.ptr(obs),
+                        _lib.ptr(win),
+                        _lib.ptr(ts.reshape(-1).contiguous()),
+                        N,
+                        win.shape[1],
+                        _lib.ptr(out),
+                        _lib.ptr(ws),
+                    )
+                )
+            return torch.squeeze(out.view(N, 1, d)).to(out_device)
+        # staged path (de Hoog, or several time points per row): HIP GRU -> torch MLP -> HIP ILT
+        desc = self.model_desc()
+        sm = torch.tensor(list(desc.state_mean)[:d], dtype=torch.float64, device=dev)
+        ss = torch.tensor(list(desc.state_std)[:d], dtype=torch.float64, device=dev)
+        p = torch.cat(((obs - sm) / ss, self.encode_actions(win)), dim=1)
+        rep = self.laplace_rep_func
+        if next(rep.parameters()).device != dev:
+            key = (self._weights_key(), str(dev))
+            if self._rep_dev is None or self._rep_dev[0] != key:
+                self._rep_dev = (key, copy.deepcopy(rep).to(dev))
+            rep = self._rep_dev[1]
+        return torch.squeeze(
+            laplace_reconstruct(
+                rep,
+                p,
+                ts / desc.time_div,
+                recon_dim=d,
+                ilt_algorithm=self.ilt_algorithm,
+                ilt_reconstruction_terms=self.s_recon_terms,
+                options=self.ilt_options,
+            )
+        ).to(out_device)
+
+
+def load_replay_buffer(fn):
+    """Same helper as the reference (w_nl.py:148-150)."""
+    return np.load(fn, allow_pickle=True).item()

@@ -1,0 +1,391 @@
+"""MI355X drop-in for the reference planner ``planners/mppi_delay.py`` (class ``MPPIDelay`` :54-381).
+
+Same constructor signature, ``command(state, action_buffer)``, ``reset()``, ``get_rollouts()`` and public
+attributes (``U noise perturbed_action cost_total cost_total_non_zero omega states actions K T nx nu
+lambda_ u_scale``).  Everything numeric runs in HIP kernels behind ``libnlc_hip.so``:
+
+* fused path -- ``dynamics`` is an :class:`~neurallaplacecontrol_amd.envs.NLDynamics` or
+  :class:`~neurallaplacecontrol_amd.envs.OracleDynamics` and ``running_cost`` an
+  :class:`~neurallaplacecontrol_amd.envs.EnvCost`: one ``command()`` = shift/perturb kernel, hoisted GRU
+  encode over all K*T windows, one persistent T-step rollout kernel, softmax-weight reduction, U update.
+* generic path -- arbitrary callables (the reference's contract): sampling, bounding, weighting and the
+  U update are the same HIP kernels; the T-step loop calls the user's callables on device tensors.
+
+Extra keyword-only arguments (not in the reference): ``noise_rng`` ("torch": draw with
+``MultivariateNormal`` on ``device`` exactly like the reference, so a CPU-seeded run reproduces the
+reference's noise bit for bit; "philox": draw inside the perturb kernel), ``seed``, ``process_group``
+(shard the K samples over the ranks of a torch.distributed group; RCCL all-gather of 2+T*nu doubles per
+command), ``compute_device``, ``store_rollouts``.
+"""
+
+import ctypes as C
+
+import torch
+from torch.distributions.multivariate_normal import MultivariateNormal
+
+from .. import _lib
+from ..envs import EnvCost, NLDynamics, OracleDynamics
+
+
+def _per_dim(v, nu, name):
+    t = torch.as_tensor(v, dtype=torch.float64).detach().cpu().reshape(-1)
+    if t.numel() == 1:
+        t = t.expand(nu)
+    if t.numel() != nu:
+        raise ValueError(f"{name} must be a scalar or have nu={nu} entries")
+    return [float(x) for x in t]
+
+
+class MPPIDelay:
+    def __init__(
+        self,
+        dynamics,
+        running_cost,
+        nx,
+        noise_sigma,
+        num_samples=100,
+        horizon=15,
+        device="cpu",
+        terminal_state_cost=None,
+        lambda_=1.0,
+        noise_mu=None,
+        u_min=None,
+        u_max=None,
+        u_init=None,
+        U_init=None,
+        u_scale=1,
+        u_per_command=1,
+        step_dependent_dynamics=False,
+        rollout_samples=1,
+        rollout_var_cost=0,
+        rollout_var_discount=0.95,
+        dt=0.05,
+        sample_null_action=False,
+        noise_abs_cost=False,
+        encode_obs_time=False,
+        *,
+        noise_rng="torch",
+        seed=0,
+        process_group=None,
+        compute_device=None,
+        store_rollouts=True,
+    ):
+        self.d = torch.device(device)
+        self.dtype = noise_sigma.dtype
+        if self.dtype != torch.float64:
+            raise NotImplementedError("the HIP planner computes in float64 (the reference harness uses torch.double)")
+        self.K = int(num_samples)
+        self.T = int(horizon)
+        self.encode_obs_time = encode_obs_time
+        self.dt = dt
+        self.nx = nx
+        self.nu = 1 if len(noise_sigma.shape) == 0 else noise_sigma.shape[0]
+        if self.nu > _lib.NLC_MAX_NU:
+            raise NotImplementedError(f"nu={self.nu}: the HIP planner supports up to {_lib.NLC_MAX_NU} action dims")
+        self.lambda_ = lambda_
+        if noise_mu is None:
+            noise_mu = torch.zeros(self.nu, dtype=self.dtype)
+        if u_init is None:
+            u_init = torch.zeros_like(noise_mu)
+        if self.nu == 1:
+            noise_mu = noise_mu.view(-1)
+            noise_sigma = noise_sigma.view(-1, 1)
+        # bounds: if only one of them is given the other is its negation (reference :143-153)
+        self.u_min, self.u_max = u_min, u_max
+        self.u_scale = u_scale
+        self.u_per_command = u_per_command
+        if self.u_max is not None and self.u_min is None:
+            self.u_max = torch.as_tensor(self.u_max)
+            self.u_min = -self.u_max
+        if self.u_min is not None and self.u_max is None:
+            self.u_min = torch.as_tensor(self.u_min)
+            self.u_max = -self.u_min
+        if self.u_min is not None:
+            self.u_min = torch.as_tensor(self.u_min).to(device=self.d)
+            self.u_max = torch.as_tensor(self.u_max).to(device=self.d)
+        self.noise_mu = noise_mu.to(self.d)
+        self.noise_sigma = noise_sigma.to(self.d)
+        self.noise_sigma_inv = torch.inverse(self.noise_sigma)
+        self.noise_dist = MultivariateNormal(self.noise_mu, covariance_matrix=self.noise_sigma)
+        self.u_init = u_init.to(self.d)
+
+        if rollout_samples != 1 or rollout_var_cost != 0:
+            raise NotImplementedError("rollout_samples > 1 / rollout_var_cost are not implemented on the HIP planner")
+        self.M = rollout_samples
+        self.rollout_var_cost = rollout_var_cost
+        self.rollout_var_discount = rollout_var_discount
+        self.step_dependency = step_dependent_dynamics
+        self.F = dynamics
+        self.running_cost = running_cost
+        self.terminal_state_cost = terminal_state_cost
+        self.sample_null_action = sample_null_action
+        self.noise_abs_cost = noise_abs_cost
+        self.state = None
+
+        if noise_rng not in ("torch", "philox"):
+            raise ValueError("noise_rng must be 'torch' or 'philox'")
+        self.noise_rng = noise_rng
+        self.seed = int(seed)
+        self._commands = 0
+        self.store_rollouts = store_rollouts
+
+        # ---- K-sharding over a process group
+        self.pg = process_group
+        if process_group is not None:
+            import torch.distributed as dist
+
+            self.G, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        else:
+            self.G, self.rank = 1, 0
+        if self.K % self.G:
+            raise ValueError(f"num_samples={self.K} must be divisible by the group size {self.G}")
+        self.K_local = self.K // self.G
+        self.k_offset = self.rank * self.K_local
+
+        self.fused = (
+            isinstance(dynamics, (NLDynamics, OracleDynamics))
+            and isinstance(running_cost, EnvCost)
+            and terminal_state_cost is None
+            and not step_dependent_dynamics
+            and not encode_obs_time
+        )
+        if isinstance(dynamics, OracleDynamics) and not self.fused:
+            raise NotImplementedError("OracleDynamics needs an EnvCost running_cost and the default rollout options")
+
+        if compute_device is None:
+            if self.d.type == "cuda":
+                compute_device = self.d
+            elif isinstance(dynamics, NLDynamics) and next(dynamics.model.parameters()).is_cuda:
+                compute_device = next(dynamics.model.parameters()).device
+        if not torch.cuda.is_available():
+            raise RuntimeError("neurallaplacecontrol_amd.MPPIDelay needs an AMD MI355X; there is no CPU path")
+        self.cd = torch.device(compute_device) if compute_device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.cd.index is None:
+            self.cd = torch.device("cuda", torch.cuda.current_device())
+        if isinstance(dynamics, NLDynamics):
+            self.ctx = dynamics.model.hip_ctx(self.cd)
+        else:
+            self.ctx = _lib.Ctx(self.cd.index)
+        self._B = None
+        self._buf = None
+        self._pending_U = None
+
+        # sampled results from the last command (device tensors; exposed through the properties below)
+        self._noise = self._perturbed = self._states = self._actions = None
+        self._cost_total = self._cost_nz = self._omega = None
+
+        # T x nu control sequence; defaults to a noise draw (consumes the RNG like the reference :161-164)
+        self.U = U_init if U_init is not None else self.noise_dist.sample((self.T,))
+
+    # ------------------------------------------------------------------ configuration
+    def _configure(self, B):
+        d = _lib.MppiDesc()
+        d.K, d.K_global, d.k_offset = self.K_local, self.K, self.k_offset
+        d.T, d.nu, d.d, d.B = self.T, self.nu, self.nx, B
+        d.lambda_, d.u_scale = float(self.lambda_), float(self.u_scale)
+        d.has_bounds = int(self.u_max is not None)
+        if self.u_max is not None:
+            lo, hi = _per_dim(self.u_min, self.nu, "u_min"), _per_dim(self.u_max, self.nu, "u_max")
+            for i in range(self.nu):
+                d.u_min[i], d.u_max[i] = lo[i], hi[i]
+        ui, mu = _per_dim(self.u_init, self.nu, "u_init"), _per_dim(self.noise_mu, self.nu, "noise_mu")
+        sig = self.noise_sigma.detach().cpu().to(torch.float64)
+        inv = self.noise_sigma_inv.detach().cpu().to(torch.float64)
+        chol = torch.linalg.cholesky(sig)
+        for i in range(self.nu):
+            d.u_init[i], d.noise_mu[i] = ui[i], mu[i]
+            for j in range(self.nu):
+                d.noise_sigma[i * self.nu + j] = float(sig[i, j])
+                d.noise_sigma_inv[i * self.nu + j] = float(inv[i, j])
+                d.noise_chol[i * self.nu + j] = float(chol[i, j])
+        d.sample_null_action = int(bool(self.sample_null_action))
+        d.noise_abs_cost = int(bool(self.noise_abs_cost))
+        d.u_per_command = int(self.u_per_command)
+        if self.fused:
+            d.env = _lib.ENV_IDS[self.running_cost.env_name]
+            if isinstance(self.F, NLDynamics):
+                d.dynamics, d.ts_pred = _lib.DYN_NL, self.F.ts_pred
+                self.F.model.hip_ctx(self.cd)  # make sure the current weights are on the device
+            else:
+                if self.F.env_name != self.running_cost.env_name:
+                    raise ValueError("OracleDynamics and EnvCost name different envs")
+                d.dynamics, d.ts_pred = _lib.DYN_ORACLE, self.F.ts
+                d.delay, d.friction = self.F.delay, int(self.F.friction)
+        else:
+            d.dynamics = _lib.DYN_EXTERNAL
+        old_U = None
+        if self._B is not None:
+            old_U = self.U
+        self.ctx.check(self.ctx.lib.nlc_mppi_configure(self.ctx.h, C.byref(d)))
+        self._B = B
+        K, T, nu, nx, dev = self.K_local, self.T, self.nu, self.nx, self.cd
+        mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)  # noqa: E731
+        self._noise, self._perturbed = mk(K, T, nu), mk(K, T, nu)
+        self._states = mk(K, T, nx) if self.store_rollouts else None
+        self._actions = mk(K, T, nu) if self.store_rollouts else None
+        self._cost_total, self._cost_nz, self._omega = mk(K), mk(K), mk(K)
+        self._partials = mk(2 + T * nu)
+        self._gathered = mk(self.G, 2 + T * nu) if self.G > 1 else None
+        self._ws = torch.empty(self.ctx.lib.nlc_mppi_workspace_bytes(self.ctx.h) // 8, dtype=torch.float64, device=dev)
+        b = _lib.MppiBuffers()
+        b.noise, b.perturbed = self._noise.data_ptr(), self._perturbed.data_ptr()
+        b.states = self._states.data_ptr() if self._states is not None else None
+        b.actions = self._actions.data_ptr() if self._actions is not None else None
+        b.cost_total, b.cost_nz, b.omega = self._cost_total.data_ptr(), self._cost_nz.data_ptr(), self._omega.data_ptr()
+        b.partials, b.workspace = self._partials.data_ptr(), self._ws.data_ptr()
+        self._buf = b
+        if old_U is not None:
+            self._pending_U = old_U
+        if self._pending_U is not None:
+            self._upload_U(self._pending_U)
+            self._pending_U = None
+
+    def _upload_U(self, U):
+        Uh = torch.as_tensor(U).detach().to("cpu", torch.float64).reshape(self.T, self.nu).contiguous()
+        self.ctx.check(self.ctx.lib.nlc_mppi_set_U(self.ctx.h, _lib.ptr(Uh)))
+
+    # ------------------------------------------------------------------ public state
+    @property
+    def U(self):
+        if self._buf is None:
+            return self._pending_U
+        Uh = torch.empty((self.T, self.nu), dtype=torch.float64)
+        self.ctx.check(self.ctx.lib.nlc_mppi_get_U(self.ctx.h, _lib.ptr(Uh)))
+        return Uh.to(self.d)
+
+    @U.setter
+    def U(self, value):
+        value = torch.as_tensor(value).detach().to(dtype=torch.float64).reshape(self.T, self.nu).clone()
+        if self._buf is None:
+            self._pending_U = value
+        else:
+            self._upload_U(value)
+
+    def _out(self, t):
+        return None if t is None else (t if self.d == t.device else t.to(self.d))
+
+    noise = property(lambda self: self._out(self._noise))
+    perturbed_action = property(lambda self: self._out(self._perturbed))
+    states = property(lambda self: self._out(self._states))
+    actions = property(lambda self: self._out(self._actions))
+    cost_total = property(lambda self: self._out(self._cost_total))
+    cost_total_non_zero = property(lambda self: self._out(self._cost_nz))
+    omega = property(lambda self: self._out(self._omega))
+
+    # ------------------------------------------------------------------ command
+    def command(self, state, action_buffer):
+        """
+        :param state: (nx) or (K x nx) current state, or samples of states
+        :param action_buffer: (B x nu) most recent actions, oldest first (harness get_action contract)
+        :returns action: (nu) best action, or (u_per_command x nu)
+        """
+        if not torch.is_tensor(state):
+            state = torch.tensor(state)
+        self.state = state.to(dtype=self.dtype, device=self.d)
+        st = self.state.detach().to("cpu", torch.float64).contiguous()
+        per_sample = tuple(st.shape) == (self.K, self.nx)
+        if per_sample:
+            st = st[self.k_offset : self.k_offset + self.K_local].contiguous()
+        elif st.numel() != self.nx:
+            raise ValueError(f"state must have nx={self.nx} entries or be (K, nx)")
+        ab = torch.as_tensor(action_buffer).detach().to("cpu", torch.float64).contiguous()
+        if ab.dim() != 2:
+            raise ValueError("action_buffer must be (B, nu)")
+        if self._buf is None or ab.shape[0] != self._B:
+            self._configure(ab.shape[0])
+        lib, ctx = self.ctx.lib, self.ctx
+        rng = 1 if self.noise_rng == "philox" else 0
+        with torch.cuda.device(self.cd):
+            ctx.use_torch_stream()
+            if not rng:
+                # K x T x nu draw on `device`, same generator consumption as the reference (:319)
+                raw = self.noise_dist.sample((self.K, self.T))
+                self._noise.copy_(raw[self.k_offset : self.k_offset + self.K_local].reshape(self.K_local, self.T, self.nu))
+            if self.fused:
+                if ab.shape[1] != self.nu:
+                    raise ValueError("action_buffer must have nu columns")
+                ctx.check(
+                    lib.nlc_mppi_rollout(
+                        ctx.h, _lib.ptr(st), int(per_sample), _lib.ptr(ab), C.byref(self._buf), rng, self.seed, self._commands
+                    )
+                )
+            else:
+                ctx.check(lib.nlc_mppi_rollout(ctx.h, None, 0, None, C.byref(self._buf), rng, self.seed, self._commands))
+                self._external_rollout(st, per_sample, ab)
+                ctx.check(lib.nlc_mppi_weights(ctx.h, C.byref(self._buf)))
+            self._commands += 1
+            if self.G > 1:
+                import torch.distributed as dist
+
+                dist.all_gather_into_tensor(self._gathered.view(-1), self._partials, group=self.pg)
+                gathered = self._gathered
+            else:
+                gathered = self._partials
+            act = torch.empty(self.u_per_command * self.nu, dtype=torch.float64)
+            ctx.check(lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act)))
+        action = act.view(self.u_per_command, self.nu)
+        if self.u_per_command == 1:
+            action = action[0]
+        return action.to(self.d)
+
+    # ------------------------------------------------------------------ generic callables (reference :232-313)
+    def _dynamics(self, state, u, t):
+        return self.F(state, u, t) if self.step_dependency else self.F(state, u)
+
+    def _running_cost(self, state, u):
+        return self.running_cost(state, u)
+
+    def _external_rollout(self, st, per_sample, action_buffer):
+        dev, K, T, nu = self.cd, self.K_local, self.T, self.nu
+        ab = action_buffer.to(dev)
+        x = st.to(dev) if per_sample else st.to(dev).view(1, -1).repeat(K, 1)
+        A = self.u_scale * self._perturbed
+        hist = torch.cat((ab[1:, :nu].reshape(1, -1, nu).repeat(K, 1, 1), A), dim=1)
+        window = ab.shape[0]
+        time_buffer = ab[:, nu:].clone() if self.encode_obs_time else None
+        cost = torch.zeros(K, dtype=torch.float64, device=dev)
+        states, actions = [], []
+        for t in range(T):
+            win = hist[:, t : t + window, :]
+            if self.encode_obs_time:
+                # rolling time-stamp channel of the dataset collector's variant (reference :279-287)
+                time_buffer = time_buffer + self.dt
+                time_buffer = time_buffer.roll(-1, dims=0)
+                time_buffer[-1] = 0
+                win = torch.cat((win, time_buffer.view(1, -1, 1).repeat(K, 1, 1)), dim=2)
+            x = self._dynamics(x, win, t)
+            u = hist[:, t + window - 1, :]
+            cost = cost + self._running_cost(x, u)
+            states.append(x)
+            actions.append(u)
+        actions = torch.stack(actions, dim=-2)
+        states = torch.stack(states, dim=-2)
+        if self.terminal_state_cost:
+            cost = cost + self.terminal_state_cost(states, actions)
+        # action perturbation cost (reference :329-344)
+        Ud = self.U.to(dev)
+        sig_inv = self.noise_sigma_inv.to(dev)
+        eps = torch.abs(self._noise) if self.noise_abs_cost else self._noise
+        cost = cost + torch.sum(Ud * (self.lambda_ * eps @ sig_inv), dim=(1, 2))
+        self._cost_total.copy_(cost)
+        if self._states is not None:
+            self._states.copy_(states.reshape(K, T, self.nx))
+
+    # ------------------------------------------------------------------ misc reference API
+    def reset(self):
+        """Clear controller state after finishing a trial (re-draws U, reference :226-230)."""
+        self.U = self.noise_dist.sample((self.T,))
+
+    def get_rollouts(self, state, num_rollouts=1):
+        """Open-loop replay of U through the dynamics callable (reference :358-381)."""
+        U = self.U.to(self.cd)
+        state = torch.as_tensor(state).to(self.cd, torch.float64).view(-1, self.nx)
+        if state.size(0) == 1:
+            state = state.repeat(num_rollouts, 1)
+        states = torch.zeros((num_rollouts, self.T + 1, self.nx), dtype=torch.float64, device=self.cd)
+        states[:, 0] = state
+        for t in range(self.T):
+            states[:, t + 1] = self._dynamics(
+                states[:, t].view(num_rollouts, -1), self.u_scale * U[t].view(num_rollouts, -1), t
+            )
+        return states[:, 1:].to(self.d)

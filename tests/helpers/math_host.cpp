@@ -1,0 +1,10 @@
+// Host build of neurallaplacecontrol_amd/csrc/nlc_math.h for tests/test_math_host.py (g++, no GPU).
+#include "../../neurallaplacecontrol_amd/csrc/nlc_math.h"
+extern "C" {
+void nlc_t_tanh(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tanh_d(x[i]); }
+void nlc_t_sigmoid(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::sigmoid_d(x[i]); }
+void nlc_t_exp(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::exp_d(x[i]); }
+void nlc_t_sin(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) { double s, c; nlc::m::sincos_bounded(x[i], &s, &c); y[i] = s; } }
+void nlc_t_cos(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) { double s, c; nlc::m::sincos_bounded(x[i], &s, &c); y[i] = c; } }
+void nlc_t_tan(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tan_0_halfpi(x[i]); }
+}

@@ -1,0 +1,453 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI of
+libnlc_hip.so via the drop-in Python mirror, against (a) the golden fixtures captured from the imported
+reference and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances: the north-star bar is 1e-5 on float64 results.  The checks below use 1e-9 (relative+absolute)
+for single model evaluations and planner outputs at fixture size, i.e. four orders tighter than required;
+full-size (K=16384, T=40) checks use 1e-7 on states after 40 sequential steps.
+"""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = dict(rtol=1e-9, atol=1e-9)
+
+
+def T64(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float64)
+
+
+@pytest.fixture(scope="module")
+def nlc():
+    import neurallaplacecontrol_amd as n
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return n
+
+
+def load_sd(g, prefix="w::"):
+    return {k[len(prefix):]: T64(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def build_model(nlc, sd, S=17, algo="fourier", device="cuda"):
+    d = sd["state_mean"].numel()
+    nu = sd["action_encoder.gru.weight_ih_l0"].shape[1]
+    m = nlc.NeuralLaplaceModel(
+        d, nu, d, hidden_units=128, s_recon_terms=S, ilt_algorithm=algo,
+        state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0] * nu), action_std=np.array([1.0]),
+        normalize=True, normalize_time=True,
+    ).double()
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+# --------------------------------------------------------------------------- ILT (a9)
+@pytest.mark.parametrize("d,S", [(5, 17), (3, 17), (6, 33), (4, 9), (5, 32)])
+def test_ilt_fourier_vs_oracle(nlc, d, S):
+    from oracle import ilt as oilt
+
+    torch.manual_seed(d * 100 + S)
+    N = 1537  # ragged: not a multiple of the block tile
+    theta = (torch.rand(N, d, S, dtype=torch.float64) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S, dtype=torch.float64) * 2 - 1) * np.pi / 2 * 0.999
+    t = torch.rand(N, dtype=torch.float64) * 2 + 0.05
+    for opts in (None, dict(scale=3.0, alpha=1e-2)):
+        ref = oilt.ilt_from_sphere(theta, phi, t, "fourier", opts)
+        got = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), "fourier", opts).cpu()
+        scale = ref.abs().max()
+        np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
+
+
+def test_ilt_empty_and_single(nlc):
+    z = nlc.ilt_reconstruct(torch.zeros(0, 5, 17).double().cuda(), torch.zeros(0, 5, 17).double().cuda(),
+                            torch.zeros(0).double().cuda())
+    assert z.shape == (0, 5)
+    one = nlc.ilt_reconstruct(torch.zeros(1, 1, 17).double().cuda(), torch.zeros(1, 1, 17).double().cuda(),
+                              torch.full((1,), 0.125).double().cuda())
+    assert one.shape == (1, 1) and torch.isfinite(one).all()
+
+
+@pytest.mark.parametrize("S", [33, 17, 9])
+def test_ilt_dehoog_vs_oracle(nlc, S):
+    from oracle import ilt as oilt
+
+    torch.manual_seed(S)
+    N, d = 700, 5
+    # smooth F(s) (a rational transform sampled at the query points + small noise) keeps the QD table
+    # well conditioned; the oracle and the kernel follow the same mpmath recurrences
+    t = torch.rand(N, dtype=torch.float64) * 2 + 0.05
+    alpha, tol, scale = oilt.ilt_options("dehoog")
+    sr, si, _, _ = oilt.query_points(t, S, alpha, tol, scale)
+    s = torch.complex(sr, si).unsqueeze(1)
+    a = (torch.rand(N, d, 1, dtype=torch.float64) + 0.5)
+    w = (torch.rand(N, d, 1, dtype=torch.float64) * 3 + 0.5)
+    F = (s + a) / ((s + a) ** 2 + w**2)
+    theta, phi = oilt.complex_to_sphere(F.real, F.imag)
+    ref = oilt.ilt_from_sphere(theta, phi, t, "dehoog")
+    got = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), "dehoog").cpu()
+    exact = torch.exp(-a.squeeze(-1) * t.view(-1, 1)) * torch.cos(w.squeeze(-1) * t.view(-1, 1))
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6, atol=1e-8)
+    if S == 33:
+        np.testing.assert_allclose(got.numpy(), exact.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_ilt_known_answers_golden(nlc):
+    """G4: analytic pairs / mpmath de Hoog, F sampled at the query points -> sphere -> HIP ILT."""
+    from oracle import ilt as oilt
+
+    g = np.load(f"{GOLD}/g4_ilt_known.npz")
+    ts = T64(g["ts"])
+    for name in ("exp_decay", "cosine", "sine_damped", "ramp"):
+        th, ph = oilt.complex_to_sphere(T64(g[f"{name}_dehoog33_Fre"]), T64(g[f"{name}_dehoog33_Fim"]))
+        got = nlc.ilt_reconstruct(th.unsqueeze(1).cuda(), ph.unsqueeze(1).cuda(), ts.cuda(), "dehoog").cpu()
+        np.testing.assert_allclose(got.numpy()[:, 0], g[f"{name}_mp_dehoog"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(got.numpy()[:, 0], g[f"{name}_exact"], rtol=1e-6, atol=1e-7)
+
+
+def test_rep_inputs_vs_oracle(nlc):
+    from oracle import ilt as oilt
+
+    torch.manual_seed(3)
+    p = torch.randn(37, 7, dtype=torch.float64)
+    for t in (torch.rand(37, 3, dtype=torch.float64) + 0.05, torch.rand(4, dtype=torch.float64) + 0.05):
+        for algo, S in (("fourier", 17), ("dehoog", 33)):
+            ref, _ = oilt.rep_func_inputs(p, t, S, algo)
+            got, _ = nlc.rep_func_inputs(p.cuda(), t.cuda(), S, algo)
+            np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-12, atol=1e-13)
+
+
+def test_laplace_reconstruct_generic_rep_func(nlc):
+    """Full torchlaplace-style call with an arbitrary torch representation function."""
+    from oracle import ilt as oilt
+
+    torch.manual_seed(5)
+    d, S, P, B = 3, 17, 6, 50
+    lin = torch.nn.Linear(2 * S + P, 2 * d * S).double()
+
+    def rep(i):
+        out = lin.to(i.device)(i.view(-1, 2 * S + P)).view(-1, 2 * d, S)
+        return torch.tanh(out[:, :d]) * torch.pi, torch.tanh(out[:, d:]) * torch.pi / 2
+
+    p = torch.randn(B, P, dtype=torch.float64)
+    t = torch.rand(B, 4, dtype=torch.float64) + 0.1
+    with torch.no_grad():
+        ref = oilt.laplace_reconstruct(rep, p, t, recon_dim=d, ilt_reconstruction_terms=S)
+        got = nlc.laplace_reconstruct(rep, p.cuda(), t.cuda(), recon_dim=d, ilt_reconstruction_terms=S).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **TOL)
+
+
+# --------------------------------------------------------------------------- model stages (a6-a8)
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_gru_encoder_vs_reference_golden(nlc, env):
+    """G2: HIP GRU encoder vs the REAL reference ReverseGRUEncoder (nn.GRU) outputs."""
+    g = np.load(f"{GOLD}/g2_stages_{env}.npz")
+    sd = load_sd(g)
+    model = build_model(nlc, sd)
+    # G2 fed already-normalised windows; un-normalise so the kernel's (x - mean)/std reproduces them
+    win = T64(g["gru_in"]) * sd["action_std"] + sd["action_mean"]
+    with torch.no_grad():
+        got = model.encode_actions(win.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), g["gru_out"], **TOL)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_model_forward_vs_golden(nlc, env):
+    """G3: fused HIP NeuralLaplaceModel.forward vs the reference model (ILT body = build's restatement)."""
+    g = np.load(f"{GOLD}/g3_nl_{env}.npz")
+    model = build_model(nlc, load_sd(g))
+    with torch.no_grad():
+        got = model(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), g["fwd_out"], **TOL)
+    # CPU-resident inputs (the reference's default device) give the same numbers, returned on the CPU
+    with torch.no_grad():
+        got_cpu = model(T64(g["fwd_obs"]), T64(g["fwd_window"]), T64(g["fwd_ts"]))
+    assert got_cpu.device.type == "cpu"
+    np.testing.assert_allclose(got_cpu.numpy(), g["fwd_out"], **TOL)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "acrobot"])
+def test_model_forward_dehoog_staged(nlc, env):
+    g = np.load(f"{GOLD}/g3_nl_{env}.npz")
+    model = build_model(nlc, load_sd(g, "w33::"), S=33, algo="dehoog")
+    with torch.no_grad():
+        got = model(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), g["fwd33_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_model_forward_general_t_and_ragged(nlc):
+    """Per-row prediction times (not the planner's constant dt), N not a multiple of the wave tile."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-acrobot"]
+    sd = onl.make_synthetic_state_dict(3, st["d"], st["nu"], 128, 17, st["state_std"], [st["act_high"] / 2], tame=True)
+    model = build_model(nlc, sd)
+    torch.manual_seed(9)
+    for N in (1, 15, 16, 17, 129):
+        obs = torch.randn(N, st["d"], dtype=torch.float64)
+        win = torch.randn(N, 5, st["nu"], dtype=torch.float64) * 2  # B = 5 window
+        ts = torch.rand(N, 1, dtype=torch.float64) * 0.2 + 0.01
+        ref = onl.nl_forward(sd, obs, win, ts, S=17).reshape(N, -1)
+        with torch.no_grad():
+            got = model(obs.cuda(), win.cuda(), ts.cuda()).cpu().reshape(N, -1)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), **TOL)
+
+
+def test_model_requires_no_grad_and_double(nlc):
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-cartpole"]
+    sd = onl.make_synthetic_state_dict(0, 5, 1, 128, 17, st["state_std"], [1.5])
+    model = build_model(nlc, sd)
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(2, 5).double().cuda(), torch.zeros(2, 4, 1).double().cuda(), torch.ones(2, 1).double().cuda())
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        model.float()(torch.zeros(2, 5).cuda(), torch.zeros(2, 4, 1).cuda(), torch.ones(2, 1).cuda())
+
+
+# --------------------------------------------------------------------------- planner (a1-a4, a10-a12)
+def check_command_steps(nlc, g, make_planner, tol=TOL):
+    mppi = None
+    for step in range(2):
+        pre = f"s{step}_"
+        if mppi is None:
+            mppi = make_planner(T64(g[pre + "U_before"]))
+        # the reference samples noise inside command(); replay its draw by seeding U and feeding the raw draw
+        mppi.U = T64(g[pre + "U_before"])
+        raw = T64(g[pre + "noise_raw"])
+        mppi.noise_dist = type("Replay", (), {"sample": staticmethod(lambda shape, raw=raw: raw)})()
+        action = mppi.command(g[pre + "state"], T64(g[pre + "action_buffer"]))
+        np.testing.assert_allclose(action.cpu().numpy(), g[pre + "action"], err_msg=pre + "action", **tol)
+        for attr, key in (("U", "U_after"), ("cost_total", "cost_total"), ("omega", "omega"), ("noise", "noise"),
+                          ("perturbed_action", "perturbed_action"), ("states", "states"), ("actions", "actions")):
+            np.testing.assert_allclose(getattr(mppi, attr).cpu().numpy(), g[pre + key], err_msg=pre + attr, **tol)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1_*.npz"))))
+def test_mppi_oracle_dynamics_vs_reference_golden(nlc, path):
+    """G1: whole command() with oracle dynamics + env cost vs the REAL reference MPPIDelay/oracle/env code."""
+    g = np.load(path)
+    env = "oderl-" + os.path.basename(path).split("_")[2]
+    K, T, nx, nu, A, delay = int(g["K"]), int(g["T"]), int(g["nx"]), int(g["nu"]), float(g["A"]), int(g["delay"])
+
+    def make(U0):
+        return nlc.MPPIDelay(
+            nlc.OracleDynamics(env, ts=0.05, delay=delay), nlc.EnvCost(env), nx, nlc.noise_sigma(nu),
+            num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+            u_scale=A, U_init=U0,
+        )
+
+    check_command_steps(nlc, g, make)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_mppi_nl_dynamics_vs_reference_golden(nlc, env):
+    """G3: command() with Neural-Laplace dynamics vs reference MPPIDelay + reference model."""
+    g = np.load(f"{GOLD}/g3_nl_{env}.npz")
+    model = build_model(nlc, load_sd(g))
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+
+    def make(U0):
+        return nlc.MPPIDelay(
+            nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-" + env), d, nlc.noise_sigma(nu),
+            num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+            u_scale=A, U_init=U0,
+        )
+
+    check_command_steps(nlc, g, make)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "acrobot"])
+def test_mppi_generic_callables_match_fused(nlc, env):
+    """The external-callable path (reference contract: arbitrary closures) equals the fused path."""
+    g = np.load(f"{GOLD}/g3_nl_{env}.npz")
+    model = build_model(nlc, load_sd(g))
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    dyn, cost = nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-" + env)
+
+    def make(U0):
+        with torch.no_grad():
+            return nlc.MPPIDelay(
+                lambda s, a: dyn(s, a), lambda s, u: cost(s, u), d, nlc.noise_sigma(nu), num_samples=K, horizon=T,
+                device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0,
+            )
+
+    with torch.no_grad():
+        check_command_steps(nlc, g, make)
+
+
+def test_mppi_seeded_torch_noise_matches_oracle_class(nlc):
+    """Identical seeds => identical noise stream as the reference-style oracle (ctor draw + command draws)."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+
+    env, K, T, A = "oderl-pendulum", 96, 6, 2.0
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    torch.manual_seed(42)
+    ref = omppi.MPPIOracle(lambda s, w: oenvs.ORACLE_DYNAMICS[env](s, w, ts, 1), oenvs.RUNNING_COST[env], 3,
+                           nlc.noise_sigma(1), K, T, 1.0, torch.tensor(-A), torch.tensor(A), A)
+    state = oenvs.initial_state(env)
+    ab = torch.zeros(4, 1, dtype=torch.float64)
+    ref_actions = [ref.command(state, ab).clone() for _ in range(3)]
+    torch.manual_seed(42)
+    mine = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 3, nlc.noise_sigma(1), K, T, "cpu",
+                         lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+    for a_ref in ref_actions:
+        np.testing.assert_allclose(mine.command(state, ab).numpy(), a_ref.numpy(), **TOL)
+    mine.reset()
+    assert mine.U.shape == (T, 1)
+
+
+def test_mppi_options_null_action_abs_cost_per_sample_state(nlc):
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+
+    env, K, T, A, nu, nx = "oderl-acrobot", 80, 5, 5.0, 2, 6  # K not a multiple of 64
+    torch.manual_seed(1)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.3
+    raw = torch.randn(K, T, nu, dtype=torch.float64)
+    states0 = torch.stack([oenvs.initial_state(env, s) for s in range(K)])
+    ab = torch.randn(4, nu, dtype=torch.float64)
+    sig = nlc.noise_sigma(nu)
+    mine = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 2), nlc.EnvCost(env), nx, sig, K, T, "cpu", lambda_=0.7,
+                         u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.roll(U0, 1, 0),
+                         u_per_command=2, sample_null_action=True, noise_abs_cost=True)
+    # U_init rolled by +1 so that command()'s roll(-1) restores rows 0..T-2 of U0 ... except the last row,
+    # which becomes u_init = 0: give the oracle the same starting point
+    U_start = torch.roll(U0, 1, 0)
+    ref = omppi.mppi_command(U_start.clone(), states0, ab, raw.clone(),
+                             lambda s, w: oenvs.ORACLE_DYNAMICS[env](s, w, ts, 2), oenvs.RUNNING_COST[env], nx,
+                             torch.inverse(sig), 0.7, A, torch.tensor(-A), torch.tensor(A), sample_null_action=True,
+                             noise_abs_cost=True, u_per_command=2)
+    mine.noise_dist = type("Replay", (), {"sample": staticmethod(lambda shape: raw)})()
+    act = mine.command(states0, ab)
+    assert act.shape == (2, nu)
+    np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), **TOL)
+    np.testing.assert_allclose(mine.cost_total.numpy(), ref["cost_total"].numpy(), **TOL)
+    np.testing.assert_allclose(mine.omega.numpy(), ref["omega"].numpy(), **TOL)
+    assert torch.all(mine.perturbed_action[-1] == 0)
+
+
+def test_mppi_philox_noise_statistics_and_shard_invariance(nlc):
+    """Device RNG: N(0, Sigma) moments, determinism in (seed, command index), and K-shard invariance."""
+    env, K, T, A, nu = "oderl-acrobot", 4096, 10, 5.0, 2
+    sig = nlc.noise_sigma(nu)
+
+    def planner(**kw):
+        return nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 0), nlc.EnvCost(env), 6, sig, K, T, "cuda", lambda_=1.0,
+                             u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=7, **kw)
+
+    st, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    a = planner()
+    a.command(st, ab)
+    eps = a.noise.cpu().reshape(-1, nu)  # no bounds => noise is the raw draw
+    assert abs(float(eps.mean())) < 0.02
+    cov = (eps.T @ eps) / eps.shape[0]
+    np.testing.assert_allclose(cov.numpy(), sig.numpy(), atol=0.03)
+    kurt = float((eps[:, 0] ** 4).mean())
+    assert abs(kurt - 3.0) < 0.15
+    b = planner()
+    b.command(st, ab)
+    assert torch.equal(a.noise, b.noise)
+    # a shard configured with k_offset draws exactly its slice of the global stream
+    half = planner()
+    half.K_local, half.k_offset = K // 2, K // 2
+    half.command(st, ab)
+    assert torch.equal(half.noise, a.noise[K // 2 :])
+    # the device-generated noise fed back through the CPU oracle reproduces the device result
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    ref = omppi.mppi_command(torch.zeros(T, nu, dtype=torch.float64), st, ab, a.noise.cpu().clone(),
+                             lambda s, w: oenvs.ORACLE_DYNAMICS[env](s, w, ts, 0), oenvs.RUNNING_COST[env], 6,
+                             torch.inverse(sig), 1.0, A)
+    np.testing.assert_allclose(a.cost_total.cpu().numpy(), ref["cost_total"].numpy(), **TOL)
+    np.testing.assert_allclose(a.U.cpu().numpy(), ref["U"].numpy(), **TOL)
+
+
+def test_mppi_two_shards_merge_equals_single(nlc):
+    """SURVEY §8e on one GPU: two K/2 planners' partials merged through nlc_mppi_finish == one K planner."""
+    import ctypes as C
+
+    from neurallaplacecontrol_amd import _lib
+
+    env, K, T, A = "oderl-cartpole", 256, 7, 3.0
+    sig = nlc.noise_sigma(1)
+    torch.manual_seed(0)
+    raw = torch.randn(K, T, 1, dtype=torch.float64)
+    U0 = torch.randn(T, 1, dtype=torch.float64) * 0.2
+    st, ab = nlc.initial_state(env), torch.randn(4, 1, dtype=torch.float64)
+
+    def planner(**kw):
+        return nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 5, sig, K, T, "cpu", lambda_=1.0,
+                             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(), **kw)
+
+    full = planner()
+    full.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+    a_full = full.command(st, ab)
+    shards = []
+    for r in range(2):
+        p = planner()
+        p.K_local, p.k_offset = K // 2, r * (K // 2)
+        p.G, p.rank = 1, 0  # run phase 1 stand-alone; merge by hand below
+        p.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+        p.command(st, ab)  # fills partials (and applies a local-only update we overwrite next)
+        shards.append(p)
+    gathered = torch.stack([s._partials for s in shards]).contiguous()
+    for r, p in enumerate(shards):
+        p.U = torch.roll(U0, -1, 0).index_fill(0, torch.tensor([T - 1]), 0.0)  # U after the shift, before update
+        act = torch.empty(1, dtype=torch.float64)
+        p.ctx.check(p.ctx.lib.nlc_mppi_finish(p.ctx.h, _lib.ptr(gathered), 2, r, C.byref(p._buf), _lib.ptr(act)))
+        np.testing.assert_allclose(act.numpy(), a_full.numpy(), **TOL)
+        np.testing.assert_allclose(p.U.numpy(), full.U.numpy(), **TOL)
+        np.testing.assert_allclose(p.omega.numpy(), full.omega[r * (K // 2) : (r + 1) * (K // 2)].numpy(), **TOL)
+
+
+# --------------------------------------------------------------------------- full size (BASELINE cfg2)
+def test_full_size_cfg2_properties(nlc):
+    """K=16384, T=40 cartpole, NL dynamics: a sample subset against the oracle + size-independent properties."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    env, K, T, A, d, nu = "oderl-cartpole", 16384, 40, 3.0, 5, 1
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    sig = nlc.noise_sigma(nu)
+    torch.manual_seed(0)
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cuda", lambda_=1.0,
+                         u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    U_before = mppi.U.cpu()
+    action = mppi.command(state, ab.cuda())
+    V, eps = mppi.perturbed_action.cpu(), mppi.noise.cpu()
+    # (1) sample subset through the oracle (same bounded actions): states after 40 sequential steps
+    idx = torch.arange(0, K, K // 128)
+    ts = torch.full((len(idx), 1), 0.05, dtype=torch.float64)
+    cost_ref, states_ref, _ = omppi.rollout(state, ab, V[idx], A, onl.nl_dynamics(sd, ts, S=17),
+                                            oenvs.RUNNING_COST[env], d)
+    np.testing.assert_allclose(mppi.states.cpu()[idx].numpy(), states_ref.numpy(), rtol=1e-7, atol=1e-7)
+    U_shift = torch.roll(U_before, -1, 0)
+    U_shift[-1] = 0
+    pc = torch.sum(U_shift * (eps[idx] @ torch.inverse(sig)), dim=(1, 2))
+    np.testing.assert_allclose(mppi.cost_total.cpu()[idx].numpy(), (cost_ref + pc).numpy(), rtol=1e-7, atol=1e-7)
+    # (2) properties over the whole population
+    assert torch.all(V.abs() <= 1.0 + 1e-15)  # bounded to [-A, A]/A
+    np.testing.assert_allclose((U_shift + eps).clamp(-1, 1).numpy(), V.numpy(), rtol=0, atol=1e-15)
+    omega = mppi.omega.cpu()
+    assert abs(float(omega.sum()) - 1.0) < 1e-12 and float(mppi.cost_total_non_zero.max()) == 1.0
+    cost = mppi.cost_total.cpu()
+    w = torch.exp(-(cost - cost.min()))
+    np.testing.assert_allclose(omega.numpy(), (w / w.sum()).numpy(), rtol=1e-10, atol=1e-16)
+    U_after = U_shift + torch.einsum("k,ktj->tj", omega, eps)
+    np.testing.assert_allclose(mppi.U.cpu().numpy(), U_after.numpy(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(action.cpu().numpy(), (U_after[0] * A).numpy(), rtol=1e-10, atol=1e-13)

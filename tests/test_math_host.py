@@ -1,0 +1,70 @@
+"""CPU: the bounded-range FP64 math used inside the HIP kernels (csrc/nlc_math.h), built with g++,
+against numpy/libm on dense grids.  The device build differs only in v_rcp_f64-based division."""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = tmp_path_factory.mktemp("mathhost") / "libmath_host.so"
+    subprocess.check_call(
+        ["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(out), os.path.join(HERE, "helpers", "math_host.cpp")]
+    )
+    return ctypes.CDLL(str(out))
+
+
+def call(lib, name, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    f = getattr(lib, name)
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    f(x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
+def ulp_err(y, ref):
+    return np.abs(y - ref) / np.spacing(np.abs(ref) + 1e-300)
+
+
+def test_tanh(lib):
+    x = np.concatenate([np.linspace(-40, 40, 400001), np.logspace(-300, 1, 20001), -np.logspace(-12, 1, 2001), [0.0]])
+    assert ulp_err(call(lib, "nlc_t_tanh", x), np.tanh(x)).max() <= 4
+
+
+def test_sigmoid(lib):
+    x = np.concatenate([np.linspace(-800, 800, 400001), np.logspace(-12, 2, 2001)])
+    ref = np.where(x >= 0, 1 / (1 + np.exp(-np.abs(x))), np.exp(-np.abs(x)) / (1 + np.exp(-np.abs(x))))
+    y = call(lib, "nlc_t_sigmoid", x)
+    ok = np.abs(x) < 700
+    assert ulp_err(y[ok], ref[ok]).max() <= 4
+    assert np.all(np.isfinite(y)) and np.all(y >= 0) and np.all(y <= 1)
+
+
+def test_exp(lib):
+    x = np.linspace(-700, 700, 400001)
+    assert ulp_err(call(lib, "nlc_t_exp", x), np.exp(x)).max() <= 2
+
+
+def test_sincos(lib):
+    x = np.concatenate([np.linspace(-2 * np.pi, 2 * np.pi, 800001), np.logspace(-300, 0, 3001)])
+    s, c = call(lib, "nlc_t_sin", x), call(lib, "nlc_t_cos", x)
+    # absolute accuracy 1e-16-ish everywhere (near the zeros relative error is limited by the 2-term pi/2)
+    assert np.abs(s - np.sin(x)).max() < 2.5e-16
+    assert np.abs(c - np.cos(x)).max() < 2.5e-16
+    small = np.abs(x) < 0.7
+    assert ulp_err(s[small], np.sin(x[small])).max() <= 2
+
+
+def test_tan(lib):
+    x = np.concatenate([np.linspace(0, np.pi / 2, 400001), np.logspace(-300, -1, 2001)])
+    y, ref = call(lib, "nlc_t_tan", x), np.tan(x)
+    ok = x < 1.5707
+    assert ulp_err(y[ok], ref[ok]).max() <= 4
+    assert np.all(np.abs(y[~ok] - ref[~ok]) <= 1e-11 * np.abs(ref[~ok]))
