@@ -12,7 +12,7 @@
  *   - "_dev" pointers are DEVICE pointers (HBM of the ctx's GPU; e.g. torch.Tensor.data_ptr()),
  *     "_host" pointers are host pointers.  All payloads are float64, row-major, contiguous.
  *   - the caller owns every pointer for the duration of the call only; the ctx copies what it keeps.
- *   - kernels are enqueued on the stream given to nlc_set_stream() (default: the ctx's own stream).
+ *   - kernels are enqueued on the stream given to nlc_set_stream() (until then: a stream the ctx created).
  *     Functions that return host data synchronise that stream before returning; the others are
  *     asynchronous with respect to the host, ordered on the stream.
  *   - a ctx is not thread-safe: one ctx per (process, device).  HIP is initialised lazily inside
@@ -64,7 +64,9 @@ int nlc_abi_version(void);
 int nlc_create(int device, nlc_ctx** out);
 void nlc_destroy(nlc_ctx* ctx);
 const char* nlc_last_error(const nlc_ctx* ctx); /* ctx may be NULL: error of the last failed nlc_create */
-int nlc_set_stream(nlc_ctx* ctx, void* hip_stream); /* hipStream_t; NULL restores the ctx's own stream */
+/* hipStream_t to enqueue on from now on, used as given: NULL is HIP's legacy default (null) stream, which
+ * is what torch.cuda.current_stream().cuda_stream reports for torch's default stream. */
+int nlc_set_stream(nlc_ctx* ctx, void* hip_stream);
 int nlc_synchronize(nlc_ctx* ctx);
 /* device properties the bench reports next to its roofline numbers */
 int nlc_device_info(nlc_ctx* ctx, char* name, int name_len, int* num_cus, int* clock_mhz, double* hbm_gib);

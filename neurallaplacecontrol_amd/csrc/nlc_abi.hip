@@ -255,7 +255,7 @@ extern "C" const char* nlc_last_error(const nlc_ctx* c) { return c ? c->err.c_st
 
 extern "C" int nlc_set_stream(nlc_ctx* c, void* s) {
   if (!c) return NLC_ERR_BAD_ARG;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;
   return NLC_OK;
 }
 
