@@ -25,6 +25,7 @@ from torch.distributions.multivariate_normal import MultivariateNormal
 
 from .. import _lib
 from ..envs import EnvCost, NLDynamics, OracleDynamics
+from ..sharding import gather_partials, shard_range, slice_noise
 
 
 def _per_dim(v, nu, name):
@@ -137,10 +138,7 @@ class MPPIDelay:
             self.G, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         else:
             self.G, self.rank = 1, 0
-        if self.K % self.G:
-            raise ValueError(f"num_samples={self.K} must be divisible by the group size {self.G}")
-        self.K_local = self.K // self.G
-        self.k_offset = self.rank * self.K_local
+        self.k_offset, self.K_local = shard_range(self.K, self.G, self.rank)
 
         self.fused = (
             isinstance(dynamics, (NLDynamics, OracleDynamics))
@@ -300,7 +298,7 @@ class MPPIDelay:
             if not rng:
                 # K x T x nu draw on `device`, same generator consumption as the reference (:319)
                 raw = self.noise_dist.sample((self.K, self.T))
-                self._noise.copy_(raw[self.k_offset : self.k_offset + self.K_local].reshape(self.K_local, self.T, self.nu))
+                self._noise.copy_(slice_noise(raw, self.k_offset, self.K_local).reshape(self.K_local, self.T, self.nu))
             if self.fused:
                 if ab.shape[1] != self.nu:
                     raise ValueError("action_buffer must have nu columns")
@@ -315,10 +313,7 @@ class MPPIDelay:
                 ctx.check(lib.nlc_mppi_weights(ctx.h, C.byref(self._buf)))
             self._commands += 1
             if self.G > 1:
-                import torch.distributed as dist
-
-                dist.all_gather_into_tensor(self._gathered.view(-1), self._partials, group=self.pg)
-                gathered = self._gathered
+                gathered = gather_partials(self._partials, self._gathered, self.pg)
             else:
                 gathered = self._partials
             act = torch.empty(self.u_per_command * self.nu, dtype=torch.float64)

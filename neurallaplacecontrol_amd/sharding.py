@@ -1,0 +1,32 @@
+"""Host-side logic of the K-sharded planner: which samples a rank owns and the one
+collective per command().  Kept free of GPU calls so the world_size > 1 path is testable with gloo on CPU."""
+
+import torch
+
+
+def shard_range(K, world_size, rank):
+    """Rank r of G owns global samples [r*K/G, (r+1)*K/G); K must divide evenly (all BASELINE configs do)."""
+    if K % world_size:
+        raise ValueError(f"num_samples={K} must be divisible by the group size {world_size}")
+    k_local = K // world_size
+    return rank * k_local, k_local
+
+
+def partial_width(T, nu):
+    """(beta_r, eta_r, S_r[t, j]) -> 2 + T*nu doubles per rank (336 B at T=40, nu=1)."""
+    return 2 + T * nu
+
+
+def gather_partials(partials, gathered, group):
+    """One all-gather of every rank's (2 + T*nu) partial vector; RCCL over xGMI on GPUs, gloo in CPU tests."""
+    import torch.distributed as dist
+
+    assert gathered.shape == (dist.get_world_size(group), partials.numel())
+    dist.all_gather_into_tensor(gathered.view(-1), partials.contiguous(), group=group)
+    return gathered
+
+
+def slice_noise(raw, k_offset, k_local):
+    """Every rank draws the SAME (K, T, nu) tensor from the same seed and keeps its slice, so the sharded
+    run consumes the torch generator exactly like the single-GPU / reference run."""
+    return raw[k_offset : k_offset + k_local]

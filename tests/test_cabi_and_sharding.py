@@ -1,0 +1,161 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nlc.h declares; entry points fail loudly
+without a GPU; and the world_size-2 sharded planner path (host logic + collective) with gloo."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from neurallaplacecontrol_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "neurallaplacecontrol_amd", "csrc"), "-j", "8"])
+    return _lib.load_library()
+
+
+def test_header_symbols_exported(lib):
+    from neurallaplacecontrol_amd import _lib
+
+    hdr = open(os.path.join(REPO, "include", "nlc.h")).read()
+    declared = sorted(set(re.findall(r"\b(nlc_[a-z_A-Z0-9]+)\s*\(", hdr)))
+    assert declared == sorted(_lib.SYMBOLS), "include/nlc.h and _lib.SYMBOLS disagree"
+    for name in declared:
+        assert hasattr(lib, name), f"libnlc_hip.so does not export {name}"
+    assert lib.nlc_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors must have the sizes the C compiler gives the header structs."""
+    from neurallaplacecontrol_amd import _lib
+
+    src = r"""
+    #include <stdio.h>
+    #include "nlc.h"
+    int main(){ printf("%zu %zu %zu %zu\n", sizeof(nlc_ilt_desc), sizeof(nlc_model_desc), sizeof(nlc_mppi_desc), sizeof(nlc_mppi_buffers)); return 0; }
+    """
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), "-o", os.path.join(td, "s"), os.path.join(td, "s.c")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
+    assert sizes == [C.sizeof(_lib.IltDesc), C.sizeof(_lib.ModelDesc), C.sizeof(_lib.MppiDesc), C.sizeof(_lib.MppiBuffers)]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu(lib):
+    from neurallaplacecontrol_amd import _lib
+
+    h = C.c_void_p()
+    rc = lib.nlc_create(0, C.byref(h))
+    assert rc != 0 and not h.value
+    assert b"" != lib.nlc_last_error(None)
+    import neurallaplacecontrol_amd as nlc
+
+    with pytest.raises(RuntimeError):
+        nlc.ilt_reconstruct(torch.zeros(1, 1, 17).double(), torch.zeros(1, 1, 17).double(), torch.ones(1).double())
+    with pytest.raises(RuntimeError):
+        nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum"), nlc.EnvCost("oderl-pendulum"), 3, nlc.noise_sigma(1), 8, 4)
+    with pytest.raises(_lib.NlcError):
+        _lib.Ctx(0)
+
+
+def test_product_does_not_import_oracle():
+    """The product path must not route through the CPU oracle (it is test infrastructure)."""
+    pkg = os.path.join(REPO, "neurallaplacecontrol_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_bench_weights_equal_oracle_synthetic_weights():
+    """bench.py's product-side synthetic model == oracle.make_synthetic_state_dict(tame=True) == reference ctor + shift."""
+    sys.path.insert(0, REPO)
+    import bench
+    from oracle import nl_model as onl
+
+    model = bench.synthetic_state_dict(5, 1, 17)
+    st = onl.ENV_STATS["oderl-cartpole"]
+    ref = onl.make_synthetic_state_dict(0, 5, 1, 128, 17, st["state_std"], [1.5], tame=True)
+    sd = model.state_dict()
+    for k, v in ref.items():
+        assert torch.equal(sd[k].to(torch.float64), v), k
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from neurallaplacecontrol_amd.sharding import shard_range, gather_partials, slice_noise, partial_width
+from oracle import envs as oenvs, mppi as omppi
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+env, K, T, A, nu, nx = "oderl-pendulum", 64, 6, 2.0, 1, 3
+torch.manual_seed(123)                     # same seed on every rank -> same global draw
+U = torch.randn(T, nu, dtype=torch.float64) * 0.3
+raw = torch.randn(K, T, nu, dtype=torch.float64)
+state, ab = oenvs.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+sig_inv = torch.ones(1, 1, dtype=torch.float64)
+k0, kl = shard_range(K, world, rank)
+ts = torch.full((kl, 1), 0.05, dtype=torch.float64)
+dyn = lambda s, w: oenvs.ORACLE_DYNAMICS[env](s, w, ts, 1)
+# per-shard phase 1 (what nlc_mppi_rollout does on each GPU), with the oracle as the arithmetic
+out = omppi.mppi_command(U.clone(), state, ab, slice_noise(raw, k0, kl).clone(), dyn, oenvs.RUNNING_COST[env], nx,
+                         sig_inv, 1.0, A, torch.tensor(-A), torch.tensor(A))
+partials = omppi.shard_partials(out["cost_total"], out["noise"])
+assert partials.numel() == partial_width(T, nu)
+gathered = gather_partials(partials, torch.empty(world, partials.numel(), dtype=torch.float64), dist.group.WORLD)
+beta, eta, dU = omppi.merge_partials(gathered)
+Ush = torch.roll(U, -1, 0); Ush[-1] = 0
+U_new = Ush + dU.view(T, nu)
+torch.save(dict(U=U_new, beta=beta, eta=eta), os.path.join(sys.argv[2], f"r{rank}.pt"))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_sharded_command(tmp_path):
+    """world_size=2 over gloo: per-shard rollout + all-gather of (beta, eta, S) + merge == unsharded command."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29531", str(script), REPO, str(tmp_path)],
+        env=env, timeout=300,
+    )
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["U"], r1["U"]), "ranks disagree after the merge"
+    # unsharded reference
+    envn, K, T, A, nu, nx = "oderl-pendulum", 64, 6, 2.0, 1, 3
+    torch.manual_seed(123)
+    U = torch.randn(T, nu, dtype=torch.float64) * 0.3
+    raw = torch.randn(K, T, nu, dtype=torch.float64)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    full = omppi.mppi_command(U.clone(), oenvs.initial_state(envn), torch.zeros(4, nu, dtype=torch.float64), raw,
+                              lambda s, w: oenvs.ORACLE_DYNAMICS[envn](s, w, ts, 1), oenvs.RUNNING_COST[envn], nx,
+                              torch.ones(1, 1, dtype=torch.float64), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    np.testing.assert_allclose(r0["U"].numpy(), full["U"].numpy(), rtol=1e-12, atol=1e-14)
+    assert float(r0["beta"]) == float(full["beta"])
+    np.testing.assert_allclose(float(r0["eta"]), float(full["eta"]), rtol=1e-12)
+
+
+def test_shard_range():
+    from neurallaplacecontrol_amd.sharding import shard_range
+
+    assert [shard_range(16384, 8, r) for r in (0, 7)] == [(0, 2048), (14336, 2048)]
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 0)
