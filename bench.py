@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--samples", type=int, default=K_SAMPLES,
+                    help="override K (experiments only; the headline metric is quoted at the default 16384)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -133,15 +135,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     pg = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run even a 1-rank job goes through RCCL
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = dist.group.WORLD
+    K_total = args.samples
 
     d, nu = 5, 1
     model = synthetic_state_dict(d, nu, S_TERMS).to(f"cuda:{local}")
     sd_cpu = {k: v.detach().cpu().to(torch.float64) for k, v in model.state_dict().items()}
     planner = nlc.MPPIDelay(
-        nlc.NLDynamics(model, 0.05), nlc.EnvCost(ENV), d, nlc.noise_sigma(nu), num_samples=K_SAMPLES, horizon=HORIZON,
+        nlc.NLDynamics(model, 0.05), nlc.EnvCost(ENV), d, nlc.noise_sigma(nu), num_samples=K_total, horizon=HORIZON,
         device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A_HIGH), u_max=torch.tensor(A_HIGH), u_scale=A_HIGH,
         noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(HORIZON, nu, dtype=torch.float64),
     )
@@ -156,7 +159,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +175,7 @@ def main():
     elapsed = time.perf_counter() - t0
     planner.ctx.profile(False)
     prof = planner.ctx.profile_read()
-    if world > 1:
+    if pg is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -199,18 +202,24 @@ def main():
         p = ictx.profile_read()["ilt_fourier_kernel"]
         ms = p["total_ms"] / p["launches"]
         nbytes = N * (2 * d * S_TERMS + d) * 8
+        traffic, traffic_src = None, None
+        pmc = os.path.join(REPO, "profiles", "r1_pmc_ilt.json")
+        if os.path.exists(pmc):  # PMC passes cannot run inside this process: separate rocprofv3 --pmc runs
+            pj = json.load(open(pmc))
+            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/r1_pmc_ilt.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction, same N)"
         ilt = dict(bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                   frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="ilt_fourier_kernel",
+                   frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                   algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
                    avg_launch_ms=ms, points=N, bytes_per_point=(2 * d * S_TERMS + d) * 8)
         del theta, phi
 
     if rank != 0:
-        if world > 1:
+        if pg is not None:
             dist.destroy_process_group()
         return
 
     kernels = {k: dict(avg_ms=v["total_ms"] / max(v["launches"], 1), launches=v["launches"]) for k, v in prof.items()}
-    k_local = K_SAMPLES // world
+    k_local = K_total // world
     gru_flops = flops_gru_per_window(HIDDEN // 2, 4, ABUF) * k_local * HORIZON
     roll_flops = flops_rollout_per_sample_step(HIDDEN, 11) * k_local * HORIZON  # nt3 = 11 tiles for d=5, S=17
     gk = kernels.get("gru_encode_kernel", dict(avg_ms=float("nan")))
@@ -249,8 +258,10 @@ def main():
     )
     if cpu:
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+    if K_total != K_SAMPLES:
+        out["config"]["workload"] += f" -- EXPERIMENT with K={K_total}, not the headline configuration"
     print(json.dumps(out))
-    if world > 1:
+    if pg is not None:
         dist.destroy_process_group()
 
 

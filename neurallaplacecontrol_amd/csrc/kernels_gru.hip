@@ -6,60 +6,56 @@
 // from L2; the 16 windows are the B/D columns.  The encoder input does not depend on the state
 // (SURVEY F6), so the planner runs this ONCE over all K*T windows instead of inside the horizon loop.
 //
-// Roofline: FP64 MFMA bound.  Per 16 windows: 4*MT (input) + 3*KS*MT (l0 hh) + 4*KS*MT (l1 ih)
-// + 3*KS*MT (l1 hh) + KS (head) MFMAs of 2048 flop; HBM traffic is nu*8 B in + 16 B out per window.
+// Roofline: FP64 MFMA bound.  Per 16 windows (B = 4): B*MT (input) + (B-1)*KS*MT (l0 hh) + B*KS*MT (l1 ih)
+// + (B-1)*KS*MT (l1 hh) + KS (head) = 1984 MFMAs of 2048 flop; HBM traffic is nu*8 B in + 16 B out per window.
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
 namespace nlc {
 
-// Hidden-side GEMM of one GRU step: r,z rows of W_hh accumulate into acc (joining the input side),
-// n rows into accn so that r * (W_hn h + b_hn) can be formed afterwards.
-template <int GT, int KS>
-__device__ __forceinline__ void gru_hidden_gemm(v4d (&acc)[3 * GT], v4d (&accn)[GT], const double* __restrict__ whp,
-                                                int lane, const v4d (&h)[GT]) {
-  constexpr int MT = 3 * GT;
-  double a_cur[MT], a_nxt[MT];
-  gptr p = opaque(whp);
+// Gate GEMMs are processed in CHUNKS of one 16-feature tile per gate (r_j, z_j, n_j): only four accumulator
+// tiles are live at a time instead of sixteen, which keeps the kernel under 256 VGPRs -> two waves per SIMD,
+// so one wave's gate transcendentals (FP64 VALU) overlap the other wave's MFMAs.
+// Chunk-packed weights: Wc[((j*KS + ks)*3 + g)*64 + lane], g in {r, z, n}: row g*G + 16 j + (lane & 15).
+template <int KS, typename BF>
+__device__ __forceinline__ void chunk_gemm(v4d& c0, v4d& c1, v4d& c2, const double* __restrict__ wc, int lane, BF bfrag) {
+  double a_cur[3], a_nxt[3];
+  gptr p = opaque(wc);
 #pragma unroll
-  for (int m = 0; m < MT; ++m) a_cur[m] = p[m * 64 + lane];
+  for (int g = 0; g < 3; ++g) a_cur[g] = p[g * 64 + lane];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
-      p = opaque(p + MT * 64);
+      p = opaque(p + 3 * 64);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a_nxt[m] = p[m * 64 + lane];
+      for (int g = 0; g < 3; ++g) a_nxt[g] = p[g * 64 + lane];
     }
-    const double b = h[ks >> 2][ks & 3];
+    const double b = bfrag(ks);
+    c0 = mfma(a_cur[0], b, c0);
+    c1 = mfma(a_cur[1], b, c1);
+    c2 = mfma(a_cur[2], b, c2);
 #pragma unroll
-    for (int m = 0; m < 2 * GT; ++m) acc[m] = mfma(a_cur[m], b, acc[m]);
-#pragma unroll
-    for (int m = 0; m < GT; ++m) accn[m] = mfma(a_cur[2 * GT + m], b, accn[m]);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    for (int g = 0; g < 3; ++g) a_cur[g] = a_nxt[g];
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int GT>
-__device__ __forceinline__ void gru_gates(const v4d (&acc)[3 * GT], const v4d (&accn)[GT], v4d (&h)[GT]) {
+__device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d& ain, const v4d& ahn, const v4d& hold) {
+  v4d hnew;
 #pragma unroll
-  for (int j = 0; j < GT; ++j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double rg = m::sigmoid_d(acc[j][r]);
-      const double zg = m::sigmoid_d(acc[GT + j][r]);
-      const double ng = m::tanh_d(acc[2 * GT + j][r] + rg * accn[j][r]);
-      h[j][r] = (1.0 - zg) * ng + zg * h[j][r];
-    }
+  for (int r = 0; r < 4; ++r) {
+    const double rg = m::sigmoid_d(ar[r]);
+    const double zg = m::sigmoid_d(az[r]);
+    const double ng = m::tanh_d(ain[r] + rg * ahn[r]);
+    hnew[r] = (1.0 - zg) * ng + zg * hold[r];
   }
+  return hnew;
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void gru_encode_kernel(const GruArgs a) {
-  constexpr int GT = G / 16;   // tiles per gate
+__global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
+  constexpr int GT = G / 16;   // tiles per gate = chunks
   constexpr int KS = G / 4;    // k-steps over the hidden dimension
-  constexpr int MT = 3 * GT;   // gate tiles r|z|n
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, c = lane & 15;
   const int64_t w = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
@@ -79,7 +75,7 @@ __global__ __launch_bounds__(256) void gru_encode_kernel(const GruArgs a) {
     tt = (int)(wc - kk * a.T);
   }
 
-  v4d h0[GT], h1[GT];
+  v4d h0[GT], h1[GT], hn[GT];
 #pragma unroll
   for (int j = 0; j < GT; ++j) {
     h0[j] = splat(0.0);
@@ -103,32 +99,34 @@ __global__ __launch_bounds__(256) void gru_encode_kernel(const GruArgs a) {
     } else if (q == 3) {
       xin = 1.0;  // bias column of the packed W_ih0
     }
-
-    v4d acc[MT];   // r: 0..GT-1, z: GT..2GT-1, n(input part): 2GT..3GT-1
-    v4d accn[GT];  // n(hidden part): W_hn h + b_hn
-    // ---------------- layer 0
-    {
-      gptr wp = opaque(a.Wih0p);
+    // ---------------- layer 0: input side is one k-step (K = nin padded to 4, bias folded into column 3)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = mfma(wp[m * 64 + lane], xin, splat(0.0));
-#pragma unroll
-      for (int j = 0; j < GT; ++j) accn[j] = load_bias_tile(a.bhn0, j, q);
-      if (s > 0) gru_hidden_gemm<GT, KS>(acc, accn, a.Whh0p, lane, h0);
-      gru_gates<GT>(acc, accn, h0);
+    for (int j = 0; j < GT; ++j) {
+      gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
+      v4d ar = mfma(wp[lane], xin, splat(0.0));
+      v4d az = mfma(wp[64 + lane], xin, splat(0.0));
+      v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
+      v4d ahn = load_bias_tile(a.bhn0, j, q);
+      if (s > 0)
+        chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
+      hn[j] = gru_gates(ar, az, ain, ahn, h0[j]);
     }
+#pragma unroll
+    for (int j = 0; j < GT; ++j) h0[j] = hn[j];
     // ---------------- layer 1
-    {
 #pragma unroll
-      for (int j = 0; j < 2 * GT; ++j) acc[j] = load_bias_tile(a.brz1, j, q);
-#pragma unroll
-      for (int j = 0; j < GT; ++j) {
-        acc[2 * GT + j] = load_bias_tile(a.bin1, j, q);
-        accn[j] = load_bias_tile(a.bhn1, j, q);
-      }
-      gemm_acc<MT, KS>(acc, a.Wih1p, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
-      if (s > 0) gru_hidden_gemm<GT, KS>(acc, accn, a.Whh1p, lane, h1);
-      gru_gates<GT>(acc, accn, h1);
+    for (int j = 0; j < GT; ++j) {
+      v4d ar = load_bias_tile(a.brz1, j, q);
+      v4d az = load_bias_tile(a.brz1, GT + j, q);
+      v4d ain = load_bias_tile(a.bin1, j, q);
+      v4d ahn = load_bias_tile(a.bhn1, j, q);
+      chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
+      if (s > 0)
+        chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
+      hn[j] = gru_gates(ar, az, ain, ahn, h1[j]);
     }
+#pragma unroll
+    for (int j = 0; j < GT; ++j) h1[j] = hn[j];
   }
   // ---------------- linear_out (2 x g): rows 0,1 of one output tile
   v4d o[1];

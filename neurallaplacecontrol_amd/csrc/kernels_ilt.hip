@@ -90,21 +90,39 @@ __global__ __launch_bounds__(256) void ilt_fourier_kernel(const IltArgs a) {
     const int64_t rows_here = (rows_total - row0 < kIltRows) ? (rows_total - row0) : kIltRows;
     const int64_t elems = rows_here * S;
     const int64_t base = row0 * S;
-    // (r, k) of this thread's first element, then advanced by 256 elements per iteration
+    // (r, k) of this thread's first element, then advanced by 256 elements per iteration.  Loads are issued
+    // in batches of UB iterations before any arithmetic so each lane keeps 2*UB 8-byte loads in flight
+    // (one load pair per iteration leaves the HBM pipe latency-bound at ~3 TB/s).
     int r = threadIdx.x / S, k = threadIdx.x - r * S;
     const int dr = 256 / S, dk = 256 - dr * S;
-    for (int64_t e = threadIdx.x; e < elems; e += 256) {
-      const double theta = a.theta[base + e];
-      const double phi = a.phi[base + e];
-      const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
-      double sn, cs;
-      m::sincos_bounded(theta, &sn, &cs);
-      val[r * SP + k] = rad * (cw[k] * cs + sw[k] * sn);
-      r += dr;
-      k += dk;
-      if (k >= S) {
-        k -= S;
-        r += 1;
+    constexpr int UB = 6;
+    for (int64_t e0 = threadIdx.x; e0 < elems; e0 += 256 * UB) {
+      double th[UB], ph[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int64_t e = e0 + 256 * u;
+        th[u] = 0.0;
+        ph[u] = 0.0;
+        if (e < elems) {
+          th[u] = __builtin_nontemporal_load(a.theta + base + e);
+          ph[u] = __builtin_nontemporal_load(a.phi + base + e);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int64_t e = e0 + 256 * u;
+        if (e < elems) {
+          const double rad = m::tan_0_halfpi(ph[u] / 2.0 + kPi / 4.0);
+          double sn, cs;
+          m::sincos_bounded(th[u], &sn, &cs);
+          val[r * SP + k] = rad * (cw[k] * cs + sw[k] * sn);
+          r += dr;
+          k += dk;
+          if (k >= S) {
+            k -= S;
+            r += 1;
+          }
+        }
       }
     }
     __syncthreads();

@@ -137,21 +137,24 @@ __global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a,
   }
 }
 
-// pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r)
+// pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r).
+// One wavefront per output entry: lanes stride over the blocks, then a wave reduction.
 __global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
   const int TN = a.T * a.nu;
-  for (int i = threadIdx.x; i < 1 + TN; i += 256) {
-    double acc = 0.0;
-    for (int b = 0; b < a.nblk; ++b) acc += a.block_part[(int64_t)b * (1 + TN) + i];
-    a.partials[1 + i] = acc;
-  }
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= 1 + TN) return;
+  double acc = 0.0;
+  for (int b = lane; b < a.nblk; b += 64) acc += a.block_part[(int64_t)b * (1 + TN) + i];
+  acc = wave_sum(acc);
+  if (lane == 0) a.partials[1 + i] = acc;
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
   const int nmin = (int)((a.K + 255) / 256 < 256 ? (a.K + 255) / 256 : 256);
   hipLaunchKernelGGL(cost_min_kernel, dim3(nmin), dim3(256), 0, s, a);
   hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk), dim3(256), 0, s, a, nmin);
-  hipLaunchKernelGGL(weight_final_kernel, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(weight_final_kernel, dim3((1 + a.T * a.nu + 3) / 4), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -96,6 +96,9 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
     }
   }
   gemm_acc<HT, 2>(h1, n.W1p, lane, [&](int ks) { return ks == 0 ? p0 : p1; });
+  // Activations are applied as one batch of 32 independent tanh chains per layer.  (On gfx950 an FP64 MFMA
+  // holds the SIMD's VALU issue for its whole 64 cycles -- tools/ubench_f64.hip -- so interleaving the
+  // activation with the next layer's MFMAs buys nothing, while batching keeps the FP64 VALU latency hidden.)
 #pragma unroll
   for (int j = 0; j < HT; ++j)
 #pragma unroll

@@ -154,6 +154,20 @@ std::vector<double> pack_A(const double* W, int ldw, int K, const std::vector<in
       }
   return out;
 }
+// GRU gate matrices, chunk-packed: out[((j*KS + ks)*3 + g)*64 + lane] = W[g*G + 16 j + (lane & 15)][4 ks + (lane >> 4)]
+std::vector<double> pack_gru_chunked(const double* W, int ldw, int K, int G) {
+  const int GT = G / 16, KS = (K + 3) / 4;
+  std::vector<double> out((size_t)GT * KS * 3 * 64, 0.0);
+  for (int j = 0; j < GT; ++j)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int g = 0; g < 3; ++g)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = g * G + 16 * j + (lane & 15), col = 4 * ks + (lane >> 4);
+          if (col >= K) continue;
+          out[(((size_t)j * KS + ks) * 3 + g) * 64 + lane] = W[(size_t)row * ldw + col];
+        }
+  return out;
+}
 std::vector<int> identity_rows(int n) {
   std::vector<int> r(n);
   for (int i = 0; i < n; ++i) r[i] = i;
@@ -365,11 +379,10 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
     for (int j = 0; j < nin; ++j) Wih0b[(size_t)r * 4 + j] = Wih0[(size_t)r * nin + j];
     Wih0b[(size_t)r * 4 + 3] = bih0[r] + (r < 2 * g ? bhh0[r] : 0.0);
   }
-  const auto rows3g = identity_rows(3 * g);
-  const size_t o_Wih0 = ar.push(pack_A(Wih0b.data(), 4, 4, rows3g));
-  const size_t o_Whh0 = ar.push(pack_A(Whh0, g, g, rows3g));
-  const size_t o_Wih1 = ar.push(pack_A(Wih1, g, g, rows3g));
-  const size_t o_Whh1 = ar.push(pack_A(Whh1, g, g, rows3g));
+  const size_t o_Wih0 = ar.push(pack_gru_chunked(Wih0b.data(), 4, 4, g));
+  const size_t o_Whh0 = ar.push(pack_gru_chunked(Whh0, g, g, g));
+  const size_t o_Wih1 = ar.push(pack_gru_chunked(Wih1, g, g, g));
+  const size_t o_Whh1 = ar.push(pack_gru_chunked(Whh1, g, g, g));
   const size_t o_Wo = ar.push(pack_A(Wo, g, g, identity_rows(2)));
   std::vector<double> bhn0(bhh0 + 2 * g, bhh0 + 3 * g), brz1(2 * g), bin1(bih1 + 2 * g, bih1 + 3 * g),
       bhn1(bhh1 + 2 * g, bhh1 + 3 * g);

@@ -43,18 +43,22 @@ __device__ __forceinline__ void gemm_acc(v4d (&acc)[MT], const double* __restric
   gptr p = opaque(Wp);
 #pragma unroll
   for (int m = 0; m < MT; ++m) a_cur[m] = p[m * 64 + lane];
+  // B fragments are produced one k-step ahead as well: when bfrag() is an activation (tanh of the previous
+  // layer's accumulator) its VALU work sits next to independent MFMAs and hides in their shadow
+  double b_cur = bfrag(0), b_nxt = 0.0;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
       p = opaque(p + MT * 64);
 #pragma unroll
       for (int m = 0; m < MT; ++m) a_nxt[m] = p[m * 64 + lane];
+      b_nxt = bfrag(ks + 1);
     }
-    const double b = bfrag(ks);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = mfma(a_cur[m], b, acc[m]);
+    for (int m = 0; m < MT; ++m) acc[m] = mfma(a_cur[m], b_cur, acc[m]);
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    b_cur = b_nxt;
     // keep the scheduler from hoisting every k-step's fragment loads to the top
     __builtin_amdgcn_sched_barrier(0);
   }

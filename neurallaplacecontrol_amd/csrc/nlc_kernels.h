@@ -47,10 +47,11 @@ struct GruArgs {
   int B, nin;
   double mean[NLC_MAX_NIN], std[NLC_MAX_NIN];
   // fragment-packed weights (device)
-  const double* Wih0p;  // [1][MT][64]   k = input dims, k == 3 carries the folded bias
-  const double* Whh0p;  // [KS][MT][64]
-  const double* Wih1p;  // [KS][MT][64]
-  const double* Whh1p;  // [KS][MT][64]
+  // gate matrices are chunk-packed [GT chunks][KS][3 gates r,z,n][64] (see kernels_gru.hip)
+  const double* Wih0p;  // KS = 1: k = input dims, k == 3 carries the folded bias
+  const double* Whh0p;
+  const double* Wih1p;
+  const double* Whh1p;
   const double* Wop;    // [KS][1][64]   linear_out, rows 0..1
   const double* bhn0;   // (g)   b_hn layer 0
   const double* brz1;   // (2g)  b_ih + b_hh, gates r,z, layer 1

@@ -146,6 +146,9 @@ class MPPIDelay:
             and terminal_state_cost is None
             and not step_dependent_dynamics
             and not encode_obs_time
+            # the fused rollout kernel implements the Fourier ILT; a de Hoog model runs on the generic path
+            # (HIP GRU + PyTorch-ROCm MLP + HIP de Hoog ILT per horizon step)
+            and not (isinstance(dynamics, NLDynamics) and dynamics.model.ilt_algorithm != "fourier")
         )
         if isinstance(dynamics, OracleDynamics) and not self.fused:
             raise NotImplementedError("OracleDynamics needs an EnvCost running_cost and the default rollout options")
@@ -223,7 +226,7 @@ class MPPIDelay:
         self._actions = mk(K, T, nu) if self.store_rollouts else None
         self._cost_total, self._cost_nz, self._omega = mk(K), mk(K), mk(K)
         self._partials = mk(2 + T * nu)
-        self._gathered = mk(self.G, 2 + T * nu) if self.G > 1 else None
+        self._gathered = mk(self.G, 2 + T * nu) if self.pg is not None else None
         self._ws = torch.empty(self.ctx.lib.nlc_mppi_workspace_bytes(self.ctx.h) // 8, dtype=torch.float64, device=dev)
         b = _lib.MppiBuffers()
         b.noise, b.perturbed = self._noise.data_ptr(), self._perturbed.data_ptr()
@@ -312,7 +315,7 @@ class MPPIDelay:
                 self._external_rollout(st, per_sample, ab)
                 ctx.check(lib.nlc_mppi_weights(ctx.h, C.byref(self._buf)))
             self._commands += 1
-            if self.G > 1:
+            if self.pg is not None:  # also for a 1-rank group: the collective path is the same code
                 gathered = gather_partials(self._partials, self._gathered, self.pg)
             else:
                 gathered = self._partials
