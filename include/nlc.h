@@ -161,6 +161,7 @@ typedef struct {
   double* cost_nz;    /* (K) out: exp(-(cost-beta)/lambda) */
   double* omega;      /* (K) out: cost_nz/eta, may be NULL */
   double* partials;   /* (2+T*nu) out: this shard's (beta_r, eta_r, S_r[t,j]) */
+  double* action;     /* (u_per_command*nu) out: the returned action, on the device; may be NULL */
   void* workspace;    /* nlc_mppi_workspace_bytes() bytes of scratch */
 } nlc_mppi_buffers;
 
@@ -181,7 +182,8 @@ int nlc_mppi_rollout(nlc_ctx* ctx, const double* state_host, int state_per_sampl
 int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
 /* Phase 2: merge G shard partials (gathered_dev: (G, 2+T*nu); pass buf->partials and G=1 on one GPU),
  * omega, U[t] += sum_k omega_k noise[k,t] (:210-216) and return action = U[:u_per_command]*u_scale
- * (:217-224) into action_host (u_per_command*nu).  Synchronises. */
+ * (:217-224) into action_host (u_per_command*nu) -- synchronises the stream -- and/or into buf->action on
+ * the device.  With action_host == NULL nothing is copied back and the call does not synchronise. */
 int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
                     double* action_host);
 

@@ -111,6 +111,7 @@ class MppiBuffers(C.Structure):
         ("cost_nz", C.c_void_p),
         ("omega", C.c_void_p),
         ("partials", C.c_void_p),
+        ("action", C.c_void_p),
         ("workspace", C.c_void_p),
     ]
 

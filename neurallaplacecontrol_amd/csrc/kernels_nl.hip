@@ -206,6 +206,180 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
   if (valid && q == 0) a.cost_total[k] = cost + pcost;
 }
 
+// ------------------------------------------------------------------ latency-split rollout (small K per GPU)
+// nl_rollout_kernel gives every wavefront a whole 16-sample tile, which fills the chip only when K/16 >= 1024
+// wavefronts.  When the population is sharded over several GPUs (K/G = 2048 at 8 GPUs) most SIMDs would idle
+// while 40 strictly sequential horizon steps run at single-wave speed.  Here ONE workgroup (4 waves = the 4
+// SIMDs of a CU) owns the 16-sample tile and splits every layer's OUTPUT tiles over its waves; the full
+// activation vector is exchanged through LDS ([k-step][lane] images, conflict-free ds_read_b64/ds_write_b64),
+// three barriers per horizon step.  Per-step latency drops ~4x; total MFMA work is unchanged.
+template <int HT, int NT3>
+__global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs a) {
+  constexpr int KS = HT * 4;           // k-steps over the hidden dimension
+  constexpr int TW = HT / 4;           // layer-1/2 output tiles per wave
+  constexpr int NTW = (NT3 + 3) / 4;   // layer-3 output tiles per wave (tile j = wave + 4 i)
+  __shared__ double H1[KS * 64], H2[KS * 64], AX[4 * 2 * 64];
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = (int64_t)blockIdx.x * 16 + c;
+  const bool valid = k < a.K;
+  const int64_t kc = valid ? k : a.K - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
+  const double* st = a.state0 + (a.state_per_sample ? kc * d : 0);
+  if (i0 < d) {
+    x0 = st[i0];
+    m0 = n.state_mean[i0];
+    s0 = n.state_std[i0];
+  }
+  if (i1 < d) {
+    x1 = st[i1];
+    m1 = n.state_mean[i1];
+    s1 = n.state_std[i1];
+  }
+  const double Tt = n.scale * a.tn;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double factor = exp(gamma * a.tn) / Tt;
+  // this wave's layer-3 tiles (clamped: a wave with fewer tiles recomputes the last one and drops it)
+  int j3[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) j3[i] = (wv + 4 * i < NT3) ? wv + 4 * i : NT3 - 1;
+
+  double cost = 0.0, pcost = 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    const double* pa = a.pa + (kc * a.T + t) * 2;
+    const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+    const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+    // ---- layer 1: output tiles TW*wv .. TW*wv+TW-1
+    {
+      v4d acc[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b1, TW * wv + i, q);
+      gptr p = opaque(n.W1p + (size_t)TW * wv * 64);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const double b = ks == 0 ? p0 : p1;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = mfma(p[(ks * HT + i) * 64 + lane], b, acc[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H1[(4 * (TW * wv + i) + r) * 64 + lane] = m::tanh_d(acc[i][r]);
+    }
+    __syncthreads();
+    // ---- layer 2
+    {
+      v4d acc[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b2, TW * wv + i, q);
+      gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
+      double a_cur[TW], a_nxt[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
+      double b_cur = H1[lane], b_nxt = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          p = opaque(p + HT * 64);
+#pragma unroll
+          for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
+          b_nxt = H1[(ks + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
+#pragma unroll
+        for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
+        b_cur = b_nxt;
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H2[(4 * (TW * wv + i) + r) * 64 + lane] = m::tanh_d(acc[i][r]);
+    }
+    __syncthreads();
+    // ---- layer 3 (own tiles) + sphere->complex + partial ILT sum
+    v4d ax = splat(0.0);
+    {
+      v4d o[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile(n.b3p, j3[i], q);
+      gptr p = opaque(n.W3p);
+      double a_cur[NTW], a_nxt[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
+      double b_cur = H2[lane], b_nxt = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          p = opaque(p + NT3 * 64);
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
+          b_nxt = H2[(ks + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
+        b_cur = b_nxt;
+      }
+      gptr cp = opaque(n.Cp);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        if (wv + 4 * i < NT3) {  // wave-uniform
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int g = 2 * j3[i] + r;
+            const double theta = m::tanh_d(o[i][r]) * kPi;
+            const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
+            const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
+            double sn, cs;
+            m::sincos_bounded(theta, &sn, &cs);
+            const double trig = (g < n.n_even_groups) ? cs : sn;
+            ax = mfma(cp[g * 64 + lane], rad * trig, ax);
+          }
+        }
+      }
+    }
+    AX[(wv * 2 + 0) * 64 + lane] = ax[0];
+    AX[(wv * 2 + 1) * 64 + lane] = ax[1];
+    __syncthreads();
+    // every wave forms the same full sums (fixed order) and keeps its own copy of the state
+    const double ax0 = ((AX[0 * 64 + lane] + AX[2 * 64 + lane]) + AX[4 * 64 + lane]) + AX[6 * 64 + lane];
+    const double ax1 = ((AX[1 * 64 + lane] + AX[3 * 64 + lane]) + AX[5 * 64 + lane]) + AX[7 * 64 + lane];
+    if (i0 < d) x0 = x0 + factor * ax0;
+    if (i1 < d) x1 = x1 + factor * ax1;
+    if (wv == 0) {
+      if (valid && a.states != nullptr) {
+        double* so = a.states + (k * a.T + t) * d;
+        if (i0 < d) so[i0] = x0;
+        if (i1 < d) so[i1] = x1;
+      }
+      double xs[NLC_MAX_D];
+#pragma unroll
+      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+      double u[NLC_MAX_NU] = {0.0, 0.0};
+      double pc = 0.0;
+      for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(kc * a.T + t) * a.nu + j];
+      for (int j = 0; j < a.nu; ++j) {
+        double acj = 0.0;
+        for (int i = 0; i < a.nu; ++i) {
+          double e = a.noise[(kc * a.T + t) * a.nu + i];
+          if (a.noise_abs_cost) e = fabs(e);
+          acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+        }
+        pc += a.U[t * a.nu + j] * acj;
+      }
+      cost += running_cost(a.env, xs, u, a.nu);
+      pcost += pc;
+    }
+  }
+  if (wv == 0 && valid && q == 0) a.cost_total[k] = cost + pcost;
+}
+
 // ------------------------------------------------------------------ single model forward, per-sample t
 template <int HT, int NT3>
 __global__ __launch_bounds__(256) void nl_forward_kernel(const ForwardArgs a) {
@@ -245,9 +419,26 @@ int nl_pick_nt3(int need) {
   return -1;
 }
 
-hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s) {
+hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s, int force_variant) {
   if (a.K <= 0) return hipSuccess;
   if (a.net.h != 128) return hipErrorInvalidValue;
+  // one wave per 16-sample tile fills the 1024 SIMDs only for K >= 16384; below that, split the tile over
+  // the 4 waves of a workgroup (force_variant: 0 auto, 1 wave-per-tile, 2 split)
+  const bool split = force_variant == 2 || (force_variant == 0 && a.K <= 8192);
+  if (split) {
+    const unsigned g16 = (unsigned)((a.K + 15) / 16);
+    switch (a.net.nt3) {
+#define X(N)                                                                                \
+  case N:                                                                                   \
+    hipLaunchKernelGGL((nl_rollout_split_kernel<8, N>), dim3(g16), dim3(256), 0, s, a); \
+    break;
+      NLC_FOR_NT3(X)
+#undef X
+      default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   const unsigned grid = (unsigned)((a.K + 63) / 64);
   switch (a.net.nt3) {
 #define X(N)                                                                          \

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -71,6 +72,12 @@ struct nlc_ctx {
 
   bool profiling = false;
   std::vector<ProfEntry> prof;
+  std::vector<hipEvent_t> event_pool;
+
+  // pinned host staging for the per-command small transfers (state, action_buffer, action)
+  double* pinned = nullptr;
+  size_t pinned_n = 0;
+  hipEvent_t stage_ev = nullptr;  // recorded after the staged H2D copies of a command
 };
 
 namespace {
@@ -102,6 +109,16 @@ struct ProfScope {
   nlc_ctx* c;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ProfEntry* entry = nullptr;
+  hipEvent_t take_event() {
+    if (!c->event_pool.empty()) {
+      hipEvent_t e = c->event_pool.back();
+      c->event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+  }
   ProfScope(nlc_ctx* ctx, const char* name) : c(ctx) {
     if (!c->profiling) return;
     for (auto& p : c->prof)
@@ -111,8 +128,8 @@ struct ProfScope {
       c->prof.back().name = name;
       entry = &c->prof.back();
     }
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    e0 = take_event();
+    e1 = take_event();
     hipEventRecord(e0, c->stream);
   }
   ~ProfScope() {
@@ -130,8 +147,8 @@ void prof_flush(nlc_ctx* c) {
       float ms = 0.f;
       hipEventElapsedTime(&ms, ev.first, ev.second);
       p.total_ms += ms;
-      hipEventDestroy(ev.first);
-      hipEventDestroy(ev.second);
+      c->event_pool.push_back(ev.first);
+      c->event_pool.push_back(ev.second);
     }
     p.pending.clear();
   }
@@ -261,6 +278,9 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
     if (c->U[i]) hipFree(c->U[i]);
   if (c->b1fold) hipFree(c->b1fold);
   if (c->small) hipFree(c->small);
+  if (c->pinned) hipHostFree(c->pinned);
+  if (c->stage_ev) hipEventDestroy(c->stage_ev);
+  for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -614,6 +634,13 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if (c->small) hipFree(c->small);
   c->small = nullptr;
   NLC_HIP(c, hipMalloc((void**)&c->small, (un + 2) * sizeof(double)));
+  const size_t pin_need = (size_t)d->d + (size_t)d->B * d->nu + un + 8;
+  if (pin_need > c->pinned_n) {
+    if (c->pinned) hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    NLC_HIP(c, hipHostMalloc((void**)&c->pinned, pin_need * sizeof(double), hipHostMallocDefault));
+    c->pinned_n = pin_need;
+  }
   c->pd = *d;
   c->nblk = (int)((d->K + kWeightBlockSamples - 1) / kWeightBlockSamples);
   if (d->dynamics == NLC_DYN_NL) {
@@ -725,10 +752,22 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   double* state_dev = ws + w.state0;
   double* abuf_dev = ws + w.abuf;
   if (!external) {
-    NLC_HIP(c, hipMemcpyAsync(state_dev, state, (size_t)(state_per_sample ? d.K : 1) * d.d * sizeof(double),
-                              hipMemcpyHostToDevice, c->stream));
-    NLC_HIP(c, hipMemcpyAsync(abuf_dev, abuf_host, (size_t)d.B * d.nu * sizeof(double), hipMemcpyHostToDevice,
+    // small inputs go through pinned staging (truly asynchronous copies).  The staging slots are rewritten
+    // only after the previous command's copies out of them have completed (stage_ev).
+    if (c->stage_ev) NLC_HIP(c, hipEventSynchronize(c->stage_ev));
+    double* pin_state = c->pinned;
+    double* pin_abuf = c->pinned + d.d;
+    std::memcpy(pin_abuf, abuf_host, (size_t)d.B * d.nu * sizeof(double));
+    if (state_per_sample) {
+      NLC_HIP(c, hipMemcpyAsync(state_dev, state, (size_t)d.K * d.d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+      std::memcpy(pin_state, state, (size_t)d.d * sizeof(double));
+      NLC_HIP(c, hipMemcpyAsync(state_dev, pin_state, (size_t)d.d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    NLC_HIP(c, hipMemcpyAsync(abuf_dev, pin_abuf, (size_t)d.B * d.nu * sizeof(double), hipMemcpyHostToDevice,
                               c->stream));
+    if (!c->stage_ev) NLC_HIP(c, hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming));
+    NLC_HIP(c, hipEventRecord(c->stage_ev, c->stream));
   }
   PerturbArgs p{};
   p.K = d.K;
@@ -800,8 +839,11 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     r.tn = c->tn;
     r.states = buf->states;
     r.cost_total = buf->cost_total;
+    // NLC_ROLLOUT_VARIANT=1|2 pins the wave-per-tile / latency-split kernel (tests, experiments); default auto
+    int variant = 0;
+    if (const char* ev = std::getenv("NLC_ROLLOUT_VARIANT")) variant = std::atoi(ev);
     ProfScope ps(c, "nl_rollout_kernel");
-    NLC_HIP(c, launch_nl_rollout(r, c->stream));
+    NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
   } else {
     OracleRolloutArgs r{};
     r.K = d.K;
@@ -848,7 +890,8 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
   if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
-  if (!gathered || !buf || !action_host || !buf->cost_nz) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
+  if (!gathered || !buf || !buf->cost_nz) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
+  if (!action_host && !buf->action) return fail(c, NLC_ERR_BAD_ARG, "neither action_host nor buf->action given");
   if (G < 1 || rank < 0 || rank >= G) return fail(c, NLC_ERR_BAD_ARG, "bad G / rank");
   const nlc_mppi_desc& d = c->pd;
   NLC_HIP(c, hipSetDevice(c->device));
@@ -865,15 +908,19 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   m.U = c->U[c->ucur];
   m.cost_nz = buf->cost_nz;
   m.omega = buf->omega;
-  m.action = c->small;
+  m.action = buf->action ? buf->action : c->small;
   m.beta_eta = c->small + (size_t)d.T * d.nu;
   {
     ProfScope ps(c, "merge_kernel");
     NLC_HIP(c, launch_merge(m, c->stream));
   }
-  NLC_HIP(c, hipMemcpyAsync(action_host, c->small, (size_t)d.u_per_command * d.nu * sizeof(double),
-                            hipMemcpyDeviceToHost, c->stream));
-  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  if (action_host) {
+    const size_t na = (size_t)d.u_per_command * d.nu;
+    double* pin_act = c->pinned + d.d + (size_t)d.B * d.nu;
+    NLC_HIP(c, hipMemcpyAsync(pin_act, m.action, na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NLC_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(action_host, pin_act, na * sizeof(double));
+  }
   return NLC_OK;
   NLC_GUARD_END(c)
 }

@@ -95,7 +95,7 @@ struct RolloutArgs {
   double* states;           // (K, T, d) or NULL
   double* cost_total;       // (K)
 };
-hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s);
+hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s, int force_variant = 0);
 
 struct ForwardArgs {
   NlNetArgs net;

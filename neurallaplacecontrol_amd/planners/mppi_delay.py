@@ -226,6 +226,7 @@ class MPPIDelay:
         self._actions = mk(K, T, nu) if self.store_rollouts else None
         self._cost_total, self._cost_nz, self._omega = mk(K), mk(K), mk(K)
         self._partials = mk(2 + T * nu)
+        self._action = mk(self.u_per_command * nu)
         self._gathered = mk(self.G, 2 + T * nu) if self.pg is not None else None
         self._ws = torch.empty(self.ctx.lib.nlc_mppi_workspace_bytes(self.ctx.h) // 8, dtype=torch.float64, device=dev)
         b = _lib.MppiBuffers()
@@ -234,6 +235,7 @@ class MPPIDelay:
         b.actions = self._actions.data_ptr() if self._actions is not None else None
         b.cost_total, b.cost_nz, b.omega = self._cost_total.data_ptr(), self._cost_nz.data_ptr(), self._omega.data_ptr()
         b.partials, b.workspace = self._partials.data_ptr(), self._ws.data_ptr()
+        b.action = self._action.data_ptr()
         self._buf = b
         if old_U is not None:
             self._pending_U = old_U
@@ -319,12 +321,20 @@ class MPPIDelay:
                 gathered = gather_partials(self._partials, self._gathered, self.pg)
             else:
                 gathered = self._partials
-            act = torch.empty(self.u_per_command * self.nu, dtype=torch.float64)
-            ctx.check(lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act)))
+            if self.d.type == "cuda":
+                # the action stays on the device (like the reference on a CUDA device): no copy-back, no host
+                # synchronisation here -- the caller's .cpu() / .item() is the sync point
+                ctx.check(lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), None))
+                act = self._action.clone()
+            else:
+                act = torch.empty(self.u_per_command * self.nu, dtype=torch.float64)
+                ctx.check(
+                    lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act))
+                )
         action = act.view(self.u_per_command, self.nu)
         if self.u_per_command == 1:
             action = action[0]
-        return action.to(self.d)
+        return action if action.device == self.d or self.d.index is None and action.is_cuda == (self.d.type == "cuda") else action.to(self.d)
 
     # ------------------------------------------------------------------ generic callables (reference :232-313)
     def _dynamics(self, state, u, t):

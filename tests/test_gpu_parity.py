@@ -451,3 +451,130 @@ def test_full_size_cfg2_properties(nlc):
     U_after = U_shift + torch.einsum("k,ktj->tj", omega, eps)
     np.testing.assert_allclose(mppi.U.cpu().numpy(), U_after.numpy(), rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(action.cpu().numpy(), (U_after[0] * A).numpy(), rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("env,K,T", [("oderl-cartpole", 1024, 20), ("oderl-acrobot", 4096, 12), ("oderl-pendulum", 16400, 6)])
+def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
+    """Wave-per-tile and latency-split (4 waves per 16-sample tile, LDS exchange) rollout kernels: same numbers."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    torch.manual_seed(4)
+    raw = torch.randn(K, T, nu, dtype=torch.float64)
+    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.2
+    state, ab = nlc.initial_state(env), torch.randn(4, nu, dtype=torch.float64)
+    out = {}
+    for variant in ("1", "2"):
+        monkeypatch.setenv("NLC_ROLLOUT_VARIANT", variant)
+        mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                             lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+        mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+        act = mppi.command(state, ab)
+        out[variant] = (act.clone(), mppi.states.clone(), mppi.cost_total.clone())
+    for a, b in zip(out["1"], out["2"]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-11, atol=1e-11)
+
+
+def _subset_check(nlc, env, K, T, B, n_check=64, seed=0):
+    """Shared body of the full-size configs: command() on the GPU, a strided sample subset through the oracle."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    sig = nlc.noise_sigma(nu)
+    torch.manual_seed(seed)
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cuda", lambda_=1.0,
+                         u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=seed)
+    state = nlc.initial_state(env)
+    ab = (torch.rand(B, nu, dtype=torch.float64) * 2 - 1) * A
+    U_before = mppi.U.cpu()
+    action = mppi.command(state, ab)
+    V, eps = mppi.perturbed_action.cpu(), mppi.noise.cpu()
+    idx = torch.arange(0, K, K // n_check)
+    ts = torch.full((len(idx), 1), 0.05, dtype=torch.float64)
+    cost_ref, states_ref, _ = omppi.rollout(state, ab, V[idx], A, onl.nl_dynamics(sd, ts, S=17), oenvs.RUNNING_COST[env], d)
+    np.testing.assert_allclose(mppi.states.cpu()[idx].numpy(), states_ref.numpy(), rtol=1e-7, atol=1e-7)
+    U_shift = torch.roll(U_before, -1, 0)
+    U_shift[-1] = 0
+    pc = torch.sum(U_shift * (eps[idx] @ torch.inverse(sig)), dim=(1, 2))
+    np.testing.assert_allclose(mppi.cost_total.cpu()[idx].numpy(), (cost_ref + pc).numpy(), rtol=1e-7, atol=1e-7)
+    cost, omega = mppi.cost_total.cpu(), mppi.omega.cpu()
+    w = torch.exp(-(cost - cost.min()))
+    np.testing.assert_allclose(omega.numpy(), (w / w.sum()).numpy(), rtol=1e-10, atol=1e-16)
+    U_after = U_shift + torch.einsum("k,ktj->tj", omega, eps)
+    np.testing.assert_allclose(mppi.U.cpu().numpy(), U_after.numpy(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(action.cpu().numpy(), (U_after[0] * A).numpy(), rtol=1e-10, atol=1e-13)
+
+
+def test_cfg1_cartpole_1024x20(nlc):
+    """BASELINE configs[0] shape: K=1024, H=20 (latency-split rollout kernel)."""
+    _subset_check(nlc, "oderl-cartpole", 1024, 20, 4, n_check=128)
+
+
+def test_cfg3_pendulum_shard_32768x40_window5(nlc):
+    """BASELINE configs[2] per-GPU shard: pendulum, 65536/2 samples, H=40, action_buffer_size=5 (delay 4)."""
+    _subset_check(nlc, "oderl-pendulum", 32768, 40, 5)
+
+
+def test_cfg4_acrobot_shard_32768x60(nlc):
+    """BASELINE configs[3] per-GPU shard: acrobot (nx=6, nu=2), 262144/8 samples, H=60."""
+    _subset_check(nlc, "oderl-acrobot", 32768, 60, 4)
+
+
+def test_cfg5_dehoog_planner_generic_path(nlc):
+    """BASELINE configs[4] ablation: a de Hoog (33 terms) model plans through the staged/generic path."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    env, K, T, A, d, nu = "oderl-cartpole", 128, 6, 3.0, 5, 1
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(2, d, nu, 128, 33, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd, S=33, algo="dehoog")
+    sig = nlc.noise_sigma(nu)
+    torch.manual_seed(3)
+    raw = torch.randn(K, T, nu, dtype=torch.float64)
+    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.2
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cpu", lambda_=1.0,
+                         u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+    assert not mppi.fused
+    mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+    with torch.no_grad():
+        act = mppi.command(state, ab)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    ref = omppi.mppi_command(U0.clone(), state, ab, raw.clone(), onl.nl_dynamics(sd, ts, S=33, ilt_algorithm="dehoog"),
+                             oenvs.RUNNING_COST[env], d, torch.inverse(sig), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    np.testing.assert_allclose(mppi.states.numpy(), ref["states"].numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_error_paths_raise(nlc):
+    from neurallaplacecontrol_amd import _lib
+
+    with pytest.raises(NotImplementedError):
+        nlc.ilt_reconstruct(torch.zeros(2, 1, 17).double().cuda(), torch.zeros(2, 1, 17).double().cuda(),
+                            torch.ones(2).double().cuda(), "cme")
+    with pytest.raises(_lib.NlcError):  # de Hoog needs 9/17/33 terms
+        nlc.ilt_reconstruct(torch.zeros(2, 1, 21).double().cuda(), torch.zeros(2, 1, 21).double().cuda(),
+                            torch.ones(2).double().cuda(), "dehoog")
+    with pytest.raises(ValueError):
+        nlc.ilt_reconstruct(torch.zeros(2, 1, 17).double().cuda(), torch.zeros(2, 2, 17).double().cuda(),
+                            torch.ones(2).double().cuda())
+    with pytest.raises(NotImplementedError):
+        nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum"), nlc.EnvCost("oderl-pendulum"), 3, nlc.noise_sigma(1), 8, 4,
+                      rollout_samples=3)
+    with pytest.raises(_lib.NlcError):  # nx does not match the env
+        m = nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum"), nlc.EnvCost("oderl-pendulum"), 5, nlc.noise_sigma(1), 8, 4)
+        m.command(torch.zeros(5).double(), torch.zeros(4, 1).double())
+    with pytest.raises(_lib.NlcError):  # delay beyond the action buffer (SURVEY F10)
+        m = nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum", delay=4), nlc.EnvCost("oderl-pendulum"), 3,
+                          nlc.noise_sigma(1), 8, 4)
+        m.command(torch.zeros(3).double(), torch.zeros(4, 1).double())
