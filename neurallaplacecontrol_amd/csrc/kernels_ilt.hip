@@ -9,6 +9,9 @@
 //   ilt_dehoog_kernel   same map, de Hoog-Knight-Stokes quotient-difference acceleration
 //                       (mpmath inverselaplace.py:476-531); O(M^2) complex ops per (point, dim) -> FP64
 //                       VALU bound, not HBM bound.
+#include <cstdlib>
+#include <type_traits>
+
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
@@ -59,74 +62,97 @@ hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s) {
 // coalesced loads (lane i <-> flat element i), parks the per-element contribution in LDS and lets one
 // thread per row add its S terms (row stride padded odd: conflict-free ds_read_b64).
 
+// DBG: 0 = product; 1 / 2 = timing experiments (memory only / arithmetic only), env NLC_ILT_DBG
+// ITERS > 0: passes per tile known at compile time -> the pass loop is fully unrolled (straight-line code is
+// what lets the compiler keep counted s_waitcnt vmcnt(N) instead of draining the pipeline); 0: runtime loop.
+template <int DBG, int ITERS>
 __global__ __launch_bounds__(256) void ilt_fourier_kernel(const IltArgs a) {
-  extern __shared__ double lds[];
+  extern __shared__ double val[];  // [rows][SP]
   const int S = a.S;
   const int SP = S | 1;
-  double* cw = lds;              // [S]  w_k cos(pi k/scale)
-  double* sw = lds + S;          // [S] -w_k sin(pi k/scale)
-  double* val = lds + 2 * S;     // [rows][SP]
-  const int kIltRows = a.rows;
-  for (int k = threadIdx.x; k < S; k += blockDim.x) {
-    const double w = k == 0 ? 0.5 : 1.0;
-    double sn, cs;
-    if (a.scale == 2.0) {  // exact powers of i
-      const int r = k & 3;
-      cs = (r == 0) ? 1.0 : (r == 2 ? -1.0 : 0.0);
-      sn = (r == 1) ? 1.0 : (r == 3 ? -1.0 : 0.0);
-    } else {
-      const double ang = kPi * (double)k / a.scale;
-      sn = sin(ang);
-      cs = cos(ang);
-    }
-    cw[k] = w * cs;
-    sw[k] = -w * sn;
+  // A pass covers RPP = 256/S whole rows = RPP*S consecutive doubles, one per active thread, so a thread's
+  // term index k never changes (phase/weight stay in registers) and its row advances by RPP per pass.
+  const int rpp = a.rpp, iters = ITERS > 0 ? ITERS : a.iters, rows = rpp * iters;
+  const int act = rpp * S;
+  const bool active = (int)threadIdx.x < act;
+  const int k = (int)threadIdx.x % S, rloc = (int)threadIdx.x / S;
+  const bool pow_i = a.scale == 2.0;  // e^{i pi k t/T} = i^k: exact quadrant offsets
+  const double wk = k == 0 ? 0.5 : 1.0;
+  double psi = 0.0;
+  if (!pow_i) {
+    psi = kPi * (double)k / a.scale;
+    psi -= 2.0 * kPi * rint(psi / (2.0 * kPi));
   }
-  __syncthreads();
+  const int j0 = pow_i ? k : 0;
   const int64_t rows_total = a.N * a.d;
-  const int64_t nblk = (rows_total + kIltRows - 1) / kIltRows;
+  const int64_t nblk = (rows_total + rows - 1) / rows;
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t row0 = blk * kIltRows;
-    const int64_t rows_here = (rows_total - row0 < kIltRows) ? (rows_total - row0) : kIltRows;
-    const int64_t elems = rows_here * S;
-    const int64_t base = row0 * S;
-    // (r, k) of this thread's first element, then advanced by 256 elements per iteration.  Loads are issued
-    // in batches of UB iterations before any arithmetic so each lane keeps 2*UB 8-byte loads in flight
-    // (one load pair per iteration leaves the HBM pipe latency-bound at ~3 TB/s).
-    int r = threadIdx.x / S, k = threadIdx.x - r * S;
-    const int dr = 256 / S, dk = 256 - dr * S;
-    constexpr int UB = 6;
-    for (int64_t e0 = threadIdx.x; e0 < elems; e0 += 256 * UB) {
+    const int64_t row0 = blk * rows;
+    const int rows_here = (int)((rows_total - row0 < rows) ? (rows_total - row0) : rows);
+    const double* __restrict__ tp = a.theta + row0 * S + threadIdx.x;
+    const double* __restrict__ pp = a.phi + row0 * S + threadIdx.x;
+    // Software pipeline of depth UB over the passes: pass i is computed while the loads of passes
+    // i+1 .. i+UB are in flight (2*UB 8-byte loads per lane outstanding at all times).
+    // Per element: Re(F_k e^{i pi k/scale}) = tan(phi/2 + pi/4) cos(theta + pi k/scale); tan as
+    // (cos a + sin a)/(cos a - sin a) (no range reduction, no branch), its division folded into the product.
+    constexpr int UB = 8;  // the launcher makes iters a multiple of UB
+    auto tile = [&](auto full_tile) {
+      constexpr bool FULL = decltype(full_tile)::value;
       double th[UB], ph[UB];
+      // No branch may sit between a load and its use, or the compiler falls back to s_waitcnt vmcnt(0) and the
+      // pipeline collapses: out-of-range passes re-load the last valid pass (cache hit) instead of being skipped.
+      const int last_i = FULL ? iters - 1 : (rows_here - 1 - rloc >= 0 ? (rows_here - 1 - rloc) / rpp : 0);
+      const bool lane_has_rows = FULL || rloc < rows_here;
+      auto fetch = [&](int u, int i) {
+        if (DBG == 2) {  // timing experiment: arithmetic only
+          th[u] = 0.3 + 1e-3 * i;
+          ph[u] = -0.4 + 1e-3 * i;
+        } else {
+          const int ic = i < last_i ? i : last_i;
+          th[u] = __builtin_nontemporal_load(tp + (int64_t)act * ic);
+          ph[u] = __builtin_nontemporal_load(pp + (int64_t)act * ic);
+        }
+      };
+      if (!lane_has_rows) return;  // (tail tile only) this lane's first row is already past the end
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int64_t e = e0 + 256 * u;
-        th[u] = 0.0;
-        ph[u] = 0.0;
-        if (e < elems) {
-          th[u] = __builtin_nontemporal_load(a.theta + base + e);
-          ph[u] = __builtin_nontemporal_load(a.phi + base + e);
+      for (int u = 0; u < UB; ++u) fetch(u, u);
+      auto pass = [&](int u, int i) {
+        const int r = rloc + rpp * i;
+        const double t_u = th[u], p_u = ph[u];
+        fetch(u, i + UB);
+        double v;
+        if (DBG == 1) {  // timing experiment: memory only
+          v = t_u + p_u;
+        } else {
+          double num, den;
+          m::tan_parts_0_halfpi(p_u / 2.0 + kPi / 4.0, &num, &den);
+          const double cs = m::cos_quadrant(t_u + psi, j0);
+          v = (wk * num) * cs * m::rcp_refined(den);
+        }
+        if (FULL || r < rows_here) val[r * SP + k] = v;
+      };
+      if constexpr (ITERS > 0) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+          pass(i % UB, i);
+          __builtin_amdgcn_sched_barrier(0);  // keep the refill of slot u next to its use: no load clustering
+        }
+      } else {
+        for (int i0 = 0; i0 < iters; i0 += UB) {
+#pragma unroll
+          for (int u = 0; u < UB; ++u) pass(u, i0 + u);
         }
       }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int64_t e = e0 + 256 * u;
-        if (e < elems) {
-          const double rad = m::tan_0_halfpi(ph[u] / 2.0 + kPi / 4.0);
-          double sn, cs;
-          m::sincos_bounded(th[u], &sn, &cs);
-          val[r * SP + k] = rad * (cw[k] * cs + sw[k] * sn);
-          r += dr;
-          k += dk;
-          if (k >= S) {
-            k -= S;
-            r += 1;
-          }
-        }
+    };
+    if (active) {
+      if (rows_here == rows) {
+        tile(std::true_type{});
+      } else {
+        tile(std::false_type{});
       }
     }
     __syncthreads();
-    if ((int64_t)threadIdx.x < rows_here) {
+    if ((int)threadIdx.x < rows_here) {
       const double* v = val + threadIdx.x * SP;
       double acc = 0.0;
       for (int kk = 0; kk < S; ++kk) acc += v[kk];
@@ -144,16 +170,37 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   IltArgs a = a_in;
   const int64_t rows_total = a.N * a.d;
   if (rows_total <= 0) return hipSuccess;
-  // rows per block: one thread per row for the final sum, LDS tile kept under the 64 KiB default
+  if (a.S > 256) return hipErrorInvalidValue;
+  // rows per block tile = rpp * iters: one thread per row for the final sum (<= 256), LDS tile under 60 KiB
   const int SP = a.S | 1;
-  int rows = (int)((60 * 1024 / 8 - 2 * a.S) / SP);
-  if (rows > 256) rows = 256;
-  if (rows < 1) return hipErrorInvalidValue;
-  a.rows = rows;
+  a.rpp = 256 / a.S;
+  int max_rows = (60 * 1024 / 8) / SP;
+  if (max_rows > 256) max_rows = 256;
+  if (a.rpp > 32) a.rpp = 32;          // rpp * 8 passes must fit the 256 row-sum threads
+  a.iters = max_rows / a.rpp / 8 * 8;  // multiple of the kernel's pipeline depth
+  if (a.iters < 8) return hipErrorInvalidValue;
+  const int rows = a.rpp * a.iters;
   const int64_t nblk = (rows_total + rows - 1) / rows;
   const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
-  const size_t shmem = (size_t)(2 * a.S + rows * SP) * sizeof(double);
-  hipLaunchKernelGGL(ilt_fourier_kernel, dim3(grid), dim3(256), shmem, s, a);
+  const size_t shmem = (size_t)rows * SP * sizeof(double);
+  a.dbg = 0;
+  if (const char* ev = std::getenv("NLC_ILT_DBG")) a.dbg = std::atoi(ev);  // 1 memory-only, 2 arithmetic-only (timing)
+#define NLC_ILT_LAUNCH(D)                                                                              \
+  switch (a.iters) {                                                                                   \
+    case 8: hipLaunchKernelGGL((ilt_fourier_kernel<D, 8>), dim3(grid), dim3(256), shmem, s, a); break;   \
+    case 16: hipLaunchKernelGGL((ilt_fourier_kernel<D, 16>), dim3(grid), dim3(256), shmem, s, a); break; \
+    case 24: hipLaunchKernelGGL((ilt_fourier_kernel<D, 24>), dim3(grid), dim3(256), shmem, s, a); break; \
+    case 32: hipLaunchKernelGGL((ilt_fourier_kernel<D, 32>), dim3(grid), dim3(256), shmem, s, a); break; \
+    default: hipLaunchKernelGGL((ilt_fourier_kernel<D, 0>), dim3(grid), dim3(256), shmem, s, a); break;  \
+  }
+  if (a.dbg == 1) {
+    NLC_ILT_LAUNCH(1)
+  } else if (a.dbg == 2) {
+    NLC_ILT_LAUNCH(2)
+  } else {
+    NLC_ILT_LAUNCH(0)
+  }
+#undef NLC_ILT_LAUNCH
   return hipGetLastError();
 }
 

@@ -18,7 +18,8 @@ struct IltArgs {
   int64_t N;
   int d, S;
   double alpha, log_tol, scale;
-  int rows;  // rows per block (set by the launcher)
+  int rpp, iters;  // rows per pass / passes per block tile (set by the launcher)
+  int dbg;         // 0 normal; timing experiments only: 1 memory-only, 2 arithmetic-only
 };
 hipError_t launch_ilt_fourier(const IltArgs& a, hipStream_t s);
 hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s);

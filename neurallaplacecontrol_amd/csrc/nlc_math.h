@@ -154,5 +154,34 @@ NLC_HD double tan_0_halfpi(double x) {
   return hi ? div_fast(cy, sy) : div_fast(sy, cy);
 }
 
+// tan(x) for x in [0, pi/2] as (cos a + sin a)/(cos a - sin a) with a = x - pi/4 in [-pi/4, pi/4]: the
+// polynomials' range, so no branch.  x is the reference's rounded phi/2 + pi/4 and a = (x - pi4_hi) - pi4_lo
+// recovers it to ~1e-33, so the result tracks tan(x) of that very double (the dominant error of the sphere map is
+// the rounding of x itself).  num/den are returned separately so a caller can fold the division into a later
+// product.  den is clamped at the value that reproduces tan of the double nearest pi/2 (1.633e16), the
+// reference's saturated |F| when tanh rounds to 1.
+NLC_HD void tan_parts_0_halfpi(double x, double* num, double* den) {
+  const double a = (x - 0.5 * kPio2Hi) - 0.5 * kPio2Lo;
+  const double sa = sin_poly(a), ca = cos_poly(a);
+  *num = ca + sa;
+  *den = fmax(ca - sa, 8.659560562354934e-17);
+}
+NLC_HD double tan_pi4_plus(double x) {
+  double num, den;
+  tan_parts_0_halfpi(x, &num, &den);
+  return div_fast(num, den);
+}
+
+// cos(x + j0*pi/2) for |x| <= ~2 pi and an integer quadrant offset j0 (exact phase i^k of the Fourier ILT)
+NLC_HD double cos_quadrant(double x, int j0) {
+  const double fk = rint(x * 6.36619772367581382433e-01);
+  double y = fma(-fk, kPio2Hi, x);
+  y = fma(-fk, kPio2Lo, y);
+  const int j = (int)fk + j0;
+  const double sy = sin_poly(y), cy = cos_poly(y);
+  const double cc = (j & 1) ? sy : cy;
+  return ((j + 1) & 2) ? -cc : cc;
+}
+
 }  // namespace m
 }  // namespace nlc

@@ -8,3 +8,7 @@ void nlc_t_sin(const double* x, double* y, long n) { for (long i = 0; i < n; ++i
 void nlc_t_cos(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) { double s, c; nlc::m::sincos_bounded(x[i], &s, &c); y[i] = c; } }
 void nlc_t_tan(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tan_0_halfpi(x[i]); }
 }
+extern "C" {
+void nlc_t_tan_pi4(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tan_pi4_plus(x[i]); }
+void nlc_t_cosq(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::cos_quadrant(x[i], (int)(i % 7) - 3); }
+}

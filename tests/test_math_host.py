@@ -68,3 +68,22 @@ def test_tan(lib):
     ok = x < 1.5707
     assert ulp_err(y[ok], ref[ok]).max() <= 4
     assert np.all(np.abs(y[~ok] - ref[~ok]) <= 1e-11 * np.abs(ref[~ok]))
+
+
+def test_tan_pi4_plus(lib):
+    x = np.concatenate([np.linspace(0, np.pi / 2, 400001), np.logspace(-18, -1, 2001)])
+    ref = np.tan(x.astype(np.longdouble)).astype(np.float64)  # tan of that very double, 80-bit
+    y = call(lib, "nlc_t_tan_pi4", x)
+    # (cos a + sin a)/(cos a - sin a) amplifies the 1e-16 absolute rounding of sin/cos near the zero and the pole:
+    # absolute error O(1e-16 (1 + tan^2)), the same conditioning tan has w.r.t. a one-ulp change of its argument
+    ok = x < 1.57
+    assert np.all(np.abs(y[ok] - ref[ok]) <= 4e-16 * (1.0 + ref[ok] ** 2))
+    assert np.isfinite(y).all() and y.min() > -3e-16 and y[400000] > 1e15
+
+
+def test_cos_quadrant(lib):
+    x = np.linspace(-2 * np.pi, 2 * np.pi, 700001)
+    j0 = (np.arange(x.size) % 7) - 3
+    pi_l = np.longdouble("3.14159265358979323846264338327950288")
+    ref = np.cos(x.astype(np.longdouble) + j0 * pi_l / 2).astype(np.float64)
+    assert np.abs(call(lib, "nlc_t_cosq", x) - ref).max() < 3e-16
