@@ -145,7 +145,9 @@ class MPPIDelay:
             and isinstance(running_cost, EnvCost)
             and terminal_state_cost is None
             and not step_dependent_dynamics
-            and not encode_obs_time
+            # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
+            # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
+            and not (encode_obs_time and not isinstance(dynamics, OracleDynamics))
             # the fused rollout kernel implements the Fourier ILT; a de Hoog model runs on the generic path
             # (HIP GRU + PyTorch-ROCm MLP + HIP de Hoog ILT per horizon step)
             and not (isinstance(dynamics, NLDynamics) and dynamics.model.ilt_algorithm != "fourier")
@@ -305,6 +307,8 @@ class MPPIDelay:
                 raw = self.noise_dist.sample((self.K, self.T))
                 self._noise.copy_(slice_noise(raw, self.k_offset, self.K_local).reshape(self.K_local, self.T, self.nu))
             if self.fused:
+                if self.encode_obs_time and ab.shape[1] == self.nu + 1:
+                    ab = ab[:, : self.nu].contiguous()  # drop the time-stamp column (mppi_delay.py:262-264)
                 if ab.shape[1] != self.nu:
                     raise ValueError("action_buffer must have nu columns")
                 ctx.check(

@@ -578,3 +578,24 @@ def test_error_paths_raise(nlc):
         m = nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum", delay=4), nlc.EnvCost("oderl-pendulum"), 3,
                           nlc.noise_sigma(1), 8, 4)
         m.command(torch.zeros(3).double(), torch.zeros(4, 1).double())
+
+
+def test_collector_variant_encode_obs_time_with_oracle_dynamics(nlc):
+    """Dataset-collector call pattern (mppi_dataset_collector.py:166-180,249): encode_obs_time=True, action_buffer
+    carries an extra time-stamp column, oracle dynamics ignore it -> same result as the plain call."""
+    env, K, T, A = "oderl-cartpole", 128, 8, 3.0
+    torch.manual_seed(2)
+    raw = torch.randn(K, T, 1, dtype=torch.float64)
+    U0 = torch.randn(T, 1, dtype=torch.float64) * 0.2
+    st = nlc.initial_state(env)
+    ab = torch.randn(4, 1, dtype=torch.float64)
+    ab_t = torch.cat((ab, torch.tensor([[0.15], [0.10], [0.05], [0.0]], dtype=torch.float64)), dim=1)
+    acts = []
+    for enc, buf in ((False, ab), (True, ab_t)):
+        m = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 5, nlc.noise_sigma(1), K, T, "cpu",
+                          lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(),
+                          encode_obs_time=enc)
+        assert m.fused
+        m.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+        acts.append(m.command(st, buf))
+    assert torch.equal(acts[0], acts[1])
