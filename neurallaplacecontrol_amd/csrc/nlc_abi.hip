@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "nlc_kernels.h"
+#include "nlc_pack.h"
 
 namespace nlc {
 int nl_pick_nt3(int need);
@@ -152,43 +153,6 @@ void prof_flush(nlc_ctx* c) {
     }
     p.pending.clear();
   }
-}
-
-// ---- MFMA A-fragment packing:  out[(ks*MT + mt)*64 + lane] = W[row(16 mt + (lane & 15))][4 ks + (lane >> 4)]
-// rowmap[i] = source row of packed row i (-1 = zero row); cols beyond K are zero.
-std::vector<double> pack_A(const double* W, int ldw, int K, const std::vector<int>& rowmap) {
-  const int MT = (int)(rowmap.size() + 15) / 16;
-  const int KS = (K + 3) / 4;
-  std::vector<double> out((size_t)KS * MT * 64, 0.0);
-  for (int ks = 0; ks < KS; ++ks)
-    for (int mt = 0; mt < MT; ++mt)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int prow = 16 * mt + (lane & 15), col = 4 * ks + (lane >> 4);
-        if (prow >= (int)rowmap.size() || col >= K) continue;
-        const int src = rowmap[prow];
-        if (src < 0) continue;
-        out[((size_t)ks * MT + mt) * 64 + lane] = W[(size_t)src * ldw + col];
-      }
-  return out;
-}
-// GRU gate matrices, chunk-packed: out[((j*KS + ks)*3 + g)*64 + lane] = W[g*G + 16 j + (lane & 15)][4 ks + (lane >> 4)]
-std::vector<double> pack_gru_chunked(const double* W, int ldw, int K, int G) {
-  const int GT = G / 16, KS = (K + 3) / 4;
-  std::vector<double> out((size_t)GT * KS * 3 * 64, 0.0);
-  for (int j = 0; j < GT; ++j)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int g = 0; g < 3; ++g)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int row = g * G + 16 * j + (lane & 15), col = 4 * ks + (lane >> 4);
-          if (col >= K) continue;
-          out[(((size_t)j * KS + ks) * 3 + g) * 64 + lane] = W[(size_t)row * ldw + col];
-        }
-  return out;
-}
-std::vector<int> identity_rows(int n) {
-  std::vector<int> r(n);
-  for (int i = 0; i < n; ++i) r[i] = i;
-  return r;
 }
 
 struct Blob {
@@ -422,46 +386,17 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   const size_t o_b1 = ar.push(std::vector<double>(b1, b1 + h));
   const size_t o_W2 = ar.push(pack_A(W2, h, h, rowsh));
   const size_t o_b2 = ar.push(std::vector<double>(b2, b2 + h));
-  // layer 3: slot layout.  Element list = even-k (c,k) pairs, padded to a multiple of 4, then odd-k pairs.
-  std::vector<std::pair<int, int>> elems;
-  for (int cc = 0; cc < dd; ++cc)
-    for (int k = 0; k < S; k += 2) elems.emplace_back(cc, k);
-  while (elems.size() % 4) elems.emplace_back(-1, -1);
-  const int n_even_groups = (int)elems.size() / 4;
-  for (int cc = 0; cc < dd; ++cc)
-    for (int k = 1; k < S; k += 2) elems.emplace_back(cc, k);
-  while (elems.size() % 4) elems.emplace_back(-1, -1);
-  const int groups = (int)elems.size() / 4;
-  const int nt3 = nl_pick_nt3((groups + 1) / 2);
+  // layer 3: slot layout + ILT coefficient matrix (nlc_pack.h)
+  const int nt3 = nl_pick_nt3(ilt_tiles_needed(dd, S));
   if (nt3 < 0) return fail(c, NLC_ERR_UNSUPPORTED, "2*d*S too large for the fused kernel (max 25 output tiles)");
-  elems.resize((size_t)nt3 * 8, {-1, -1});
-  std::vector<int> rowmap3((size_t)nt3 * 16, -1);
+  const IltSlots slots = make_ilt_slots(dd, S, nt3);
+  const int n_even_groups = slots.n_even_groups;
   std::vector<double> b3p((size_t)nt3 * 16, 0.0);
-  for (int j = 0; j < nt3; ++j)
-    for (int m = 0; m < 16; ++m) {
-      const int r = m >> 2, q = m & 3;
-      const int gi = 2 * j + (r & 1);
-      const auto el = elems[(size_t)4 * gi + q];
-      if (el.first < 0) continue;
-      const int src = (r < 2 ? 0 : dd * S) + el.first * S + el.second;
-      rowmap3[(size_t)16 * j + m] = src;
-      b3p[(size_t)16 * j + m] = b3[src];
-    }
-  const size_t o_W3 = ar.push(pack_A(W3, h, h, rowmap3));
+  for (size_t i = 0; i < slots.rowmap3.size(); ++i)
+    if (slots.rowmap3[i] >= 0) b3p[i] = b3[slots.rowmap3[i]];
+  const size_t o_W3 = ar.push(pack_A(W3, h, h, slots.rowmap3));
   const size_t o_b3 = ar.push(b3p);
-  // ILT coefficient matrix C[dim][element]: w_k * Re-part selector of i^k (k even: cos, +1/-1; k odd: sin, -1/+1)
-  std::vector<double> Cp((size_t)2 * nt3 * 64, 0.0);
-  for (int gi = 0; gi < 2 * nt3; ++gi)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int m = lane & 15, kk = lane >> 4;
-      const auto el = elems[(size_t)4 * gi + kk];
-      if (el.first != m) continue;
-      const int k = el.second;
-      const double wk = (k == 0) ? 0.5 : 1.0;
-      const double sgn = ((k & 3) == 0 || (k & 3) == 3) ? 1.0 : -1.0;
-      Cp[(size_t)gi * 64 + lane] = wk * sgn;
-    }
-  const size_t o_Cp = ar.push(Cp);
+  const size_t o_Cp = ar.push(slots.Cp);
 
   // ---- upload
   double* base = nullptr;

@@ -1,0 +1,95 @@
+// Host-side weight re-packing for the MFMA kernels: pure C++ (no HIP), shared by nlc_abi.hip and the CPU
+// emulation test (tests/helpers/pack_host.cpp), which replays the kernels' dataflow lane by lane.
+#pragma once
+#include <cstddef>
+#include <utility>
+#include <vector>
+
+namespace nlc {
+
+// ---- MFMA A-fragment packing:  out[(ks*MT + mt)*64 + lane] = W[row(16 mt + (lane & 15))][4 ks + (lane >> 4)]
+// rowmap[i] = source row of packed row i (-1 = zero row); cols beyond K are zero.
+inline std::vector<double> pack_A(const double* W, int ldw, int K, const std::vector<int>& rowmap) {
+  const int MT = (int)(rowmap.size() + 15) / 16;
+  const int KS = (K + 3) / 4;
+  std::vector<double> out((size_t)KS * MT * 64, 0.0);
+  for (int ks = 0; ks < KS; ++ks)
+    for (int mt = 0; mt < MT; ++mt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int prow = 16 * mt + (lane & 15), col = 4 * ks + (lane >> 4);
+        if (prow >= (int)rowmap.size() || col >= K) continue;
+        const int src = rowmap[prow];
+        if (src < 0) continue;
+        out[((size_t)ks * MT + mt) * 64 + lane] = W[(size_t)src * ldw + col];
+      }
+  return out;
+}
+// GRU gate matrices, chunk-packed: out[((j*KS + ks)*3 + g)*64 + lane] = W[g*G + 16 j + (lane & 15)][4 ks + (lane >> 4)]
+inline std::vector<double> pack_gru_chunked(const double* W, int ldw, int K, int G) {
+  const int GT = G / 16, KS = (K + 3) / 4;
+  std::vector<double> out((size_t)GT * KS * 3 * 64, 0.0);
+  for (int j = 0; j < GT; ++j)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int g = 0; g < 3; ++g)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = g * G + 16 * j + (lane & 15), col = 4 * ks + (lane >> 4);
+          if (col >= K) continue;
+          out[(((size_t)j * KS + ks) * 3 + g) * 64 + lane] = W[(size_t)row * ldw + col];
+        }
+  return out;
+}
+inline std::vector<int> identity_rows(int n) {
+  std::vector<int> r(n);
+  for (int i = 0; i < n; ++i) r[i] = i;
+  return r;
+}
+
+
+// ---- layer-3 slot layout of the fused sphere-map / Fourier-ILT epilogue (kernels_nl.hip).
+// Elements (dim c, term k): all even-k pairs, padded to a multiple of 4, then all odd-k pairs (scale == 2: the
+// Fourier phase is i^k, even terms need cos(theta), odd terms sin(theta)).  Group g = 4 consecutive elements =
+// the four lane groups q of one accumulator register; tile j, register r in {0,1} holds theta of group 2j+r,
+// register r+2 its phi.
+struct IltSlots {
+  int nt3 = 0, n_even_groups = 0;
+  std::vector<std::pair<int, int>> elems;  // (dim, k) per slot, (-1,-1) = padding; size 8*nt3
+  std::vector<int> rowmap3;                // packed row -> source row of the last Linear (or -1); size 16*nt3
+  std::vector<double> Cp;                  // coefficient fragments [2*nt3][64]
+};
+inline int ilt_tiles_needed(int d, int S) {
+  const int n_even = d * ((S + 1) / 2), n_odd = d * (S / 2);
+  const int groups = (n_even + 3) / 4 + (n_odd + 3) / 4;
+  return (groups + 1) / 2;
+}
+inline IltSlots make_ilt_slots(int d, int S, int nt3) {
+  IltSlots s;
+  s.nt3 = nt3;
+  for (int c = 0; c < d; ++c)
+    for (int k = 0; k < S; k += 2) s.elems.emplace_back(c, k);
+  while (s.elems.size() % 4) s.elems.emplace_back(-1, -1);
+  s.n_even_groups = (int)s.elems.size() / 4;
+  for (int c = 0; c < d; ++c)
+    for (int k = 1; k < S; k += 2) s.elems.emplace_back(c, k);
+  s.elems.resize((size_t)nt3 * 8, {-1, -1});
+  s.rowmap3.assign((size_t)nt3 * 16, -1);
+  for (int j = 0; j < nt3; ++j)
+    for (int m = 0; m < 16; ++m) {
+      const int r = m >> 2, q = m & 3;
+      const auto el = s.elems[(size_t)4 * (2 * j + (r & 1)) + q];
+      if (el.first < 0) continue;
+      s.rowmap3[(size_t)16 * j + m] = (r < 2 ? 0 : d * S) + el.first * S + el.second;
+    }
+  // C[dim][element] = w_k * Re-part selector of i^k (k even: cos, +1/-1; k odd: sin, -1/+1); fragment layout of an
+  // MFMA A operand: lane -> (row m = lane & 15 = dim, k-index lane >> 4 = slot within the group)
+  s.Cp.assign((size_t)2 * nt3 * 64, 0.0);
+  for (int g = 0; g < 2 * nt3; ++g)
+    for (int lane = 0; lane < 64; ++lane) {
+      const auto el = s.elems[(size_t)4 * g + (lane >> 4)];
+      if (el.first != (lane & 15)) continue;
+      const int k = el.second;
+      s.Cp[(size_t)g * 64 + lane] = ((k == 0) ? 0.5 : 1.0) * (((k & 3) == 0 || (k & 3) == 3) ? 1.0 : -1.0);
+    }
+  return s;
+}
+
+}  // namespace nlc

@@ -1,0 +1,68 @@
+"""CPU: lane-by-lane emulation of the MFMA kernels' dataflow on the fragment-packed weights (csrc/nlc_pack.h),
+against the oracle.  Covers the packing order, the layer-3 slot permutation, the ILT coefficient matrix and the
+accumulator-register-as-next-B-fragment chaining for every (d, S) the reference envs use."""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ilt as oilt
+from oracle import nl_model as onl
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = tmp_path_factory.mktemp("packhost") / "libpack_host.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(out), os.path.join(HERE, "helpers", "pack_host.cpp")])
+    return ctypes.CDLL(str(out))
+
+
+def P(t):
+    return ctypes.c_void_p(np.ascontiguousarray(t.numpy() if torch.is_tensor(t) else t, dtype=np.float64).ctypes.data)
+
+
+def arr(t):
+    return np.ascontiguousarray(t.numpy() if torch.is_tensor(t) else t, dtype=np.float64)
+
+
+@pytest.mark.parametrize("env,S", [("oderl-cartpole", 17), ("oderl-pendulum", 17), ("oderl-acrobot", 17), ("oderl-cartpole", 33),
+                                   ("oderl-acrobot", 33), ("oderl-pendulum", 9)])
+def test_mlp_ilt_dataflow(lib, env, S):
+    st = onl.ENV_STATS[env]
+    d, nu = st["d"], st["nu"]
+    sd = onl.make_synthetic_state_dict(1, d, nu, 128, S, st["state_std"], [1.0], tame=True)
+    torch.manual_seed(d + S)
+    p = torch.randn(16, d + 2, dtype=torch.float64)
+    tn = 0.125
+    pre = "laplace_rep_func.linear_tanh_stack."
+    keep = [arr(sd[pre + k]) for k in ("0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias")]
+    alpha, tol, scale = oilt.ilt_options("fourier")
+    out = np.zeros((16, d))
+    pa = arr(p)
+    lib.emu_mlp_ilt(*[ctypes.c_void_p(a.ctypes.data) for a in keep], d, S, 128, ctypes.c_void_p(pa.ctypes.data),
+                    ctypes.c_double(tn), ctypes.c_double(alpha), ctypes.c_double(np.log(tol)), ctypes.c_double(scale),
+                    ctypes.c_void_p(out.ctypes.data))
+    ref = oilt.laplace_reconstruct(lambda i: onl.rep_func(sd, i, d, S), p, torch.full((16, 1), tn, dtype=torch.float64),
+                                   recon_dim=d, ilt_reconstruction_terms=S).view(16, d)
+    np.testing.assert_allclose(out, ref.numpy(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("nu,B", [(1, 4), (2, 4), (1, 5), (3, 3)])
+def test_gru_chunked_dataflow(lib, nu, B):
+    sd = onl.make_synthetic_state_dict(2, 4, nu, 128, 17)
+    torch.manual_seed(nu * 10 + B)
+    win = torch.randn(16, B, nu, dtype=torch.float64)
+    pre = "action_encoder.gru."
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1"]
+    keep = [arr(sd[pre + n]) for n in names] + [arr(sd["action_encoder.linear_out.weight"]), arr(sd["action_encoder.linear_out.bias"])]
+    out = np.zeros((16, 2))
+    w = arr(win)
+    lib.emu_gru(*[ctypes.c_void_p(a.ctypes.data) for a in keep], 64, nu, B, ctypes.c_void_p(w.ctypes.data),
+                ctypes.c_void_p(out.ctypes.data))
+    np.testing.assert_allclose(out, onl.gru_encoder(sd, win).numpy(), rtol=1e-11, atol=1e-13)
