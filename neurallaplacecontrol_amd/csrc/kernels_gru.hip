@@ -8,11 +8,15 @@
 //
 // Roofline: FP64 MFMA bound.  Per 16 windows (B = 4): B*MT (input) + (B-1)*KS*MT (l0 hh) + B*KS*MT (l1 ih)
 // + (B-1)*KS*MT (l1 hh) + KS (head) = 1984 MFMAs of 2048 flop; HBM traffic is nu*8 B in + 16 B out per window.
+#include <cstdlib>
+
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
 namespace nlc {
 
+// (Measured on MI355X, cfg2: gates replaced by plain FMAs (NLC_GRU_DBG=1) -> 2.65 ms vs 3.43 ms, i.e. MFMA + weight
+// streaming 2.65 ms, gate transcendentals 0.8 ms; a two-k-step fragment prefetch changed nothing: loads are hidden.)
 // Gate GEMMs are processed in CHUNKS of one 16-feature tile per gate (r_j, z_j, n_j): only four accumulator
 // tiles are live at a time instead of sixteen, which keeps the kernel under 256 VGPRs -> two waves per SIMD,
 // so one wave's gate transcendentals (FP64 VALU) overlap the other wave's MFMAs.
@@ -40,10 +44,16 @@ __device__ __forceinline__ void chunk_gemm(v4d& c0, v4d& c1, v4d& c2, const doub
   }
 }
 
+// DBG = 1: timing experiment only (env NLC_GRU_DBG=1): gates replaced by a few FMAs -> MFMA + load time
+template <int DBG>
 __device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d& ain, const v4d& ahn, const v4d& hold) {
   v4d hnew;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+    if (DBG == 1) {
+      hnew[r] = 0.25 * ar[r] + 0.125 * az[r] + 0.01 * (ain[r] + ahn[r]) + 0.5 * hold[r];
+      continue;
+    }
     const double rg = m::sigmoid_d(ar[r]);
     const double zg = m::sigmoid_d(az[r]);
     const double ng = m::tanh_d(ain[r] + rg * ahn[r]);
@@ -52,7 +62,7 @@ __device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d
   return hnew;
 }
 
-template <int G>
+template <int G, int DBG>
 __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
   constexpr int GT = G / 16;   // tiles per gate = chunks
   constexpr int KS = G / 4;    // k-steps over the hidden dimension
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
       v4d ahn = load_bias_tile(a.bhn0, j, q);
       if (s > 0)
         chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
-      hn[j] = gru_gates(ar, az, ain, ahn, h0[j]);
+      hn[j] = gru_gates<DBG>(ar, az, ain, ahn, h0[j]);
     }
 #pragma unroll
     for (int j = 0; j < GT; ++j) h0[j] = hn[j];
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
       chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
       if (s > 0)
         chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
-      hn[j] = gru_gates(ar, az, ain, ahn, h1[j]);
+      hn[j] = gru_gates<DBG>(ar, az, ain, ahn, h1[j]);
     }
 #pragma unroll
     for (int j = 0; j < GT; ++j) h1[j] = hn[j];
@@ -138,10 +148,13 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s) {
   if (a.N <= 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.N + 63) / 64);
-  if (g == 64) {
-    hipLaunchKernelGGL(gru_encode_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+  static const bool dbg = std::getenv("NLC_GRU_DBG") && std::atoi(std::getenv("NLC_GRU_DBG")) == 1;
+  if (g == 64 && dbg) {
+    hipLaunchKernelGGL((gru_encode_kernel<64, 1>), dim3(grid), dim3(256), 0, s, a);
+  } else if (g == 64) {
+    hipLaunchKernelGGL((gru_encode_kernel<64, 0>), dim3(grid), dim3(256), 0, s, a);
   } else if (g == 32) {
-    hipLaunchKernelGGL(gru_encode_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gru_encode_kernel<32, 0>), dim3(grid), dim3(256), 0, s, a);
   } else {
     return hipErrorInvalidValue;
   }
