@@ -12,3 +12,8 @@ extern "C" {
 void nlc_t_tan_pi4(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tan_pi4_plus(x[i]); }
 void nlc_t_cosq(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::cos_quadrant(x[i], (int)(i % 7) - 3); }
 }
+static const double kTab[64] = {NLC_EXP_TABLE_VALUES};
+extern "C" {
+void nlc_t_tanh_t(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tanh_t(x[i], kTab); }
+void nlc_t_sigmoid_t(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::sigmoid_t(x[i], kTab); }
+}

@@ -87,3 +87,19 @@ def test_cos_quadrant(lib):
     pi_l = np.longdouble("3.14159265358979323846264338327950288")
     ref = np.cos(x.astype(np.longdouble) + j0 * pi_l / 2).astype(np.float64)
     assert np.abs(call(lib, "nlc_t_cosq", x) - ref).max() < 3e-16
+
+
+def test_table_driven_tanh_sigmoid(lib):
+    x = np.concatenate([np.linspace(-40, 40, 400001), np.logspace(-300, 1, 20001), -np.logspace(-12, 1, 2001), [0.0]])
+    # the rounded table entry leaves an ABSOLUTE error of ~1e-16 on e^{-2a}-1, so for 0.003 < |x| < 0.03 the
+    # result is exact to 2e-16 absolute rather than to a few ulp (it feeds matmuls: same as any rounding of O(1) data)
+    y, ref = call(lib, "nlc_t_tanh_t", x), np.tanh(x)
+    assert np.all(np.abs(y - ref) <= 2.5e-16 + 4 * np.spacing(np.abs(ref)))
+    assert ulp_err(y[np.abs(x) > 0.05], ref[np.abs(x) > 0.05]).max() <= 6
+    assert ulp_err(y[np.abs(x) < 0.002], ref[np.abs(x) < 0.002]).max() <= 4
+    xs = np.concatenate([np.linspace(-800, 800, 400001), np.logspace(-12, 2, 2001)])
+    ref = np.where(xs >= 0, 1 / (1 + np.exp(-np.abs(xs))), np.exp(-np.abs(xs)) / (1 + np.exp(-np.abs(xs))))
+    y = call(lib, "nlc_t_sigmoid_t", xs)
+    ok = np.abs(xs) < 700
+    assert ulp_err(y[ok], ref[ok]).max() <= 4
+    assert np.all(np.isfinite(y)) and np.all(y >= 0) and np.all(y <= 1)
