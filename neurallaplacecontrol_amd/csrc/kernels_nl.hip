@@ -129,11 +129,11 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
       const int g = 2 * j + r;
       const double theta = m::tanh_d(o[j][r]) * kPi;                               // w_nl.py:59
       const double phi = m::tanh_d(o[j][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
-      const double rad = m::tan_pi4_plus(phi / 2.0 + kPi / 4.0);
-      double sn, cs;
-      m::sincos_bounded(theta, &sn, &cs);
-      const double trig = (g < n.n_even_groups) ? cs : sn;
-      ax[0] = mfma(cp[g * 64 + lane], rad * trig, ax[0]);
+      // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
+      double num, den;
+      m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+      const double trig = m::cos_quadrant(theta, (g < n.n_even_groups) ? 0 : -1);
+      ax[0] = mfma(cp[g * 64 + lane], (num * trig) * m::rcp_refined(den), ax[0]);
     }
   }
   return ax[0];
@@ -335,11 +335,10 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
             const int g = 2 * j3[i] + r;
             const double theta = m::tanh_d(o[i][r]) * kPi;
             const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
-            const double rad = m::tan_pi4_plus(phi / 2.0 + kPi / 4.0);
-            double sn, cs;
-            m::sincos_bounded(theta, &sn, &cs);
-            const double trig = (g < n.n_even_groups) ? cs : sn;
-            ax = mfma(cp[g * 64 + lane], rad * trig, ax);
+            double num, den;
+            m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+            const double trig = m::cos_quadrant(theta, (g < n.n_even_groups) ? 0 : -1);
+            ax = mfma(cp[g * 64 + lane], (num * trig) * m::rcp_refined(den), ax);
           }
         }
       }

@@ -91,17 +91,25 @@ NLC_HD double expm1_neg(double y) {
   return fma(two_n, p, two_n - 1.0);
 }
 
+// exp(y) for y <= 0 (one-sided clamp: callers pass -|x|)
+NLC_HD double exp_neg(double y) {
+  y = fmax(y, -745.0);
+  int n;
+  const double r = exp_reduce(y, &n);
+  return ldexp(1.0 + expm1_poly(r), n);
+}
+
 NLC_HD double sigmoid_d(double x) {
-  const double e = exp_d(-fabs(x));  // (0, 1]
+  const double e = exp_neg(-fabs(x));  // (0, 1]
   const double inv = rcp_refined(1.0 + e);
   return x >= 0.0 ? inv : e * inv;
 }
 
+// tanh(x) = -em/(2 + em), em = e^{-2|x|} - 1.  No saturation branch: for large |x| em rounds to -1 and the
+// quotient to exactly 1.  The denominator is in [1, 2], so the refined reciprocal (< 1 ulp) replaces a division.
 NLC_HD double tanh_d(double x) {
-  const double a = fabs(x);
-  const double em = expm1_neg(-2.0 * a);  // e^{-2a} - 1 in (-1, 0]
-  double t = div_fast(-em, 2.0 + em);
-  t = a > 20.0 ? 1.0 : t;
+  const double em = expm1_neg(-2.0 * fabs(x));  // (-1, 0]
+  const double t = -em * rcp_refined(2.0 + em);
   return copysign(t, x);
 }
 
