@@ -43,21 +43,21 @@ NLC_HD double div_fast(double n, double d) {
 #endif
 }
 
-// expm1(r) for |r| <= ln2/2: Taylor/Horner to r^13 (remainder < 5e-18 relative)
+// expm1(r) = r + r^2 q(r) for |r| <= ln2/2.  q: degree-9 Chebyshev-interpolation polynomial of
+// (e^r - 1 - r)/r^2 on the interval (near-minimax; max relative error of the expm1 result 4.1e-17 in exact
+// arithmetic, vs degree 11 for the same accuracy with Taylor coefficients) -- two FMAs fewer per call.
 NLC_HD double expm1_poly(double r) {
-  double p = 1.0 / 6227020800.0;  // 1/13!
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  return fma(p * r, r, r);
+  double q = 0x1.af38a9b0ec855p-26;
+  q = fma(q, r, 0x1.289185613a3d6p-22);
+  q = fma(q, r, 0x1.71de0dae63bb3p-19);
+  q = fma(q, r, 0x1.a019b90d2ae7ap-16);
+  q = fma(q, r, 0x1.a01a01a7c41d5p-13);
+  q = fma(q, r, 0x1.6c16c1788bd90p-10);
+  q = fma(q, r, 0x1.11111111109b3p-7);
+  q = fma(q, r, 0x1.5555555553d63p-5);
+  q = fma(q, r, 0x1.5555555555556p-3);
+  q = fma(q, r, 0x1.0000000000001p-1);
+  return fma(q * r, r, r);
 }
 
 // y = n ln2 + r
