@@ -99,6 +99,8 @@ NLC_HD double exp_neg(double y) {
   return ldexp(1.0 + expm1_poly(r), n);
 }
 
+// (the one-line form rcp(1 + exp(-x)) is 3 instructions shorter but tips the GRU kernel, which sits at exactly
+// 256 VGPRs for 2 waves/SIMD, into 308 B/lane of scratch: 3.29 -> 3.94 ms.  Measured; keep the two-sided form.)
 NLC_HD double sigmoid_d(double x) {
   const double e = exp_neg(-fabs(x));  // (0, 1]
   const double inv = rcp_refined(1.0 + e);
