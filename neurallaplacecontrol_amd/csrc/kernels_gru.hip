@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
   int64_t kk = 0;
   int tt = 0;
   if (a.mode == 1) {
-    kk = wc / a.T;
-    tt = (int)(wc - kk * a.T);
+    kk = wc / a.Tc;
+    tt = a.t0 + (int)(wc - kk * a.Tc);
   }
 
   v4d h0[GT], h1[GT], hn[GT];
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
   v4d o[1];
   o[0] = splat(0.0);
   gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
-  if (valid && q < 2) a.out[w * 2 + q] = o[0][0] + a.bo[q];
+  if (valid && q < 2) {
+    const int64_t wo = (a.mode == 1) ? kk * a.T + tt : w;  // (k, t) -> row of the (K, T, 2) latent tensor
+    a.out[wo * 2 + q] = o[0][0] + a.bo[q];
+  }
 }
 
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s) {

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
   // lane (q) owns latent indices i0 = q and i1 = 4 + q: state dims, then the two GRU latents
   const int i0 = q, i1 = 4 + q;
   double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
-  const double* st = a.state0 + (a.state_per_sample ? kc * d : 0);
+  const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
+  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc * d : 0) : a.xcarry + kc * d;
   if (i0 < d) {
     x0 = st[i0];
     m0 = n.state_mean[i0];
@@ -170,7 +171,11 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
   const double factor = exp(gamma * a.tn) / Tt;
 
   double cost = 0.0, pcost = 0.0;
-  for (int t = 0; t < a.T; ++t) {
+  if (!first_chunk) {
+    cost = a.ccarry[kc * 2];
+    pcost = a.ccarry[kc * 2 + 1];
+  }
+  for (int t = a.t_begin; t < a.t_end; ++t) {
     const double* pa = a.pa + (kc * a.T + t) * 2;
     const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
     const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
@@ -203,7 +208,18 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
     cost += running_cost(a.env, xs, u, a.nu);
     pcost += pc;
   }
-  if (valid && q == 0) a.cost_total[k] = cost + pcost;
+  if (valid) {
+    if (last_chunk) {
+      if (q == 0) a.cost_total[k] = cost + pcost;
+    } else {
+      if (i0 < d) a.xcarry[k * d + i0] = x0;
+      if (i1 < d) a.xcarry[k * d + i1] = x1;
+      if (q == 0) {
+        a.ccarry[k * 2] = cost;
+        a.ccarry[k * 2 + 1] = pcost;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ latency-split rollout (small K per GPU)
@@ -229,7 +245,8 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
   const int d = n.d;
   const int i0 = q, i1 = 4 + q;
   double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
-  const double* st = a.state0 + (a.state_per_sample ? kc * d : 0);
+  const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
+  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc * d : 0) : a.xcarry + kc * d;
   if (i0 < d) {
     x0 = st[i0];
     m0 = n.state_mean[i0];
@@ -249,7 +266,11 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
   for (int i = 0; i < NTW; ++i) j3[i] = (wv + 4 * i < NT3) ? wv + 4 * i : NT3 - 1;
 
   double cost = 0.0, pcost = 0.0;
-  for (int t = 0; t < a.T; ++t) {
+  if (!first_chunk) {
+    cost = a.ccarry[kc * 2];
+    pcost = a.ccarry[kc * 2 + 1];
+  }
+  for (int t = a.t_begin; t < a.t_end; ++t) {
     const double* pa = a.pa + (kc * a.T + t) * 2;
     const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
     const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
@@ -376,7 +397,18 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
       pcost += pc;
     }
   }
-  if (wv == 0 && valid && q == 0) a.cost_total[k] = cost + pcost;
+  if (wv == 0 && valid) {
+    if (last_chunk) {
+      if (q == 0) a.cost_total[k] = cost + pcost;
+    } else {
+      if (i0 < d) a.xcarry[k * d + i0] = x0;
+      if (i1 < d) a.xcarry[k * d + i1] = x1;
+      if (q == 0) {
+        a.ccarry[k * 2] = cost;
+        a.ccarry[k * 2 + 1] = pcost;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ single model forward, per-sample t

@@ -79,6 +79,8 @@ struct nlc_ctx {
   double* pinned = nullptr;
   size_t pinned_n = 0;
   hipEvent_t stage_ev = nullptr;  // recorded after the staged H2D copies of a command
+  hipEvent_t ev_start = nullptr;  // horizon-chunk overlap: perturbation done (main stream)
+  hipEvent_t ev_chunk[8] = {};    // GRU latents of chunk c ready (side stream)
 };
 
 namespace {
@@ -120,7 +122,9 @@ struct ProfScope {
     hipEventCreate(&e);
     return e;
   }
-  ProfScope(nlc_ctx* ctx, const char* name) : c(ctx) {
+  hipStream_t st;
+  ProfScope(nlc_ctx* ctx, const char* name, hipStream_t stream = nullptr, bool use_given = false)
+      : c(ctx), st(use_given ? stream : ctx->stream) {
     if (!c->profiling) return;
     for (auto& p : c->prof)
       if (p.name == name) entry = &p;
@@ -131,11 +135,11 @@ struct ProfScope {
     }
     e0 = take_event();
     e1 = take_event();
-    hipEventRecord(e0, c->stream);
+    hipEventRecord(e0, st);
   }
   ~ProfScope() {
     if (!entry) return;
-    hipEventRecord(e1, c->stream);
+    hipEventRecord(e1, st);
     entry->pending.emplace_back(e0, e1);
     entry->launches += 1;
   }
@@ -244,6 +248,9 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   if (c->small) hipFree(c->small);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->stage_ev) hipEventDestroy(c->stage_ev);
+  if (c->ev_start) hipEventDestroy(c->ev_start);
+  for (hipEvent_t e : c->ev_chunk)
+    if (e) hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   hipStreamDestroy(c->own_stream);
   delete c;
@@ -602,7 +609,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 
 namespace {
 struct WsLayout {
-  size_t block_min, block_part, pa, state0, abuf, total;
+  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, total;
 };
 WsLayout ws_layout(const nlc_ctx* c) {
   const nlc_mppi_desc& d = c->pd;
@@ -618,6 +625,8 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.pa = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * d.T * 2 : 0);
   w.state0 = take(d.dynamics == NLC_DYN_EXTERNAL ? 0 : (size_t)d.K * d.d);
   w.abuf = take((size_t)d.B * d.nu);
+  w.xcarry = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * d.d : 0);
+  w.ccarry = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * 2 : 0);
   w.total = off;
   return w;
 }
@@ -746,13 +755,8 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     g.abuf = abuf_dev;
     g.u_scale = d.u_scale;
     g.T = d.T;
-    g.N = d.K * d.T;
     g.B = d.B;
     g.out = pa;
-    {
-      ProfScope ps(c, "gru_encode_kernel");
-      NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
-    }
     RolloutArgs r{};
     r.net = c->net;
     r.net.b1 = c->b1fold;
@@ -774,11 +778,51 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     r.tn = c->tn;
     r.states = buf->states;
     r.cost_total = buf->cost_total;
+    r.xcarry = ws + w.xcarry;
+    r.ccarry = ws + w.ccarry;
     // NLC_ROLLOUT_VARIANT=1|2 pins the wave-per-tile / latency-split kernel (tests, experiments); default auto
     int variant = 0;
     if (const char* ev = std::getenv("NLC_ROLLOUT_VARIANT")) variant = std::atoi(ev);
-    ProfScope ps(c, "nl_rollout_kernel");
-    NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
+    // Horizon chunking (experiment knob, OFF by default): NLC_HORIZON_CHUNKS=n cuts the horizon into n chunks and
+    // runs the GRU encode of chunk c+1 on the ctx's side stream while the rollout of chunk c runs on the main
+    // stream, so the encoder could fill the CUs a small shard's rollout leaves idle.  Measured on MI355X at
+    // K = 2048 / 4096 / 8192: 0.98 / 1.43 / 2.55 ms unchunked vs 1.04 / 1.54 / 2.65 ms with 4 chunks -- the
+    // co-running kernels slow each other down by more than the overlap buys, so the default stays 1.
+    int chunks = 1;
+    if (const char* ev = std::getenv("NLC_HORIZON_CHUNKS")) chunks = std::atoi(ev);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 8) chunks = 8;
+    if (chunks > d.T) chunks = d.T;
+    hipStream_t side = (chunks > 1) ? c->own_stream : c->stream;
+    if (chunks > 1) {
+      if (!c->ev_start) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+      NLC_HIP(c, hipEventRecord(c->ev_start, c->stream));
+      NLC_HIP(c, hipStreamWaitEvent(side, c->ev_start, 0));
+    }
+    const int base = d.T / chunks, extra = d.T % chunks;
+    int t0 = 0;
+    for (int ci = 0; ci < chunks; ++ci) {
+      const int tc = base + (ci < extra ? 1 : 0);
+      g.t0 = t0;
+      g.Tc = tc;
+      g.N = d.K * tc;
+      {
+        ProfScope ps(c, "gru_encode_kernel", side, true);
+        NLC_HIP(c, launch_gru_encode(g, c->g, side));
+      }
+      if (chunks > 1) {
+        if (!c->ev_chunk[ci]) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_chunk[ci], hipEventDisableTiming));
+        NLC_HIP(c, hipEventRecord(c->ev_chunk[ci], side));
+        NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_chunk[ci], 0));
+      }
+      r.t_begin = t0;
+      r.t_end = t0 + tc;
+      {
+        ProfScope ps(c, "nl_rollout_kernel");
+        NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
+      }
+      t0 += tc;
+    }
   } else {
     OracleRolloutArgs r{};
     r.K = d.K;

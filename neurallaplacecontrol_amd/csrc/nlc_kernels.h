@@ -44,7 +44,8 @@ struct GruArgs {
   const double* abuf;       // mode 1: (B, nu) device copy of action_buffer
   double u_scale;
   int mode, T;
-  int64_t N;  // windows (mode 1: K*T)
+  int t0, Tc;  // mode 1: this launch encodes horizon steps [t0, t0+Tc) of every sample (N = K*Tc)
+  int64_t N;  // windows (mode 1: K*Tc)
   int B, nin;
   double mean[NLC_MAX_NIN], std[NLC_MAX_NIN];
   // fragment-packed weights (device)
@@ -93,6 +94,11 @@ struct RolloutArgs {
   double lambda_, u_scale;
   int noise_abs_cost;
   double tn;                // normalised prediction time (constant over the rollout)
+  // horizon chunking: this launch runs steps [t_begin, t_end); state and the two cost sums are carried between
+  // launches in xcarry (K, d) / ccarry (K, 2) so the GRU encode of later steps can overlap earlier rollout steps
+  int t_begin, t_end;
+  double* xcarry;
+  double* ccarry;
   double* states;           // (K, T, d) or NULL
   double* cost_total;       // (K)
 };

@@ -599,3 +599,33 @@ def test_collector_variant_encode_obs_time_with_oracle_dynamics(nlc):
         m.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
         acts.append(m.command(st, buf))
     assert torch.equal(acts[0], acts[1])
+
+
+def test_horizon_chunked_two_stream_rollout_agrees(nlc, monkeypatch):
+    """NLC_HORIZON_CHUNKS (GRU encode on the side stream overlapping the rollout, state carried between launches)
+    gives the same numbers as the single-launch path."""
+    from oracle import nl_model as onl
+
+    env, K, T = "oderl-acrobot", 1040, 13  # ragged K, T not divisible by the chunk count
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    torch.manual_seed(8)
+    raw = torch.randn(K, T, nu, dtype=torch.float64)
+    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.2
+    state, ab = nlc.initial_state(env), torch.randn(4, nu, dtype=torch.float64)
+    out = {}
+    for chunks in ("1", "4"):
+        monkeypatch.setenv("NLC_HORIZON_CHUNKS", chunks)
+        for variant in ("1", "2"):
+            monkeypatch.setenv("NLC_ROLLOUT_VARIANT", variant)
+            mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                                 lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+            mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+            act = mppi.command(state, ab)
+            out[(chunks, variant)] = (act.clone(), mppi.states.clone(), mppi.cost_total.clone())
+    ref = out[("1", "1")]
+    for key, val in out.items():
+        for a, b in zip(ref, val):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-11, atol=1e-11, err_msg=str(key))
