@@ -250,13 +250,18 @@ __global__ __launch_bounds__(64) void ilt_dehoog_kernel(const IltArgs a) {
     int r = threadIdx.x / S, k = threadIdx.x - r * S;
     constexpr int dr = ROWS / S, dk = ROWS - dr * S;
     for (int64_t e = threadIdx.x; e < elems; e += ROWS) {
-      const double theta = a.theta[base + e];
-      const double phi = a.phi[base + e];
-      const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
-      double sn, cs;
-      m::sincos_bounded(theta, &sn, &cs);
-      fr[r * SP + k] = rad * cs;
-      fi[r * SP + k] = rad * sn;
+      if (a.fre != nullptr) {  // F_k supplied directly (staged planner / model path)
+        fr[r * SP + k] = a.fre[base + e];
+        fi[r * SP + k] = a.fim[base + e];
+      } else {
+        const double theta = a.theta[base + e];
+        const double phi = a.phi[base + e];
+        const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
+        double sn, cs;
+        m::sincos_bounded(theta, &sn, &cs);
+        fr[r * SP + k] = rad * cs;
+        fi[r * SP + k] = rad * sn;
+      }
       r += dr;
       k += dk;
       if (k >= S) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(64) void ilt_dehoog_kernel(const IltArgs a) {
 #pragma unroll
       for (int i = 0; i <= 2 * M; ++i) e[i] = {0.0, 0.0};
       const int64_t row = row0 + threadIdx.x;
-      const double t = a.t[row / a.d];
+      const double t = (a.t_stride ? a.t[row / a.d] : a.t[0]) / a.t_div;
       const double Tt = a.scale * t;
       const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
       const double ang = kPi * (t / Tt);

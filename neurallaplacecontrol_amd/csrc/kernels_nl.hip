@@ -64,8 +64,18 @@ __device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MA
 // ------------------------------------------------------------------ one model evaluation
 // p0/p1: layer-1 latent B fragments (index 4s+q).  Returns acc_x: ILT sums, rows = dims (reg r -> dim q+4r).
 // GENERAL_T: sphere coordinates of the per-sample query points enter layer 1 through W1s.
-template <int HT, int NT3, bool GENERAL_T>
-__device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn) {
+// FOUT != nullptr-mode (WRITE_F): instead of the Fourier sum, F_k = |F| e^{i theta} of every Laplace term is
+// written to (N, d, S) arrays for the de Hoog kernel (nonlinear in F, cannot be an MFMA).
+struct FOut {
+  double* fre;
+  double* fim;
+  const int* slot;  // slot index (8 per layer-3 tile) -> c*S + k, -1 = padding
+  int64_t row;      // sample row; < 0: do not store
+  int dS;
+};
+template <int HT, int NT3, bool GENERAL_T, bool WRITE_F = false>
+__device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn,
+                                       const FOut* fo = nullptr) {
   constexpr int KS = HT * 4;  // h / 4
   v4d h1[HT];
 #pragma unroll
@@ -132,8 +142,19 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
       // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
       double num, den;
       m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
-      const double trig = m::cos_quadrant(theta, (g < n.n_even_groups) ? 0 : -1);
-      ax[0] = mfma(cp[g * 64 + lane], (num * trig) * m::rcp_refined(den), ax[0]);
+      if constexpr (WRITE_F) {
+        const int idx = fo->slot[4 * g + q];
+        if (fo->row >= 0 && idx >= 0) {
+          double sn, cs;
+          m::sincos_bounded(theta, &sn, &cs);
+          const double rad = num * m::rcp_refined(den);
+          fo->fre[fo->row * fo->dS + idx] = rad * cs;
+          fo->fim[fo->row * fo->dS + idx] = rad * sn;
+        }
+      } else {
+        const double trig = m::cos_quadrant(theta, (g < n.n_even_groups) ? 0 : -1);
+        ax[0] = mfma(cp[g * 64 + lane], (num * trig) * m::rcp_refined(den), ax[0]);
+      }
     }
   }
   return ax[0];
@@ -439,6 +460,30 @@ __global__ __launch_bounds__(256) void nl_forward_kernel(const ForwardArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ representation function only (de Hoog path)
+// One model evaluation per sample, output = F_k (re, im) of all d*S Laplace terms.  Used (a) per horizon step by
+// the de Hoog planner path (folded constant-t bias) and (b) by NeuralLaplaceModel.forward with per-row t.
+template <int HT, int NT3, bool GENERAL_T>
+__global__ __launch_bounds__(256) void nl_repfunc_kernel(const RepFuncArgs a) {
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool valid = k < a.N;
+  const int64_t kc = valid ? k : a.N - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  const double* ob = a.obs + (a.obs_per_sample ? kc * d : 0);
+  const double* pa = a.pa + kc * a.pa_stride;
+  const double p0 = (i0 < d) ? (ob[i0] - n.state_mean[i0]) / n.state_std[i0]
+                             : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+  const double p1 = (i1 < d) ? (ob[i1] - n.state_mean[i1]) / n.state_std[i1]
+                             : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+  const double tn = GENERAL_T ? a.ts[kc] / n.time_div : a.tn;
+  const FOut fo{a.fre, a.fim, a.slot, valid ? k : -1, d * n.S};
+  nl_eval<HT, NT3, GENERAL_T, true>(n, lane, q, p0, p1, tn, &fo);
+}
+
 // instantiated layer-3 tile counts; other (d,S) round up to the next one (zero-padded tiles)
 #define NLC_FOR_NT3(X) X(7) X(9) X(11) X(13) X(17) X(21) X(25)
 
@@ -492,6 +537,27 @@ hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s) {
 #define X(N)                                                                          \
   case N:                                                                             \
     hipLaunchKernelGGL((nl_forward_kernel<8, N>), dim3(grid), dim3(256), 0, s, a); \
+    break;
+    NLC_FOR_NT3(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s) {
+  if (a.N <= 0) return hipSuccess;
+  if (a.net.h != 128) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((a.N + 63) / 64);
+  switch (a.net.nt3) {
+#define X(N)                                                                                        \
+  case N:                                                                                           \
+    if (a.general_t) {                                                                              \
+      hipLaunchKernelGGL((nl_repfunc_kernel<8, N, true>), dim3(grid), dim3(256), 0, s, a);        \
+    } else {                                                                                        \
+      hipLaunchKernelGGL((nl_repfunc_kernel<8, N, false>), dim3(grid), dim3(256), 0, s, a);       \
+    }                                                                                               \
     break;
     NLC_FOR_NT3(X)
 #undef X

@@ -60,6 +60,7 @@ struct nlc_ctx {
   GruArgs gru{};   // weight pointers + normalisation filled in
   NlNetArgs net{}; // general-t variant (b1 = raw bias)
   std::vector<double> W1s_host, b1_host;  // for folding the constant sphere inputs at configure time
+  int* slot_dev = nullptr;                // (8*nt3) layer-3 slot -> c*S + k (de Hoog path)
 
   // planner
   bool has_mppi = false;
@@ -242,6 +243,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_flush(c);
   if (c->arena.base) hipFree(c->arena.base);
+  if (c->slot_dev) hipFree(c->slot_dev);
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
   if (c->b1fold) hipFree(c->b1fold);
@@ -316,7 +318,7 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
   if (N == 0) return NLC_OK;
   if (!theta || !phi || !t || !x) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
-  IltArgs a{theta, phi, t, x, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, 0, 0, 0};
+  IltArgs a{theta, phi, t, x, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr, 1.0, 1, 0, 0, 0};
   if (d->algo == NLC_ILT_FOURIER) {
     ProfScope ps(c, "ilt_fourier_kernel");
     NLC_HIP(c, launch_ilt_fourier(a, c->stream));
@@ -413,6 +415,15 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
     hipFree(base);
     return fail(c, NLC_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e));
   }
+  {
+    std::vector<int> slot((size_t)nt3 * 8, -1);
+    for (size_t i = 0; i < slot.size(); ++i)
+      if (slots.elems[i].first >= 0) slot[i] = slots.elems[i].first * S + slots.elems[i].second;
+    if (c->slot_dev) hipFree(c->slot_dev);
+    c->slot_dev = nullptr;
+    NLC_HIP(c, hipMalloc((void**)&c->slot_dev, slot.size() * sizeof(int)));
+    NLC_HIP(c, hipMemcpy(c->slot_dev, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   NLC_HIP(c, hipStreamSynchronize(c->stream));
   if (c->arena.base) hipFree(c->arena.base);
   c->arena = std::move(ar);
@@ -493,8 +504,10 @@ extern "C" int nlc_gru_encode(nlc_ctx* c, const double* window, int64_t N, int B
 }
 
 extern "C" int64_t nlc_model_workspace_bytes(nlc_ctx* c, int64_t N) {
-  (void)c;
-  return N < 0 ? -1 : (N * 2 + 64) * (int64_t)sizeof(double);
+  if (N < 0) return -1;
+  int64_t n = N * 2 + 64;  // GRU latents
+  if (c && c->has_model && c->md.ilt.algo == NLC_ILT_DEHOOG) n += 2 * N * c->md.d * c->S + 64;  // F_k re/im
+  return n * (int64_t)sizeof(double);
 }
 
 extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* window, const double* ts, int64_t N,
@@ -502,8 +515,8 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
   if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
-  if (c->md.ilt.algo != NLC_ILT_FOURIER)
-    return fail(c, NLC_ERR_UNSUPPORTED, "fused model forward implements ilt_algorithm='fourier' (use the staged path)");
+  if (c->md.ilt.algo == NLC_ILT_DEHOOG && c->S != 33 && c->S != 17 && c->S != 9)
+    return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
   if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
   if (N == 0) return NLC_OK;
   if (!obs || !window || !ts || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
@@ -518,6 +531,32 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
     a.out = pa;
     ProfScope ps(c, "gru_encode_kernel");
     NLC_HIP(c, launch_gru_encode(a, c->g, c->stream));
+  }
+  if (c->md.ilt.algo == NLC_ILT_DEHOOG) {
+    // staged: representation function -> F_k (re, im) in HBM -> de Hoog kernel (nonlinear in F: not an MFMA epilogue)
+    double* fre = pa + (N * 2 + 63) / 64 * 64;
+    double* fim = fre + N * c->md.d * c->S;
+    RepFuncArgs rf{};
+    rf.net = c->net;
+    rf.N = N;
+    rf.obs = obs;
+    rf.obs_per_sample = 1;
+    rf.pa = pa;
+    rf.pa_stride = 2;
+    rf.ts = ts;
+    rf.general_t = 1;
+    rf.slot = c->slot_dev;
+    rf.fre = fre;
+    rf.fim = fim;
+    {
+      ProfScope ps(c, "nl_repfunc_kernel");
+      NLC_HIP(c, launch_nl_repfunc(rf, c->stream));
+    }
+    IltArgs ia{nullptr, nullptr, ts, out, N, c->md.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol), c->md.ilt.scale,
+               fre, fim, c->md.time_div, 1, 0, 0, 0};
+    ProfScope ps(c, "ilt_dehoog_kernel");
+    NLC_HIP(c, launch_ilt_dehoog(ia, c->stream));
+    return NLC_OK;
   }
   {
     ForwardArgs f{};
@@ -556,8 +595,8 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     if (!c->has_model) return fail(c, NLC_ERR_STATE, "NL dynamics need nlc_set_model first");
     if (c->md.d != d->d || c->md.nin != d->nu)
       return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
-    if (c->md.ilt.algo != NLC_ILT_FOURIER)
-      return fail(c, NLC_ERR_UNSUPPORTED, "fused rollout implements ilt_algorithm='fourier'");
+    if (c->md.ilt.algo == NLC_ILT_DEHOOG && c->S != 33 && c->S != 17 && c->S != 9)
+      return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
   } else if (d->dynamics == NLC_DYN_ORACLE) {
     if (d->delay < 0 || d->delay > d->B - 1)
       return fail(c, NLC_ERR_BAD_ARG, "oracle dynamics: delay must be in [0, action_buffer_size-1]");
@@ -609,7 +648,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 
 namespace {
 struct WsLayout {
-  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, total;
+  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, total;
 };
 WsLayout ws_layout(const nlc_ctx* c) {
   const nlc_mppi_desc& d = c->pd;
@@ -627,6 +666,11 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.abuf = take((size_t)d.B * d.nu);
   w.xcarry = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * d.d : 0);
   w.ccarry = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * 2 : 0);
+  const bool dh = d.dynamics == NLC_DYN_NL && c->md.ilt.algo == NLC_ILT_DEHOOG;
+  w.fre = take(dh ? (size_t)d.K * d.d * c->S : 0);
+  w.fim = take(dh ? (size_t)d.K * d.d * c->S : 0);
+  w.dx = take(dh ? (size_t)d.K * d.d : 0);
+  w.tconst = take(dh ? 8 : 0);
   w.total = off;
   return w;
 }
@@ -780,6 +824,69 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     r.cost_total = buf->cost_total;
     r.xcarry = ws + w.xcarry;
     r.ccarry = ws + w.ccarry;
+    if (c->md.ilt.algo == NLC_ILT_DEHOOG) {
+      // staged de Hoog planner path (BASELINE configs[4]): hoisted GRU, then per horizon step three launches --
+      // representation function -> F_k, de Hoog ILT -> dx, state/cost tail.  Everything stays on the device.
+      g.t0 = 0;
+      g.Tc = d.T;
+      g.N = d.K * d.T;
+      {
+        ProfScope ps(c, "gru_encode_kernel");
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
+      }
+      double* tconst = ws + w.tconst;
+      NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      RepFuncArgs rf{};
+      rf.net = r.net;
+      rf.N = d.K;
+      rf.pa_stride = (int64_t)d.T * 2;
+      rf.tn = c->tn;
+      rf.general_t = 0;
+      rf.slot = c->slot_dev;
+      rf.fre = ws + w.fre;
+      rf.fim = ws + w.fim;
+      IltArgs ia{nullptr, nullptr, tconst, ws + w.dx, d.K, d.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol),
+                 c->md.ilt.scale, rf.fre, rf.fim, 1.0, 0, 0, 0, 0};
+      StepTailArgs st{};
+      st.K = d.K;
+      st.T = d.T;
+      st.nu = d.nu;
+      st.d = d.d;
+      st.env = d.env;
+      st.state_per_sample = state_per_sample;
+      st.state0 = state_dev;
+      st.x = r.xcarry;
+      st.dx = ws + w.dx;
+      st.ccarry = r.ccarry;
+      st.perturbed = buf->perturbed;
+      st.noise = buf->noise;
+      st.U = r.U;
+      for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) st.sigma_inv[i] = d.noise_sigma_inv[i];
+      st.lambda_ = d.lambda_;
+      st.u_scale = d.u_scale;
+      st.noise_abs_cost = d.noise_abs_cost;
+      st.states = buf->states;
+      st.cost_total = buf->cost_total;
+      for (int t = 0; t < d.T; ++t) {
+        rf.obs = (t == 0) ? state_dev : r.xcarry;
+        rf.obs_per_sample = (t == 0) ? state_per_sample : 1;
+        rf.pa = pa + (size_t)t * 2;
+        {
+          ProfScope ps(c, "nl_repfunc_kernel");
+          NLC_HIP(c, launch_nl_repfunc(rf, c->stream));
+        }
+        {
+          ProfScope ps(c, "ilt_dehoog_kernel");
+          NLC_HIP(c, launch_ilt_dehoog(ia, c->stream));
+        }
+        st.t = t;
+        st.first = t == 0;
+        st.last = t == d.T - 1;
+        ProfScope ps(c, "step_tail_kernel");
+        NLC_HIP(c, launch_step_tail(st, c->stream));
+      }
+      return run_weights(c, buf);
+    }
     // NLC_ROLLOUT_VARIANT=1|2 pins the wave-per-tile / latency-split kernel (tests, experiments); default auto
     int variant = 0;
     if (const char* ev = std::getenv("NLC_ROLLOUT_VARIANT")) variant = std::atoi(ev);

@@ -18,6 +18,10 @@ struct IltArgs {
   int64_t N;
   int d, S;
   double alpha, log_tol, scale;
+  const double* fre;  // de Hoog only: when non-NULL, F_k is read from (fre, fim) (N, d, S) instead of theta/phi
+  const double* fim;
+  double t_div;  // de Hoog: t is divided by this (model time normalisation); 1 otherwise
+  int t_stride;  // de Hoog: 1 = one t per point, 0 = t[0] for all points
   int rpp, iters;  // rows per pass / passes per block tile (set by the launcher)
   int dbg;         // 0 normal; timing experiments only: 1 memory-only, 2 arithmetic-only
 };
@@ -113,6 +117,43 @@ struct ForwardArgs {
   double* out;        // (N, d)
 };
 hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s);
+
+// representation function only: F_k (re, im) of every Laplace term -> (N, d, S) arrays (de Hoog path)
+struct RepFuncArgs {
+  NlNetArgs net;
+  int64_t N;
+  const double* obs;  // (N, d) or (d) broadcast
+  int obs_per_sample;
+  const double* pa;   // GRU latents, row n at pa + n*pa_stride
+  int64_t pa_stride;
+  const double* ts;   // (N) raw ts_pred (general_t)
+  double tn;          // constant normalised time (!general_t; net.b1 must be the folded bias)
+  int general_t;
+  const int* slot;    // (8*nt3) slot -> c*S + k or -1
+  double* fre;        // (N, d, S)
+  double* fim;
+};
+hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s);
+
+// x <- x + dx, running cost, state store: the per-step tail of the staged (de Hoog) planner path
+struct StepTailArgs {
+  int64_t K;
+  int T, t, nu, d, env, first, last;
+  int state_per_sample;
+  const double* state0;  // read when first
+  double* x;             // (K, d) carried state
+  const double* dx;      // (K, d)
+  double* ccarry;        // (K, 2) running cost / perturbation cost
+  const double* perturbed;
+  const double* noise;
+  const double* U;
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale;
+  int noise_abs_cost;
+  double* states;      // (K, T, d) or NULL
+  double* cost_total;  // (K), written when last
+};
+hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ oracle-dynamics rollout (§8f-1)
 struct OracleRolloutArgs {

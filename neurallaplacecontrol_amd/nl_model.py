@@ -235,7 +235,7 @@ class NeuralLaplaceModel(nn.Module):
             win = win.unsqueeze(1)
         ts = torch.as_tensor(ts_pred).detach().to(dev, torch.float64)
         N, d = obs.shape
-        fused = self.ilt_algorithm == "fourier" and ts.numel() == N
+        fused = self.ilt_algorithm in ("fourier", "dehoog") and ts.numel() == N
         if fused:
             out = torch.empty((N, d), dtype=torch.float64, device=dev)
             ws = torch.empty(ctx.lib.nlc_model_workspace_bytes(ctx.h, N) // 8, dtype=torch.float64, device=dev)
@@ -254,7 +254,7 @@ class NeuralLaplaceModel(nn.Module):
                     )
                 )
             return torch.squeeze(out.view(N, 1, d)).to(out_device)
-        # staged path (de Hoog, or several time points per row): HIP GRU -> torch MLP -> HIP ILT
+        # several time points per row: HIP GRU -> PyTorch-ROCm MLP (laplace_rep_func) -> HIP ILT
         desc = self.model_desc()
         sm = torch.tensor(list(desc.state_mean)[:d], dtype=torch.float64, device=dev)
         ss = torch.tensor(list(desc.state_std)[:d], dtype=torch.float64, device=dev)

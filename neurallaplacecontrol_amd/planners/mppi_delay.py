@@ -148,9 +148,9 @@ class MPPIDelay:
             # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
             # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
             and not (encode_obs_time and not isinstance(dynamics, OracleDynamics))
-            # the fused rollout kernel implements the Fourier ILT; a de Hoog model runs on the generic path
-            # (HIP GRU + PyTorch-ROCm MLP + HIP de Hoog ILT per horizon step)
-            and not (isinstance(dynamics, NLDynamics) and dynamics.model.ilt_algorithm != "fourier")
+            # Fourier models run the single persistent rollout kernel; de Hoog models the staged all-HIP path
+            # (rep-func kernel -> de Hoog kernel -> state/cost kernel per horizon step) inside nlc_mppi_rollout
+            and not (isinstance(dynamics, NLDynamics) and dynamics.model.ilt_algorithm not in ("fourier", "dehoog"))
         )
         if isinstance(dynamics, OracleDynamics) and not self.fused:
             raise NotImplementedError("OracleDynamics needs an EnvCost running_cost and the default rollout options")

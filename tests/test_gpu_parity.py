@@ -173,7 +173,7 @@ def test_model_forward_vs_golden(nlc, env):
 
 
 @pytest.mark.parametrize("env", ["cartpole", "acrobot"])
-def test_model_forward_dehoog_staged(nlc, env):
+def test_model_forward_dehoog(nlc, env):
     g = np.load(f"{GOLD}/g3_nl_{env}.npz")
     model = build_model(nlc, load_sd(g, "w33::"), S=33, algo="dehoog")
     with torch.no_grad():
@@ -528,8 +528,9 @@ def test_cfg4_acrobot_shard_32768x60(nlc):
     _subset_check(nlc, "oderl-acrobot", 32768, 60, 4)
 
 
-def test_cfg5_dehoog_planner_generic_path(nlc):
-    """BASELINE configs[4] ablation: a de Hoog (33 terms) model plans through the staged/generic path."""
+def test_cfg5_dehoog_planner_staged_hip_path(nlc):
+    """BASELINE configs[4] ablation: a de Hoog (33 terms) model plans through the staged all-HIP path
+    (rep-func kernel -> de Hoog kernel -> state/cost kernel per horizon step)."""
     from oracle import envs as oenvs
     from oracle import mppi as omppi
     from oracle import nl_model as onl
@@ -545,7 +546,7 @@ def test_cfg5_dehoog_planner_generic_path(nlc):
     state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
     mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cpu", lambda_=1.0,
                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
-    assert not mppi.fused
+    assert mppi.fused
     mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
     with torch.no_grad():
         act = mppi.command(state, ab)
@@ -629,3 +630,20 @@ def test_horizon_chunked_two_stream_rollout_agrees(nlc, monkeypatch):
     for key, val in out.items():
         for a, b in zip(ref, val):
             np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-11, atol=1e-11, err_msg=str(key))
+
+
+def test_dehoog_model_forward_multi_time_uses_torch_repfunc(nlc):
+    """Several time points per row (Tt > 1) go through laplace_reconstruct with the torch rep-func: same numbers."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-pendulum"]
+    sd = onl.make_synthetic_state_dict(4, 3, 1, 128, 17, st["state_std"], [1.0], tame=True)
+    for algo in ("fourier", "dehoog"):
+        model = build_model(nlc, sd, S=17, algo=algo)
+        torch.manual_seed(1)
+        obs, win = torch.randn(9, 3, dtype=torch.float64), torch.randn(9, 4, 1, dtype=torch.float64)
+        ts = torch.rand(9, 3, dtype=torch.float64) * 0.2 + 0.02
+        ref = onl.nl_forward(sd, obs, win, ts, S=17, ilt_algorithm=algo)
+        with torch.no_grad():
+            got = model(obs.cuda(), win.cuda(), ts.cuda()).cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
