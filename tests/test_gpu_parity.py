@@ -647,3 +647,53 @@ def test_dehoog_model_forward_multi_time_uses_torch_repfunc(nlc):
         with torch.no_grad():
             got = model(obs.cuda(), win.cuda(), ts.cuda()).cpu()
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_get_rollouts_open_loop_replay(nlc):
+    """MPPIDelay.get_rollouts (reference :358-381): open-loop replay of U through the dynamics callable."""
+    from oracle import nl_model as onl
+
+    env, T, A = "oderl-cartpole", 6, 3.0
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(0, 5, 1, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    U0 = torch.linspace(-0.5, 0.5, T, dtype=torch.float64).view(T, 1)
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), 5, nlc.noise_sigma(1), 64, T, "cpu",
+                         u_scale=A, U_init=U0.clone())
+    x0 = nlc.initial_state(env)
+    with torch.no_grad():
+        got = mppi.get_rollouts(x0)
+    ts = torch.full((1, 1), 0.05, dtype=torch.float64)
+    x, ref = x0.view(1, -1), []
+    for t in range(T):
+        x = x + onl.nl_forward(sd, x, (A * U0[t]).view(1, 1, 1), ts, S=17).view(1, -1)
+        ref.append(x)
+    np.testing.assert_allclose(got.numpy(), torch.stack(ref, dim=1).numpy(), **TOL)
+
+
+def _spawn_worker(q):
+    import torch as _t
+
+    import neurallaplacecontrol_amd as n
+
+    m = n.MPPIDelay(n.OracleDynamics("oderl-pendulum", 0.05, 0), n.EnvCost("oderl-pendulum"), 3, n.noise_sigma(1), 128, 5,
+                    "cpu", u_scale=2.0, U_init=_t.zeros(5, 1, dtype=_t.float64), noise_rng="philox", seed=3)
+    q.put(m.command(n.initial_state("oderl-pendulum"), _t.zeros(4, 1, dtype=_t.float64)).tolist())
+
+
+def test_spawned_worker_creates_its_own_ctx(nlc):
+    """The harness fans out with multiprocessing 'spawn' (run_exp_multi.py:145,207): HIP is initialised lazily in
+    the worker, and the Philox stream makes the result identical to the parent's."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_spawn_worker, args=(q,))
+    p.start()
+    child = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    m = nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum", 0.05, 0), nlc.EnvCost("oderl-pendulum"), 3, nlc.noise_sigma(1),
+                      128, 5, "cpu", u_scale=2.0, U_init=torch.zeros(5, 1, dtype=torch.float64), noise_rng="philox", seed=3)
+    mine = m.command(nlc.initial_state("oderl-pendulum"), torch.zeros(4, 1, dtype=torch.float64)).tolist()
+    assert child == mine
