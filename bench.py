@@ -225,10 +225,18 @@ def main():
     gk = kernels.get("gru_encode_kernel", dict(avg_ms=float("nan")))
     rk = kernels.get("nl_rollout_kernel", dict(avg_ms=float("nan")))
     gru_tf = gru_flops / (gk["avg_ms"] * 1e-3) / 1e12
+    g_traffic, r_traffic, t_src = None, None, None
+    pmc = os.path.join(REPO, "profiles", "r1_pmc_planner_traffic.json")
+    if os.path.exists(pmc) and k_local == K_SAMPLES:  # measured at the headline size only
+        pj = json.load(open(pmc))
+        g_traffic, r_traffic = pj["gru_encode"]["hbm_bytes_per_launch"], pj["nl_rollout_kernel"]["hbm_bytes_per_launch"]
+        t_src = "profiles/r1_pmc_planner_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
     roofline = dict(bound="mfma", achieved=gru_tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=gru_tf / FP64_MFMA_PEAK_TFLOPS, traffic=None, kernel="gru_encode_kernel",
+                    frac=gru_tf / FP64_MFMA_PEAK_TFLOPS, traffic=g_traffic, traffic_source=t_src,
+                    algorithmic_hbm_bytes=24 * k_local * HORIZON, kernel="gru_encode_kernel",
                     avg_launch_ms=gk["avg_ms"], flops_per_launch=gru_flops,
                     also=dict(kernel="nl_rollout_kernel", avg_launch_ms=rk["avg_ms"], flops_per_launch=roll_flops,
+                              traffic=r_traffic,
                               achieved=roll_flops / (rk["avg_ms"] * 1e-3) / 1e12,
                               frac=roll_flops / (rk["avg_ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS))
     cpu = None
