@@ -697,3 +697,32 @@ def test_spawned_worker_creates_its_own_ctx(nlc):
                       128, 5, "cpu", u_scale=2.0, U_init=torch.zeros(5, 1, dtype=torch.float64), noise_rng="philox", seed=3)
     mine = m.command(nlc.initial_state("oderl-pendulum"), torch.zeros(4, 1, dtype=torch.float64)).tolist()
     assert child == mine
+
+
+@pytest.mark.parametrize("env,published,random_policy", [("oderl-cartpole", -139.69, -14246.30),
+                                                         ("oderl-pendulum", -121.05, -616.77)])
+def test_closed_loop_episode_return_near_published_oracle_mpc(nlc, env, published, random_policy):
+    """Behavioural check: 200 control steps of the reference's evaluation loop (mppi_with_model.py:244-317) with
+    oracle dynamics (K=1000, T=40 as in config.py:52-53), planner on the GPU, the env's Euler step on the host.
+    The return must be in the neighbourhood of the reference's published oracle+MPC return
+    (process_results/plot_util.py:7-11) -- far from the random-policy return (:2-6)."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+
+    nx, nu, A = oenvs.OBS_DIM[env], oenvs.ACT_DIM[env], oenvs.ACTION_HIGH[env]
+    mppi = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 0), nlc.EnvCost(env), nx, nlc.noise_sigma(nu), 1000, 40, "cpu",
+                         lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=0,
+                         U_init=torch.zeros(40, nu, dtype=torch.float64))
+    obs = oenvs.initial_state(env, 0)
+    if env == "oderl-pendulum":
+        obs = torch.tensor([-1.0, 0.0, 1.0], dtype=torch.float64)  # harness start [pi, 1] (mppi_with_model.py:188-189)
+    ab = torch.zeros(4, nu, dtype=torch.float64)
+    ts = torch.full((1, 1), 0.05, dtype=torch.float64)
+    total = 0.0
+    for _ in range(200):
+        a = mppi.command(obs, ab)
+        ab, applied = omppi.get_action(ab, a, 0)
+        obs = oenvs.ORACLE_DYNAMICS[env](obs.view(1, -1), applied.view(1, 1, nu), ts, 0).view(-1)
+        total += -float(oenvs.RUNNING_COST[env](obs.view(1, -1), applied.view(1, nu)))
+    assert 1.6 * published < total < 0.6 * published, (total, published)
+    assert total > 0.2 * random_policy
