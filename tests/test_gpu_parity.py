@@ -725,4 +725,4 @@ def test_closed_loop_episode_return_near_published_oracle_mpc(nlc, env, publishe
         obs = oenvs.ORACLE_DYNAMICS[env](obs.view(1, -1), applied.view(1, 1, nu), ts, 0).view(-1)
         total += -float(oenvs.RUNNING_COST[env](obs.view(1, -1), applied.view(1, nu)))
     assert 1.6 * published < total < 0.6 * published, (total, published)
-    assert total > 0.2 * random_policy
+    assert total > 0.5 * random_policy
