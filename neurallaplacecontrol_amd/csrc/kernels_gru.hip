@@ -1,9 +1,12 @@
 // ReverseGRUEncoder (w_nl.py:14-29) on FP64 matrix cores.
 //
 // One wavefront encodes 16 action windows.  Hidden state and gate pre-activations live in MFMA
-// accumulator layout (feature on rows/registers, window on columns/lanes), so the recurrence
-// h -> gates -> h' never leaves registers.  Weights are the MFMA A operand, streamed fragment-packed
-// from L2; the 16 windows are the B/D columns.  The encoder input does not depend on the state
+// accumulator layout (feature on rows/registers, window on columns/lanes): accumulator register r of tile j IS
+// the B fragment of k-step 4j+r of the next GEMM, so the recurrence h -> gates -> h' needs no lane movement.
+// The two layers' hidden states are parked in LDS as per-lane images of exactly those B fragments (each entry
+// written and read by the same lane: no barrier), which keeps the kernel at ~200 VGPRs = 2 waves/SIMD with room
+// for two-wide gate math.  Weights are the MFMA A operand, streamed fragment-packed from L2; the 16 windows are
+// the B/D columns.  The encoder input does not depend on the state
 // (SURVEY F6), so the planner runs this ONCE over all K*T windows instead of inside the horizon loop.
 //
 // Roofline: FP64 MFMA bound.  Per 16 windows (B = 4): B*MT (input) + (B-1)*KS*MT (l0 hh) + B*KS*MT (l1 ih)
@@ -21,43 +24,108 @@ namespace nlc {
 // tiles are live at a time instead of sixteen, which keeps the kernel under 256 VGPRs -> two waves per SIMD,
 // so one wave's gate transcendentals (FP64 VALU) overlap the other wave's MFMAs.
 // Chunk-packed weights: Wc[((j*KS + ks)*3 + g)*64 + lane], g in {r, z, n}: row g*G + 16 j + (lane & 15).
-template <int KS, typename BF>
-__device__ __forceinline__ void chunk_gemm(v4d& c0, v4d& c1, v4d& c2, const double* __restrict__ wc, int lane, BF bfrag) {
+template <int KS>
+__device__ __forceinline__ void chunk_gemm(v4d& c0, v4d& c1, v4d& c2, const double* __restrict__ wc, int lane,
+                                           const double* __restrict__ hb) {
+  // hb: this wave's hidden-state image in LDS, hb[ks*64 + lane] = B fragment of k-step ks (written by the same lane)
   double a_cur[3], a_nxt[3];
   gptr p = opaque(wc);
 #pragma unroll
   for (int g = 0; g < 3; ++g) a_cur[g] = p[g * 64 + lane];
+  double b_cur = hb[lane], b_nxt = 0.0;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
       p = opaque(p + 3 * 64);
 #pragma unroll
       for (int g = 0; g < 3; ++g) a_nxt[g] = p[g * 64 + lane];
+      b_nxt = hb[(ks + 1) * 64 + lane];
     }
-    const double b = bfrag(ks);
-    c0 = mfma(a_cur[0], b, c0);
-    c1 = mfma(a_cur[1], b, c1);
-    c2 = mfma(a_cur[2], b, c2);
+    c0 = mfma(a_cur[0], b_cur, c0);
+    c1 = mfma(a_cur[1], b_cur, c1);
+    c2 = mfma(a_cur[2], b_cur, c2);
 #pragma unroll
     for (int g = 0; g < 3; ++g) a_cur[g] = a_nxt[g];
+    b_cur = b_nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// ---- two-wide gate math: the r/z sigmoids and the n tanh of TWO hidden units are evaluated in lockstep (clang
+// ext-vector arithmetic = two independent FP64 instruction streams), so each wave issues two dependent chains
+// instead of one and the FP64 VALU latency is covered without relying on the partner wave.
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2d fma2(v2d a, v2d b, v2d c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2d splat2(double x) { return v2d{x, x}; }
+__device__ __forceinline__ v2d rcp_refined2(v2d d) {
+  v2d r = {__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
+  r = fma2(fma2(-d, r, splat2(1.0)), r, r);
+  r = fma2(fma2(-d, r, splat2(1.0)), r, r);
+  return r;
+}
+__device__ __forceinline__ v2d expm1_poly2(v2d r) {
+  v2d q = splat2(0x1.af38a9b0ec855p-26);
+  q = fma2(q, r, splat2(0x1.289185613a3d6p-22));
+  q = fma2(q, r, splat2(0x1.71de0dae63bb3p-19));
+  q = fma2(q, r, splat2(0x1.a019b90d2ae7ap-16));
+  q = fma2(q, r, splat2(0x1.a01a01a7c41d5p-13));
+  q = fma2(q, r, splat2(0x1.6c16c1788bd90p-10));
+  q = fma2(q, r, splat2(0x1.11111111109b3p-7));
+  q = fma2(q, r, splat2(0x1.5555555553d63p-5));
+  q = fma2(q, r, splat2(0x1.5555555555556p-3));
+  q = fma2(q, r, splat2(0x1.0000000000001p-1));
+  return fma2(q * r, r, r);
+}
+__device__ __forceinline__ v2d exp_reduce2(v2d y, v2i* n) {
+  const v2d fn = __builtin_elementwise_rint(y * 1.44269504088896338700e+00);
+  v2d r = fma2(-fn, splat2(6.93147180369123816490e-01), y);
+  r = fma2(-fn, splat2(1.90821492927058770002e-10), r);
+  *n = __builtin_convertvector(fn, v2i);
+  return r;
+}
+// sigmoid(x) = 1/(1 + e^{-x}) for either sign: e^{-x} >= 0 so nothing cancels; e^{-x} -> inf gives 0
+__device__ __forceinline__ v2d sigmoid2(v2d x) {
+  const v2d y = __builtin_elementwise_min(__builtin_elementwise_max(-x, splat2(-745.0)), splat2(709.0));
+  v2i n;
+  const v2d r = exp_reduce2(y, &n);
+  const v2d p = splat2(1.0) + expm1_poly2(r);
+  const v2d e = {ldexp(p.x, n.x), ldexp(p.y, n.y)};
+  return rcp_refined2(splat2(1.0) + e);
+}
+__device__ __forceinline__ v2d tanh2(v2d x) {
+  const v2d y = __builtin_elementwise_max(-2.0 * __builtin_elementwise_abs(x), splat2(-745.0));
+  v2i n;
+  const v2d r = exp_reduce2(y, &n);
+  const v2d p = expm1_poly2(r);
+  const v2d two_n = {ldexp(1.0, n.x), ldexp(1.0, n.y)};
+  const v2d em = fma2(two_n, p, two_n - splat2(1.0));
+  const v2d t = -em * rcp_refined2(splat2(2.0) + em);
+  return __builtin_elementwise_copysign(t, x);
 }
 
 // DBG = 1: timing experiment only (env NLC_GRU_DBG=1): gates replaced by a few FMAs -> MFMA + load time
 template <int DBG>
 __device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d& ain, const v4d& ahn, const v4d& hold) {
   v4d hnew;
+  if (DBG == 1) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (DBG == 1) {
-      hnew[r] = 0.25 * ar[r] + 0.125 * az[r] + 0.01 * (ain[r] + ahn[r]) + 0.5 * hold[r];
-      continue;
+    for (int r = 0; r < 4; ++r) hnew[r] = 0.25 * ar[r] + 0.125 * az[r] + 0.01 * (ain[r] + ahn[r]) + 0.5 * hold[r];
+    return hnew;
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const v2d r2 = half ? ar.zw : ar.xy, z2 = half ? az.zw : az.xy, in2 = half ? ain.zw : ain.xy;
+    const v2d hn2 = half ? ahn.zw : ahn.xy, ho2 = half ? hold.zw : hold.xy;
+    const v2d rg = sigmoid2(r2);
+    const v2d zg = sigmoid2(z2);
+    const v2d ng = tanh2(fma2(rg, hn2, in2));
+    const v2d hv = (splat2(1.0) - zg) * ng + zg * ho2;
+    if (half) {
+      hnew.zw = hv;
+    } else {
+      hnew.xy = hv;
     }
-    const double rg = m::sigmoid_d(ar[r]);
-    const double zg = m::sigmoid_d(az[r]);
-    const double ng = m::tanh_d(ain[r] + rg * ahn[r]);
-    hnew[r] = (1.0 - zg) * ng + zg * hold[r];
   }
   return hnew;
 }
@@ -85,12 +153,18 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
     tt = a.t0 + (int)(wc - kk * a.Tc);
   }
 
-  v4d h0[GT], h1[GT], hn[GT];
+  // Hidden states live in LDS as per-lane B-fragment images (H[ks*64 + lane], ks = 4*tile + reg): every entry is
+  // written and read by the same lane, so there is no cross-lane hazard and no barrier; registers only hold the
+  // chunk accumulators and the new state being assembled.
+  __shared__ double Hs[4][2][KS * 64];
+  double* H0 = Hs[wave][0];
+  double* H1 = Hs[wave][1];
 #pragma unroll
-  for (int j = 0; j < GT; ++j) {
-    h0[j] = splat(0.0);
-    h1[j] = splat(0.0);
+  for (int ks = 0; ks < KS; ++ks) {
+    H0[ks * 64 + lane] = 0.0;
+    H1[ks * 64 + lane] = 0.0;
   }
+  v4d hn[GT];
 
   for (int s = 0; s < a.B; ++s) {
     // reversed time: GRU step s consumes window element B-1-s  (torch.flip, w_nl.py:27)
@@ -117,12 +191,15 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
       v4d az = mfma(wp[64 + lane], xin, splat(0.0));
       v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
       v4d ahn = load_bias_tile(a.bhn0, j, q);
-      if (s > 0)
-        chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
-      hn[j] = gru_gates<DBG>(ar, az, ain, ahn, h0[j]);
+      if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, H0);
+      const v4d hold = {H0[(4 * j + 0) * 64 + lane], H0[(4 * j + 1) * 64 + lane], H0[(4 * j + 2) * 64 + lane],
+                        H0[(4 * j + 3) * 64 + lane]};
+      hn[j] = gru_gates<DBG>(ar, az, ain, ahn, hold);
     }
 #pragma unroll
-    for (int j = 0; j < GT; ++j) h0[j] = hn[j];
+    for (int j = 0; j < GT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H0[(4 * j + r) * 64 + lane] = hn[j][r];
     // ---------------- layer 1
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
@@ -130,18 +207,21 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
       v4d az = load_bias_tile(a.brz1, GT + j, q);
       v4d ain = load_bias_tile(a.bin1, j, q);
       v4d ahn = load_bias_tile(a.bhn1, j, q);
-      chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h0[ks >> 2][ks & 3]; });
-      if (s > 0)
-        chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
-      hn[j] = gru_gates<DBG>(ar, az, ain, ahn, h1[j]);
+      chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, H0);
+      if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, H1);
+      const v4d hold = {H1[(4 * j + 0) * 64 + lane], H1[(4 * j + 1) * 64 + lane], H1[(4 * j + 2) * 64 + lane],
+                        H1[(4 * j + 3) * 64 + lane]};
+      hn[j] = gru_gates<DBG>(ar, az, ain, ahn, hold);
     }
 #pragma unroll
-    for (int j = 0; j < GT; ++j) h1[j] = hn[j];
+    for (int j = 0; j < GT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1[(4 * j + r) * 64 + lane] = hn[j][r];
   }
   // ---------------- linear_out (2 x g): rows 0,1 of one output tile
   v4d o[1];
   o[0] = splat(0.0);
-  gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
+  gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return H1[ks * 64 + lane]; });
   if (valid && q < 2) {
     const int64_t wo = (a.mode == 1) ? kk * a.T + tt : w;  // (k, t) -> row of the (K, T, 2) latent tensor
     a.out[wo * 2 + q] = o[0][0] + a.bo[q];
