@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 1
+#define NLC_ABI_VERSION 2
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -147,11 +147,17 @@ typedef struct {
   int32_t env;                /* NLC_ENV_* running cost (and oracle dynamics) */
   int32_t delay;              /* oracle dynamics: action applied = window[-(delay+1)] */
   int32_t friction;           /* oracle cartpole only */
+  int32_t E;                  /* episodes: independent planning problems batched in this ctx, each with its own
+                               * state, action_buffer, U and K samples (0 or 1 = one problem = the reference's
+                               * MPPIDelay; > 1 = the dataset collector's many episodes,
+                               * mppi_dataset_collector.py:224-321,402-424, planned side by side) */
   double ts_pred;             /* raw dt handed to the dynamics (mppi_with_model.py:74) */
 } nlc_mppi_desc;
 
 /* caller-owned device buffers the kernels read/write (the Python mirror keeps them as the public
- * attributes .noise .perturbed_action .states .actions .cost_total .cost_total_non_zero .omega) */
+ * attributes .noise .perturbed_action .states .actions .cost_total .cost_total_non_zero .omega).
+ * With E > 1 episodes every buffer gains a leading E: per-sample ones are (E,K,...), partials
+ * (E, 2+T*nu), action (E, u_per_command*nu); U is (E,T,nu). */
 typedef struct {
   double* noise;      /* (K,T,nu) in: raw N(mu,Sigma) draw when rng == 0; out: bounded noise (:328) */
   double* perturbed;  /* (K,T,nu) out: bounded perturbed action, normalised units (:325-326) */
@@ -167,12 +173,13 @@ typedef struct {
 
 int nlc_mppi_configure(nlc_ctx* ctx, const nlc_mppi_desc* desc);
 int64_t nlc_mppi_workspace_bytes(nlc_ctx* ctx);
-int nlc_mppi_set_U(nlc_ctx* ctx, const double* U_host); /* (T,nu) control sequence, :161-164 */
+int nlc_mppi_set_U(nlc_ctx* ctx, const double* U_host); /* (E,T,nu) control sequence(s), :161-164 */
 int nlc_mppi_get_U(nlc_ctx* ctx, double* U_host);
 /* Phase 1 of command(): shift U (:199-200), sample/perturb/bound (:319-335), hoisted GRU encode,
  * T-step rollout + running cost (:232-313), perturbation cost (:343-344), and this shard's
  * softmax partials (beta_r, eta_r, S_r) into buf->partials.
  *   state_host: (d) or (K,d) if state_per_sample (:243-246); action_buffer_host: (B,nu).
+ *   E > 1: state (E,d) or (E,K,d), action_buffer (E,B,nu); both may then be host OR device pointers.
  *   rng: 0 = buf->noise holds the caller's raw draw; 1 = device Philox4x32-10(seed, counter). */
 int nlc_mppi_rollout(nlc_ctx* ctx, const double* state_host, int state_per_sample,
                      const double* action_buffer_host, const nlc_mppi_buffers* buf, int rng, uint64_t seed,
@@ -180,9 +187,9 @@ int nlc_mppi_rollout(nlc_ctx* ctx, const double* state_host, int state_per_sampl
 /* NLC_DYN_EXTERNAL only: nlc_mppi_rollout stops after the perturbation; once the caller has filled
  * buf->cost_total (rollout cost + perturbation cost, :339-344) this computes the softmax partials. */
 int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
-/* Phase 2: merge G shard partials (gathered_dev: (G, 2+T*nu); pass buf->partials and G=1 on one GPU),
+/* Phase 2: merge G shard partials (gathered_dev: (G, E, 2+T*nu); pass buf->partials and G=1 on one GPU),
  * omega, U[t] += sum_k omega_k noise[k,t] (:210-216) and return action = U[:u_per_command]*u_scale
- * (:217-224) into action_host (u_per_command*nu) -- synchronises the stream -- and/or into buf->action on
+ * (:217-224) into action_host (E*u_per_command*nu) -- synchronises the stream -- and/or into buf->action on
  * the device.  With action_host == NULL nothing is copied back and the call does not synchronise. */
 int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
                     double* action_host);

@@ -97,6 +97,7 @@ class MppiDesc(C.Structure):
         ("env", C.c_int32),
         ("delay", C.c_int32),
         ("friction", C.c_int32),
+        ("E", C.c_int32),
         ("ts_pred", C.c_double),
     ]
 

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
     kk = wc / a.Tc;
     tt = a.t0 + (int)(wc - kk * a.Tc);
   }
+  const int ab_off = (a.mode == 1) ? (int)(kk / a.Kep) * a.B : 0;  // this sample's episode block of action_buffer
 
   // Hidden states live in LDS as per-lane B-fragment images (H[ks*64 + lane], ks = 4*tile + reg): every entry is
   // written and read by the same lane, so there is no cross-lane hazard and no barrier; registers only hold the
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
         raw = a.window[(wc * a.B + j_win) * a.nin + q];
       } else {
         const int i = tt + j_win;
-        raw = (i < a.B - 1) ? a.abuf[(1 + i) * a.nin + q]
+        raw = (i < a.B - 1) ? a.abuf[(ab_off + 1 + i) * a.nin + q]
                             : a.u_scale * a.perturbed[(kk * a.T + (i - (a.B - 1))) * a.nin + q];
       }
       xin = (raw - in_mean) / in_std;

@@ -9,28 +9,34 @@
 namespace nlc {
 
 // ------------------------------------------------------------------ U <- roll(U, -1); U[-1] = u_init  (:199-200)
+// blockIdx.x = episode
 __global__ void shift_U_kernel(const PerturbArgs a) {
   const int n = a.T * a.nu;
+  const double* Uo = a.U_old + (int64_t)blockIdx.x * n;
+  double* Un = a.U_new + (int64_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int t = i / a.nu, j = i - t * a.nu;
-    a.U_new[i] = (t + 1 < a.T) ? a.U_old[i + a.nu] : a.u_init[j];
+    Un[i] = (t + 1 < a.T) ? Uo[i + a.nu] : a.u_init[j];
   }
 }
 hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(shift_U_kernel, dim3(1), dim3(128), 0, s, a);
+  hipLaunchKernelGGL(shift_U_kernel, dim3((unsigned)a.E), dim3(128), 0, s, a);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ sample / perturb / bound (:319-328)
 // One thread per (k, t).  rng == 1 draws eps ~ N(mu, Sigma) on the device: Philox4x32-10 keyed by the
 // seed, counter (global sample index, t, command counter) -> the draw does not depend on the sharding.
+// Episode e of a batched planner continues the index space at e * K_global (e == 0: the single planner's stream).
 __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
   const int64_t total = a.K * a.T;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = idx / a.T;
     const int t = (int)(idx - k * a.T);
-    const int64_t kg = a.k_offset + k;
+    const int64_t e = k / a.Kep;
+    const int64_t ke = a.k_offset + (k - e * a.Kep);  // index within the episode's whole population
+    const int64_t kg = e * a.K_global + ke;
     double eps[NLC_MAX_NU];
     if (a.rng) {
       double z[NLC_MAX_NU];
@@ -51,9 +57,9 @@ __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
     } else {
       for (int i = 0; i < a.nu; ++i) eps[i] = a.noise[idx * a.nu + i];
     }
-    const bool null_action = a.sample_null_action && (kg == a.K_global - 1);
+    const bool null_action = a.sample_null_action && (ke == a.K_global - 1);
     for (int i = 0; i < a.nu; ++i) {
-      const double U = a.U_new[t * a.nu + i];
+      const double U = a.U_new[(e * a.T + t) * a.nu + i];
       double V = U + eps[i];
       if (null_action) V = 0.0;  // :322-323
       double Vs = V * a.u_scale;
@@ -84,16 +90,18 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// pass 1: per-block min of cost
+// pass 1: per-block min of cost (blockIdx.y = episode in all three passes)
 __global__ __launch_bounds__(256) void cost_min_kernel(const WeightArgs a) {
   __shared__ double sm[4];
   double v = INFINITY;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.K; i += (int64_t)gridDim.x * 256)
-    v = fmin(v, a.cost[i]);
+  const double* cost = a.cost + (int64_t)blockIdx.y * a.Kep;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.Kep; i += (int64_t)gridDim.x * 256)
+    v = fmin(v, cost[i]);
   v = wave_min(v);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) a.block_min[blockIdx.x] = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
+  if (threadIdx.x == 0)
+    a.block_min[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
 }
 
 // pass 2: w_k = exp(-(c_k - beta)/lambda); per-block partial eta and S[t,j] = sum_k w_k eps[k,t,j].
@@ -104,15 +112,17 @@ __global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a,
   __shared__ double sbeta;
   __shared__ double sm[4];
   double v = INFINITY;
-  for (int i = threadIdx.x; i < nmin; i += 256) v = fmin(v, a.block_min[i]);
+  const int e = blockIdx.y;
+  for (int i = threadIdx.x; i < nmin; i += 256) v = fmin(v, a.block_min[(int64_t)e * nmin + i]);
   v = wave_min(v);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) sbeta = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
   __syncthreads();
   const double beta = sbeta;
-  const int64_t k0 = (int64_t)blockIdx.x * kWeightBlockSamples;
-  const int ns = (int)((a.K - k0 < kWeightBlockSamples) ? (a.K - k0) : kWeightBlockSamples);
+  const int64_t kb = (int64_t)blockIdx.x * kWeightBlockSamples;  // within the episode
+  const int ns = (int)((a.Kep - kb < kWeightBlockSamples) ? (a.Kep - kb) : kWeightBlockSamples);
+  const int64_t k0 = (int64_t)e * a.Kep + kb;
   const int TN = a.T * a.nu;
   double wk = 0.0;
   if ((int)threadIdx.x < ns) {
@@ -121,12 +131,12 @@ __global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a,
     sw[threadIdx.x] = wk;
   }
   __syncthreads();
-  double* out = a.block_part + (int64_t)blockIdx.x * (1 + TN);
+  double* out = a.block_part + ((int64_t)e * a.nblk + blockIdx.x) * (1 + TN);
   if (threadIdx.x < 64) {
-    const double e = wave_sum(wk);  // threads 0..63 hold all (<= 64) weights of the block
+    const double es = wave_sum(wk);  // threads 0..63 hold all (<= 64) weights of the block
     if (threadIdx.x == 0) {
-      out[0] = e;
-      if (blockIdx.x == 0) a.partials[0] = beta;
+      out[0] = es;
+      if (blockIdx.x == 0) a.partials[(int64_t)e * (2 + TN)] = beta;
     }
   }
   for (int tj = threadIdx.x; tj < TN; tj += 256) {
@@ -144,17 +154,19 @@ __global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= 1 + TN) return;
+  const int64_t e = blockIdx.y;
   double acc = 0.0;
-  for (int b = lane; b < a.nblk; b += 64) acc += a.block_part[(int64_t)b * (1 + TN) + i];
+  for (int b = lane; b < a.nblk; b += 64) acc += a.block_part[(e * a.nblk + b) * (1 + TN) + i];
   acc = wave_sum(acc);
-  if (lane == 0) a.partials[1 + i] = acc;
+  if (lane == 0) a.partials[e * (2 + TN) + 1 + i] = acc;
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
-  const int nmin = (int)((a.K + 255) / 256 < 256 ? (a.K + 255) / 256 : 256);
-  hipLaunchKernelGGL(cost_min_kernel, dim3(nmin), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk), dim3(256), 0, s, a, nmin);
-  hipLaunchKernelGGL(weight_final_kernel, dim3((1 + a.T * a.nu + 3) / 4), dim3(256), 0, s, a);
+  const int nmin = weight_min_blocks(a.Kep);
+  const unsigned E = (unsigned)a.E;
+  hipLaunchKernelGGL(cost_min_kernel, dim3(nmin, E), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk, E), dim3(256), 0, s, a, nmin);
+  hipLaunchKernelGGL(weight_final_kernel, dim3((1 + a.T * a.nu + 3) / 4, E), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -165,45 +177,49 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
   __shared__ double s_scale_self, s_eta;
   const int TN = a.T * a.nu;
   const int W = 2 + TN;
+  const int64_t e = blockIdx.y;
+  const double* gat = a.gathered + e * W;       // rank g's row of this episode: gat + g * E * W
+  const int64_t gs = (int64_t)a.E * W;
   double beta = INFINITY;
-  for (int g = 0; g < a.G; ++g) beta = fmin(beta, a.gathered[(int64_t)g * W]);
+  for (int g = 0; g < a.G; ++g) beta = fmin(beta, gat[g * gs]);
   double eta = 0.0;
-  for (int g = 0; g < a.G; ++g)
-    eta += exp(-(a.gathered[(int64_t)g * W] - beta) / a.lambda_) * a.gathered[(int64_t)g * W + 1];
+  for (int g = 0; g < a.G; ++g) eta += exp(-(gat[g * gs] - beta) / a.lambda_) * gat[g * gs + 1];
   if (blockIdx.x == 0) {
+    double* U = a.U + e * TN;
     for (int i = threadIdx.x; i < TN; i += 256) {
       double acc = 0.0;
-      for (int g = 0; g < a.G; ++g)
-        acc += exp(-(a.gathered[(int64_t)g * W] - beta) / a.lambda_) * a.gathered[(int64_t)g * W + 2 + i];
-      const double u = a.U[i] + (1.0 / eta) * acc;  // omega = (1/eta) w, :214-216
-      a.U[i] = u;
-      if (i < a.u_per_command * a.nu) a.action[i] = u * a.u_scale;  // :217-224
+      for (int g = 0; g < a.G; ++g) acc += exp(-(gat[g * gs] - beta) / a.lambda_) * gat[g * gs + 2 + i];
+      const double u = U[i] + (1.0 / eta) * acc;  // omega = (1/eta) w, :214-216
+      U[i] = u;
+      if (i < a.u_per_command * a.nu) a.action[e * a.u_per_command * a.nu + i] = u * a.u_scale;  // :217-224
     }
     if (threadIdx.x == 0) {
-      a.beta_eta[0] = beta;
-      a.beta_eta[1] = eta;
+      a.beta_eta[e * 2] = beta;
+      a.beta_eta[e * 2 + 1] = eta;
     }
   }
   // omega / cost_total_non_zero relative to the GLOBAL beta
   if (threadIdx.x == 0) {
-    s_scale_self = (a.G == 1) ? 1.0 : exp(-(a.gathered[(int64_t)a.rank * W] - beta) / a.lambda_);
+    s_scale_self = (a.G == 1) ? 1.0 : exp(-(gat[a.rank * gs] - beta) / a.lambda_);
     s_eta = eta;
   }
   __syncthreads();
   const double sc = s_scale_self, inv = 1.0 / s_eta;
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.K; k += (int64_t)gridDim.x * 256) {
-    double w = a.cost_nz[k];
+  double* cost_nz = a.cost_nz + e * a.Kep;
+  double* omega = a.omega != nullptr ? a.omega + e * a.Kep : nullptr;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.Kep; k += (int64_t)gridDim.x * 256) {
+    double w = cost_nz[k];
     if (a.G != 1) {
       w *= sc;
-      a.cost_nz[k] = w;
+      cost_nz[k] = w;
     }
-    if (a.omega != nullptr) a.omega[k] = inv * w;
+    if (omega != nullptr) omega[k] = inv * w;
   }
 }
 hipError_t launch_merge(const MergeArgs& a, hipStream_t s) {
-  const int64_t want = (a.K + 255) / 256;
+  const int64_t want = (a.Kep + 255) / 256;
   const unsigned grid = (unsigned)(want < 1024 ? (want > 0 ? want : 1) : 1024);
-  hipLaunchKernelGGL(merge_kernel, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(merge_kernel, dim3(grid, (unsigned)a.E), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -310,7 +326,10 @@ __global__ __launch_bounds__(256) void oracle_rollout_kernel(const OracleRollout
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= a.K) return;
   double x[NLC_MAX_D];
-  const double* st = a.state0 + (a.state_per_sample ? k * a.d : 0);
+  const int64_t e = k / a.Kep;
+  const double* st = a.state0 + (a.state_per_sample ? k : e) * a.d;
+  const double* abuf = a.abuf + e * a.B * a.nu;
+  const double* U = a.U + e * a.T * a.nu;
   for (int i = 0; i < a.d; ++i) x[i] = st[i];
   double cost = 0.0, pcost = 0.0;
   for (int t = 0; t < a.T; ++t) {
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(256) void oracle_rollout_kernel(const OracleRollout
     double ud[NLC_MAX_NU], u[NLC_MAX_NU];
     const int i = t + a.B - 1 - a.delay;
     for (int j = 0; j < a.nu; ++j) {
-      ud[j] = (i < a.B - 1) ? a.abuf[(1 + i) * a.nu + j]
+      ud[j] = (i < a.B - 1) ? abuf[(1 + i) * a.nu + j]
                             : a.u_scale * a.perturbed[(k * a.T + (i - (a.B - 1))) * a.nu + j];
       u[j] = a.u_scale * a.perturbed[(k * a.T + t) * a.nu + j];
     }
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void oracle_rollout_kernel(const OracleRollout
         if (a.noise_abs_cost) e = fabs(e);
         acj += (a.lambda_ * e) * a.sigma_inv[ii * a.nu + j];
       }
-      pc += a.U[t * a.nu + j] * acj;
+      pc += U[t * a.nu + j] * acj;
     }
     cost += running_cost_o(a.env, x, u, a.nu);
     pcost += pc;
@@ -352,7 +371,8 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepTailArgs a) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= a.K) return;
   double x[NLC_MAX_D];
-  const double* src = a.first ? a.state0 + (a.state_per_sample ? k * a.d : 0) : a.x + k * a.d;
+  const int64_t e = k / a.Kep;
+  const double* src = a.first ? a.state0 + (a.state_per_sample ? k : e) * a.d : a.x + k * a.d;
   for (int i = 0; i < a.d; ++i) {
     x[i] = src[i] + a.dx[k * a.d + i];
     a.x[k * a.d + i] = x[i];
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StepTailArgs a) {
       if (a.noise_abs_cost) e = fabs(e);
       acj += (a.lambda_ * e) * a.sigma_inv[ii * a.nu + j];
     }
-    pc += a.U[a.t * a.nu + j] * acj;
+    pc += a.U[(e * a.T + a.t) * a.nu + j] * acj;
   }
   const double cost = (a.first ? 0.0 : a.ccarry[k * 2]) + running_cost_o(a.env, x, u, a.nu);
   const double pcost = (a.first ? 0.0 : a.ccarry[k * 2 + 1]) + pc;

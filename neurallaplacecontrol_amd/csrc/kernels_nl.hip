@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
   const int i0 = q, i1 = 4 + q;
   double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
   const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
-  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc * d : 0) : a.xcarry + kc * d;
+  const int ep = (int)(kc / a.Kep);  // episode of this lane's sample (0 for the single planner)
+  const int uoff = ep * a.T * a.nu;
+  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * d : a.xcarry + kc * d;
   if (i0 < d) {
     x0 = st[i0];
     m0 = n.state_mean[i0];
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
         if (a.noise_abs_cost) e = fabs(e);
         acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
       }
-      pc += a.U[t * a.nu + j] * acj;
+      pc += a.U[uoff + t * a.nu + j] * acj;
     }
     cost += running_cost(a.env, xs, u, a.nu);
     pcost += pc;
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
   const int i0 = q, i1 = 4 + q;
   double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
   const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
-  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc * d : 0) : a.xcarry + kc * d;
+  const int ep = (int)(kc / a.Kep);  // episode of this lane's sample (0 for the single planner)
+  const int uoff = ep * a.T * a.nu;
+  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * d : a.xcarry + kc * d;
   if (i0 < d) {
     x0 = st[i0];
     m0 = n.state_mean[i0];
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
           if (a.noise_abs_cost) e = fabs(e);
           acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
         }
-        pc += a.U[t * a.nu + j] * acj;
+        pc += a.U[uoff + t * a.nu + j] * acj;
       }
       cost += running_cost(a.env, xs, u, a.nu);
       pcost += pc;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256) void nl_repfunc_kernel(const RepFuncArgs a) {
   const int64_t kc = valid ? k : a.N - 1;
   const int d = n.d;
   const int i0 = q, i1 = 4 + q;
-  const double* ob = a.obs + (a.obs_per_sample ? kc * d : 0);
+  const double* ob = a.obs + (a.obs_per_sample ? kc : kc / a.Kep) * d;
   const double* pa = a.pa + kc * a.pa_stride;
   const double p0 = (i0 < d) ? (ob[i0] - n.state_mean[i0]) / n.state_std[i0]
                              : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));

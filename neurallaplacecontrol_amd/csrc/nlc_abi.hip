@@ -585,6 +585,10 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if (d->B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "action_buffer needs at least one row");
   if (!(d->lambda_ > 0.0) || d->u_scale == 0.0) return fail(c, NLC_ERR_BAD_ARG, "lambda_ must be > 0, u_scale != 0");
   if (d->u_per_command < 1 || d->u_per_command > d->T) return fail(c, NLC_ERR_BAD_ARG, "bad u_per_command");
+  if (d->E < 0 || d->E > 65535) return fail(c, NLC_ERR_BAD_ARG, "episodes E must be in [0, 65535]");
+  const int E = d->E < 1 ? 1 : d->E;
+  if ((double)E * (double)d->K * d->T * d->nu > 2.0e9)
+    return fail(c, NLC_ERR_BAD_SHAPE, "E*K*T*nu exceeds the planner's index range");
   if (d->env < 0 || d->env > 2) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
   static const int env_d[3] = {5, 3, 6}, env_nu[3] = {1, 1, 2};
   if (d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
@@ -604,7 +608,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     return fail(c, NLC_ERR_UNSUPPORTED, "unknown dynamics id");
   }
   NLC_HIP(c, hipSetDevice(c->device));
-  const size_t un = (size_t)d->T * d->nu;
+  const size_t un = (size_t)E * d->T * d->nu;
   for (int i = 0; i < 2; ++i) {
     if (c->U[i]) hipFree(c->U[i]);
     c->U[i] = nullptr;
@@ -614,8 +618,8 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   c->ucur = 0;
   if (c->small) hipFree(c->small);
   c->small = nullptr;
-  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 2) * sizeof(double)));
-  const size_t pin_need = (size_t)d->d + (size_t)d->B * d->nu + un + 8;
+  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 2 * (size_t)E) * sizeof(double)));
+  const size_t pin_need = (size_t)E * d->d + (size_t)E * d->B * d->nu + un + 8;
   if (pin_need > c->pinned_n) {
     if (c->pinned) hipHostFree(c->pinned);
     c->pinned = nullptr;
@@ -623,6 +627,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     c->pinned_n = pin_need;
   }
   c->pd = *d;
+  c->pd.E = E;
   c->nblk = (int)((d->K + kWeightBlockSamples - 1) / kWeightBlockSamples);
   if (d->dynamics == NLC_DYN_NL) {
     // constant prediction time => the 2S sphere-coordinate inputs of layer 1 are constants: fold into the bias
@@ -659,17 +664,18 @@ WsLayout ws_layout(const nlc_ctx* c) {
     off += (n + 63) / 64 * 64;
     return o;
   };
-  w.block_min = take(256);
-  w.block_part = take((size_t)c->nblk * (1 + (size_t)d.T * d.nu));
-  w.pa = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * d.T * 2 : 0);
-  w.state0 = take(d.dynamics == NLC_DYN_EXTERNAL ? 0 : (size_t)d.K * d.d);
-  w.abuf = take((size_t)d.B * d.nu);
-  w.xcarry = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * d.d : 0);
-  w.ccarry = take(d.dynamics == NLC_DYN_NL ? (size_t)d.K * 2 : 0);
+  const size_t KE = (size_t)d.K * d.E;  // all local samples
+  w.block_min = take((size_t)d.E * 256);
+  w.block_part = take((size_t)d.E * c->nblk * (1 + (size_t)d.T * d.nu));
+  w.pa = take(d.dynamics == NLC_DYN_NL ? KE * d.T * 2 : 0);
+  w.state0 = take(d.dynamics == NLC_DYN_EXTERNAL ? 0 : KE * d.d);
+  w.abuf = take((size_t)d.E * d.B * d.nu);
+  w.xcarry = take(d.dynamics == NLC_DYN_NL ? KE * d.d : 0);
+  w.ccarry = take(d.dynamics == NLC_DYN_NL ? KE * 2 : 0);
   const bool dh = d.dynamics == NLC_DYN_NL && c->md.ilt.algo == NLC_ILT_DEHOOG;
-  w.fre = take(dh ? (size_t)d.K * d.d * c->S : 0);
-  w.fim = take(dh ? (size_t)d.K * d.d * c->S : 0);
-  w.dx = take(dh ? (size_t)d.K * d.d : 0);
+  w.fre = take(dh ? KE * d.d * c->S : 0);
+  w.fim = take(dh ? KE * d.d * c->S : 0);
+  w.dx = take(dh ? KE * d.d : 0);
   w.tconst = take(dh ? 8 : 0);
   w.total = off;
   return w;
@@ -681,7 +687,8 @@ static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   const WsLayout w = ws_layout(c);
   double* ws = (double*)buf->workspace;
   WeightArgs wa{};
-  wa.K = d.K;
+  wa.Kep = d.K;
+  wa.E = d.E;
   wa.T = d.T;
   wa.nu = d.nu;
   wa.lambda_ = d.lambda_;
@@ -707,7 +714,7 @@ extern "C" int nlc_mppi_set_U(nlc_ctx* c, const double* U) {
   if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
   if (!U) return fail(c, NLC_ERR_BAD_ARG, "NULL U");
   NLC_HIP(c, hipSetDevice(c->device));
-  NLC_HIP(c, hipMemcpyAsync(c->U[c->ucur], U, (size_t)c->pd.T * c->pd.nu * sizeof(double), hipMemcpyHostToDevice,
+  NLC_HIP(c, hipMemcpyAsync(c->U[c->ucur], U, (size_t)c->pd.E * c->pd.T * c->pd.nu * sizeof(double), hipMemcpyHostToDevice,
                             c->stream));
   NLC_HIP(c, hipStreamSynchronize(c->stream));
   return NLC_OK;
@@ -718,7 +725,7 @@ extern "C" int nlc_mppi_get_U(nlc_ctx* c, double* U) {
   if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
   if (!U) return fail(c, NLC_ERR_BAD_ARG, "NULL U");
   NLC_HIP(c, hipSetDevice(c->device));
-  NLC_HIP(c, hipMemcpyAsync(U, c->U[c->ucur], (size_t)c->pd.T * c->pd.nu * sizeof(double), hipMemcpyDeviceToHost,
+  NLC_HIP(c, hipMemcpyAsync(U, c->U[c->ucur], (size_t)c->pd.E * c->pd.T * c->pd.nu * sizeof(double), hipMemcpyDeviceToHost,
                             c->stream));
   NLC_HIP(c, hipStreamSynchronize(c->stream));
   return NLC_OK;
@@ -739,7 +746,15 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   double* ws = (double*)buf->workspace;
   double* state_dev = ws + w.state0;
   double* abuf_dev = ws + w.abuf;
-  if (!external) {
+  const int64_t KE = d.K * d.E;  // all local samples, episode-major
+  if (!external && d.E > 1) {
+    // batched episodes: the (E,d) states and (E,B,nu) action buffers usually live on the device already (a device-side
+    // env loop); hipMemcpyDefault takes either kind of pointer
+    const size_t ns = (size_t)(state_per_sample ? KE : d.E) * d.d;
+    NLC_HIP(c, hipMemcpyAsync(state_dev, state, ns * sizeof(double), hipMemcpyDefault, c->stream));
+    NLC_HIP(c, hipMemcpyAsync(abuf_dev, abuf_host, (size_t)d.E * d.B * d.nu * sizeof(double), hipMemcpyDefault,
+                              c->stream));
+  } else if (!external) {
     // small inputs go through pinned staging (truly asynchronous copies).  The staging slots are rewritten
     // only after the previous command's copies out of them have completed (stage_ev).
     if (c->stage_ev) NLC_HIP(c, hipEventSynchronize(c->stage_ev));
@@ -758,7 +773,9 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     NLC_HIP(c, hipEventRecord(c->stage_ev, c->stream));
   }
   PerturbArgs p{};
-  p.K = d.K;
+  p.K = KE;
+  p.Kep = d.K;
+  p.E = d.E;
   p.K_global = d.K_global;
   p.k_offset = d.k_offset;
   p.T = d.T;
@@ -800,11 +817,13 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     g.u_scale = d.u_scale;
     g.T = d.T;
     g.B = d.B;
+    g.Kep = d.K;
     g.out = pa;
     RolloutArgs r{};
     r.net = c->net;
     r.net.b1 = c->b1fold;
-    r.K = d.K;
+    r.K = KE;
+    r.Kep = d.K;
     r.T = d.T;
     r.nu = d.nu;
     r.B = d.B;
@@ -829,7 +848,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       // representation function -> F_k, de Hoog ILT -> dx, state/cost tail.  Everything stays on the device.
       g.t0 = 0;
       g.Tc = d.T;
-      g.N = d.K * d.T;
+      g.N = KE * d.T;
       {
         ProfScope ps(c, "gru_encode_kernel");
         NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
@@ -838,17 +857,19 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
       RepFuncArgs rf{};
       rf.net = r.net;
-      rf.N = d.K;
+      rf.N = KE;
+      rf.Kep = d.K;
       rf.pa_stride = (int64_t)d.T * 2;
       rf.tn = c->tn;
       rf.general_t = 0;
       rf.slot = c->slot_dev;
       rf.fre = ws + w.fre;
       rf.fim = ws + w.fim;
-      IltArgs ia{nullptr, nullptr, tconst, ws + w.dx, d.K, d.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol),
+      IltArgs ia{nullptr, nullptr, tconst, ws + w.dx, KE, d.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol),
                  c->md.ilt.scale, rf.fre, rf.fim, 1.0, 0, 0, 0, 0};
       StepTailArgs st{};
-      st.K = d.K;
+      st.K = KE;
+      st.Kep = d.K;
       st.T = d.T;
       st.nu = d.nu;
       st.d = d.d;
@@ -912,7 +933,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       const int tc = base + (ci < extra ? 1 : 0);
       g.t0 = t0;
       g.Tc = tc;
-      g.N = d.K * tc;
+      g.N = KE * tc;
       {
         ProfScope ps(c, "gru_encode_kernel", side, true);
         NLC_HIP(c, launch_gru_encode(g, c->g, side));
@@ -932,7 +953,8 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     }
   } else {
     OracleRolloutArgs r{};
-    r.K = d.K;
+    r.K = KE;
+    r.Kep = d.K;
     r.T = d.T;
     r.nu = d.nu;
     r.B = d.B;
@@ -982,7 +1004,8 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   const nlc_mppi_desc& d = c->pd;
   NLC_HIP(c, hipSetDevice(c->device));
   MergeArgs m{};
-  m.K = d.K;
+  m.Kep = d.K;
+  m.E = d.E;
   m.T = d.T;
   m.nu = d.nu;
   m.G = G;
@@ -995,14 +1018,14 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   m.cost_nz = buf->cost_nz;
   m.omega = buf->omega;
   m.action = buf->action ? buf->action : c->small;
-  m.beta_eta = c->small + (size_t)d.T * d.nu;
+  m.beta_eta = c->small + (size_t)d.E * d.T * d.nu;
   {
     ProfScope ps(c, "merge_kernel");
     NLC_HIP(c, launch_merge(m, c->stream));
   }
   if (action_host) {
-    const size_t na = (size_t)d.u_per_command * d.nu;
-    double* pin_act = c->pinned + d.d + (size_t)d.B * d.nu;
+    const size_t na = (size_t)d.E * d.u_per_command * d.nu;
+    double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;
     NLC_HIP(c, hipMemcpyAsync(pin_act, m.action, na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     NLC_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(action_host, pin_act, na * sizeof(double));

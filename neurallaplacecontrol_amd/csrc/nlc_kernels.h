@@ -49,6 +49,7 @@ struct GruArgs {
   double u_scale;
   int mode, T;
   int t0, Tc;  // mode 1: this launch encodes horizon steps [t0, t0+Tc) of every sample (N = K*Tc)
+  int64_t Kep;  // mode 1: samples per episode; sample k reads action_buffer row block k / Kep (abuf is (E, B, nu))
   int64_t N;  // windows (mode 1: K*Tc)
   int B, nin;
   double mean[NLC_MAX_NIN], std[NLC_MAX_NIN];
@@ -84,16 +85,18 @@ struct NlNetArgs {
   double alpha, log_tol, scale, time_div;
 };
 
+// Episodes (nlc_mppi_desc.E): K counts ALL local samples (E * Kep); sample k belongs to episode e = k / Kep and
+// reads that episode's state0 row, action_buffer block and U block.  E == 1 <=> Kep == K.
 struct RolloutArgs {
   NlNetArgs net;
-  int64_t K;
+  int64_t K, Kep;
   int T, nu, B, env;
   int state_per_sample;
-  const double* state0;     // (d) or (K,d) device
+  const double* state0;     // (E,d) or (K,d) device
   const double* pa;         // (K, T, 2) GRU latents
   const double* perturbed;  // (K, T, nu)
   const double* noise;      // (K, T, nu) bounded noise
-  const double* U;          // (T, nu)
+  const double* U;          // (E, T, nu)
   double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
   double lambda_, u_scale;
   int noise_abs_cost;
@@ -122,8 +125,9 @@ hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s);
 struct RepFuncArgs {
   NlNetArgs net;
   int64_t N;
-  const double* obs;  // (N, d) or (d) broadcast
+  const double* obs;  // (N, d), or (E, d) rows broadcast over the Kep samples of each episode
   int obs_per_sample;
+  int64_t Kep;
   const double* pa;   // GRU latents, row n at pa + n*pa_stride
   int64_t pa_stride;
   const double* ts;   // (N) raw ts_pred (general_t)
@@ -137,7 +141,7 @@ hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s);
 
 // x <- x + dx, running cost, state store: the per-step tail of the staged (de Hoog) planner path
 struct StepTailArgs {
-  int64_t K;
+  int64_t K, Kep;
   int T, t, nu, d, env, first, last;
   int state_per_sample;
   const double* state0;  // read when first
@@ -157,11 +161,11 @@ hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ oracle-dynamics rollout (§8f-1)
 struct OracleRolloutArgs {
-  int64_t K;
+  int64_t K, Kep;
   int T, nu, B, d, env, delay, friction;
   int state_per_sample;
   const double* state0;
-  const double* abuf;  // (B, nu)
+  const double* abuf;  // (E, B, nu)
   const double* perturbed;
   const double* noise;
   const double* U;
@@ -175,10 +179,10 @@ hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ MPPI sampling / weighting
 struct PerturbArgs {
-  int64_t K, K_global, k_offset;
-  int T, nu;
-  const double* U_old;  // (T, nu) before the shift
-  double* U_new;        // (T, nu) after roll(-1) + u_init
+  int64_t K, Kep, K_global, k_offset;  // K_global / k_offset are per episode
+  int T, nu, E;
+  const double* U_old;  // (E, T, nu) before the shift
+  double* U_new;        // (E, T, nu) after roll(-1) + u_init
   double* noise;        // in (rng==0) / out
   double* perturbed;
   double* actions;      // may be NULL
@@ -192,30 +196,32 @@ hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s);
 hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s);
 
 struct WeightArgs {
-  int64_t K;
-  int T, nu;
+  int64_t Kep;  // samples per episode; blockIdx.y = episode
+  int T, nu, E;
   double lambda_;
-  const double* cost;   // (K)
-  const double* noise;  // (K, T, nu)
-  double* cost_nz;      // (K)
-  double* block_min;    // (nblk)
-  double* block_part;   // (nblk, 1 + T*nu)
-  double* partials;     // (2 + T*nu)
-  int nblk;
+  const double* cost;   // (E, Kep)
+  const double* noise;  // (E, Kep, T, nu)
+  double* cost_nz;      // (E, Kep)
+  double* block_min;    // (E, nmin)
+  double* block_part;   // (E, nblk, 1 + T*nu)
+  double* partials;     // (E, 2 + T*nu)
+  int nblk;             // weight blocks per episode
 };
 constexpr int kWeightBlockSamples = 64;
+// pass-1 blocks per episode (the workspace holds E * this many block minima)
+inline int weight_min_blocks(int64_t Kep) { return (int)((Kep + 255) / 256 < 256 ? (Kep + 255) / 256 : 256); }
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s);
 
 struct MergeArgs {
-  int64_t K;
-  int T, nu, G, rank, u_per_command;
+  int64_t Kep;  // samples per episode; blockIdx.y = episode
+  int T, nu, G, rank, u_per_command, E;
   double lambda_, u_scale;
-  const double* gathered;  // (G, 2 + T*nu)
-  double* U;               // (T, nu) updated in place
-  double* cost_nz;         // (K) rescaled to the global beta
-  double* omega;           // (K) or NULL
-  double* action;          // (u_per_command * nu) device
-  double* beta_eta;        // (2) device: merged beta, eta
+  const double* gathered;  // (G, E, 2 + T*nu)
+  double* U;               // (E, T, nu) updated in place
+  double* cost_nz;         // (E, Kep) rescaled to the global beta
+  double* omega;           // (E, Kep) or NULL
+  double* action;          // (E, u_per_command * nu) device
+  double* beta_eta;        // (E, 2) device: merged beta, eta
 };
 hipError_t launch_merge(const MergeArgs& a, hipStream_t s);
 

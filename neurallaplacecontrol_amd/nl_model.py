@@ -179,26 +179,31 @@ class NeuralLaplaceModel(nn.Module):
             desc.action_mean[i], desc.action_std[i] = float(am[i]), float(a_s[i])
         return desc
 
-    def hip_ctx(self, device=None):
-        """The model's ``nlc_ctx`` with its current weights uploaded (re-packed when they change)."""
+    def upload(self, ctx):
+        """Pack the current weights into ``ctx`` (``nlc_set_model``); returns the key they were taken at.  Planners
+        keep their own ctx (planner state lives there) and call this when the key changes."""
         if any(p.dtype != torch.float64 for p in self.parameters()):
             raise NotImplementedError(
                 "the HIP path computes in float64 only: call model.double() first (reference: mppi_with_model.py:101)"
             )
+        key = self._weights_key()
+        sd = self.state_dict()
+        blob = torch.cat([sd[k].detach().to("cpu", torch.float64).reshape(-1) for k in _BLOB_KEYS]).contiguous()
+        desc = self.model_desc()
+        n = ctx.lib.nlc_model_blob_size(C.byref(desc))
+        if n != blob.numel():
+            raise ValueError(f"weight blob has {blob.numel()} doubles, library expects {n}")
+        ctx.check(ctx.lib.nlc_set_model(ctx.h, C.byref(desc), _lib.ptr(blob), blob.numel()))
+        return key
+
+    def hip_ctx(self, device=None):
+        """The model's own ``nlc_ctx`` (forward / encode_actions) with its current weights uploaded."""
         dev = compute_device(next(self.parameters())) if device is None else torch.device(device)
         if self._ctx is None or self._ctx.device_index != dev.index:
             self._ctx = _lib.Ctx(dev.index)
             self._uploaded_key = None
-        key = self._weights_key()
-        if key != self._uploaded_key:
-            sd = self.state_dict()
-            blob = torch.cat([sd[k].detach().to("cpu", torch.float64).reshape(-1) for k in _BLOB_KEYS]).contiguous()
-            desc = self.model_desc()
-            n = self._ctx.lib.nlc_model_blob_size(C.byref(desc))
-            if n != blob.numel():
-                raise ValueError(f"weight blob has {blob.numel()} doubles, library expects {n}")
-            self._ctx.check(self._ctx.lib.nlc_set_model(self._ctx.h, C.byref(desc), _lib.ptr(blob), blob.numel()))
-            self._uploaded_key = key
+        if self._weights_key() != self._uploaded_key:
+            self._uploaded_key = self.upload(self._ctx)
         return self._ctx
 
     @staticmethod

@@ -77,6 +77,7 @@ class MPPIDelay:
             raise NotImplementedError("the HIP planner computes in float64 (the reference harness uses torch.double)")
         self.K = int(num_samples)
         self.T = int(horizon)
+        self.E = int(getattr(self, "E", 1))  # episodes planned side by side (BatchedMPPIDelay sets it first)
         self.encode_obs_time = encode_obs_time
         self.dt = dt
         self.nx = nx
@@ -165,10 +166,10 @@ class MPPIDelay:
         self.cd = torch.device(compute_device) if compute_device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.cd.index is None:
             self.cd = torch.device("cuda", torch.cuda.current_device())
-        if isinstance(dynamics, NLDynamics):
-            self.ctx = dynamics.model.hip_ctx(self.cd)
-        else:
-            self.ctx = _lib.Ctx(self.cd.index)
+        # every planner owns its ctx: U and the folded layer-1 bias live there, so two planners over one model
+        # must not share one (the model's own ctx serves model.forward only)
+        self.ctx = _lib.Ctx(self.cd.index)
+        self._model_key = None
         self._B = None
         self._buf = None
         self._pending_U = None
@@ -178,12 +179,17 @@ class MPPIDelay:
         self._cost_total = self._cost_nz = self._omega = None
 
         # T x nu control sequence; defaults to a noise draw (consumes the RNG like the reference :161-164)
-        self.U = U_init if U_init is not None else self.noise_dist.sample((self.T,))
+        self.U = U_init if U_init is not None else self.noise_dist.sample(self._lead(self.T))
+
+    def _lead(self, *shape):
+        """Shape with the leading episode dimension of a batched planner."""
+        return tuple(shape) if self.E == 1 else (self.E,) + tuple(shape)
 
     # ------------------------------------------------------------------ configuration
     def _configure(self, B):
         d = _lib.MppiDesc()
         d.K, d.K_global, d.k_offset = self.K_local, self.K, self.k_offset
+        d.E = self.E
         d.T, d.nu, d.d, d.B = self.T, self.nu, self.nx, B
         d.lambda_, d.u_scale = float(self.lambda_), float(self.u_scale)
         d.has_bounds = int(self.u_max is not None)
@@ -208,7 +214,6 @@ class MPPIDelay:
             d.env = _lib.ENV_IDS[self.running_cost.env_name]
             if isinstance(self.F, NLDynamics):
                 d.dynamics, d.ts_pred = _lib.DYN_NL, self.F.ts_pred
-                self.F.model.hip_ctx(self.cd)  # make sure the current weights are on the device
             else:
                 if self.F.env_name != self.running_cost.env_name:
                     raise ValueError("OracleDynamics and EnvCost name different envs")
@@ -222,14 +227,16 @@ class MPPIDelay:
         self.ctx.check(self.ctx.lib.nlc_mppi_configure(self.ctx.h, C.byref(d)))
         self._B = B
         K, T, nu, nx, dev = self.K_local, self.T, self.nu, self.nx, self.cd
-        mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)  # noqa: E731
+        mk = lambda *s: torch.empty(self._lead(*s), dtype=torch.float64, device=dev)  # noqa: E731
         self._noise, self._perturbed = mk(K, T, nu), mk(K, T, nu)
         self._states = mk(K, T, nx) if self.store_rollouts else None
         self._actions = mk(K, T, nu) if self.store_rollouts else None
         self._cost_total, self._cost_nz, self._omega = mk(K), mk(K), mk(K)
         self._partials = mk(2 + T * nu)
         self._action = mk(self.u_per_command * nu)
-        self._gathered = mk(self.G, 2 + T * nu) if self.pg is not None else None
+        self._gathered = (
+            torch.empty((self.G,) + self._lead(2 + T * nu), dtype=torch.float64, device=dev) if self.pg is not None else None
+        )
         self._ws = torch.empty(self.ctx.lib.nlc_mppi_workspace_bytes(self.ctx.h) // 8, dtype=torch.float64, device=dev)
         b = _lib.MppiBuffers()
         b.noise, b.perturbed = self._noise.data_ptr(), self._perturbed.data_ptr()
@@ -245,8 +252,21 @@ class MPPIDelay:
             self._upload_U(self._pending_U)
             self._pending_U = None
 
+    def _ensure_configured(self, B):
+        """(Re)configure when the action-buffer length or the model's weights changed since the last command."""
+        stale = self._buf is None or B != self._B
+        if self.fused and isinstance(self.F, NLDynamics):
+            model = self.F.model
+            if model._weights_key() != self._model_key:
+                if self._buf is not None:  # nlc_set_model drops the planner configuration: carry U over
+                    self._pending_U, self._buf, self._B = self.U, None, None
+                self._model_key = model.upload(self.ctx)
+                stale = True  # the constant sphere inputs are folded into the layer-1 bias at configure time
+        if stale:
+            self._configure(B)
+
     def _upload_U(self, U):
-        Uh = torch.as_tensor(U).detach().to("cpu", torch.float64).reshape(self.T, self.nu).contiguous()
+        Uh = torch.as_tensor(U).detach().to("cpu", torch.float64).reshape(self._lead(self.T, self.nu)).contiguous()
         self.ctx.check(self.ctx.lib.nlc_mppi_set_U(self.ctx.h, _lib.ptr(Uh)))
 
     # ------------------------------------------------------------------ public state
@@ -254,13 +274,13 @@ class MPPIDelay:
     def U(self):
         if self._buf is None:
             return self._pending_U
-        Uh = torch.empty((self.T, self.nu), dtype=torch.float64)
+        Uh = torch.empty(self._lead(self.T, self.nu), dtype=torch.float64)
         self.ctx.check(self.ctx.lib.nlc_mppi_get_U(self.ctx.h, _lib.ptr(Uh)))
         return Uh.to(self.d)
 
     @U.setter
     def U(self, value):
-        value = torch.as_tensor(value).detach().to(dtype=torch.float64).reshape(self.T, self.nu).clone()
+        value = torch.as_tensor(value).detach().to(dtype=torch.float64).reshape(self._lead(self.T, self.nu)).clone()
         if self._buf is None:
             self._pending_U = value
         else:
@@ -296,8 +316,7 @@ class MPPIDelay:
         ab = torch.as_tensor(action_buffer).detach().to("cpu", torch.float64).contiguous()
         if ab.dim() != 2:
             raise ValueError("action_buffer must be (B, nu)")
-        if self._buf is None or ab.shape[0] != self._B:
-            self._configure(ab.shape[0])
+        self._ensure_configured(ab.shape[0])
         lib, ctx = self.ctx.lib, self.ctx
         rng = 1 if self.noise_rng == "philox" else 0
         with torch.cuda.device(self.cd):
@@ -386,7 +405,7 @@ class MPPIDelay:
     # ------------------------------------------------------------------ misc reference API
     def reset(self):
         """Clear controller state after finishing a trial (re-draws U, reference :226-230)."""
-        self.U = self.noise_dist.sample((self.T,))
+        self.U = self.noise_dist.sample(self._lead(self.T))
 
     def get_rollouts(self, state, num_rollouts=1):
         """Open-loop replay of U through the dynamics callable (reference :358-381)."""

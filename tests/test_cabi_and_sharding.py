@@ -31,7 +31,7 @@ def test_header_symbols_exported(lib):
     assert declared == sorted(_lib.SYMBOLS), "include/nlc.h and _lib.SYMBOLS disagree"
     for name in declared:
         assert hasattr(lib, name), f"libnlc_hip.so does not export {name}"
-    assert lib.nlc_abi_version() == 1
+    assert lib.nlc_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -726,3 +726,173 @@ def test_closed_loop_episode_return_near_published_oracle_mpc(nlc, env, publishe
         total += -float(oenvs.RUNNING_COST[env](obs.view(1, -1), applied.view(1, nu)))
     assert 1.6 * published < total < 0.6 * published, (total, published)
     assert total > 0.5 * random_policy
+
+
+# --------------------------------------------------------------------------- batched episodes
+class _Replay:
+    """Stands in for MultivariateNormal: hands back preset draws (one per sample() call)."""
+
+    def __init__(self, *draws):
+        self.draws = list(draws)
+
+    def sample(self, shape):
+        return self.draws.pop(0)
+
+
+def _state(nlc, env, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = nlc.initial_state(env, g)
+    return x + 0.1 * torch.randn(x.shape, dtype=torch.float64, generator=g)
+
+
+def _batched_vs_singles(nlc, make_dyn, env, E, K, T, n_cmd=3, per_sample=False, exact=True, **kw):
+    """E episodes through BatchedMPPIDelay vs E separate MPPIDelay objects fed the same draws, over several
+    closed-loop-like commands (different state / action buffer per episode and per command)."""
+    nu = {"oderl-cartpole": 1, "oderl-pendulum": 1, "oderl-acrobot": 2}[env]
+    nx = {"oderl-cartpole": 5, "oderl-pendulum": 3, "oderl-acrobot": 6}[env]
+    A = {"oderl-cartpole": 3.0, "oderl-pendulum": 2.0, "oderl-acrobot": 5.0}[env]
+    sig = nlc.noise_sigma(nu)
+    g = torch.Generator().manual_seed(1234)
+    U0 = torch.randn(E, T, nu, dtype=torch.float64, generator=g) * 0.3
+    raws = [torch.randn(E, K, T, nu, dtype=torch.float64, generator=g) for _ in range(n_cmd)]
+    if per_sample:
+        states = [torch.stack([torch.stack([_state(nlc, env, 7 * c + 3 * e + k) for k in range(K)])
+                               for e in range(E)]) for c in range(n_cmd)]
+    else:
+        states = [torch.stack([_state(nlc, env, 100 * c + e) for e in range(E)]) for c in range(n_cmd)]
+    abufs = [torch.randn(E, 4, nu, dtype=torch.float64, generator=g) * A / 2 for _ in range(n_cmd)]
+    common = dict(lambda_=0.9, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, **kw)
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    bat = BatchedMPPIDelay(make_dyn(), nlc.EnvCost(env), nx, sig, E, K, T, "cpu", U_init=U0.clone(), **common)
+    bat.noise_dist = _Replay(*[r.clone() for r in raws])
+    singles = []
+    for e in range(E):
+        m = nlc.MPPIDelay(make_dyn(), nlc.EnvCost(env), nx, sig, K, T, "cpu", U_init=U0[e].clone(), **common)
+        m.noise_dist = _Replay(*[r[e].clone() for r in raws])
+        singles.append(m)
+    cmp = (lambda a, b: torch.equal(a, b)) if exact else (lambda a, b: torch.allclose(a, b, rtol=1e-12, atol=1e-12))
+    with torch.no_grad():
+        for c in range(n_cmd):
+            act = bat.command(states[c], abufs[c])
+            assert act.shape == (E, nu)
+            for e in range(E):
+                a1 = singles[e].command(states[c][e], abufs[c][e])
+                assert cmp(act[e], a1), (c, e, act[e], a1)
+                assert cmp(bat.cost_total[e], singles[e].cost_total)
+                assert cmp(bat.omega[e], singles[e].omega)
+                assert cmp(bat.states[e], singles[e].states)
+                assert cmp(bat.noise[e], singles[e].noise)
+                assert cmp(bat.U[e], singles[e].U)
+    return bat
+
+
+@pytest.mark.parametrize("env,delay", [("oderl-cartpole", 2), ("oderl-pendulum", 0), ("oderl-acrobot", 3)])
+def test_batched_planner_oracle_dynamics_equals_single_planners(nlc, env, delay):
+    """Collector shape (K = 1000 is ragged against every block size): bit-identical to E single planners."""
+    bat = _batched_vs_singles(nlc, lambda: nlc.OracleDynamics(env, 0.05, delay), env, E=5, K=1000, T=12)
+    assert bat.U.shape[0] == 5 and bat.noise.shape[:2] == (5, 1000)
+
+
+def test_batched_planner_oracle_options_and_per_sample_state(nlc):
+    _batched_vs_singles(nlc, lambda: nlc.OracleDynamics("oderl-acrobot", 0.05, 1), "oderl-acrobot", E=3, K=70, T=5,
+                        per_sample=True, sample_null_action=True, noise_abs_cost=True)
+
+
+@pytest.mark.parametrize("algo,S,K", [("fourier", 17, 100), ("fourier", 17, 8200), ("dehoog", 17, 72)])
+def test_batched_planner_nl_dynamics_equals_single_planners(nlc, algo, S, K):
+    """NL dynamics: K = 100 makes the 16-sample MFMA tiles straddle episodes; 8200 takes the wave-per-tile kernel."""
+    from oracle import nl_model as onl
+
+    env, d, nu, A = "oderl-cartpole", 5, 1, 3.0
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(4, d, nu, 128, S, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd, S=S, algo=algo)
+    E = 3 if K < 1000 else 2
+    _batched_vs_singles(nlc, lambda: nlc.NLDynamics(model, 0.05), env, E=E, K=K, T=6, n_cmd=2)
+
+
+def test_batched_planner_philox_streams_and_device_inputs(nlc):
+    """Device RNG: episode 0 continues the single planner's stream, other episodes draw different noise; states and
+    action buffers handed over as device tensors give the same result as host tensors; reset(env_ids) is per episode."""
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    env, E, K, T, A = "oderl-cartpole", 4, 512, 10, 3.0
+    sig = nlc.noise_sigma(1)
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=11)
+    U0 = torch.zeros(E, T, 1, dtype=torch.float64)
+    states = torch.stack([_state(nlc, env, e) for e in range(E)])
+    ab = torch.zeros(E, 4, 1, dtype=torch.float64)
+    mk = lambda dev: BatchedMPPIDelay(nlc.OracleDynamics(env, 0.05, 2), nlc.EnvCost(env), 5, sig, E, K, T, dev,  # noqa: E731
+                                      U_init=U0.clone(), **kw)
+    host, devp = mk("cpu"), mk("cuda")
+    a_h = host.command(states, ab)
+    a_d = devp.command(states.cuda(), ab.cuda())
+    assert a_d.is_cuda and torch.equal(a_h, a_d.cpu())
+    single = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 2), nlc.EnvCost(env), 5, sig, K, T, "cpu", U_init=U0[0].clone(), **kw)
+    a_s = single.command(states[0], ab[0])
+    assert torch.equal(a_s, a_h[0]) and torch.equal(single.noise, host.noise[0])
+    n = host.noise
+    assert not torch.equal(n[0], n[1]) and not torch.equal(n[1], n[2])
+    # U = 0 and bounds +-1 in normalised units: the bounded noise is N(0,1) clipped to [-1, 1] (std 0.718)
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 0.718) < 0.02 and float(n.abs().max()) <= 1.0
+    U_before = host.U.clone()
+    torch.manual_seed(5)
+    host.reset([1, 3])
+    U_after = host.U
+    assert torch.equal(U_after[0], U_before[0]) and torch.equal(U_after[2], U_before[2])
+    assert not torch.equal(U_after[1], U_before[1]) and not torch.equal(U_after[3], U_before[3])
+    host.reset()
+    assert host.U.shape == (E, T, 1)
+
+
+def test_batched_planner_rejects_unsupported(nlc):
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    sig = nlc.noise_sigma(1)
+    with pytest.raises(NotImplementedError):
+        BatchedMPPIDelay(lambda s, a: s, lambda s, a: s.sum(1), 5, sig, 4, 64, 5, "cpu")
+    b = BatchedMPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 0), nlc.EnvCost("oderl-cartpole"), 5, sig, 4, 64, 5, "cpu")
+    with pytest.raises(ValueError):
+        b.command(torch.zeros(5, dtype=torch.float64), torch.zeros(4, 4, 1, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        b.command(torch.zeros(4, 5, dtype=torch.float64), torch.zeros(4, 1, dtype=torch.float64))
+
+
+def test_planners_sharing_a_model_are_independent_and_track_weight_updates(nlc):
+    """Each planner owns its ctx (U, folded bias): interleaving two planners over ONE model changes nothing, and a
+    planner picks up new weights (load_state_dict) on its next command, carrying its U over."""
+    from oracle import nl_model as onl
+
+    env, d, nu, A, K, T = "oderl-cartpole", 5, 1, 3.0, 64, 5
+    st = onl.ENV_STATS[env]
+    sd1 = onl.make_synthetic_state_dict(5, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    sd2 = onl.make_synthetic_state_dict(6, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    g = torch.Generator().manual_seed(9)
+    raws = [torch.randn(K, T, nu, dtype=torch.float64, generator=g) for _ in range(3)]
+    Ua, Ub = torch.randn(T, nu, dtype=torch.float64, generator=g) * 0.2, torch.randn(T, nu, dtype=torch.float64, generator=g)
+    state, ab = _state(nlc, env, 1), torch.zeros(4, nu, dtype=torch.float64)
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+
+    def planner(model, U0, draws):
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                          U_init=U0.clone(), **kw)
+        p.noise_dist = _Replay(*[r.clone() for r in draws])
+        return p
+
+    with torch.no_grad():
+        alone = planner(build_model(nlc, sd1), Ua, raws)
+        a1, a2 = alone.command(state, ab).clone(), alone.command(state, ab).clone()
+        U_after2 = alone.U.clone()
+        shared = build_model(nlc, sd1)
+        pa, pb = planner(shared, Ua, raws), planner(shared, Ub, raws)
+        assert pa.ctx is not pb.ctx
+        b1 = pa.command(state, ab)
+        pb.command(state, ab)
+        b2 = pa.command(state, ab)
+        assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(pa.U, U_after2)
+        shared.load_state_dict(sd2)  # new weights, same module
+        b3 = pa.command(state, ab)
+        fresh = planner(build_model(nlc, sd2), U_after2, raws[2:])
+        assert torch.equal(b3, fresh.command(state, ab))
+        assert not torch.equal(b3, alone.command(state, ab))
