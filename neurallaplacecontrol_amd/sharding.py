@@ -21,8 +21,15 @@ def gather_partials(partials, gathered, group):
     """One all-gather of every rank's (2 + T*nu) partial vector; RCCL over xGMI on GPUs, gloo in CPU tests."""
     import torch.distributed as dist
 
-    assert gathered.shape == (dist.get_world_size(group), partials.numel())
-    dist.all_gather_into_tensor(gathered.view(-1), partials.contiguous(), group=group)
+    assert gathered.numel() == dist.get_world_size(group) * partials.numel()
+    if partials.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: stage through the host (tests that run two ranks on ONE GPU; RCCL refuses
+        # two ranks per device)
+        host = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(host.view(-1), partials.detach().cpu().contiguous().view(-1), group=group)
+        gathered.copy_(host)
+        return gathered
+    dist.all_gather_into_tensor(gathered.view(-1), partials.contiguous().view(-1), group=group)
     return gathered
 
 

@@ -896,3 +896,71 @@ def test_planners_sharing_a_model_are_independent_and_track_weight_updates(nlc):
         fresh = planner(build_model(nlc, sd2), U_after2, raws[2:])
         assert torch.equal(b3, fresh.command(state, ab))
         assert not torch.equal(b3, alone.command(state, ab))
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import neurallaplacecontrol_amd as n
+dist.init_process_group("gloo")            # both ranks share cuda:0 here; bench.py uses "nccl" (= RCCL), one GPU per rank
+rank = dist.get_rank()
+sd = torch.load(os.path.join(sys.argv[2], "sd.pt"))
+d, nu, A, K, T = 5, 1, 3.0, 1024, 8
+import numpy as np
+model = n.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", state_mean=np.zeros(d),
+                             state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]),
+                             normalize=True, normalize_time=True).double()
+model.load_state_dict(sd)
+model = model.cuda()
+out = {}
+for name, dyn in (("nl", n.NLDynamics(model, 0.05)), ("oracle", n.OracleDynamics("oderl-cartpole", 0.05, 2))):
+    p = n.MPPIDelay(dyn, n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+                    u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                    noise_rng="philox", seed=21, process_group=dist.group.WORLD)
+    assert p.K_local == K // 2 and p.k_offset == rank * (K // 2)
+    state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
+    with torch.no_grad():
+        acts = [p.command(state, ab).cpu() for _ in range(3)]
+    out[name] = dict(acts=torch.stack(acts), U=p.U.cpu(), noise=p.noise.cpu(), omega=p.omega.cpu())
+torch.save(out, os.path.join(sys.argv[2], f"r{rank}.pt"))
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
+    """`MPPIDelay(process_group=...)` through torch.distributed.run with world_size 2 (both ranks on this one GPU,
+    gloo collective): every rank returns the same action, and it equals the unsharded planner's (Philox counters are
+    global sample indices, so the draw does not depend on the sharding)."""
+    import subprocess
+    import sys
+
+    from oracle import nl_model as onl
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    d, nu, A, K, T = 5, 1, 3.0, 1024, 8
+    st = onl.ENV_STATS["oderl-cartpole"]
+    sd = onl.make_synthetic_state_dict(8, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    torch.save(sd, tmp_path / "sd.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29541", str(script), repo, str(tmp_path)], env=env, timeout=600)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    model = build_model(nlc, sd)
+    state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
+    for name, dyn in (("nl", nlc.NLDynamics(model, 0.05)), ("oracle", nlc.OracleDynamics("oderl-cartpole", 0.05, 2))):
+        assert torch.equal(r0[name]["acts"], r1[name]["acts"]) and torch.equal(r0[name]["U"], r1[name]["U"])
+        p = nlc.MPPIDelay(dyn, nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                          U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=21)
+        with torch.no_grad():
+            acts = torch.stack([p.command(state, ab) for _ in range(3)])
+        np.testing.assert_allclose(r0[name]["acts"].numpy(), acts.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r0[name]["U"].numpy(), p.U.numpy(), rtol=1e-10, atol=1e-12)
+        # the shards hold the two halves of the unsharded planner's last draw and weights
+        both = torch.cat((r0[name]["noise"], r1[name]["noise"]))
+        np.testing.assert_allclose(both.numpy(), p.noise.numpy(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(torch.cat((r0[name]["omega"], r1[name]["omega"])).numpy(), p.omega.numpy(),
+                                   rtol=1e-9, atol=1e-15)
