@@ -18,6 +18,10 @@ __global__ void shift_U_kernel(const PerturbArgs a) {
     const int t = i / a.nu, j = i - t * a.nu;
     Un[i] = (t + 1 < a.T) ? Uo[i + a.nu] : a.u_init[j];
   }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < a.n_state_in; i += blockDim.x) a.state_dst[i] = a.state_in[i];
+    for (int i = threadIdx.x; i < a.n_abuf_in; i += blockDim.x) a.abuf_dst[i] = a.abuf_in[i];
+  }
 }
 hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(shift_U_kernel, dim3((unsigned)a.E), dim3(128), 0, s, a);
@@ -191,7 +195,10 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
       for (int g = 0; g < a.G; ++g) acc += exp(-(gat[g * gs] - beta) / a.lambda_) * gat[g * gs + 2 + i];
       const double u = U[i] + (1.0 / eta) * acc;  // omega = (1/eta) w, :214-216
       U[i] = u;
-      if (i < a.u_per_command * a.nu) a.action[e * a.u_per_command * a.nu + i] = u * a.u_scale;  // :217-224
+      if (i < a.u_per_command * a.nu) {
+        a.action[e * a.u_per_command * a.nu + i] = u * a.u_scale;  // :217-224
+        if (a.action_pinned != nullptr) a.action_pinned[e * a.u_per_command * a.nu + i] = u * a.u_scale;
+      }
     }
     if (threadIdx.x == 0) {
       a.beta_eta[e * 2] = beta;

@@ -623,7 +623,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if (pin_need > c->pinned_n) {
     if (c->pinned) hipHostFree(c->pinned);
     c->pinned = nullptr;
-    NLC_HIP(c, hipHostMalloc((void**)&c->pinned, pin_need * sizeof(double), hipHostMallocDefault));
+    NLC_HIP(c, hipHostMalloc((void**)&c->pinned, pin_need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     c->pinned_n = pin_need;
   }
   c->pd = *d;
@@ -747,6 +747,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   double* state_dev = ws + w.state0;
   double* abuf_dev = ws + w.abuf;
   const int64_t KE = d.K * d.E;  // all local samples, episode-major
+  bool inline_inputs = false;
   if (!external && d.E > 1) {
     // batched episodes: the (E,d) states and (E,B,nu) action buffers usually live on the device already (a device-side
     // env loop); hipMemcpyDefault takes either kind of pointer
@@ -754,6 +755,8 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     NLC_HIP(c, hipMemcpyAsync(state_dev, state, ns * sizeof(double), hipMemcpyDefault, c->stream));
     NLC_HIP(c, hipMemcpyAsync(abuf_dev, abuf_host, (size_t)d.E * d.B * d.nu * sizeof(double), hipMemcpyDefault,
                               c->stream));
+  } else if (!external && !state_per_sample && d.B * d.nu <= kMaxInlineAbuf) {
+    inline_inputs = true;  // state and action_buffer travel in the shift kernel's arguments (below)
   } else if (!external) {
     // small inputs go through pinned staging (truly asynchronous copies).  The staging slots are rewritten
     // only after the previous command's copies out of them have completed (stage_ev).
@@ -798,6 +801,14 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) p.chol[i] = d.noise_chol[i];
   p.seed = seed;
   p.counter = counter;
+  if (inline_inputs) {
+    p.n_state_in = d.d;
+    p.n_abuf_in = d.B * d.nu;
+    p.state_dst = state_dev;
+    p.abuf_dst = abuf_dev;
+    std::memcpy(p.state_in, state, (size_t)d.d * sizeof(double));
+    std::memcpy(p.abuf_in, abuf_host, (size_t)d.B * d.nu * sizeof(double));
+  }
   {
     ProfScope ps(c, "shift_U_kernel");
     NLC_HIP(c, launch_shift_U(p, c->stream));
@@ -1019,14 +1030,16 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   m.omega = buf->omega;
   m.action = buf->action ? buf->action : c->small;
   m.beta_eta = c->small + (size_t)d.E * d.T * d.nu;
+  // the returned action is stored by the kernel straight into pinned (host-coherent) memory: the only thing left
+  // on the host's critical path is the stream synchronisation
+  double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;
+  m.action_pinned = action_host ? pin_act : nullptr;
   {
     ProfScope ps(c, "merge_kernel");
     NLC_HIP(c, launch_merge(m, c->stream));
   }
   if (action_host) {
     const size_t na = (size_t)d.E * d.u_per_command * d.nu;
-    double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;
-    NLC_HIP(c, hipMemcpyAsync(pin_act, m.action, na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     NLC_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(action_host, pin_act, na * sizeof(double));
   }

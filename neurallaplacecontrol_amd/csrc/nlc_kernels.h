@@ -178,6 +178,7 @@ struct OracleRolloutArgs {
 hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ MPPI sampling / weighting
+constexpr int kMaxInlineAbuf = 32;  // action_buffer doubles carried in the kernel arguments (B*nu <= 32)
 struct PerturbArgs {
   int64_t K, Kep, K_global, k_offset;  // K_global / k_offset are per episode
   int T, nu, E;
@@ -191,6 +192,13 @@ struct PerturbArgs {
   double u_min[NLC_MAX_NU], u_max[NLC_MAX_NU], u_init[NLC_MAX_NU], mu[NLC_MAX_NU];
   double chol[NLC_MAX_NU * NLC_MAX_NU];
   uint64_t seed, counter;
+  // single planner: the command's state (d) and action_buffer (B, nu) ride in the kernel arguments and the shift
+  // kernel stores them into the workspace -- no host-to-device copy commands on the command's critical path
+  int n_state_in, n_abuf_in;  // 0 = not carried (batched / per-sample state / oversize: copied by the host API)
+  double* state_dst;
+  double* abuf_dst;
+  double state_in[NLC_MAX_D];
+  double abuf_in[kMaxInlineAbuf];
 };
 hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s);
 hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s);
@@ -221,6 +229,7 @@ struct MergeArgs {
   double* cost_nz;         // (E, Kep) rescaled to the global beta
   double* omega;           // (E, Kep) or NULL
   double* action;          // (E, u_per_command * nu) device
+  double* action_pinned;   // same, in pinned host memory the kernel stores to directly (NULL = not wanted)
   double* beta_eta;        // (E, 2) device: merged beta, eta
 };
 hipError_t launch_merge(const MergeArgs& a, hipStream_t s);

@@ -143,18 +143,32 @@ class NeuralLaplaceModel(nn.Module):
         self.register_buffer("action_std", torch.tensor(action_std))
         self.register_buffer("dt", torch.tensor(dt))
         self._ctx = None
+        self._key_ts = None
         self._uploaded_key = None
         self._rep_dev = None  # (key, device copy of laplace_rep_func) for the staged path
 
     # ------------------------------------------------------------------ HIP plumbing
     def _weights_key(self):
-        ts = [p for p in self.parameters()] + [b for b in self.buffers()]
-        return tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in ts) + (
+        """Changes whenever a parameter / buffer is written in place (``_version``), replaced or moved (``data_ptr``;
+        a dtype or device change always re-allocates).  Planners evaluate this once per command, so the tensor list
+        is cached; ``_apply`` (.to/.double/.cuda) and ``load_state_dict`` drop the cache."""
+        ts = self._key_ts
+        if ts is None:
+            ts = self._key_ts = [p for p in self.parameters()] + [b for b in self.buffers()]
+        return tuple([(t.data_ptr(), t._version) for t in ts]) + (
             self.normalize,
             self.normalize_time,
             self.ilt_algorithm,
-            repr(self.ilt_options),
+            repr(self.ilt_options) if self.ilt_options is not None else None,
         )
+
+    def _apply(self, fn, *args, **kwargs):
+        self._key_ts = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._key_ts = None
+        return super().load_state_dict(*args, **kwargs)
 
     def model_desc(self):
         d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)

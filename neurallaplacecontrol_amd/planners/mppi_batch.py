@@ -55,7 +55,7 @@ class BatchedMPPIDelay(MPPIDelay):
             raise ValueError(f"state must be (E={E}, nx={self.nx}) or (E, K, nx)")
         if ab.dim() != 3 or ab.shape[0] != E:
             raise ValueError("action_buffer must be (E, B, nu)")
-        self.state = st.to(dtype=self.dtype, device=self.d)
+        self._state_in = st
 
         def stage(t):  # device tensors stay where they are; host tensors are read by the library directly
             t = t.detach().to(dtype=torch.float64)

@@ -122,7 +122,7 @@ class MPPIDelay:
         self.terminal_state_cost = terminal_state_cost
         self.sample_null_action = sample_null_action
         self.noise_abs_cost = noise_abs_cost
-        self.state = None
+        self._state_in = None
 
         if noise_rng not in ("torch", "philox"):
             raise ValueError("noise_rng must be 'torch' or 'philox'")
@@ -289,6 +289,16 @@ class MPPIDelay:
     def _out(self, t):
         return None if t is None else (t if self.d == t.device else t.to(self.d))
 
+    @property
+    def state(self):
+        """The state handed to the last command, on ``device`` (reference :196-198)."""
+        s = self._state_in
+        return None if s is None else s.to(dtype=self.dtype, device=self.d)
+
+    @state.setter
+    def state(self, value):
+        self._state_in = value
+
     noise = property(lambda self: self._out(self._noise))
     perturbed_action = property(lambda self: self._out(self._perturbed))
     states = property(lambda self: self._out(self._states))
@@ -306,8 +316,8 @@ class MPPIDelay:
         """
         if not torch.is_tensor(state):
             state = torch.tensor(state)
-        self.state = state.to(dtype=self.dtype, device=self.d)
-        st = self.state.detach().to("cpu", torch.float64).contiguous()
+        self._state_in = state  # .state (reference attribute) converts lazily: no device round trip per command
+        st = state.detach().to("cpu", torch.float64).contiguous()
         per_sample = tuple(st.shape) == (self.K, self.nx)
         if per_sample:
             st = st[self.k_offset : self.k_offset + self.K_local].contiguous()
