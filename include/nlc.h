@@ -171,6 +171,8 @@ typedef struct {
   void* workspace;    /* nlc_mppi_workspace_bytes() bytes of scratch */
 } nlc_mppi_buffers;
 
+/* NLC_DYN_NL: the model's GRU input dim must be nu, or nu+1 for an encode_obs_time model -- the rollout then
+ * appends the constant time channel B-1 .. 0 the harness closure builds (mppi_with_model.py:110-119). */
 int nlc_mppi_configure(nlc_ctx* ctx, const nlc_mppi_desc* desc);
 int64_t nlc_mppi_workspace_bytes(nlc_ctx* ctx);
 int nlc_mppi_set_U(nlc_ctx* ctx, const double* U_host); /* (E,T,nu) control sequence(s), :161-164 */

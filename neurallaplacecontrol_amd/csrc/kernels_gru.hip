@@ -177,8 +177,11 @@ __global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
         raw = a.window[(wc * a.B + j_win) * a.nin + q];
       } else {
         const int i = tt + j_win;
-        raw = (i < a.B - 1) ? a.abuf[(ab_off + 1 + i) * a.nin + q]
-                            : a.u_scale * a.perturbed[(kk * a.T + (i - (a.B - 1))) * a.nin + q];
+        if (q < a.nact)
+          raw = (i < a.B - 1) ? a.abuf[(ab_off + 1 + i) * a.nact + q]
+                              : a.u_scale * a.perturbed[(kk * a.T + (i - (a.B - 1))) * a.nact + q];
+        else
+          raw = (double)(a.B - 1 - j_win);  // encode_obs_time model: the harness's constant time channel
       }
       xin = (raw - in_mean) / in_std;
     } else if (q == 3) {

@@ -597,7 +597,8 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     // the caller owns dynamics and cost
   } else if (d->dynamics == NLC_DYN_NL) {
     if (!c->has_model) return fail(c, NLC_ERR_STATE, "NL dynamics need nlc_set_model first");
-    if (c->md.d != d->d || c->md.nin != d->nu)
+    // nin == nu + 1: an encode_obs_time model; the rollout appends the harness's constant time channel
+    if (c->md.d != d->d || (c->md.nin != d->nu && c->md.nin != d->nu + 1))
       return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
     if (c->md.ilt.algo == NLC_ILT_DEHOOG && c->S != 33 && c->S != 17 && c->S != 9)
       return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
@@ -829,6 +830,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     g.T = d.T;
     g.B = d.B;
     g.Kep = d.K;
+    g.nact = d.nu;
     g.out = pa;
     RolloutArgs r{};
     r.net = c->net;

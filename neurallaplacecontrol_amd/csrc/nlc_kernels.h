@@ -52,6 +52,8 @@ struct GruArgs {
   int64_t Kep;  // mode 1: samples per episode; sample k reads action_buffer row block k / Kep (abuf is (E, B, nu))
   int64_t N;  // windows (mode 1: K*Tc)
   int B, nin;
+  int nact;  // mode 1: action dims nu; an encode_obs_time model (nin == nu + 1) gets the time channel
+             // flip(arange(B)) the harness closure appends (mppi_with_model.py:110-119)
   double mean[NLC_MAX_NIN], std[NLC_MAX_NIN];
   // fragment-packed weights (device)
   // gate matrices are chunk-packed [GT chunks][KS][3 gates r,z,n][64] (see kernels_gru.hip)

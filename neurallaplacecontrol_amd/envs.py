@@ -37,6 +37,11 @@ class NLDynamics:
 
     def __call__(self, state, perturbed_action):
         ts = torch.full((state.shape[0], 1), self.ts_pred, dtype=torch.float64, device=state.device)
+        if self.model.encode_obs_time and perturbed_action.shape[2] == self.model.action_dim:
+            # the harness closure appends a constant time channel B-1 .. 0 (mppi_with_model.py:110-119)
+            B = perturbed_action.shape[1]
+            tch = torch.flip(torch.arange(B, device=perturbed_action.device), (0,)).view(1, B, 1)
+            perturbed_action = torch.cat((perturbed_action, tch.repeat(perturbed_action.shape[0], 1, 1)), dim=2)
         return state + self.model(state, perturbed_action, ts).view(state.shape)
 
 

@@ -161,10 +161,16 @@ def nl_forward(
     return torch.squeeze(out)
 
 
-def nl_dynamics(sd, ts_pred, **kw):
-    """Harness closure mppi_with_model.py:103-122: state + model(state, window, ts_pred)."""
+def nl_dynamics(sd, ts_pred, time_channel=False, **kw):
+    """Harness closure mppi_with_model.py:103-122: state + model(state, window, ts_pred).
+    time_channel: the ``encode_obs_time and model_name == "nl"`` branch (:110-119) appends the constant channel
+    flip(arange(B)) = B-1 .. 0 to every window (int64 promoted to float64 by the cat)."""
 
     def dynamics(state, window):
+        if time_channel:
+            B = window.shape[1]
+            tch = torch.flip(torch.arange(B), (0,)).view(1, B, 1).repeat(window.shape[0], 1, 1)
+            window = torch.cat((window, tch), dim=2)
         return state + nl_forward(sd, state, window, ts_pred[: state.shape[0]], **kw).view(state.shape)
 
     return dynamics

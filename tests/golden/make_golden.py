@@ -15,6 +15,12 @@ Fixtures:
                               with NL dynamics; ONLY laplace_reconstruct is the build's
                               restatement (torchlaplace is absent: parity unpinned for a9)
   g4_ilt_known.npz            analytic Laplace pairs + mpmath.invertlaplace(method='dehoog')
+  g5_collector_<env>.npz      dataset-collector call pattern: reference MPPIDelay(encode_obs_time=True) with the
+                              rolling time-stamp column in action_buffer (mppi_delay.py:261-287) + reference
+                              oracle dynamics; records action_buffer before/after (the reference adds dt to the
+                              caller's time column in place)
+  g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
+                              constant time channel B-1..0 (mppi_with_model.py:110-119) + reference MPPIDelay
 """
 
 import os
@@ -288,6 +294,100 @@ def make_g2_g3(MPPIDelay, w_nl, envs):
             print("g3", env_name, "action", out["s1_action"], "fwd[0]", out["fwd_out"][0])
 
 
+def make_g5(MPPIDelay, w_nl, envs, dyn):
+    from functools import partial
+
+    K, T, B, dt = 64, 8, 4, 0.05
+    for env_name, delay in (("oderl-cartpole", 2), ("oderl-acrobot", 1), ("oderl-pendulum", 0)):
+        short = env_name.split("-")[1]
+        env = envs[env_name]()
+        nx, nu, A = oenvs.OBS_DIM[env_name], oenvs.ACT_DIM[env_name], oenvs.ACTION_HIGH[env_name]
+        ts_pred = torch.full((K, 1), dt, dtype=torch.double)
+
+        def running_cost(state, action, env=env):
+            return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+        # ---- (a) collector: planner-side rolling time stamps, oracle dynamics (mppi_dataset_collector.py:166-180,228-231)
+        torch.manual_seed(300 + delay)
+        mppi = MPPIDelay(
+            partial(dyn[env_name], ts=ts_pred, delay=delay, friction=False), running_cost, nx, noise_sigma(nu),
+            num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+            u_scale=A, encode_obs_time=True, dt=dt,
+        )
+        state = oenvs.initial_state(env_name, seed=5)
+        action_buffer = torch.zeros((B, nu + 1), dtype=torch.double)
+        action_buffer[:, nu:] = (torch.flip(torch.arange(4), (0,)) * dt).view(-1, 1)
+        action_buffer[:, :nu] = (torch.rand(B, nu, dtype=torch.double) - 0.5) * A
+        out = {}
+        for step in range(2):
+            out[f"s{step}_action_buffer"] = np_(action_buffer)
+            c = capture_command(mppi, state.numpy(), action_buffer)
+            out[f"s{step}_action_buffer_after"] = np_(action_buffer)
+            for k, v in c.items():
+                out[f"s{step}_{k}"] = v
+            out[f"s{step}_state"] = np_(state)
+            state = mppi.states[0, 0].clone()
+            # get_action_with_encode_obs_time-like hand-over: roll, append [action, 0], age the time stamps
+            action_buffer = torch.roll(action_buffer, -1, dims=0)
+            action_buffer[-1, :nu] = torch.as_tensor(c["action"])
+            action_buffer[:, nu:] += dt
+            action_buffer[-1, nu:] = 0
+        np.savez_compressed(f"{HERE}/g5_collector_{short}.npz", K=K, T=T, B=B, delay=delay, nx=nx, nu=nu, A=A, dt=dt, **out)
+        print("g5 collector", env_name, "action", out["s1_action"])
+
+        # ---- (b) encode_obs_time NL model behind the harness closure (mppi_with_model.py:103-122)
+        if nu != 1:
+            continue  # the reference itself cannot run it: action_mean = [0]*nu does not broadcast over nu+1 channels
+        st = onl.ENV_STATS[env_name]
+        torch.manual_seed(2)
+        model = w_nl.NeuralLaplaceModel(
+            nx, nu, nx, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", encode_obs_time=True,
+            state_mean=np.zeros(nx), state_std=np.array(st["state_std"]), action_mean=np.array([0] * nu),
+            action_std=np.array([A / 2.0]), normalize=True, normalize_time=True,
+        ).double()
+        with torch.no_grad():
+            model.laplace_rep_func.linear_tanh_stack[4].bias[nx * 17 :] += onl.PHI_BIAS_SHIFT
+            sd = {k: np_(v) for k, v in model.state_dict().items()}
+
+            def dynamics(state, perturbed_action, action_buffer_size=B):
+                perturbed_action = torch.cat(
+                    (
+                        perturbed_action,
+                        torch.flip(torch.arange(action_buffer_size), (0,)).view(1, action_buffer_size, 1)
+                        .repeat(perturbed_action.shape[0], 1, 1),
+                    ),
+                    dim=2,
+                )
+                return state + model(state, perturbed_action, ts_pred)
+
+            torch.manual_seed(13)
+            mppi = MPPIDelay(
+                dynamics, running_cost, nx, noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+            )
+            state = oenvs.initial_state(env_name, seed=4)
+            action_buffer = (torch.rand(B, nu, dtype=torch.double) - 0.5) * A
+            out = {}
+            N = 40
+            obs = torch.randn(N, nx, dtype=torch.double) * torch.tensor(st["state_std"])
+            window = torch.cat(((torch.rand(N, B, nu, dtype=torch.double) * 2 - 1) * A,
+                                torch.rand(N, B, 1, dtype=torch.double) * 0.2), dim=2)
+            ts = torch.full((N, 1), dt, dtype=torch.double)
+            out.update(fwd_obs=np_(obs), fwd_window=np_(window), fwd_ts=np_(ts), fwd_out=np_(model(obs, window, ts)))
+            for step in range(2):
+                c = capture_command(mppi, state.numpy(), action_buffer)
+                for k, v in c.items():
+                    out[f"s{step}_{k}"] = v
+                out[f"s{step}_state"] = np_(state)
+                out[f"s{step}_action_buffer"] = np_(action_buffer)
+                state = mppi.states[0, 0].clone()
+                action_buffer = torch.roll(action_buffer, -1, dims=0)
+                action_buffer[-1] = torch.as_tensor(c["action"])
+        np.savez_compressed(f"{HERE}/g5_nl_obs_time_{short}.npz", K=K, T=T, B=B, nx=nx, nu=nu, A=A, S=17, h=128, d=nx,
+                            **out, **{f"w::{k}": v for k, v in sd.items()})
+        print("g5 nl", env_name, "action", out["s1_action"])
+
+
 def make_g4():
     """ILT known answers: analytic pairs + mpmath de Hoog (degree 16 -> 33 terms)."""
     import mpmath as mp
@@ -325,6 +425,7 @@ def main():
     make_g1(MPPIDelay, envs, dyn)
     make_g2_g3(MPPIDelay, w_nl, envs)
     make_g4()
+    make_g5(MPPIDelay, w_nl, envs, dyn)
 
 
 if __name__ == "__main__":

@@ -964,3 +964,59 @@ def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
         np.testing.assert_allclose(both.numpy(), p.noise.numpy(), rtol=0, atol=1e-12)
         np.testing.assert_allclose(torch.cat((r0[name]["omega"], r1[name]["omega"])).numpy(), p.omega.numpy(),
                                    rtol=1e-9, atol=1e-15)
+
+
+# --------------------------------------------------------------------------- G5: encode_obs_time variants
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_collector_variant_vs_reference_golden(nlc, env):
+    """G5a: reference MPPIDelay(encode_obs_time=True) + reference oracle dynamics with the (B, nu+1) action buffer
+    of the dataset collector; the fused path reproduces it and leaves the caller's buffer untouched."""
+    g = np.load(f"{GOLD}/g5_collector_{env}.npz")
+    K, T, nx, nu, A, delay = int(g["K"]), int(g["T"]), int(g["nx"]), int(g["nu"]), float(g["A"]), int(g["delay"])
+
+    def make(U0):
+        m = nlc.MPPIDelay(
+            nlc.OracleDynamics("oderl-" + env, ts=0.05, delay=delay), nlc.EnvCost("oderl-" + env), nx, nlc.noise_sigma(nu),
+            num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+            u_scale=A, U_init=U0, encode_obs_time=True, dt=float(g["dt"]),
+        )
+        assert m.fused
+        return m
+
+    check_command_steps(nlc, g, make)
+    ab = T64(g["s0_action_buffer"])
+    keep = ab.clone()
+    make(T64(g["s0_U_before"])).command(g["s0_state"], ab)
+    assert torch.equal(ab, keep)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum"])
+def test_nl_model_with_time_channel_vs_reference_golden(nlc, env):
+    """G5b: encode_obs_time NL model (GRU input nu+1).  forward() on explicit (N, B, nu+1) windows, and the planner with
+    the harness closure's constant time channel B-1..0 (mppi_with_model.py:110-119): fused kernel and generic path."""
+    g = np.load(f"{GOLD}/g5_nl_obs_time_{env}.npz")
+    sd = load_sd(g)
+    d, nu, K, T, A = int(g["d"]), int(g["nu"]), int(g["K"]), int(g["T"]), float(g["A"])
+    m = nlc.NeuralLaplaceModel(
+        d, nu, d, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", encode_obs_time=True,
+        state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0] * nu), action_std=np.array([1.0]),
+        normalize=True, normalize_time=True,
+    ).double()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    with torch.no_grad():
+        out = m(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda())
+        np.testing.assert_allclose(out.cpu().numpy(), g["fwd_out"], **TOL)
+
+        def make(U0, fused=True):
+            dyn = nlc.NLDynamics(m, 0.05)
+            p = nlc.MPPIDelay(
+                dyn if fused else (lambda s, w: dyn(s, w)), nlc.EnvCost("oderl-" + env), d, nlc.noise_sigma(nu),
+                num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+                u_scale=A, U_init=U0,
+            )
+            assert p.fused == fused
+            return p
+
+        check_command_steps(nlc, g, make)
+        check_command_steps(nlc, g, lambda U0: make(U0, fused=False))

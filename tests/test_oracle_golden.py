@@ -174,3 +174,34 @@ def test_shard_merge_equals_unsharded():
         assert beta == full[0]
         np.testing.assert_allclose(eta.numpy(), full[1].numpy(), rtol=1e-12)
         np.testing.assert_allclose(dU.numpy(), full[2].numpy(), rtol=1e-12, atol=1e-14)
+
+
+# --------------------------------------------------------------------------- G5: encode_obs_time variants
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_g5_collector_time_stamp_column_is_ignored_by_oracle_dynamics(env, golden_dir):
+    """Reference MPPIDelay(encode_obs_time=True) + reference oracle dynamics: the rolling time-stamp channel never
+    reaches the arithmetic (oracle.py:23 reads [:, -(delay+1), :nu]) and the caller's buffer is left untouched
+    (mppi_delay.py:236 clones it)."""
+    g = np.load(f"{golden_dir}/g5_collector_{env}.npz")
+    K, delay, nx, nu, A = int(g["K"]), int(g["delay"]), int(g["nx"]), int(g["nu"]), float(g["A"])
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    dyn = lambda s, w: oenvs.ORACLE_DYNAMICS["oderl-" + env](s, w, ts, delay)  # noqa: E731
+    g2 = {k: g[k] for k in g.files}
+    for step in range(2):
+        assert np.array_equal(g[f"s{step}_action_buffer"], g[f"s{step}_action_buffer_after"])
+        g2[f"s{step}_action_buffer"] = g[f"s{step}_action_buffer"][:, :nu]
+    run_steps(g2, dyn, oenvs.RUNNING_COST["oderl-" + env], nx, nu, A)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum"])
+def test_g5_nl_model_with_time_channel(env, golden_dir):
+    """encode_obs_time NL model (GRU input nu+1): forward on explicit windows, and the harness closure that appends
+    the constant channel B-1..0 (mppi_with_model.py:110-119) inside the reference planner."""
+    g = np.load(f"{golden_dir}/g5_nl_obs_time_{env}.npz")
+    sd = load_sd(g)
+    d, nu, S, K, A, B = int(g["d"]), int(g["nu"]), int(g["S"]), int(g["K"]), float(g["A"]), int(g["B"])
+    assert sd["action_encoder.gru.weight_ih_l0"].shape[1] == nu + 1
+    out = onl.nl_forward(sd, T(g["fwd_obs"]), T(g["fwd_window"]), T(g["fwd_ts"]), S=S)
+    np.testing.assert_allclose(out.numpy(), g["fwd_out"], **TOL)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    run_steps(g, onl.nl_dynamics(sd, ts, S=S, time_channel=True), oenvs.RUNNING_COST["oderl-" + env], d, nu, A)
