@@ -213,9 +213,12 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
+// a / b = a conj(b) / |b|^2 with ONE refined reciprocal (v_rcp_f64 + two Newton steps, < 1 ulp) instead of two IEEE
+// divisions (v_div_scale / v_div_fmas / v_div_fixup sequences with their VCC hazards): the QD table needs ~M^2 of
+// these per row, and they were 55 % of the kernel's issue slots.
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
-  const double den = b.re * b.re + b.im * b.im;
-  return {(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+  const double inv = m::rcp_refined(b.re * b.re + b.im * b.im);
+  return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
 }
 __device__ __forceinline__ cplx csqrt_(cplx z) {
   // principal branch
@@ -230,119 +233,125 @@ __device__ __forceinline__ cplx csqrt_(cplx z) {
   return {re, im};
 }
 
-// One thread per (point, dim) row.  F_k is staged through LDS by the whole block with coalesced loads; the
-// QD columns q[0..2M), e[0..2M] live in registers (compile-time M, statically indexed, in-place rhombus
-// updates), and the continued-fraction recurrence consumes d_i as soon as a column produces it.
-template <int M>
-__global__ __launch_bounds__(64) void ilt_dehoog_kernel(const IltArgs a) {
+// One thread per (point, dim) row; a block is one wavefront = 64 rows.
+//
+// The QD table is built anti-diagonal by anti-diagonal ("progressive" form): Laplace term a_n extends every column
+// by one entry, and the new diagonal is computed in place over the previous one -- D[c-1] holds the entry of column c
+// (c = 1: q_1, 2: e_1, 3: q_2, ...) on the current diagonal -- with the same rhombus rules as mpmath's column-wise
+// sweep (calculus/inverselaplace.py:476-531), so every entry is the same arithmetic on the same operands:
+//     e_r^(i)     = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)            (even column)
+//     q_(r+1)^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)                  (odd column)
+// The last entry of diagonal n is the continued-fraction coefficient d_n = -(entry at i = 0), consumed at once by the
+// A/B recurrence.  Storage is ONE diagonal (2M complex = 128 VGPRs at M = 16) instead of the two full columns of the
+// column-wise form (354 VGPRs, one wave per SIMD), and the F_k rows are staged through LDS in chunks of CH terms, so
+// two waves per SIMD share the VALU (a single wave issues FP64 VALU at half rate: tools/ubench_valu64.hip).
+// Measured (N = 655 360 points, d = 5, PMC in profiles/r1g_pmc_dehoog.json): S = 33 2.50 -> 1.65 ms, VALU 66 % busy
+// with 9.6 k VALU instructions per 64 rows (7.3 k QD + 2.3 k sphere->complex conversion); variants with the
+// quotient hoisted off the serial chain, 1 or 3-4 waves per SIMD, or without the per-diagonal scheduling fence all
+// landed within +-10 %, i.e. the kernel is bound by its FP64 instruction count, not by latency.
+template <int M, int CH, int W, bool FDIRECT>
+__global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
   constexpr int S = 2 * M + 1;
-  constexpr int SP = S | 1;
+  constexpr int CP = CH | 1;
   constexpr int ROWS = 64;
-  __shared__ double fr[ROWS * SP];
-  __shared__ double fi[ROWS * SP];
+  __shared__ double fr[ROWS * CP];
+  __shared__ double fi[ROWS * CP];
+  const int lane = threadIdx.x;
   const int64_t rows_total = a.N * a.d;
   const int64_t nblk = (rows_total + ROWS - 1) / ROWS;
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int64_t row0 = blk * ROWS;
-    const int64_t rows_here = (rows_total - row0 < ROWS) ? (rows_total - row0) : ROWS;
-    const int64_t elems = rows_here * S;
-    const int64_t base = row0 * S;
-    int r = threadIdx.x / S, k = threadIdx.x - r * S;
-    constexpr int dr = ROWS / S, dk = ROWS - dr * S;
-    for (int64_t e = threadIdx.x; e < elems; e += ROWS) {
-      if (a.fre != nullptr) {  // F_k supplied directly (staged planner / model path)
-        fr[r * SP + k] = a.fre[base + e];
-        fi[r * SP + k] = a.fim[base + e];
-      } else {
-        const double theta = a.theta[base + e];
-        const double phi = a.phi[base + e];
-        const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
-        double sn, cs;
-        m::sincos_bounded(theta, &sn, &cs);
-        fr[r * SP + k] = rad * cs;
-        fi[r * SP + k] = rad * sn;
-      }
-      r += dr;
-      k += dk;
-      if (k >= S) {
-        k -= S;
-        r += 1;
-      }
-    }
-    __syncthreads();
-    if ((int64_t)threadIdx.x < rows_here) {
-      const double* pr = fr + threadIdx.x * SP;
-      const double* pi = fi + threadIdx.x * SP;
-      cplx q[2 * M], e[2 * M + 1];
-      const cplx f0 = {pr[0], pi[0]};
-      const cplx d0 = {0.5 * f0.re, 0.5 * f0.im};
-      {
-        cplx prev = f0;
+    const int rows_here = (int)((rows_total - row0 < ROWS) ? (rows_total - row0) : ROWS);
+    const bool valid = lane < rows_here;
+    const int64_t row = row0 + (valid ? lane : 0);
+    const double t = (a.t_stride ? a.t[row / a.d] : a.t[0]) / a.t_div;
+    const double Tt = a.scale * t;
+    const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
+    const double ang = kPi * (t / Tt);
+    const cplx z = {cos(ang), sin(ang)};
+
+    cplx D[2 * M];
+    cplx a_prev = {0.0, 0.0}, d0 = {0.0, 0.0};
+    // A/B continued-fraction recurrence, fed with d_1, d_2, ... as the diagonals produce them
+    cplx A_prev = {0.0, 0.0}, A_cur = {0.0, 0.0}, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
+    cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < 2 * M; ++i) {
-          const cplx cur = {pr[i + 1], pi[i + 1]};
-          q[i] = cdiv(cur, i == 0 ? d0 : prev);
-          prev = cur;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i <= 2 * M; ++i) e[i] = {0.0, 0.0};
-      const int64_t row = row0 + threadIdx.x;
-      const double t = (a.t_stride ? a.t[row / a.d] : a.t[0]) / a.t_div;
-      const double Tt = a.scale * t;
-      const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
-      const double ang = kPi * (t / Tt);
-      const cplx z = {cos(ang), sin(ang)};
-      // A/B continued-fraction recurrence, fed with d_1, d_2, ... as they appear
-      cplx A_prev = {0.0, 0.0}, A_cur = d0, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
-      cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
-      auto feed = [&](cplx d, bool advance) {
-        d_last = d_cur;
-        d_cur = d;
-        if (advance) {
-          const cplx dz = cmul(d, z);
-          const cplx An = cadd(A_cur, cmul(dz, A_prev));
-          const cplx Bn = cadd(B_cur, cmul(dz, B_prev));
-          A_prev = A_cur;
-          A_cur = An;
-          B_prev = B_cur;
-          B_cur = Bn;
-        }
-      };
-      // d_1 = -q[0,0]
-      feed({-q[0].re, -q[0].im}, true);
-#pragma unroll
-      for (int rr = 1; rr <= M; ++rr) {
-        const int mr = 2 * (M - rr) + 1;
-        // e column rr from q column rr-1 and e column rr-1 (in place, ascending i)
-#pragma unroll
-        for (int i = 0; i < 2 * M; ++i) {
-          if (i < mr) e[i] = cadd(csub(q[i + 1 < 2 * M ? i + 1 : i], q[i]), e[i + 1]);
-        }
-        // d_{2 rr} = -e[0, rr]   (the last one, d_{2M}, only enters the remainder)
-        feed({-e[0].re, -e[0].im}, rr != M);
-        if (rr != M) {
-          const int mrq = 2 * (M - rr - 1) + 1 + 2;
-#pragma unroll
-          for (int i = 0; i < 2 * M - 1; ++i) {
-            if (i < mrq) q[i] = cdiv(cmul(q[i + 1], e[i + 1]), e[i]);
+    for (int n = 0; n <= 2 * M; ++n) {
+      if (n % CH == 0) {
+        // stage terms [n, n + nt) of the block's rows: coalesced over (row, term) pairs
+        const int nt = (S - n < CH) ? (S - n) : CH;
+        if (n != 0) __syncthreads();
+#pragma nounroll
+        for (int e = lane; e < ROWS * nt; e += ROWS) {
+          const int r = e / nt, k = e - r * nt;
+          if (r < rows_here) {
+            const int64_t gi = (row0 + r) * S + n + k;
+            if constexpr (FDIRECT) {  // F_k supplied directly (staged planner / model path)
+              fr[r * CP + k] = a.fre[gi];
+              fi[r * CP + k] = a.fim[gi];
+            } else {
+              const double theta = a.theta[gi];
+              const double phi = a.phi[gi];
+              const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
+              double sn, cs;
+              m::sincos_bounded(theta, &sn, &cs);
+              fr[r * CP + k] = rad * cs;
+              fi[r * CP + k] = rad * sn;
+            }
           }
-          // d_{2 rr + 1} = -q[0, rr]
-          feed({-q[0].re, -q[0].im}, true);
         }
+        __syncthreads();
       }
-      // here d_last = d_{2M-1}, d_cur = d_{2M}; recurrence has run for i = 1 .. 2M-1
-      const cplx diff = csub(d_last, d_cur);
-      const cplx one = {1.0, 0.0};
-      cplx brem = cadd(one, cmul(diff, z));
-      brem = {0.5 * brem.re, 0.5 * brem.im};
-      const cplx inner = cadd(one, cdiv(cmul(d_cur, z), brem));
-      const cplx rem = cmul(brem, csub(csqrt_(inner), one));
-      const cplx An = cadd(A_cur, cmul(rem, A_prev));
-      const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
-      const cplx res = cdiv(An, Bn);
-      a.x[row] = exp(gamma * t) / Tt * res.re;
+      const cplx an = {fr[lane * CP + n % CH], fi[lane * CP + n % CH]};
+      if (n == 0) {
+        d0 = {0.5 * an.re, 0.5 * an.im};  // a_0 enters halved
+        a_prev = d0;
+        A_cur = d0;
+        continue;
+      }
+      cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
+      a_prev = an;
+      cplx old1 = D[0];              // previous diagonal, column c-1
+      cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
+      D[0] = newv;
+#pragma unroll
+      for (int c = 2; c <= n; ++c) {
+        const cplx oldc = D[c - 1];
+        const cplx val = (c & 1) ? cdiv(cmul(old2, newv), old1) : cadd(csub(newv, old1), old2);
+        D[c - 1] = val;
+        old2 = old1;
+        old1 = oldc;
+        newv = val;
+      }
+      // d_n = -(entry at i = 0); d_2M only enters the remainder
+      d_last = d_cur;
+      d_cur = {-newv.re, -newv.im};
+      if (n != 2 * M) {
+        const cplx dz = cmul(d_cur, z);
+        const cplx An = cadd(A_cur, cmul(dz, A_prev));
+        const cplx Bn = cadd(B_cur, cmul(dz, B_prev));
+        A_prev = A_cur;
+        A_cur = An;
+        B_prev = B_cur;
+        B_cur = Bn;
+      }
+      // keep the diagonals apart: hoisting the next terms' LDS reads / interleaving diagonals only costs registers
+      // (the asm ties this diagonal's last value to a memory barrier, so the arithmetic cannot sink below the
+      // following reads either)
+      asm volatile("" : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
+    const cplx diff = csub(d_last, d_cur);
+    const cplx one = {1.0, 0.0};
+    cplx brem = cadd(one, cmul(diff, z));
+    brem = {0.5 * brem.re, 0.5 * brem.im};
+    const cplx inner = cadd(one, cdiv(cmul(d_cur, z), brem));
+    const cplx rem = cmul(brem, csub(csqrt_(inner), one));
+    const cplx An = cadd(A_cur, cmul(rem, A_prev));
+    const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
+    const cplx res = cdiv(An, Bn);
+    if (valid) a.x[row] = exp(gamma * t) / Tt * res.re;
     __syncthreads();
   }
 }
@@ -351,20 +360,28 @@ hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s) {
   const int64_t rows_total = a.N * a.d;
   if (rows_total <= 0) return hipSuccess;
   const int64_t nblk = (rows_total + 63) / 64;
-  const unsigned grid = (unsigned)(nblk < 8192 ? nblk : 8192);
+  const unsigned grid = (unsigned)(nblk < 16384 ? nblk : 16384);
+#define NLC_DH(...)                                                                                   \
+  do {                                                                                                \
+    if (a.fre != nullptr)                                                                             \
+      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, true>), dim3(grid), dim3(64), 0, s, a);      \
+    else                                                                                              \
+      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, false>), dim3(grid), dim3(64), 0, s, a);     \
+  } while (0)
   switch (a.S) {
     case 33:
-      hipLaunchKernelGGL(ilt_dehoog_kernel<16>, dim3(grid), dim3(64), 0, s, a);
+      NLC_DH(16, 11, 2);
       break;
     case 17:
-      hipLaunchKernelGGL(ilt_dehoog_kernel<8>, dim3(grid), dim3(64), 0, s, a);
+      NLC_DH(8, 17, 2);
       break;
     case 9:
-      hipLaunchKernelGGL(ilt_dehoog_kernel<4>, dim3(grid), dim3(64), 0, s, a);
+      NLC_DH(4, 9, 3);
       break;
     default:
       return hipErrorInvalidValue;
   }
+#undef NLC_DH
   return hipGetLastError();
 }
 

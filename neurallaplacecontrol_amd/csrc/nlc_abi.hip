@@ -319,6 +319,7 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
   if (!theta || !phi || !t || !x) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
   IltArgs a{theta, phi, t, x, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr, 1.0, 1, 0, 0, 0};
+  if (const char* ev = std::getenv("NLC_ILT_DBG")) a.dbg = std::atoi(ev);  // timing experiments only (IltArgs.dbg)
   if (d->algo == NLC_ILT_FOURIER) {
     ProfScope ps(c, "ilt_fourier_kernel");
     NLC_HIP(c, launch_ilt_fourier(a, c->stream));
