@@ -13,7 +13,8 @@ SAME K=16384 population is sharded over the ranks (strong scaling, as the metric
 command() does one RCCL all-gather of 2+T*nu doubles.
 
 Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel: the FP64-MFMA
-GRU encoder), ``roofline_ilt`` (stand-alone Fourier ILT kernel, HBM-bound) and ``cpu_baseline`` (the CPU
+GRU encoder), ``roofline_ilt`` (stand-alone Fourier ILT kernel, HBM-bound; ``dehoog33`` inside it is the de Hoog
+kernel of the ILT ablation) and ``cpu_baseline`` (the CPU
 oracle = reference op sequence, timed on this host's cores; rank 0, N=1 only).
 """
 
@@ -211,6 +212,27 @@ def main():
                    frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                    algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
                    avg_launch_ms=ms, points=N, bytes_per_point=(2 * d * S_TERMS + d) * 8)
+        del theta, phi
+        # the ablation's second kernel (BASELINE configs[4]): de Hoog with 33 terms at the same N.  FP64-VALU bound
+        # (about 150 VALU instructions per 8-byte term), so its HBM fraction is a utilisation figure, not a target.
+        S2 = 33
+        theta = (torch.rand(N, d, S2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
+        phi = (torch.rand(N, d, S2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.9
+        for _ in range(2):
+            nlc.ilt_reconstruct(theta, phi, tt, "dehoog")
+        ictx.profile_reset()
+        ictx.profile(True)
+        for _ in range(10):
+            nlc.ilt_reconstruct(theta, phi, tt, "dehoog")
+        torch.cuda.synchronize()
+        ictx.profile(False)
+        p = ictx.profile_read()["ilt_dehoog_kernel"]
+        ms2 = p["total_ms"] / p["launches"]
+        nb2 = N * (2 * d * S2 + d) * 8
+        ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
+                               algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
+                               frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               valu_busy="0.66 (profiles/r1g_pmc_dehoog.json)")
         del theta, phi
 
     if rank != 0:
