@@ -1020,3 +1020,89 @@ def test_nl_model_with_time_channel_vs_reference_golden(nlc, env):
 
         check_command_steps(nlc, g, make)
         check_command_steps(nlc, g, lambda U0: make(U0, fused=False))
+
+
+# --------------------------------------------------------------------------- small / odd shapes
+@pytest.mark.parametrize("env,K,T,B", [("oderl-cartpole", 5, 1, 1), ("oderl-acrobot", 17, 3, 2), ("oderl-pendulum", 1, 4, 6)])
+def test_tiny_and_ragged_planner_shapes_vs_oracle(nlc, env, K, T, B):
+    """K below one MFMA tile, horizon 1, a one-row action buffer (no history) and a long one (B = 6 > default)."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(12, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    g = torch.Generator().manual_seed(K * 100 + T)
+    raw = torch.randn(K, T, nu, dtype=torch.float64, generator=g)
+    U0 = torch.randn(T, nu, dtype=torch.float64, generator=g) * 0.2
+    ab = torch.randn(B, nu, dtype=torch.float64, generator=g)
+    state = _state(nlc, env, 3)
+    sig = nlc.noise_sigma(nu)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    for name, dyn_gpu, dyn_ref in (
+        ("nl", nlc.NLDynamics(model, 0.05), onl.nl_dynamics(sd, ts, S=17)),
+        ("oracle", nlc.OracleDynamics(env, 0.05, B - 1), lambda s, w: oenvs.ORACLE_DYNAMICS[env](s, w, ts, B - 1)),
+    ):
+        p = nlc.MPPIDelay(dyn_gpu, nlc.EnvCost(env), d, sig, K, T, "cpu", lambda_=1.3, u_min=torch.tensor(-A),
+                          u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+        p.noise_dist = _Replay(raw.clone())
+        with torch.no_grad():
+            # the reference accepts anything torch.tensor() takes for the state (mppi_delay.py:196-197); a float64
+            # ndarray keeps its precision (a python list would become float32 there, and here)
+            act = p.command(state.numpy().astype(np.float64), ab)
+        ref = omppi.mppi_command(U0.clone(), state, ab, raw.clone(), dyn_ref, oenvs.RUNNING_COST[env], d, torch.inverse(sig),
+                                 1.3, A, torch.tensor(-A), torch.tensor(A))
+        np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), err_msg=name, **TOL)
+        np.testing.assert_allclose(p.states.numpy(), ref["states"].numpy(), err_msg=name, **TOL)
+        np.testing.assert_allclose(p.omega.numpy(), ref["omega"].numpy(), err_msg=name, **TOL)
+        assert p.U.shape == (T, nu) and p.actions.shape == (K, T, nu)
+
+
+def test_batched_planner_acrobot_nl_u_per_command(nlc):
+    """nu = 2 NL dynamics, two actions per command, K ragged against the 16-sample tiles."""
+    from oracle import nl_model as onl
+
+    env, d, nu, A = "oderl-acrobot", 6, 2, 5.0
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(14, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    E, K, T = 3, 50, 5
+    g = torch.Generator().manual_seed(77)
+    U0 = torch.randn(E, T, nu, dtype=torch.float64, generator=g) * 0.3
+    raw = torch.randn(E, K, T, nu, dtype=torch.float64, generator=g)
+    states = torch.stack([_state(nlc, env, e) for e in range(E)])
+    ab = torch.randn(E, 4, nu, dtype=torch.float64, generator=g)
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, u_per_command=2)
+    bat = BatchedMPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), E, K, T, "cpu",
+                           U_init=U0.clone(), **kw)
+    bat.noise_dist = _Replay(raw.clone())
+    with torch.no_grad():
+        act = bat.command(states, ab)
+        assert act.shape == (E, 2, nu)
+        for e in range(E):
+            m = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                              U_init=U0[e].clone(), **kw)
+            m.noise_dist = _Replay(raw[e].clone())
+            assert torch.equal(m.command(states[e], ab[e]), act[e])
+            assert torch.equal(m.U, bat.U[e])
+
+
+def test_ilt_single_point_wide(nlc):
+    from oracle import ilt as oilt
+
+    torch.manual_seed(5)
+    for algo, S in (("fourier", 33), ("dehoog", 33), ("dehoog", 9)):
+        theta = (torch.rand(1, 6, S, dtype=torch.float64) * 2 - 1) * np.pi * 0.3
+        phi = (torch.rand(1, 6, S, dtype=torch.float64) * 2 - 1) * 0.4
+        t = torch.tensor([0.7], dtype=torch.float64)
+        ref = oilt.ilt_from_sphere(theta, phi, t, algo)
+        got = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), algo).cpu()
+        if algo == "fourier":
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-9, atol=1e-9 * float(ref.abs().max()))
+        else:
+            # random (non-smooth) F makes the QD table ill-conditioned: both sides are finite and agree loosely
+            assert torch.isfinite(got).all() == torch.isfinite(ref).all()
