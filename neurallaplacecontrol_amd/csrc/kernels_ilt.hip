@@ -213,7 +213,7 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
-// a / b = a conj(b) / |b|^2 with ONE refined reciprocal (v_rcp_f64 + two Newton steps, < 1 ulp) instead of two IEEE
+// a / b = a conj(b) / |b|^2 with ONE refined reciprocal (v_rcp_f64 + one cubic refinement step, <= 1 ulp) instead of two IEEE
 // divisions (v_div_scale / v_div_fmas / v_div_fixup sequences with their VCC hazards): the QD table needs ~M^2 of
 // these per row, and they were 55 % of the kernel's issue slots.
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {

@@ -23,10 +23,11 @@ namespace m {
 
 NLC_HD double rcp_refined(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(d);  // v_rcp_f64
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
-  return r;
+  // v_rcp_f64 is good to ~2^-24; one cubically convergent step r (1 + e + e^2), e = 1 - d r, leaves e^3 ~ 2^-72:
+  // three FMAs instead of the four of two Newton steps
+  const double r = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r, 1.0);
+  return fma(r, fma(e, e, e), r);
 #else
   return 1.0 / d;
 #endif
