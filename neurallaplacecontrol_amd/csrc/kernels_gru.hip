@@ -59,10 +59,10 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2d fma2(v2d a, v2d b, v2d c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2d splat2(double x) { return v2d{x, x}; }
 __device__ __forceinline__ v2d rcp_refined2(v2d d) {
-  v2d r = {__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
-  r = fma2(fma2(-d, r, splat2(1.0)), r, r);
-  r = fma2(fma2(-d, r, splat2(1.0)), r, r);
-  return r;
+  // v_rcp_f64 (~2^-24) + one cubic step r (1 + e + e^2), e = 1 - d r: 3 FMAs, <= 1 ulp (tools/rcp_probe.hip)
+  const v2d r = {__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
+  const v2d e = fma2(-d, r, splat2(1.0));
+  return fma2(r, fma2(e, e, e), r);
 }
 __device__ __forceinline__ v2d expm1_poly2(v2d r) {
   v2d q = splat2(0x1.af38a9b0ec855p-26);
@@ -78,20 +78,31 @@ __device__ __forceinline__ v2d expm1_poly2(v2d r) {
   return fma2(q * r, r, r);
 }
 __device__ __forceinline__ v2d exp_reduce2(v2d y, v2i* n) {
-  const v2d fn = __builtin_elementwise_rint(y * 1.44269504088896338700e+00);
+  // round-to-nearest by the 1.5 * 2^52 shift; the integer is the low word of the shifted sum (no v_rndne / v_cvt)
+  const v2d sh = fma2(y, splat2(1.44269504088896338700e+00), splat2(6755399441055744.0));
+  const v2d fn = sh - splat2(6755399441055744.0);
   v2d r = fma2(-fn, splat2(6.93147180369123816490e-01), y);
   r = fma2(-fn, splat2(1.90821492927058770002e-10), r);
-  *n = __builtin_convertvector(fn, v2i);
+  *n = v2i{__double2loint(sh.x), __double2loint(sh.y)};
   return r;
 }
-// sigmoid(x) = 1/(1 + e^{-x}) for either sign: e^{-x} >= 0 so nothing cancels; e^{-x} -> inf gives 0
-__device__ __forceinline__ v2d sigmoid2(v2d x) {
-  const v2d y = __builtin_elementwise_min(__builtin_elementwise_max(-x, splat2(-745.0)), splat2(709.0));
+// 1 + e^{-x} for either sign (e^{-x} >= 0, nothing cancels).  The argument is clamped to +-350 so that the product
+// of two such terms stays finite (below -350 the true sigmoid is < 1e-152 and this returns ~1e-152).
+__device__ __forceinline__ v2d one_plus_exp_neg2(v2d x) {
+  const v2d y = __builtin_elementwise_min(__builtin_elementwise_max(-x, splat2(-350.0)), splat2(350.0));
   v2i n;
   const v2d r = exp_reduce2(y, &n);
   const v2d p = splat2(1.0) + expm1_poly2(r);
   const v2d e = {ldexp(p.x, n.x), ldexp(p.y, n.y)};
-  return rcp_refined2(splat2(1.0) + e);
+  return splat2(1.0) + e;
+}
+// the reset and update gates share ONE reciprocal: sigmoid(a) = B / (A B), sigmoid(b) = A / (A B) with
+// A = 1 + e^{-a}, B = 1 + e^{-b}  (three multiplies instead of a second v_rcp_f64 + refinement)
+__device__ __forceinline__ void sigmoid_pair2(v2d a, v2d b, v2d* sa, v2d* sb) {
+  const v2d A = one_plus_exp_neg2(a), B = one_plus_exp_neg2(b);
+  const v2d R = rcp_refined2(A * B);
+  *sa = B * R;
+  *sb = A * R;
 }
 __device__ __forceinline__ v2d tanh2(v2d x) {
   const v2d y = __builtin_elementwise_max(-2.0 * __builtin_elementwise_abs(x), splat2(-745.0));
@@ -117,10 +128,10 @@ __device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d
   for (int half = 0; half < 2; ++half) {
     const v2d r2 = half ? ar.zw : ar.xy, z2 = half ? az.zw : az.xy, in2 = half ? ain.zw : ain.xy;
     const v2d hn2 = half ? ahn.zw : ahn.xy, ho2 = half ? hold.zw : hold.xy;
-    const v2d rg = sigmoid2(r2);
-    const v2d zg = sigmoid2(z2);
+    v2d rg, zg;
+    sigmoid_pair2(r2, z2, &rg, &zg);
     const v2d ng = tanh2(fma2(rg, hn2, in2));
-    const v2d hv = (splat2(1.0) - zg) * ng + zg * ho2;
+    const v2d hv = fma2(zg, ho2 - ng, ng);  // (h - n) z + n, the form aten's gru_cell evaluates (= (1-z) n + z h)
     if (half) {
       hnew.zw = hv;
     } else {

@@ -66,10 +66,16 @@ NLC_HD double exp_reduce(double y, int* n) {
   const double kLog2e = 1.44269504088896338700e+00;
   const double kLn2Hi = 6.93147180369123816490e-01;
   const double kLn2Lo = 1.90821492927058770002e-10;
-  const double fn = rint(y * kLog2e);
+  // round-to-nearest by the 1.5 * 2^52 shift: the integer lands in the low word of the shifted sum, so no
+  // v_rndne / v_cvt_i32 is needed (|y log2(e)| < 2^31 for every clamped argument)
+  const double kShift = 6755399441055744.0;
+  const double sh = fma(y, kLog2e, kShift);
+  const double fn = sh - kShift;
   double r = fma(-fn, kLn2Hi, y);
   r = fma(-fn, kLn2Lo, r);
-  *n = (int)fn;
+  int64_t bits;
+  __builtin_memcpy(&bits, &sh, sizeof(bits));
+  *n = (int)(uint32_t)(bits & 0xffffffffLL);
   return r;
 }
 
