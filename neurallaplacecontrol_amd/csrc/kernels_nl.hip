@@ -112,7 +112,12 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 #pragma unroll
   for (int j = 0; j < HT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h1[j][r] = m::tanh_d(h1[j][r]);
+    for (int r = 0; r < 4; r += 2) {
+      double ta, tb;
+      m::tanh_pair_d(h1[j][r], h1[j][r + 1], &ta, &tb);
+      h1[j][r] = ta;
+      h1[j][r + 1] = tb;
+    }
 
   v4d h2[HT];
 #pragma unroll
@@ -121,7 +126,12 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 #pragma unroll
   for (int j = 0; j < HT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h2[j][r] = m::tanh_d(h2[j][r]);
+    for (int r = 0; r < 4; r += 2) {
+      double ta, tb;
+      m::tanh_pair_d(h2[j][r], h2[j][r + 1], &ta, &tb);
+      h2[j][r] = ta;
+      h2[j][r + 1] = tb;
+    }
 
   v4d o[NT3];
 #pragma unroll
@@ -137,6 +147,7 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int g = 2 * j + r;
+      // (not paired: a saturated phi must be EXACTLY pi/2 to reproduce the reference's clamped |F|)
       const double theta = m::tanh_d(o[j][r]) * kPi;                               // w_nl.py:59
       const double phi = m::tanh_d(o[j][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
       // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
@@ -314,7 +325,12 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
 #pragma unroll
       for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) H1[(4 * (TW * wv + i) + r) * 64 + lane] = m::tanh_d(acc[i][r]);
+        for (int r = 0; r < 4; r += 2) {
+          double ta, tb;
+          m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+          H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+          H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+        }
     }
     __syncthreads();
     // ---- layer 2
@@ -344,7 +360,12 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
 #pragma unroll
       for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) H2[(4 * (TW * wv + i) + r) * 64 + lane] = m::tanh_d(acc[i][r]);
+        for (int r = 0; r < 4; r += 2) {
+          double ta, tb;
+          m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+          H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+          H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+        }
     }
     __syncthreads();
     // ---- layer 3 (own tiles) + sphere->complex + partial ILT sum

@@ -122,6 +122,18 @@ NLC_HD double tanh_d(double x) {
   return copysign(t, x);
 }
 
+// Two tanh values sharing ONE reciprocal: -em_a (2 + em_b) R and -em_b (2 + em_a) R with R = 1 / ((2+em_a)(2+em_b));
+// both denominators are in [1, 2], so the product cannot overflow.  Three multiplies replace the second
+// v_rcp_f64 + refinement.  A saturated input gives 1 within an ulp, not exactly 1 as tanh_d does, so this is for the
+// hidden-layer activations only (the sphere map needs the exact saturation).
+NLC_HD void tanh_pair_d(double xa, double xb, double* ta, double* tb) {
+  const double ea = expm1_neg(-2.0 * fabs(xa)), eb = expm1_neg(-2.0 * fabs(xb));
+  const double da = 2.0 + ea, db = 2.0 + eb;
+  const double R = rcp_refined(da * db);
+  *ta = copysign((-ea * db) * R, xa);
+  *tb = copysign((-eb * da) * R, xb);
+}
+
 // ---- table-driven variants: e^y = 2^n * T[j] * e^r with T[j] = 2^(j/64) (64-entry table, LDS on the device),
 // |r| <= ln2/128, so a degree-5 polynomial replaces the degree-13 one: ~6 fewer FP64 instructions per call.
 // MEASURED AND NOT USED by the kernels (MI355X, cfg2): GRU 3.43 -> 3.38 ms but rollout 1.41 -> 1.49 ms -- the
