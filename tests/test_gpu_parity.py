@@ -1023,7 +1023,8 @@ def test_nl_model_with_time_channel_vs_reference_golden(nlc, env):
 
 
 # --------------------------------------------------------------------------- small / odd shapes
-@pytest.mark.parametrize("env,K,T,B", [("oderl-cartpole", 5, 1, 1), ("oderl-acrobot", 17, 3, 2), ("oderl-pendulum", 1, 4, 6)])
+@pytest.mark.parametrize("env,K,T,B", [("oderl-cartpole", 5, 1, 1), ("oderl-acrobot", 17, 3, 2), ("oderl-pendulum", 1, 4, 6),
+                                       ("oderl-acrobot", 33, 2, 20)])  # B*nu = 40: beyond the kernel-argument staging
 def test_tiny_and_ragged_planner_shapes_vs_oracle(nlc, env, K, T, B):
     """K below one MFMA tile, horizon 1, a one-row action buffer (no history) and a long one (B = 6 > default)."""
     from oracle import envs as oenvs
