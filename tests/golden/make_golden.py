@@ -19,6 +19,10 @@ Fixtures:
                               rolling time-stamp column in action_buffer (mppi_delay.py:261-287) + reference
                               oracle dynamics; records action_buffer before/after (the reference adds dt to the
                               caller's time column in place)
+  g6_full_cfg2.npz            BASELINE configs[1] at FULL size: reference MPPIDelay + reference NeuralLaplaceModel,
+                              K=16384, T=40, cartpole, two consecutive commands from torch.manual_seed(6) (the noise is
+                              NOT stored: the test replays the seed, so the generator consumption order is pinned too);
+                              stored: U, action, cost_total, omega, a strided subset of the states
   g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
                               constant time channel B-1..0 (mppi_with_model.py:110-119) + reference MPPIDelay
 """
@@ -388,6 +392,48 @@ def make_g5(MPPIDelay, w_nl, envs, dyn):
         print("g5 nl", env_name, "action", out["s1_action"])
 
 
+def make_g6(MPPIDelay, w_nl, envs):
+    env_name, K, T, B = "oderl-cartpole", 16384, 40, 4
+    st = onl.ENV_STATS[env_name]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    model = build_ref_model(w_nl, env_name, seed=0)
+    env = envs[env_name]()
+    ts_pred = torch.full((K, 1), 0.05, dtype=torch.double)
+    with torch.no_grad():
+        model.laplace_rep_func.linear_tanh_stack[4].bias[d * 17 :] += onl.PHI_BIAS_SHIFT
+
+        def dynamics(state, perturbed_action):
+            return state + model(state, perturbed_action, ts_pred)
+
+        def running_cost(state, action):
+            return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+        torch.manual_seed(6)
+        mppi = MPPIDelay(
+            dynamics, running_cost, d, noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+            u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+        )
+        state = oenvs.initial_state(env_name, seed=0)
+        action_buffer = torch.zeros(B, nu, dtype=torch.double)
+        out = dict(U0=np_(mppi.U))
+        sub = np.arange(0, K, 128)
+        for step in range(2):
+            action = mppi.command(state.numpy(), action_buffer)
+            out[f"s{step}_state"] = np_(state)
+            out[f"s{step}_action_buffer"] = np_(action_buffer)
+            out[f"s{step}_action"] = np_(action)
+            out[f"s{step}_U_after"] = np_(mppi.U)
+            out[f"s{step}_cost_total"] = np_(mppi.cost_total)
+            out[f"s{step}_omega"] = np_(mppi.omega)
+            out[f"s{step}_states_sub"] = np_(mppi.states)[sub]
+            out[f"s{step}_noise_sub"] = np_(mppi.noise)[sub]
+            state = mppi.states[0, 0].clone()
+            action_buffer = torch.roll(action_buffer, -1, dims=0)
+            action_buffer[-1] = action
+            print("g6 step", step, "action", out[f"s{step}_action"])
+    np.savez_compressed(f"{HERE}/g6_full_cfg2.npz", K=K, T=T, B=B, d=d, nu=nu, A=A, seed=6, sub=sub, **out)
+
+
 def make_g4():
     """ILT known answers: analytic pairs + mpmath de Hoog (degree 16 -> 33 terms)."""
     import mpmath as mp
@@ -426,6 +472,7 @@ def main():
     make_g2_g3(MPPIDelay, w_nl, envs)
     make_g4()
     make_g5(MPPIDelay, w_nl, envs, dyn)
+    make_g6(MPPIDelay, w_nl, envs)
 
 
 if __name__ == "__main__":

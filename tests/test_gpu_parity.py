@@ -1107,3 +1107,32 @@ def test_ilt_single_point_wide(nlc):
         else:
             # random (non-smooth) F makes the QD table ill-conditioned: both sides are finite and agree loosely
             assert torch.isfinite(got).all() == torch.isfinite(ref).all()
+
+
+def test_full_size_cfg2_vs_reference_golden_seed_replay(nlc):
+    """G6: BASELINE configs[1] at full size (K=16384, T=40) against the REAL reference MPPIDelay + NeuralLaplaceModel,
+    two consecutive commands.  device="cpu" + torch.manual_seed replays the reference's generator stream (ctor U
+    draw, one (K, T) draw per command), so the fixture needs no noise tensor."""
+    from oracle import nl_model as onl
+
+    g = np.load(f"{GOLD}/g6_full_cfg2.npz")
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    st = onl.ENV_STATS["oderl-cartpole"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    torch.manual_seed(int(g["seed"]))
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K, T, "cpu",
+                         lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+    assert mppi.fused
+    np.testing.assert_array_equal(mppi.U.numpy(), g["U0"])
+    sub = g["sub"]
+    with torch.no_grad():
+        for step in range(2):
+            pre = f"s{step}_"
+            act = mppi.command(g[pre + "state"], T64(g[pre + "action_buffer"]))
+            np.testing.assert_allclose(act.numpy(), g[pre + "action"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(mppi.U.numpy(), g[pre + "U_after"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(mppi.cost_total.numpy(), g[pre + "cost_total"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(mppi.omega.numpy(), g[pre + "omega"], rtol=1e-7, atol=1e-30)
+            np.testing.assert_allclose(mppi.states.numpy()[sub], g[pre + "states_sub"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(mppi.noise.numpy()[sub], g[pre + "noise_sub"], rtol=0, atol=1e-11)

@@ -205,3 +205,33 @@ def test_g5_nl_model_with_time_channel(env, golden_dir):
     np.testing.assert_allclose(out.numpy(), g["fwd_out"], **TOL)
     ts = torch.full((K, 1), 0.05, dtype=torch.float64)
     run_steps(g, onl.nl_dynamics(sd, ts, S=S, time_channel=True), oenvs.RUNNING_COST["oderl-" + env], d, nu, A)
+
+
+# --------------------------------------------------------------------------- G6: the reference at BASELINE's full size
+def test_g6_full_size_cfg2_seed_replay(golden_dir):
+    """K=16384, T=40 cartpole NL planner, two consecutive commands of the REAL reference (MPPIDelay +
+    NeuralLaplaceModel; only the ILT body is the restatement).  The fixture stores no noise: replaying
+    torch.manual_seed pins the generator consumption order (ctor U draw, then one (K, T) draw per command) as well."""
+    g = np.load(f"{golden_dir}/g6_full_cfg2.npz")
+    K, T_, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    st = onl.ENV_STATS["oderl-cartpole"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    sig = torch.ones((nu, nu), dtype=torch.double) * 0.5 + torch.eye(nu, dtype=torch.double) * 0.5
+    torch.manual_seed(int(g["seed"]))
+    m = omppi.MPPIOracle(onl.nl_dynamics(sd, ts, S=17), oenvs.RUNNING_COST["oderl-cartpole"], d, sig, K, T_, 1.0,
+                         torch.tensor(-A), torch.tensor(A), A)
+    np.testing.assert_array_equal(m.U.numpy(), g["U0"])
+    sub = g["sub"]
+    for step in range(2):
+        pre = f"s{step}_"
+        act = m.command(T(g[pre + "state"]), T(g[pre + "action_buffer"]))
+        np.testing.assert_allclose(act.numpy(), g[pre + "action"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(m.U.numpy(), g[pre + "U_after"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(m.last["cost_total"].numpy(), g[pre + "cost_total"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(m.last["omega"].numpy(), g[pre + "omega"], rtol=1e-7, atol=1e-30)
+        np.testing.assert_allclose(m.last["states"].numpy()[sub], g[pre + "states_sub"], rtol=1e-9, atol=1e-9)
+        if step == 0:  # same generator stream, same U: the bounded noise is bit-identical
+            np.testing.assert_array_equal(m.last["noise"].numpy()[sub], g[pre + "noise_sub"])
+        else:          # U carries the first command's summation-order rounding (1e-13)
+            np.testing.assert_allclose(m.last["noise"].numpy()[sub], g[pre + "noise_sub"], rtol=0, atol=1e-11)
