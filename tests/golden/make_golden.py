@@ -23,6 +23,9 @@ Fixtures:
                               K=16384, T=40, cartpole, two consecutive commands from torch.manual_seed(6) (the noise is
                               NOT stored: the test replays the seed, so the generator consumption order is pinned too);
                               stored: U, action, cost_total, omega, a strided subset of the states
+  g7_full_<cfg>.npz           BASELINE configs[2] (pendulum, K=65536, T=40, 5-row action buffer) and configs[3]
+                              (acrobot, K=262144, T=60) at FULL size, one reference command each, seed replay as in g6;
+                              stored: U, action, beta/eta, and strided subsets of cost_total / omega / states / noise
   g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
                               constant time channel B-1..0 (mppi_with_model.py:110-119) + reference MPPIDelay
 """
@@ -434,6 +437,43 @@ def make_g6(MPPIDelay, w_nl, envs):
     np.savez_compressed(f"{HERE}/g6_full_cfg2.npz", K=K, T=T, B=B, d=d, nu=nu, A=A, seed=6, sub=sub, **out)
 
 
+def make_g7(MPPIDelay, w_nl, envs):
+    for tag, env_name, K, T, B, seed in (("cfg3", "oderl-pendulum", 65536, 40, 5, 7), ("cfg4", "oderl-acrobot", 262144, 60, 4, 8)):
+        st = onl.ENV_STATS[env_name]
+        d, nu, A = st["d"], st["nu"], st["act_high"]
+        model = build_ref_model(w_nl, env_name, seed=0)
+        env = envs[env_name]()
+        ts_pred = torch.full((K, 1), 0.05, dtype=torch.double)
+        with torch.no_grad():
+            model.laplace_rep_func.linear_tanh_stack[4].bias[d * 17 :] += onl.PHI_BIAS_SHIFT
+
+            def dynamics(state, perturbed_action):
+                return state + model(state, perturbed_action, ts_pred)
+
+            def running_cost(state, action):
+                return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+            torch.manual_seed(seed)
+            mppi = MPPIDelay(
+                dynamics, running_cost, d, noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+            )
+            U0 = np_(mppi.U)
+            state = oenvs.initial_state(env_name, seed=1)
+            action_buffer = (torch.rand(B, nu, dtype=torch.double) - 0.5) * A
+            action = mppi.command(state.numpy(), action_buffer)
+            sub = np.arange(0, K, K // 128)
+            cost = mppi.cost_total
+            np.savez_compressed(
+                f"{HERE}/g7_full_{tag}.npz", K=K, T=T, B=B, d=d, nu=nu, A=A, seed=seed, sub=sub, U0=U0,
+                state=np_(state), action_buffer=np_(action_buffer), action=np_(action), U_after=np_(mppi.U),
+                beta=float(cost.min()), eta=float(mppi.cost_total_non_zero.sum()), cost_sum=float(cost.sum()),
+                cost_total_sub=np_(cost)[sub], omega_sub=np_(mppi.omega)[sub], states_sub=np_(mppi.states)[sub],
+                noise_sub=np_(mppi.noise)[sub],
+            )
+            print("g7", tag, "action", np_(action))
+
+
 def make_g4():
     """ILT known answers: analytic pairs + mpmath de Hoog (degree 16 -> 33 terms)."""
     import mpmath as mp
@@ -473,6 +513,7 @@ def main():
     make_g4()
     make_g5(MPPIDelay, w_nl, envs, dyn)
     make_g6(MPPIDelay, w_nl, envs)
+    make_g7(MPPIDelay, w_nl, envs)
 
 
 if __name__ == "__main__":

@@ -1136,3 +1136,39 @@ def test_full_size_cfg2_vs_reference_golden_seed_replay(nlc):
             np.testing.assert_allclose(mppi.omega.numpy(), g[pre + "omega"], rtol=1e-7, atol=1e-30)
             np.testing.assert_allclose(mppi.states.numpy()[sub], g[pre + "states_sub"], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(mppi.noise.numpy()[sub], g[pre + "noise_sub"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag,env", [("cfg3", "oderl-pendulum"), ("cfg4", "oderl-acrobot")])
+def test_full_size_cfg3_cfg4_vs_reference_golden_seed_replay(nlc, tag, env):
+    """G7: BASELINE configs[2] (pendulum, K=65536, T=40, 5-row buffer) and configs[3] (acrobot, K=262144, T=60) at
+    their FULL population on one GPU against the real reference (seed replay, see G6); cost/omega/states on a strided
+    subset plus the population aggregates beta = min cost, eta = sum of weights, sum of costs."""
+    from oracle import nl_model as onl
+
+    g = np.load(f"{GOLD}/g7_full_{tag}.npz")
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    torch.manual_seed(int(g["seed"]))
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                         lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+    np.testing.assert_array_equal(mppi.U.numpy(), g["U0"])
+    sub = g["sub"]
+    # the fixture's action buffer came from the same global generator, between the ctor and the command
+    B = int(g["B"])
+    ab = (torch.rand(B, nu, dtype=torch.float64) - 0.5) * A
+    np.testing.assert_array_equal(ab.numpy(), g["action_buffer"])
+    with torch.no_grad():
+        act = mppi.command(g["state"], ab)
+    np.testing.assert_allclose(act.numpy(), g["action"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(mppi.U.numpy(), g["U_after"], rtol=1e-8, atol=1e-10)
+    cost = mppi._cost_total  # device tensors: only the subset travels
+    np.testing.assert_allclose(float(cost.min()), float(g["beta"]), rtol=1e-10)
+    np.testing.assert_allclose(float(mppi._cost_nz.sum()), float(g["eta"]), rtol=1e-8)
+    np.testing.assert_allclose(float(cost.sum()), float(g["cost_sum"]), rtol=1e-9)
+    idx = torch.as_tensor(sub, device=cost.device)
+    np.testing.assert_allclose(cost[idx].cpu().numpy(), g["cost_total_sub"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(mppi._omega[idx].cpu().numpy(), g["omega_sub"], rtol=1e-7, atol=1e-30)
+    np.testing.assert_allclose(mppi._states[idx].cpu().numpy(), g["states_sub"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_array_equal(mppi._noise[idx].cpu().numpy(), g["noise_sub"])
