@@ -23,7 +23,7 @@ Fixtures:
                               K=16384, T=40, cartpole, two consecutive commands from torch.manual_seed(6) (the noise is
                               NOT stored: the test replays the seed, so the generator consumption order is pinned too);
                               stored: U, action, cost_total, omega, a strided subset of the states
-  g7_full_<cfg>.npz           BASELINE configs[2] (pendulum, K=65536, T=40, 5-row action buffer) and configs[3]
+  g7_full_<cfg>.npz           BASELINE configs[0] (cartpole, K=1024, T=20: the reference's own CPU-runnable case), configs[2] (pendulum, K=65536, T=40, 5-row action buffer) and configs[3]
                               (acrobot, K=262144, T=60) at FULL size, one reference command each, seed replay as in g6;
                               stored: U, action, beta/eta, and strided subsets of cost_total / omega / states / noise
   g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
@@ -437,8 +437,11 @@ def make_g6(MPPIDelay, w_nl, envs):
     np.savez_compressed(f"{HERE}/g6_full_cfg2.npz", K=K, T=T, B=B, d=d, nu=nu, A=A, seed=6, sub=sub, **out)
 
 
-def make_g7(MPPIDelay, w_nl, envs):
-    for tag, env_name, K, T, B, seed in (("cfg3", "oderl-pendulum", 65536, 40, 5, 7), ("cfg4", "oderl-acrobot", 262144, 60, 4, 8)):
+def make_g7(MPPIDelay, w_nl, envs, only=None):
+    for tag, env_name, K, T, B, seed in (("cfg1", "oderl-cartpole", 1024, 20, 4, 9), ("cfg3", "oderl-pendulum", 65536, 40, 5, 7),
+                                         ("cfg4", "oderl-acrobot", 262144, 60, 4, 8)):
+        if only is not None and tag not in only:
+            continue
         st = onl.ENV_STATS[env_name]
         d, nu, A = st["d"], st["nu"], st["act_high"]
         model = build_ref_model(w_nl, env_name, seed=0)
@@ -513,7 +516,7 @@ def main():
     make_g4()
     make_g5(MPPIDelay, w_nl, envs, dyn)
     make_g6(MPPIDelay, w_nl, envs)
-    make_g7(MPPIDelay, w_nl, envs)
+    make_g7(MPPIDelay, w_nl, envs, only=os.environ.get("NLC_G7_ONLY", "cfg1,cfg3,cfg4").split(","))
 
 
 if __name__ == "__main__":

@@ -1138,9 +1138,9 @@ def test_full_size_cfg2_vs_reference_golden_seed_replay(nlc):
             np.testing.assert_allclose(mppi.noise.numpy()[sub], g[pre + "noise_sub"], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("tag,env", [("cfg3", "oderl-pendulum"), ("cfg4", "oderl-acrobot")])
-def test_full_size_cfg3_cfg4_vs_reference_golden_seed_replay(nlc, tag, env):
-    """G7: BASELINE configs[2] (pendulum, K=65536, T=40, 5-row buffer) and configs[3] (acrobot, K=262144, T=60) at
+@pytest.mark.parametrize("tag,env", [("cfg1", "oderl-cartpole"), ("cfg3", "oderl-pendulum"), ("cfg4", "oderl-acrobot")])
+def test_full_size_cfg1_cfg3_cfg4_vs_reference_golden_seed_replay(nlc, tag, env):
+    """G7: BASELINE configs[0] (cartpole, K=1024, T=20), configs[2] (pendulum, K=65536, T=40, 5-row buffer) and configs[3] (acrobot, K=262144, T=60) at
     their FULL population on one GPU against the real reference (seed replay, see G6); cost/omega/states on a strided
     subset plus the population aggregates beta = min cost, eta = sum of weights, sum of costs."""
     from oracle import nl_model as onl

@@ -235,3 +235,27 @@ def test_g6_full_size_cfg2_seed_replay(golden_dir):
             np.testing.assert_array_equal(m.last["noise"].numpy()[sub], g[pre + "noise_sub"])
         else:          # U carries the first command's summation-order rounding (1e-13)
             np.testing.assert_allclose(m.last["noise"].numpy()[sub], g[pre + "noise_sub"], rtol=0, atol=1e-11)
+
+
+def test_g7_cfg1_seed_replay(golden_dir):
+    """BASELINE configs[0] (the reference's own CPU-runnable case: cartpole, K=1024, T=20) by seed replay."""
+    g = np.load(f"{golden_dir}/g7_full_cfg1.npz")
+    K, T_, d, nu, A, B = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"]), int(g["B"])
+    st = onl.ENV_STATS["oderl-cartpole"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    sig = torch.ones((nu, nu), dtype=torch.double) * 0.5 + torch.eye(nu, dtype=torch.double) * 0.5
+    torch.manual_seed(int(g["seed"]))
+    m = omppi.MPPIOracle(onl.nl_dynamics(sd, ts, S=17), oenvs.RUNNING_COST["oderl-cartpole"], d, sig, K, T_, 1.0,
+                         torch.tensor(-A), torch.tensor(A), A)
+    np.testing.assert_array_equal(m.U.numpy(), g["U0"])
+    ab = (torch.rand(B, nu, dtype=torch.float64) - 0.5) * A
+    np.testing.assert_array_equal(ab.numpy(), g["action_buffer"])
+    act = m.command(T(g["state"]), ab)
+    sub = g["sub"]
+    np.testing.assert_allclose(act.numpy(), g["action"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(m.U.numpy(), g["U_after"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(float(m.last["cost_total"].min()), float(g["beta"]), rtol=1e-10)
+    np.testing.assert_allclose(m.last["cost_total"].numpy()[sub], g["cost_total_sub"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(m.last["states"].numpy()[sub], g["states_sub"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(m.last["noise"].numpy()[sub], g["noise_sub"])
