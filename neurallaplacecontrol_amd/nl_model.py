@@ -147,6 +147,31 @@ class NeuralLaplaceModel(nn.Module):
         self._uploaded_key = None
         self._rep_dev = None  # (key, device copy of laplace_rep_func) for the staged path
 
+    @classmethod
+    def from_reference(cls, ref):
+        """MI355X twin of an instance of the reference's ``w_nl.NeuralLaplaceModel`` (any module with the same
+        sub-module names and attributes, e.g. one just loaded by ``train_utils.train_model(retrain=False)``):
+        same hyper-parameters, buffers (dtypes included) and weights, on ``ref``'s device.  The harness keeps training
+        with its own class and plans with this one::
+
+            model, _ = train_model("nl", env_name, config=config, retrain=False, ...)   # mppi_with_model.py:81-93
+            model = neurallaplacecontrol_amd.NeuralLaplaceModel.from_reference(model.double())
+        """
+        gru = ref.action_encoder.gru
+        enc = bool(ref.encode_obs_time)
+        first = next(ref.parameters())
+        m = cls(
+            ref.output_dim, gru.input_size - int(enc), ref.latent_dim, hidden_units=2 * gru.hidden_size,
+            s_recon_terms=ref.s_recon_terms, ilt_algorithm=ref.ilt_algorithm, encode_obs_time=enc,
+            state_mean=[0.0] * ref.output_dim, state_std=[1.0] * ref.output_dim, action_mean=[0], action_std=[1.0],
+            normalize=ref.normalize, normalize_time=ref.normalize_time,
+        ).to(device=first.device, dtype=first.dtype)
+        for name in ("state_mean", "state_std", "action_mean", "action_std", "dt"):
+            m.register_buffer(name, getattr(ref, name).detach().clone())
+        m.load_state_dict(ref.state_dict())
+        m.train(ref.training)
+        return m
+
     # ------------------------------------------------------------------ HIP plumbing
     def _weights_key(self):
         """Changes whenever a parameter / buffer is written in place (``_version``), replaced or moved (``data_ptr``;
