@@ -1172,3 +1172,38 @@ def test_full_size_cfg1_cfg3_cfg4_vs_reference_golden_seed_replay(nlc, tag, env)
     np.testing.assert_allclose(mppi._omega[idx].cpu().numpy(), g["omega_sub"], rtol=1e-7, atol=1e-30)
     np.testing.assert_allclose(mppi._states[idx].cpu().numpy(), g["states_sub"], rtol=1e-8, atol=1e-8)
     np.testing.assert_array_equal(mppi._noise[idx].cpu().numpy(), g["noise_sub"])
+
+
+@pytest.mark.parametrize("env", ["oderl-cartpole", "oderl-acrobot"])
+def test_untamed_random_weights_short_horizon(nlc, env):
+    """Reference-constructor weights WITHOUT the 'trained-like' phi shift: the model is chaotic (outputs grow ~10x per
+    step) and some sphere angles saturate, so this only runs a short horizon and compares relative to the state scale --
+    it pins the saturation handling of the fused sphere map against the oracle's torch.tan / torch.tanh."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=False)
+    model = build_model(nlc, sd)
+    K, T = 96, 4
+    g = torch.Generator().manual_seed(8)
+    raw = torch.randn(K, T, nu, dtype=torch.float64, generator=g)
+    U0 = torch.zeros(T, nu, dtype=torch.float64)
+    state, ab = _state(nlc, env, 2), torch.zeros(4, nu, dtype=torch.float64)
+    sig = nlc.noise_sigma(nu)
+    p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cpu", lambda_=1.0,
+                      u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+    p.noise_dist = _Replay(raw.clone())
+    with torch.no_grad():
+        p.command(state, ab)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    ref = omppi.mppi_command(U0.clone(), state, ab, raw.clone(), onl.nl_dynamics(sd, ts, S=17), oenvs.RUNNING_COST[env], d,
+                             torch.inverse(sig), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    got, want = p.states, ref["states"]
+    assert torch.isfinite(got).all() and torch.isfinite(want).all()
+    for t in range(T):
+        scale = float(want[:, t].abs().max())
+        err = float((got[:, t] - want[:, t]).abs().max()) / scale
+        assert err < 1e-9 * 10.0 ** (3 * t), (t, err, scale)  # chaotic amplification: ~1000x per step at most
