@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 2
+#define NLC_ABI_VERSION 3
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -151,6 +151,12 @@ typedef struct {
                                * state, action_buffer, U and K samples (0 or 1 = one problem = the reference's
                                * MPPIDelay; > 1 = the dataset collector's many episodes,
                                * mppi_dataset_collector.py:224-321,402-424, planned side by side) */
+  int32_t cost_external;      /* 1: the dynamics run fused but the caller evaluates running_cost / terminal cost itself
+                               * (arbitrary harness closures, e.g. the state_constraint / change_goal branches of
+                               * mppi_with_model.py:145-171): nlc_mppi_rollout leaves only the perturbation cost
+                               * (:343-344) in buf->cost_total and stops before the weights; the caller adds its cost
+                               * (buf->states must be given) and calls nlc_mppi_weights.  env is then used by oracle
+                               * dynamics only and may be -1 with NL dynamics. */
   double ts_pred;             /* raw dt handed to the dynamics (mppi_with_model.py:74) */
 } nlc_mppi_desc;
 
@@ -186,8 +192,9 @@ int nlc_mppi_get_U(nlc_ctx* ctx, double* U_host);
 int nlc_mppi_rollout(nlc_ctx* ctx, const double* state_host, int state_per_sample,
                      const double* action_buffer_host, const nlc_mppi_buffers* buf, int rng, uint64_t seed,
                      uint64_t counter);
-/* NLC_DYN_EXTERNAL only: nlc_mppi_rollout stops after the perturbation; once the caller has filled
- * buf->cost_total (rollout cost + perturbation cost, :339-344) this computes the softmax partials. */
+/* NLC_DYN_EXTERNAL / cost_external: nlc_mppi_rollout stops after the perturbation / after the rollout; once the
+ * caller has completed buf->cost_total (rollout cost + perturbation cost, :339-344) this computes the softmax
+ * partials. */
 int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
 /* Phase 2: merge G shard partials (gathered_dev: (G, E, 2+T*nu); pass buf->partials and G=1 on one GPU),
  * omega, U[t] += sum_k omega_k noise[k,t] (:210-216) and return action = U[:u_per_command]*u_scale

@@ -98,6 +98,7 @@ class MppiDesc(C.Structure):
         ("delay", C.c_int32),
         ("friction", C.c_int32),
         ("E", C.c_int32),
+        ("cost_external", C.c_int32),
         ("ts_pred", C.c_double),
     ]
 

@@ -242,6 +242,7 @@ __device__ __forceinline__ double trig2angle_o(double c, double s) {
 
 // running costs: same formulas as kernels_nl.hip (kept local: this TU has no MFMA code)
 __device__ __forceinline__ double running_cost_o(int env, const double* x, const double* u, int nu) {
+  if (env < 0) return 0.0;  // cost_external: the caller evaluates its own running cost on the stored states
   double uu = 0.0;
   for (int j = 0; j < nu; ++j) uu += u[j] * u[j];
   if (env == NLC_ENV_CARTPOLE) {
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void oracle_rollout_kernel(const OracleRollout
       }
       pc += U[t * a.nu + j] * acj;
     }
-    cost += running_cost_o(a.env, x, u, a.nu);
+    cost += running_cost_o(a.cost_env, x, u, a.nu);
     pcost += pc;
   }
   a.cost_total[k] = cost + pcost;

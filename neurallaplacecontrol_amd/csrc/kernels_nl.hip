@@ -35,6 +35,7 @@ __device__ __forceinline__ double trig2angle(double c, double s) {
 
 __device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MAX_D], const double (&u)[NLC_MAX_NU],
                                                int nu) {
+  if (env < 0) return 0.0;  // cost_external: the caller evaluates its own running cost on the stored states
   double uu = 0.0;
   for (int j = 0; j < nu; ++j) uu += u[j] * u[j];
   if (env == NLC_ENV_CARTPOLE) {

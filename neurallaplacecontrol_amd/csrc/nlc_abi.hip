@@ -590,10 +590,14 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   const int E = d->E < 1 ? 1 : d->E;
   if ((double)E * (double)d->K * d->T * d->nu > 2.0e9)
     return fail(c, NLC_ERR_BAD_SHAPE, "E*K*T*nu exceeds the planner's index range");
-  if (d->env < 0 || d->env > 2) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
+  // the env id selects the running cost and the oracle dynamics; with cost_external and NL dynamics nothing needs it
+  const bool env_free = d->cost_external && d->dynamics == NLC_DYN_NL && d->env == -1;
+  if (!env_free && (d->env < 0 || d->env > 2)) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
   static const int env_d[3] = {5, 3, 6}, env_nu[3] = {1, 1, 2};
-  if (d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
+  if (!env_free && d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
     return fail(c, NLC_ERR_BAD_SHAPE, "nx / nu do not match the env's trig observation");
+  if (d->cost_external && d->dynamics == NLC_DYN_EXTERNAL)
+    return fail(c, NLC_ERR_BAD_ARG, "cost_external needs fused dynamics (NLC_DYN_NL / NLC_DYN_ORACLE)");
   if (d->dynamics == NLC_DYN_EXTERNAL) {
     // the caller owns dynamics and cost
   } else if (d->dynamics == NLC_DYN_NL) {
@@ -743,6 +747,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   if ((!external && (!state || !abuf_host)) || !buf) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
   if (!buf->noise || !buf->perturbed || !buf->cost_total || !buf->cost_nz || !buf->partials || !buf->workspace)
     return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
+  if (d.cost_external && !buf->states) return fail(c, NLC_ERR_BAD_ARG, "cost_external needs buf->states");
   NLC_HIP(c, hipSetDevice(c->device));
   const WsLayout w = ws_layout(c);
   double* ws = (double*)buf->workspace;
@@ -841,7 +846,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     r.T = d.T;
     r.nu = d.nu;
     r.B = d.B;
-    r.env = d.env;
+    r.env = d.cost_external ? -1 : d.env;  // only the running cost reads it in the NL rollout
     r.state_per_sample = state_per_sample;
     r.state0 = state_dev;
     r.pa = pa;
@@ -887,7 +892,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       st.T = d.T;
       st.nu = d.nu;
       st.d = d.d;
-      st.env = d.env;
+      st.env = d.cost_external ? -1 : d.env;
       st.state_per_sample = state_per_sample;
       st.state0 = state_dev;
       st.x = r.xcarry;
@@ -920,7 +925,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
         ProfScope ps(c, "step_tail_kernel");
         NLC_HIP(c, launch_step_tail(st, c->stream));
       }
-      return run_weights(c, buf);
+      return d.cost_external ? NLC_OK : run_weights(c, buf);
     }
     // NLC_ROLLOUT_VARIANT=1|2 pins the wave-per-tile / latency-split kernel (tests, experiments); default auto
     int variant = 0;
@@ -974,6 +979,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     r.B = d.B;
     r.d = d.d;
     r.env = d.env;
+    r.cost_env = d.cost_external ? -1 : d.env;
     r.delay = d.delay;
     r.friction = d.friction;
     r.state_per_sample = state_per_sample;
@@ -992,7 +998,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     ProfScope ps(c, "oracle_rollout_kernel");
     NLC_HIP(c, launch_oracle_rollout(r, c->stream));
   }
-  return run_weights(c, buf);
+  return d.cost_external ? NLC_OK : run_weights(c, buf);
   NLC_GUARD_END(c)
 }
 

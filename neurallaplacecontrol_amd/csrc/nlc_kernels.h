@@ -165,6 +165,7 @@ hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s);
 struct OracleRolloutArgs {
   int64_t K, Kep;
   int T, nu, B, d, env, delay, friction;
+  int cost_env;  // env of the running cost, -1 = none (the caller adds its own cost)
   int state_per_sample;
   const double* state0;
   const double* abuf;  // (E, B, nu)

@@ -8,7 +8,11 @@ lambda_ u_scale``).  Everything numeric runs in HIP kernels behind ``libnlc_hip.
   :class:`~neurallaplacecontrol_amd.envs.OracleDynamics` and ``running_cost`` an
   :class:`~neurallaplacecontrol_amd.envs.EnvCost`: one ``command()`` = shift/perturb kernel, hoisted GRU
   encode over all K*T windows, one persistent T-step rollout kernel, softmax-weight reduction, U update.
-* generic path -- arbitrary callables (the reference's contract): sampling, bounding, weighting and the
+* fused dynamics + cost callables -- same rollout kernel, but ``running_cost`` (and ``terminal_state_cost``) are
+  arbitrary callables, e.g. the harness's ``state_constraint`` / ``change_goal`` closures
+  (``mppi_with_model.py:145-171``): the states do not depend on the cost, so the callables run once per horizon step
+  on the stored (K, T, nx) device states after the kernel (``nlc_mppi_desc.cost_external``).
+* generic path -- arbitrary dynamics callables (the reference's contract): sampling, bounding, weighting and the
   U update are the same HIP kernels; the T-step loop calls the user's callables on device tensors.
 
 Extra keyword-only arguments (not in the reference): ``noise_rng`` ("torch": draw with
@@ -141,20 +145,25 @@ class MPPIDelay:
             self.G, self.rank = 1, 0
         self.k_offset, self.K_local = shard_range(self.K, self.G, self.rank)
 
-        self.fused = (
+        # fused dynamics: the whole T-step rollout is one HIP kernel (Fourier models), or the staged all-HIP path
+        # (rep-func kernel -> de Hoog kernel -> state kernel per horizon step) for de Hoog models
+        self.fused_dynamics = (
             isinstance(dynamics, (NLDynamics, OracleDynamics))
-            and isinstance(running_cost, EnvCost)
-            and terminal_state_cost is None
             and not step_dependent_dynamics
             # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
             # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
             and not (encode_obs_time and not isinstance(dynamics, OracleDynamics))
-            # Fourier models run the single persistent rollout kernel; de Hoog models the staged all-HIP path
-            # (rep-func kernel -> de Hoog kernel -> state/cost kernel per horizon step) inside nlc_mppi_rollout
             and not (isinstance(dynamics, NLDynamics) and dynamics.model.ilt_algorithm not in ("fourier", "dehoog"))
         )
-        if isinstance(dynamics, OracleDynamics) and not self.fused:
-            raise NotImplementedError("OracleDynamics needs an EnvCost running_cost and the default rollout options")
+        # fused: the running cost is evaluated inside the rollout kernel as well (EnvCost, no terminal cost)
+        self.fused = self.fused_dynamics and isinstance(running_cost, EnvCost) and terminal_state_cost is None
+        # otherwise, with fused dynamics, the cost callables (the harness's state_constraint / change_goal closures,
+        # a terminal cost, ...) run on the stored device states after the rollout: the states do not depend on them
+        self.cost_external = self.fused_dynamics and not self.fused
+        if self.cost_external:
+            self.store_rollouts = True  # the cost callables read the stored states
+        if isinstance(dynamics, OracleDynamics) and not self.fused_dynamics:
+            raise NotImplementedError("OracleDynamics needs the default rollout options (no step-dependent dynamics)")
 
         if compute_device is None:
             if self.d.type == "cuda":
@@ -210,13 +219,15 @@ class MPPIDelay:
         d.sample_null_action = int(bool(self.sample_null_action))
         d.noise_abs_cost = int(bool(self.noise_abs_cost))
         d.u_per_command = int(self.u_per_command)
-        if self.fused:
-            d.env = _lib.ENV_IDS[self.running_cost.env_name]
+        if self.fused_dynamics:
+            d.cost_external = int(self.cost_external)
             if isinstance(self.F, NLDynamics):
                 d.dynamics, d.ts_pred = _lib.DYN_NL, self.F.ts_pred
+                d.env = _lib.ENV_IDS[self.running_cost.env_name] if self.fused else -1
             else:
-                if self.F.env_name != self.running_cost.env_name:
+                if self.fused and self.F.env_name != self.running_cost.env_name:
                     raise ValueError("OracleDynamics and EnvCost name different envs")
+                d.env = _lib.ENV_IDS[self.F.env_name]
                 d.dynamics, d.ts_pred = _lib.DYN_ORACLE, self.F.ts
                 d.delay, d.friction = self.F.delay, int(self.F.friction)
         else:
@@ -255,7 +266,7 @@ class MPPIDelay:
     def _ensure_configured(self, B):
         """(Re)configure when the action-buffer length or the model's weights changed since the last command."""
         stale = self._buf is None or B != self._B
-        if self.fused and isinstance(self.F, NLDynamics):
+        if self.fused_dynamics and isinstance(self.F, NLDynamics):
             model = self.F.model
             if model._weights_key() != self._model_key:
                 if self._buf is not None:  # nlc_set_model drops the planner configuration: carry U over
@@ -335,7 +346,7 @@ class MPPIDelay:
                 # K x T x nu draw on `device`, same generator consumption as the reference (:319)
                 raw = self.noise_dist.sample((self.K, self.T))
                 self._noise.copy_(slice_noise(raw, self.k_offset, self.K_local).reshape(self.K_local, self.T, self.nu))
-            if self.fused:
+            if self.fused_dynamics:
                 if self.encode_obs_time and ab.shape[1] == self.nu + 1:
                     ab = ab[:, : self.nu].contiguous()  # drop the time-stamp column (mppi_delay.py:262-264)
                 if ab.shape[1] != self.nu:
@@ -345,6 +356,9 @@ class MPPIDelay:
                         ctx.h, _lib.ptr(st), int(per_sample), _lib.ptr(ab), C.byref(self._buf), rng, self.seed, self._commands
                     )
                 )
+                if self.cost_external:
+                    self._external_cost()
+                    ctx.check(lib.nlc_mppi_weights(ctx.h, C.byref(self._buf)))
             else:
                 ctx.check(lib.nlc_mppi_rollout(ctx.h, None, 0, None, C.byref(self._buf), rng, self.seed, self._commands))
                 self._external_rollout(st, per_sample, ab)
@@ -375,6 +389,16 @@ class MPPIDelay:
 
     def _running_cost(self, state, u):
         return self.running_cost(state, u)
+
+    def _external_cost(self):
+        """cost_external: the fused rollout left the states (K, T, nx) and the perturbation cost (:343-344) on the
+        device; add the caller's running cost step by step (reference :288-290) and its terminal cost (:306-308)."""
+        states, A = self._states, self.u_scale * self._perturbed
+        cost = self._cost_total
+        for t in range(self.T):
+            cost += self._running_cost(states[:, t], A[:, t])
+        if self.terminal_state_cost:
+            cost += self.terminal_state_cost(states, A)
 
     def _external_rollout(self, st, per_sample, action_buffer):
         dev, K, T, nu = self.cd, self.K_local, self.T, self.nu

@@ -38,6 +38,26 @@ def cartpole_cost(state, u):
     return -((state_reward + 0.01 * vel_reward) + ac_reward)
 
 
+def cartpole_cost_variant(state_constraint=False, change_goal=False, change_goal_flipped=False):
+    """The non-default branches of the harness running_cost (mppi_with_model.py:146-162) for cartpole
+    (ctcartpole.py:311-329): moved goal x = -2 / +2, or the soft wall exp(10 e0 + 7) on the cart position."""
+    goal_x = (2.0 if change_goal_flipped else -2.0) if change_goal else 0.0
+
+    def cost(state, u):
+        x, xd, cl, sl, thd = (state[..., i] for i in range(5))
+        e0 = x + sl - goal_x
+        e1 = cl - 1.0
+        if state_constraint:
+            state_reward = -((e0 * e0 + torch.exp(e0 * 10.0 + 7.0)) + e1 * e1)
+        else:
+            state_reward = -(e0 * e0 + e1 * e1)
+        vel_reward = -(xd * xd) - thd * thd
+        ac_reward = -0.01 * (u * u).sum(-1)
+        return -((state_reward + 0.01 * vel_reward) + ac_reward)
+
+    return cost
+
+
 def pendulum_cost(state, u):
     c, s, thd = state[..., 0], state[..., 1], state[..., 2]
     state_reward = -((1.0 - c) ** 2 + s * s)

@@ -25,7 +25,7 @@ def perturb(U, noise, u_scale, u_min, u_max, sample_null_action=False):
 
 
 def rollout(state, action_buffer, V, u_scale, dynamics, running_cost, nx):
-    """:232-313 with M=1, no terminal cost, encode_obs_time=False."""
+    """:232-313 with M=1, encode_obs_time=False (the terminal cost is added by the caller)."""
     K, T, nu = V.shape
     B = action_buffer.shape[0]
     x = state if state.shape == (K, nx) else state.view(1, -1).repeat(K, 1)
@@ -59,6 +59,7 @@ def mppi_command(
     sample_null_action=False,
     noise_abs_cost=False,
     u_per_command=1,
+    terminal_state_cost=None,
 ):
     """One ``command()`` given the noise draw; returns a dict of every public output."""
     U = torch.roll(U, -1, dims=0)
@@ -69,6 +70,8 @@ def mppi_command(
     else:
         action_cost = lambda_ * eps @ noise_sigma_inv
     cost, states, actions = rollout(state, action_buffer, V, u_scale, dynamics, running_cost, nx)
+    if terminal_state_cost is not None:  # :306-308, called with the (K,T,nx) states and the scaled (K,T,nu) actions
+        cost = cost + terminal_state_cost(states, actions)
     actions = actions / u_scale
     cost = cost + torch.sum(U * action_cost, dim=(1, 2))
     beta = torch.min(cost)

@@ -26,6 +26,9 @@ Fixtures:
   g7_full_<cfg>.npz           BASELINE configs[0] (cartpole, K=1024, T=20: the reference's own CPU-runnable case), configs[2] (pendulum, K=65536, T=40, 5-row action buffer) and configs[3]
                               (acrobot, K=262144, T=60) at FULL size, one reference command each, seed replay as in g6;
                               stored: U, action, beta/eta, and strided subsets of cost_total / omega / states / noise
+  g8_cost_variants.npz        cartpole, reference MPPIDelay with the harness running_cost's non-default branches
+                              (state_constraint / change_goal / change_goal_flipped, mppi_with_model.py:146-162) evaluated
+                              by the REAL env class, NL and oracle dynamics, plus a terminal_state_cost
   g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
                               constant time channel B-1..0 (mppi_with_model.py:110-119) + reference MPPIDelay
 """
@@ -477,6 +480,56 @@ def make_g7(MPPIDelay, w_nl, envs, only=None):
             print("g7", tag, "action", np_(action))
 
 
+def make_g8(MPPIDelay, w_nl, envs, dyn):
+    from functools import partial
+
+    env_name, K, T, B = "oderl-cartpole", 64, 8, 4
+    st = onl.ENV_STATS[env_name]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    env = envs[env_name]()
+    model = build_ref_model(w_nl, env_name, seed=3)
+    ts_pred = torch.full((K, 1), 0.05, dtype=torch.double)
+    out = {}
+    with torch.no_grad():
+        model.laplace_rep_func.linear_tanh_stack[4].bias[d * 17 :] += onl.PHI_BIAS_SHIFT
+        out.update({f"w::{k}": np_(v) for k, v in model.state_dict().items()})
+
+        def nl_dynamics(state, perturbed_action):
+            return state + model(state, perturbed_action, ts_pred)
+
+        variants = {
+            "constraint": dict(state_constraint=True),
+            "goal": dict(change_goal=True, change_goal_flipped=False),
+            "goal_flipped": dict(change_goal=True, change_goal_flipped=True),
+        }
+        for vname, kw in variants.items():
+            def running_cost(state, action, kw=kw):
+                return -(env.diff_obs_reward_(state, exp_reward=False, **kw) + env.diff_ac_reward_(action))
+
+            for dname, dynamics in (("nl", nl_dynamics),
+                                    ("oracle", partial(dyn[env_name], ts=ts_pred, delay=1, friction=False))):
+                torch.manual_seed(40)
+                terminal = (lambda states, actions: 0.5 * (states[..., -1, 0] ** 2).reshape(-1)) if vname == "goal" else None
+                mppi = MPPIDelay(
+                    dynamics, running_cost, d, noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                    u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, terminal_state_cost=terminal,
+                )
+                state = oenvs.initial_state(env_name, seed=2)
+                action_buffer = (torch.rand(B, nu, dtype=torch.double) - 0.5) * A
+                for step in range(2):
+                    c = capture_command(mppi, state.numpy(), action_buffer)
+                    pre = f"{vname}_{dname}_s{step}_"
+                    for k, v in c.items():
+                        out[pre + k] = v
+                    out[pre + "state"] = np_(state)
+                    out[pre + "action_buffer"] = np_(action_buffer)
+                    state = mppi.states[0, 0].clone()
+                    action_buffer = torch.roll(action_buffer, -1, dims=0)
+                    action_buffer[-1] = torch.as_tensor(c["action"])
+                print("g8", vname, dname, "action", out[pre + "action"])
+    np.savez_compressed(f"{HERE}/g8_cost_variants.npz", K=K, T=T, B=B, d=d, nu=nu, A=A, **out)
+
+
 def make_g4():
     """ILT known answers: analytic pairs + mpmath de Hoog (degree 16 -> 33 terms)."""
     import mpmath as mp
@@ -516,6 +569,7 @@ def main():
     make_g4()
     make_g5(MPPIDelay, w_nl, envs, dyn)
     make_g6(MPPIDelay, w_nl, envs)
+    make_g8(MPPIDelay, w_nl, envs, dyn)
     make_g7(MPPIDelay, w_nl, envs, only=os.environ.get("NLC_G7_ONLY", "cfg1,cfg3,cfg4").split(","))
 
 

@@ -1207,3 +1207,63 @@ def test_untamed_random_weights_short_horizon(nlc, env):
         scale = float(want[:, t].abs().max())
         err = float((got[:, t] - want[:, t]).abs().max()) / scale
         assert err < 1e-9 * 10.0 ** (3 * t), (t, err, scale)  # chaotic amplification: ~1000x per step at most
+
+
+# --------------------------------------------------------------------------- G8: fused dynamics + cost callables
+@pytest.mark.parametrize("variant", ["constraint", "goal", "goal_flipped"])
+@pytest.mark.parametrize("dyn_name", ["nl", "oracle"])
+def test_cost_callables_with_fused_dynamics_vs_reference_golden(nlc, variant, dyn_name):
+    """The harness running_cost's state_constraint / change_goal branches (mppi_with_model.py:146-162) and a
+    terminal_state_cost are arbitrary callables: the rollout still runs in the fused kernel (cost_external), the
+    callables on the stored device states.  Golden: the real planner + the real cartpole env class."""
+    from oracle import envs as oenvs
+
+    g = np.load(f"{GOLD}/g8_cost_variants.npz")
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    kw = {"constraint": dict(state_constraint=True), "goal": dict(change_goal=True),
+          "goal_flipped": dict(change_goal=True, change_goal_flipped=True)}[variant]
+    cost = oenvs.cartpole_cost_variant(**kw)  # stands in for the harness closure (the env class is not on this box)
+    terminal = (lambda states, actions: 0.5 * (states[..., -1, 0] ** 2).reshape(-1)) if variant == "goal" else None
+    dyn = nlc.NLDynamics(build_model(nlc, load_sd(g)), 0.05) if dyn_name == "nl" else nlc.OracleDynamics("oderl-cartpole", 0.05, 1)
+    calls = []
+
+    def counted_cost(state, action):
+        calls.append((tuple(state.shape), state.device.type))
+        return cost(state, action)
+
+    def make(U0):
+        p = nlc.MPPIDelay(dyn, counted_cost, d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0, terminal_state_cost=terminal)
+        assert p.fused_dynamics and p.cost_external and not p.fused
+        return p
+
+    g2 = {k[len(f"{variant}_{dyn_name}_"):]: g[k] for k in g.files if k.startswith(f"{variant}_{dyn_name}_")}
+    with torch.no_grad():
+        check_command_steps(nlc, g2, make)
+    assert calls and all(c == ((K, d), "cuda") for c in calls) and len(calls) == 2 * T
+
+
+def test_cost_callables_path_equals_fused_envcost(nlc):
+    """With the default cost written as a callable, the cost_external path gives the fused EnvCost result."""
+    from oracle import envs as oenvs
+    from oracle import nl_model as onl
+
+    env, d, nu, A, K, T = "oderl-acrobot", 6, 2, 5.0, 200, 7
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(21, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    gen = torch.Generator().manual_seed(5)
+    raw = torch.randn(K, T, nu, dtype=torch.float64, generator=gen)
+    U0 = torch.randn(T, nu, dtype=torch.float64, generator=gen) * 0.2
+    state, ab = _state(nlc, env, 4), torch.randn(4, nu, dtype=torch.float64, generator=gen)
+    out = []
+    for rc in (nlc.EnvCost(env), oenvs.RUNNING_COST[env]):
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), rc, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+        p.noise_dist = _Replay(raw.clone())
+        with torch.no_grad():
+            act = p.command(state, ab)
+        out.append((act, p.cost_total.clone(), p.states.clone(), p.U.clone()))
+    assert torch.equal(out[0][2], out[1][2])  # same kernel, same states
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-10, atol=1e-12)

@@ -259,3 +259,36 @@ def test_g7_cfg1_seed_replay(golden_dir):
     np.testing.assert_allclose(m.last["cost_total"].numpy()[sub], g["cost_total_sub"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(m.last["states"].numpy()[sub], g["states_sub"], rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(m.last["noise"].numpy()[sub], g["noise_sub"])
+
+
+# --------------------------------------------------------------------------- G8: running_cost variants + terminal cost
+G8_VARIANTS = {"constraint": dict(state_constraint=True), "goal": dict(change_goal=True),
+               "goal_flipped": dict(change_goal=True, change_goal_flipped=True)}
+
+
+def g8_terminal(states, actions):
+    return 0.5 * (states[..., -1, 0] ** 2).reshape(-1)
+
+
+@pytest.mark.parametrize("variant", sorted(G8_VARIANTS))
+@pytest.mark.parametrize("dyn_name", ["nl", "oracle"])
+def test_g8_running_cost_variants_and_terminal_cost(variant, dyn_name, golden_dir):
+    """Harness running_cost with state_constraint / change_goal(_flipped) (mppi_with_model.py:146-162) evaluated by
+    the real cartpole env class inside the real planner; 'goal' also carries a terminal_state_cost (:306-308)."""
+    g = np.load(f"{golden_dir}/g8_cost_variants.npz")
+    K, d, nu, A = int(g["K"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    if dyn_name == "nl":
+        dyn = onl.nl_dynamics(load_sd(g), ts, S=17)
+    else:
+        dyn = lambda s, w: oenvs.ORACLE_DYNAMICS["oderl-cartpole"](s, w, ts, 1)  # noqa: E731
+    cost = oenvs.cartpole_cost_variant(**G8_VARIANTS[variant])
+    for step in range(2):
+        pre = f"{variant}_{dyn_name}_s{step}_"
+        out = omppi.mppi_command(T(g[pre + "U_before"]), T(g[pre + "state"]), T(g[pre + "action_buffer"]),
+                                 T(g[pre + "noise_raw"]), dyn, cost, d, sigma_inv(nu), lambda_=1.0, u_scale=A,
+                                 u_min=torch.tensor(-A), u_max=torch.tensor(A),
+                                 terminal_state_cost=g8_terminal if variant == "goal" else None)
+        for key, ref in (("action", "action"), ("U", "U_after"), ("cost_total", "cost_total"), ("omega", "omega"),
+                         ("states", "states")):
+            np.testing.assert_allclose(out[key].numpy(), g[pre + ref], err_msg=pre + key, **TOL)
