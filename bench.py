@@ -204,10 +204,11 @@ def main():
         ms = p["total_ms"] / p["launches"]
         nbytes = N * (2 * d * S_TERMS + d) * 8
         traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, "profiles", "r1_pmc_ilt.json")
+        pmc = os.path.join(REPO, "profiles", "r1h_pmc_kernels.json")
         if os.path.exists(pmc):  # PMC passes cannot run inside this process: separate rocprofv3 --pmc runs
             pj = json.load(open(pmc))
-            traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/r1_pmc_ilt.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction, same N)"
+            traffic = pj["ilt_fourier"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r1h_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction, same N)"
         ilt = dict(bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                    algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
@@ -232,7 +233,8 @@ def main():
         ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
                                algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
                                frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               valu_busy="0.66 (profiles/r1g_pmc_dehoog.json)")
+                               traffic=pj["ilt_dehoog_final"]["hbm_bytes_per_launch"] if os.path.exists(pmc) else None,
+                               traffic_note="mean over S=33 and S=17 launches (profiles/r1h_pmc_kernels.json)")
         del theta, phi
 
     if rank != 0:
@@ -248,11 +250,11 @@ def main():
     rk = kernels.get("nl_rollout_kernel", dict(avg_ms=float("nan")))
     gru_tf = gru_flops / (gk["avg_ms"] * 1e-3) / 1e12
     g_traffic, r_traffic, t_src = None, None, None
-    pmc = os.path.join(REPO, "profiles", "r1_pmc_planner_traffic.json")
+    pmc = os.path.join(REPO, "profiles", "r1h_pmc_kernels.json")
     if os.path.exists(pmc) and k_local == K_SAMPLES:  # measured at the headline size only
         pj = json.load(open(pmc))
-        g_traffic, r_traffic = pj["gru_encode"]["hbm_bytes_per_launch"], pj["nl_rollout_kernel"]["hbm_bytes_per_launch"]
-        t_src = "profiles/r1_pmc_planner_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+        g_traffic, r_traffic = pj["gru_encode"]["hbm_bytes_per_launch"], pj["nl_rollout"]["hbm_bytes_per_launch"]
+        t_src = "profiles/r1h_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
     roofline = dict(bound="mfma", achieved=gru_tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=gru_tf / FP64_MFMA_PEAK_TFLOPS, traffic=g_traffic, traffic_source=t_src,
                     algorithmic_hbm_bytes=24 * k_local * HORIZON, kernel="gru_encode_kernel",

@@ -245,10 +245,12 @@ __device__ __forceinline__ cplx csqrt_(cplx z) {
 // A/B recurrence.  Storage is ONE diagonal (2M complex = 128 VGPRs at M = 16) instead of the two full columns of the
 // column-wise form (354 VGPRs, one wave per SIMD), and the F_k rows are staged through LDS in chunks of CH terms, so
 // two waves per SIMD share the VALU (a single wave issues FP64 VALU at half rate: tools/ubench_valu64.hip).
-// Measured (N = 655 360 points, d = 5, PMC in profiles/r1g_pmc_dehoog.json): S = 33 2.50 -> 1.65 ms, VALU 66 % busy
-// with 9.6 k VALU instructions per 64 rows (7.3 k QD + 2.3 k sphere->complex conversion); variants with the
-// quotient hoisted off the serial chain, 1 or 3-4 waves per SIMD, or without the per-diagonal scheduling fence all
-// landed within +-10 %, i.e. the kernel is bound by its FP64 instruction count, not by latency.
+// Measured (N = 655 360 points, d = 5): S = 33 2.50 -> 1.39 ms, S = 17 0.70 -> 0.48 ms; 9.6 k VALU instructions per
+// 64 rows at S = 33 (7.3 k QD + 2.3 k sphere->complex conversion): the kernel is bound by its FP64 instruction
+// count.  An intermediate version (1.65 ms) looked latency-bound at 66 % VALU utilisation; the PMC traffic counters
+// showed the real cause -- the compiler had deferred the B recurrence to the end of the kernel and spilled every
+// d_n z to scratch, 1 GB of HBM writes and 3.5x the algorithmic traffic per launch (profiles/r1g_pmc_dehoog.json
+// vs r1h_pmc_kernels.json); the per-diagonal fence below now pins both recurrences.
 template <int M, int CH, int W, bool FDIRECT>
 __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
   constexpr int S = 2 * M + 1;
@@ -336,9 +338,11 @@ __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
         B_cur = Bn;
       }
       // keep the diagonals apart: hoisting the next terms' LDS reads / interleaving diagonals only costs registers
-      // (the asm ties this diagonal's last value to a memory barrier, so the arithmetic cannot sink below the
-      // following reads either)
-      asm volatile("" : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
+      // (the asm ties this diagonal's results -- including BOTH continued-fraction recurrences, which the compiler
+      // otherwise defers to the end of the kernel, spilling every d_n z to scratch: 1 GB of HBM writes per launch --
+      // to a memory barrier, so the arithmetic cannot sink below the following reads either)
+      asm volatile(""
+                   : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
       __builtin_amdgcn_sched_barrier(0);
     }
     // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
@@ -370,10 +374,10 @@ hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s) {
   } while (0)
   switch (a.S) {
     case 33:
-      NLC_DH(16, 11, 2);
+      NLC_DH(16, 17, 2);  // 212-249 VGPRs, two 17-term chunks of 17 KB LDS: 8 waves per CU
       break;
     case 17:
-      NLC_DH(8, 17, 2);
+      NLC_DH(8, 9, 3);  // 143-148 VGPRs, two 9-term chunks of 9 KB LDS: 12 waves per CU
       break;
     case 9:
       NLC_DH(4, 9, 3);
