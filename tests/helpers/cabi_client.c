@@ -1,0 +1,69 @@
+/* Plain-C client of include/nlc.h: one MPPI command with oracle cartpole dynamics, device buffers from the HIP
+ * runtime's C API, no Python and no torch.  Prints the action, the first cost and beta/eta so the GPU test can
+ * compare them with the Python mirror driving the same library (device Philox noise, same seed and counter).
+ *   gcc -std=c99 cabi_client.c -I include -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L<libdir> -lnlc_hip
+ *       -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,<libdir> -Wl,-rpath,/opt/rocm/lib -lm -o cabi_client */
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "nlc.h"
+
+#define CHECK(call)                                                              \
+  do {                                                                           \
+    int rc_ = (call);                                                            \
+    if (rc_ != 0) {                                                              \
+      fprintf(stderr, "%s -> %d: %s\n", #call, rc_, nlc_last_error(ctx));       \
+      return 1;                                                                  \
+    }                                                                            \
+  } while (0)
+
+static double* dev_alloc(size_t n) {
+  void* p = NULL;
+  if (hipMalloc(&p, n * sizeof(double)) != hipSuccess) exit(2);
+  return (double*)p;
+}
+
+int main(void) {
+  nlc_ctx* ctx = NULL;
+  if (nlc_create(0, &ctx) != NLC_OK) {
+    fprintf(stderr, "nlc_create: %s\n", nlc_last_error(NULL));
+    return 3;
+  }
+  const int K = 512, T = 10, nu = 1, d = 5, B = 4;
+  const double A = 3.0;
+  nlc_mppi_desc md;
+  memset(&md, 0, sizeof(md));
+  md.K = K; md.K_global = K; md.k_offset = 0; md.T = T; md.nu = nu; md.d = d; md.B = B;
+  md.lambda_ = 1.0; md.u_scale = A; md.has_bounds = 1; md.u_min[0] = -A; md.u_max[0] = A;
+  md.noise_sigma[0] = 1.0; md.noise_sigma_inv[0] = 1.0; md.noise_chol[0] = 1.0;
+  md.u_per_command = 1; md.dynamics = NLC_DYN_ORACLE; md.env = NLC_ENV_CARTPOLE; md.delay = 2; md.ts_pred = 0.05;
+  CHECK(nlc_mppi_configure(ctx, &md));
+  nlc_mppi_buffers buf;
+  memset(&buf, 0, sizeof(buf));
+  buf.noise = dev_alloc((size_t)K * T * nu);
+  buf.perturbed = dev_alloc((size_t)K * T * nu);
+  buf.states = dev_alloc((size_t)K * T * d);
+  buf.cost_total = dev_alloc(K);
+  buf.cost_nz = dev_alloc(K);
+  buf.omega = dev_alloc(K);
+  buf.partials = dev_alloc(2 + T * nu);
+  buf.action = dev_alloc(nu);
+  const long long ws = nlc_mppi_workspace_bytes(ctx);
+  if (ws < 0 || hipMalloc(&buf.workspace, (size_t)ws) != hipSuccess) return 4;
+  double U[10] = {0}, state[5] = {0.01, 0.0, -1.0, 0.02, 0.0}, abuf[4] = {0.5, -0.25, 0.0, 1.0}, action[1] = {0};
+  CHECK(nlc_mppi_set_U(ctx, U));
+  for (int cmd = 0; cmd < 2; ++cmd) {
+    CHECK(nlc_mppi_rollout(ctx, state, 0, abuf, &buf, /*rng=*/1, /*seed=*/17, /*counter=*/(uint64_t)cmd));
+    CHECK(nlc_mppi_finish(ctx, buf.partials, 1, 0, &buf, action));
+    double part[2], c0;
+    if (hipMemcpy(part, buf.partials, sizeof(part), hipMemcpyDeviceToHost) != hipSuccess) return 5;
+    if (hipMemcpy(&c0, buf.cost_total, sizeof(c0), hipMemcpyDeviceToHost) != hipSuccess) return 5;
+    printf("%.17g %.17g %.17g %.17g\n", action[0], c0, part[0], part[1]);
+  }
+  CHECK(nlc_mppi_get_U(ctx, U));
+  for (int t = 0; t < T; ++t) printf("%.17g%c", U[t], t + 1 < T ? ' ' : '\n');
+  nlc_destroy(ctx);
+  return 0;
+}

@@ -189,3 +189,17 @@ def test_model_from_reference_copies_hyperparameters_buffers_and_weights():
         assert sd_a[k].dtype == sd_b[k].dtype and torch.equal(sd_a[k], sd_b[k]), k
     assert twin.action_mean.dtype == torch.int64 and twin.dt.dtype == torch.float64  # reference dtypes after .double()
     assert float(twin.dt) == float(np.float32(0.05))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_plain_c_client_compiles_and_fails_loudly_without_gpu(lib, tmp_path):
+    """tests/helpers/cabi_client.c is C99 against include/nlc.h (gcc, no Python): it must build here and report the
+    missing device through nlc_last_error (exit code 3), not crash."""
+    libdir = os.path.join(REPO, "neurallaplacecontrol_amd")
+    exe = str(tmp_path / "cabi_client")
+    subprocess.check_call(
+        ["gcc", "-std=c99", "-Wall", os.path.join(REPO, "tests", "helpers", "cabi_client.c"), "-I", os.path.join(REPO, "include"),
+         "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L" + libdir, "-lnlc_hip", "-L/opt/rocm/lib", "-lamdhip64",
+         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, timeout=120)
+    assert r.returncode == 3 and b"nlc_create" in r.stderr

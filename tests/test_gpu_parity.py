@@ -1267,3 +1267,32 @@ def test_cost_callables_path_equals_fused_envcost(nlc):
     assert torch.equal(out[0][2], out[1][2])  # same kernel, same states
     for a, b in zip(out[0], out[1]):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
+    """include/nlc.h is a real C boundary: tests/helpers/cabi_client.c (C99, gcc, HIP runtime C API for the device
+    buffers, no Python, no torch) runs two planner commands; the Python mirror driving the same library with the same
+    seed / command counters gives bit-identical numbers."""
+    import subprocess
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    libdir = os.path.join(repo, "neurallaplacecontrol_amd")
+    exe = str(tmp_path / "cabi_client")
+    subprocess.check_call(
+        ["gcc", "-std=c99", os.path.join(repo, "tests", "helpers", "cabi_client.c"), "-I", os.path.join(repo, "include"),
+         "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L" + libdir, "-lnlc_hip", "-L/opt/rocm/lib", "-lamdhip64",
+         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+    lines = subprocess.check_output([exe], timeout=300).decode().strip().splitlines()
+    c_cmds = [[float(x) for x in ln.split()] for ln in lines[:2]]
+    c_U = [float(x) for x in lines[2].split()]
+    K, T, A = 512, 10, 3.0
+    p = nlc.MPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 2), nlc.EnvCost("oderl-cartpole"), 5, torch.tensor(1.0).double(),
+                      K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                      U_init=torch.zeros(T, 1, dtype=torch.float64), noise_rng="philox", seed=17)
+    state = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64)
+    ab = torch.tensor([[0.5], [-0.25], [0.0], [1.0]], dtype=torch.float64)
+    for cmd in range(2):
+        act = p.command(state, ab)
+        part = p._partials.cpu()
+        assert [float(act[0]), float(p.cost_total[0]), float(part[0]), float(part[1])] == c_cmds[cmd]
+    assert p.U.reshape(-1).tolist() == c_U
