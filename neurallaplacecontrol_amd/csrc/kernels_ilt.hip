@@ -65,8 +65,96 @@ hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s) {
 // DBG: 0 = product; 1 / 2 = timing experiments (memory only / arithmetic only), env NLC_ILT_DBG
 // ITERS > 0: passes per tile known at compile time -> the pass loop is fully unrolled (straight-line code is
 // what lets the compiler keep counted s_waitcnt vmcnt(N) instead of draining the pipeline); 0: runtime loop.
+//
+// Whole tiles run as ONE continuous load pipeline per block: the refills issued in the last UB passes of a tile are
+// the first UB passes of the block's NEXT tile, so 2*UB loads per lane stay in flight through the tile's barriers
+// and its row-sum phase (first version: the pipeline drained at every tile, 16 passes; the kernel ran at
+// memory-only time + arithmetic time, 0.168 + 0.073 ms at N = 655 360).  The row's t is loaded at the top of the tile
+// (older than the tile's refills, so the row-sum waits with a counted vmcnt, not vmcnt(0)); row / d is a wave-uniform 64-bit
+// division plus a 32-bit one per thread, and the per-row scale e^{gamma t}/T uses the refined reciprocal.
+// split in two so the pipeline can consume a slot (ilt_args) BEFORE refilling it and finish the arithmetic after:
+// the refill then lands in the registers it just freed (one register set for the 2*UB loads in flight, not two)
+__device__ __forceinline__ void ilt_args(double t_u, double p_u, double psi, double* xt, double* xp) {
+  *xt = t_u + psi;
+  *xp = p_u / 2.0 + kPi / 4.0;
+}
+// per-lane constants of the Fourier phase e^{i pi k t/T}: with scale = 2 it is i^k, i.e. cos(theta + k pi/2) =
+// +-cos(theta + (k & 1) pi/2): the odd shift rides in the range reduction, the sign in the term weight
+struct IltLane {
+  double psi;      // added to theta (0 when scale == 2)
+  double half_m;   // m/2
+  double dm;       // m = quarter-turn parity
+  double wk;       // +-1/2 for k = 0, +-1 otherwise
+};
+__device__ __forceinline__ IltLane ilt_lane(int k, double scale) {
+  IltLane L;
+  const bool pow_i = scale == 2.0;
+  const double wk = k == 0 ? 0.5 : 1.0;
+  if (pow_i) {
+    L.psi = 0.0;
+    L.dm = (double)(k & 1);
+    L.wk = (k & 2) ? -wk : wk;
+  } else {
+    double psi = kPi * (double)k / scale;
+    psi -= 2.0 * kPi * rint(psi / (2.0 * kPi));
+    L.psi = psi;
+    L.dm = 0.0;
+    L.wk = wk;
+  }
+  L.half_m = 0.5 * L.dm;
+  return L;
+}
+// the trig constants, each pinned in an SGPR pair for the whole kernel
+__device__ __forceinline__ m::IltTrigK ilt_trig_k_sgpr() {
+  m::IltTrigK K = m::ilt_trig_k();
+#define NLC_PIN(x) asm volatile("" : "+s"(x))
+  // (the leading coefficient of each polynomial meets a second constant in its first Horner step, and an FP64 VALU
+  // instruction reads at most one scalar operand: those three stay in VGPRs)
+#define NLC_PINV(x) asm volatile("" : "+v"(x))
+  NLC_PINV(K.s[0]);
+  NLC_PINV(K.c4[0]);
+  NLC_PINV(K.c2[0]);
+#undef NLC_PINV
+#pragma unroll
+  for (int i = 1; i < 6; ++i) NLC_PIN(K.s[i]);
+#pragma unroll
+  for (int i = 1; i < 6; ++i) NLC_PIN(K.c4[i]);
+#pragma unroll
+  for (int i = 1; i < 8; ++i) NLC_PIN(K.c2[i]);
+  NLC_PIN(K.pio4_hi);
+  NLC_PIN(K.pio4_lo);
+  NLC_PIN(K.pio2_hi);
+  NLC_PIN(K.pio2_lo);
+  NLC_PIN(K.inv_pi);
+  NLC_PIN(K.round_shift);
+  // den_min stays a visible literal: an opaque value would have to be canonicalised before every v_max_f64
+#undef NLC_PIN
+  return K;
+}
+__device__ __forceinline__ double ilt_term2(const m::IltTrigK& K, double xt, double xp, const IltLane& L) {
+  double num, den;
+  m::tan_parts_short(K, xp, &num, &den);
+  const double cs = m::cos_plus_mpio2(K, xt, L.half_m, L.dm);
+  return (L.wk * num) * cs * m::rcp_refined(den);
+}
+__device__ __forceinline__ double ilt_term(const m::IltTrigK& K, double t_u, double p_u, const IltLane& L) {
+  double xt, xp;
+  ilt_args(t_u, p_u, L.psi, &xt, &xp);
+  return ilt_term2(K, xt, xp, L);
+}
+__device__ __forceinline__ double ilt_row_scale(const IltArgs& a, double t) {
+  // once per row, but at one row per 17 terms its IEEE divisions and libm exp were ~10 % of the kernel's instructions
+  const double Tt = a.scale * t;
+  const double gamma = a.alpha - m::div_fast(a.log_tol, a.scale * Tt);
+  return m::div_fast(m::exp_d(gamma * t), Tt);
+}
+// LDS-only workgroup barrier: ds traffic drained, global loads left in flight (a __syncthreads() would also be a
+// global-memory fence and wait for vmcnt(0), i.e. drain the prefetch pipeline)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 4 waves per SIMD (<= 128 VGPRs) where the unrolled tile fits without spilling, 3 otherwise
 template <int DBG, int ITERS>
-__global__ __launch_bounds__(256) void ilt_fourier_kernel(const IltArgs a) {
+__global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_fourier_kernel(const IltArgs a) {
   extern __shared__ double val[];  // [rows][SP]
   const int S = a.S;
   const int SP = S | 1;
@@ -76,17 +164,94 @@ __global__ __launch_bounds__(256) void ilt_fourier_kernel(const IltArgs a) {
   const int act = rpp * S;
   const bool active = (int)threadIdx.x < act;
   const int k = (int)threadIdx.x % S, rloc = (int)threadIdx.x / S;
-  const bool pow_i = a.scale == 2.0;  // e^{i pi k t/T} = i^k: exact quadrant offsets
-  const double wk = k == 0 ? 0.5 : 1.0;
-  double psi = 0.0;
-  if (!pow_i) {
-    psi = kPi * (double)k / a.scale;
-    psi -= 2.0 * kPi * rint(psi / (2.0 * kPi));
-  }
-  const int j0 = pow_i ? k : 0;
+  const IltLane L = ilt_lane(k, a.scale);
+  const m::IltTrigK K = ilt_trig_k_sgpr();
+  const double psi = L.psi;
   const int64_t rows_total = a.N * a.d;
   const int64_t nblk = (rows_total + rows - 1) / rows;
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  constexpr int UB = 8;  // pipeline depth in passes; the launcher makes iters a multiple of UB
+  int64_t blk = blockIdx.x;
+
+  if constexpr (ITERS > 0) {
+    const int64_t nfull = rows_total / rows;  // whole tiles
+    // No divergent region may contain the pipeline's loads: a skipped-region path makes the compiler's wait-count
+    // bookkeeping fall back to vmcnt(0) at the join, which drains the pipeline.  So EVERY thread runs the pass loop
+    // (the block's idle tail threads alias the last active one and only skip the LDS write), and every thread
+    // loads a t (clamped to the tile's last row).
+    const int tid_ld = active ? (int)threadIdx.x : act - 1;
+    const int tid_row = (int)threadIdx.x < rows ? (int)threadIdx.x : rows - 1;
+    double th[UB], ph[UB];
+    const double* __restrict__ tp = a.theta + tid_ld;
+    const double* __restrict__ pp = a.phi + tid_ld;
+    if (blk < nfull) {
+      tp += blk * rows * S;
+      pp += blk * rows * S;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (DBG == 2) {
+          th[u] = ph[u] = a.alpha * (double)threadIdx.x;
+          continue;
+        }
+        th[u] = __builtin_nontemporal_load(tp + (int64_t)act * u);
+        ph[u] = __builtin_nontemporal_load(pp + (int64_t)act * u);
+        // issue order = the loop's refill order, so the wait counts at the loop head agree on both entries
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    for (; blk < nfull; blk += gridDim.x) {
+      const int64_t row0 = blk * rows;
+      // this thread's output row: t first (oldest load of the tile)
+      const int64_t n0 = row0 / a.d;  // wave-uniform
+      const unsigned xr = (unsigned)(row0 - n0 * a.d) + (unsigned)tid_row;
+      const double t_row = a.t[n0 + xr / (unsigned)a.d];  // 32-bit division, once per tile
+      // successor tile of this block; without one the refills re-read this tile (cache hits, values unused)
+      const int64_t nxt = blk + gridDim.x;
+      const int64_t adv = (nxt < nfull ? (int64_t)gridDim.x : 0) * rows * S;
+      const double* __restrict__ tn = tp + adv;
+      const double* __restrict__ pn = pp + adv;
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        const int u = i % UB;
+        double xt, xp;
+        if (DBG == 1) {
+          xt = th[u];
+          xp = ph[u];
+        } else {
+          ilt_args(th[u], ph[u], psi, &xt, &xp);
+        }
+        asm volatile("" : "+v"(xt), "+v"(xp));  // slot u is consumed here ...
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG == 2) {  // timing experiment: arithmetic only (run-time values, nothing to fold)
+          th[u] = a.alpha * (double)(threadIdx.x + i) + (double)blk * 1e-7;
+          ph[u] = a.alpha * (double)(threadIdx.x + 3 * i);
+        } else if (i + UB < ITERS) {            // ... and refilled into the same registers
+          th[u] = __builtin_nontemporal_load(tp + (int64_t)act * (i + UB));
+          ph[u] = __builtin_nontemporal_load(pp + (int64_t)act * (i + UB));
+        } else {
+          th[u] = __builtin_nontemporal_load(tn + (int64_t)act * (i + UB - ITERS));
+          ph[u] = __builtin_nontemporal_load(pn + (int64_t)act * (i + UB - ITERS));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double v = DBG == 1 ? xt + xp : ilt_term2(K, xt, xp, L);
+        if (active) val[(rloc + rpp * i) * SP + k] = v;
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill of slot u next to its use: no load clustering
+      }
+      tp = tn;
+      pp = pn;
+      lds_barrier();
+      if ((int)threadIdx.x < rows) {
+        const double* v = val + threadIdx.x * SP;
+        double acc = 0.0;
+        for (int kk = 0; kk < S; ++kk) acc += v[kk];
+        a.x[row0 + threadIdx.x] = ilt_row_scale(a, t_row) * acc;
+      }
+      lds_barrier();
+    }
+    // the ragged last tile (if any) falls through to the generic loop of the block whose turn it is
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  for (; blk < nblk; blk += gridDim.x) {
     const int64_t row0 = blk * rows;
     const int rows_here = (int)((rows_total - row0 < rows) ? (rows_total - row0) : rows);
     const double* __restrict__ tp = a.theta + row0 * S + threadIdx.x;
@@ -95,60 +260,28 @@ __global__ __launch_bounds__(256) void ilt_fourier_kernel(const IltArgs a) {
     // i+1 .. i+UB are in flight (2*UB 8-byte loads per lane outstanding at all times).
     // Per element: Re(F_k e^{i pi k/scale}) = tan(phi/2 + pi/4) cos(theta + pi k/scale); tan as
     // (cos a + sin a)/(cos a - sin a) (no range reduction, no branch), its division folded into the product.
-    constexpr int UB = 8;  // the launcher makes iters a multiple of UB
-    auto tile = [&](auto full_tile) {
-      constexpr bool FULL = decltype(full_tile)::value;
+    if (active && rloc < rows_here) {
       double th[UB], ph[UB];
       // No branch may sit between a load and its use, or the compiler falls back to s_waitcnt vmcnt(0) and the
       // pipeline collapses: out-of-range passes re-load the last valid pass (cache hit) instead of being skipped.
-      const int last_i = FULL ? iters - 1 : (rows_here - 1 - rloc >= 0 ? (rows_here - 1 - rloc) / rpp : 0);
-      const bool lane_has_rows = FULL || rloc < rows_here;
+      const int last_i = (rows_here - 1 - rloc) / rpp;
       auto fetch = [&](int u, int i) {
-        if (DBG == 2) {  // timing experiment: arithmetic only
-          th[u] = 0.3 + 1e-3 * i;
-          ph[u] = -0.4 + 1e-3 * i;
-        } else {
-          const int ic = i < last_i ? i : last_i;
-          th[u] = __builtin_nontemporal_load(tp + (int64_t)act * ic);
-          ph[u] = __builtin_nontemporal_load(pp + (int64_t)act * ic);
-        }
+        const int ic = i < last_i ? i : last_i;
+        th[u] = __builtin_nontemporal_load(tp + (int64_t)act * ic);
+        ph[u] = __builtin_nontemporal_load(pp + (int64_t)act * ic);
       };
-      if (!lane_has_rows) return;  // (tail tile only) this lane's first row is already past the end
 #pragma unroll
       for (int u = 0; u < UB; ++u) fetch(u, u);
-      auto pass = [&](int u, int i) {
-        const int r = rloc + rpp * i;
-        const double t_u = th[u], p_u = ph[u];
-        fetch(u, i + UB);
-        double v;
-        if (DBG == 1) {  // timing experiment: memory only
-          v = t_u + p_u;
-        } else {
-          double num, den;
-          m::tan_parts_0_halfpi(p_u / 2.0 + kPi / 4.0, &num, &den);
-          const double cs = m::cos_quadrant(t_u + psi, j0);
-          v = (wk * num) * cs * m::rcp_refined(den);
-        }
-        if (FULL || r < rows_here) val[r * SP + k] = v;
-      };
-      if constexpr (ITERS > 0) {
+      for (int i0 = 0; i0 < iters; i0 += UB) {
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-          pass(i % UB, i);
-          __builtin_amdgcn_sched_barrier(0);  // keep the refill of slot u next to its use: no load clustering
+        for (int u = 0; u < UB; ++u) {
+          const int i = i0 + u;
+          const int r = rloc + rpp * i;
+          const double t_u = th[u], p_u = ph[u];
+          fetch(u, i + UB);
+          const double v = DBG == 1 ? t_u + p_u : ilt_term(K, t_u, p_u, L);
+          if (r < rows_here) val[r * SP + k] = v;
         }
-      } else {
-        for (int i0 = 0; i0 < iters; i0 += UB) {
-#pragma unroll
-          for (int u = 0; u < UB; ++u) pass(u, i0 + u);
-        }
-      }
-    };
-    if (active) {
-      if (rows_here == rows) {
-        tile(std::true_type{});
-      } else {
-        tile(std::false_type{});
       }
     }
     __syncthreads();
@@ -157,10 +290,7 @@ __global__ __launch_bounds__(256) void ilt_fourier_kernel(const IltArgs a) {
       double acc = 0.0;
       for (int kk = 0; kk < S; ++kk) acc += v[kk];
       const int64_t row = row0 + threadIdx.x;
-      const double t = a.t[row / a.d];
-      const double Tt = a.scale * t;
-      const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
-      a.x[row] = exp(gamma * t) / Tt * acc;
+      a.x[row] = ilt_row_scale(a, a.t[row / a.d]) * acc;
     }
     __syncthreads();
   }

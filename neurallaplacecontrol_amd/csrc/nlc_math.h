@@ -273,5 +273,69 @@ NLC_HD double cos_quadrant(double x, int j0) {
   return ((j + 1) & 2) ? -cc : cc;
 }
 
+// ---- short forms for the stand-alone Fourier ILT kernel, which is bound by its FP64 instruction count
+// (kernels_ilt.hip).  Chebyshev-interpolation polynomials in z = y^2; ABSOLUTE accuracy ~2e-16 (the fdlibm
+// kernels above are relative-accurate near the zeros and cost 21 instructions for the sin/cos pair).
+// Every constant comes from an IltTrigK the caller holds: the kernel pins its members in SGPRs, so each Horner step
+// is ONE v_fma_f64 with a scalar addend (left to itself the compiler parks the 64-bit constants in VGPRs and emits a
+// v_mov_b64 + v_fmac_f64 pair per step, and at 128 VGPRs it spills).
+struct IltTrigK {
+  double s[6];   // sin(a)/a - 1 = z S(z), |a| <= pi/4: fdlibm S1..S6, highest degree first
+  double c4[6];  // cos(a) = 1 + z C(z), |a| <= pi/4 (+0.1 %): degree 6 in z, approximation error 4.8e-17
+  double c2[8];  // cos(y) = 1 + z C(z), |y| <= pi/2 (+0.01 %): degree 8 in z, approximation error 3.9e-18
+  double pio4_hi, pio4_lo, pio2_hi, pio2_lo, inv_pi, round_shift, den_min;
+};
+constexpr double kRoundShift = 6755399441055744.0;  // 1.5 * 2^52
+NLC_HD IltTrigK ilt_trig_k() {
+  IltTrigK K = {
+      {1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,
+       -1.98412698298579493134e-04, 8.33333333332248946124e-03, -1.66666666666666324348e-01},
+      {0x1.1b893bd61e9c0p-29, -0x1.27df3a2ecce24p-22, 0x1.a019f7eebbb5ep-16, -0x1.6c16c163b498ep-10,
+       0x1.555555554e6d2p-5, -0x1.fffffffffff77p-2},
+      {0x1.9f230043b0248p-45, -0x1.93509d0fccb4ap-37, 0x1.1eecdf1eb9cc7p-29, -0x1.27e4f978cae28p-22,
+       0x1.a01a01994a786p-16, -0x1.6c16c16c09b0ep-10, 0x1.55555555553c4p-5, -0x1.ffffffffffffbp-2},
+      0.5 * kPio2Hi, 0.5 * kPio2Lo, kPio2Hi, kPio2Lo, 3.18309886183790691216e-01, kRoundShift,
+      // tan of the double nearest pi/2 (1.633e16) = the reference's saturated |F| when tanh rounds to 1
+      8.659560562354934e-17};
+  return K;
+}
+// cos(x + m pi/2) for m in {0, 1} and |x| < ~1e5: ONE reduction by pi, q = rint(x/pi + m/2), y = x - (2q - m) pi/2 in
+// [-pi/2, pi/2], result (-1)^q cos(y).  The rounding uses the 1.5 * 2^52 shift, so the parity of q is bit 0 of the
+// shifted sum's low word and flips the result's sign bit directly (no v_rndne / v_cvt / compare / select).
+// half_m = m/2 and dm = (double)m are lane constants of the caller.  (m/2 cannot ride in the shift constant: at
+// 1.5 * 2^52 the spacing is 1.)
+NLC_HD double cos_plus_mpio2(const IltTrigK& K, double x, double half_m, double dm) {
+  const double sh = fma(x, K.inv_pi, half_m) + K.round_shift;
+  const double q = sh - K.round_shift;
+  const double n = fma(2.0, q, -dm);
+  double y = fma(-n, K.pio2_hi, x);
+  y = fma(-n, K.pio2_lo, y);
+  const double z = y * y;
+  double p = fma(K.c2[0], z, K.c2[1]);
+  for (int i = 2; i < 8; ++i) p = fma(p, z, K.c2[i]);
+  const double c = fma(p, z, 1.0);
+  uint64_t sb, cb;
+  __builtin_memcpy(&sb, &sh, sizeof(sb));
+  __builtin_memcpy(&cb, &c, sizeof(cb));
+  cb ^= sb << 63;
+  double r;
+  __builtin_memcpy(&r, &cb, sizeof(r));
+  return r;
+}
+// tan(x) = num/den for x in [0, pi/2] as (cos a + sin a)/(cos a - sin a), a = x - pi/4 (cf. tan_parts_0_halfpi);
+// den is clamped at the value that reproduces the reference's saturated |F|.
+NLC_HD void tan_parts_short(const IltTrigK& K, double x, double* num, double* den) {
+  const double a = (x - K.pio4_hi) - K.pio4_lo;
+  const double z = a * a;
+  double p = fma(K.s[0], z, K.s[1]);
+  for (int i = 2; i < 6; ++i) p = fma(p, z, K.s[i]);
+  const double sa = fma(a * z, p, a);
+  double c = fma(K.c4[0], z, K.c4[1]);
+  for (int i = 2; i < 6; ++i) c = fma(c, z, K.c4[i]);
+  const double ca = fma(c, z, 1.0);
+  *num = ca + sa;
+  *den = fmax(ca - sa, K.den_min);
+}
+
 }  // namespace m
 }  // namespace nlc

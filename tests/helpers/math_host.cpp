@@ -17,3 +17,19 @@ extern "C" {
 void nlc_t_tanh_t(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tanh_t(x[i], kTab); }
 void nlc_t_sigmoid_t(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::sigmoid_t(x[i], kTab); }
 }
+extern "C" {
+// short forms of the Fourier ILT kernel: cos(x + m pi/2) with m = i & 1, tan(x) on [0, pi/2] as num/den
+void nlc_t_cos_mpio2(const double* x, double* y, long n) {
+  for (long i = 0; i < n; ++i) {
+    const double dm = (double)(i & 1);
+    y[i] = nlc::m::cos_plus_mpio2(nlc::m::ilt_trig_k(), x[i], 0.5 * dm, dm);
+  }
+}
+void nlc_t_tan_short(const double* x, double* y, long n) {
+  for (long i = 0; i < n; ++i) {
+    double num, den;
+    nlc::m::tan_parts_short(nlc::m::ilt_trig_k(), x[i], &num, &den);
+    y[i] = num / den;
+  }
+}
+}

@@ -65,6 +65,22 @@ def test_ilt_fourier_vs_oracle(nlc, d, S):
         np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("d,S,N", [(5, 17, 250_037), (3, 33, 200_003), (6, 9, 120_001)])
+def test_ilt_fourier_many_tiles_per_block(nlc, d, S, N):
+    """More tiles than the persistent grid has blocks: every block streams several tiles through the continuous
+    cross-tile load pipeline (successor-tile prefetch, last whole tile without a successor, ragged tail tile)."""
+    from oracle import ilt as oilt
+
+    g = torch.Generator().manual_seed(N)
+    theta = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi / 2 * 0.999
+    t = torch.rand(N, dtype=torch.float64, generator=g) * 2 + 0.05
+    ref = oilt.ilt_from_sphere(theta, phi, t, "fourier", None)
+    got = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), "fourier", None).cpu()
+    scale = ref.abs().max()
+    np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
+
+
 def test_ilt_empty_and_single(nlc):
     z = nlc.ilt_reconstruct(torch.zeros(0, 5, 17).double().cuda(), torch.zeros(0, 5, 17).double().cuda(),
                             torch.zeros(0).double().cuda())

@@ -103,3 +103,22 @@ def test_table_driven_tanh_sigmoid(lib):
     ok = np.abs(xs) < 700
     assert ulp_err(y[ok], ref[ok]).max() <= 4
     assert np.all(np.isfinite(y)) and np.all(y >= 0) and np.all(y <= 1)
+
+
+def test_ilt_short_forms(lib):
+    """The instruction-count-trimmed trig of the stand-alone Fourier ILT kernel: absolute accuracy ~2e-16 for the
+    cosine (one reduction by pi, quarter-turn parity in the reduction), tan as num/den within a few ulp away from the
+    pole and tracking the conditioning of the argument's own rounding next to it."""
+    x = np.concatenate([np.linspace(-7.0, 7.0, 800001), np.linspace(-1e3, 1e3, 20001), [0.0, np.pi, -np.pi]])
+    mm = (np.arange(x.size) & 1).astype(np.float64)
+    y = call(lib, "nlc_t_cos_mpio2", x)
+    xl = x.astype(np.longdouble)
+    ref = np.where(mm == 0, np.cos(xl), -np.sin(xl))  # cos(x + pi/2) = -sin(x)
+    bound = 3e-16 + 1.2e-16 * np.abs(x) / np.pi  # 2-term pi/2: the reduction error grows with the quotient
+    assert np.all(np.abs(y - ref.astype(np.float64)) <= bound)
+    xt = np.linspace(0.0, np.pi / 2, 400001)[:-1]
+    t = call(lib, "nlc_t_tan_short", xt)
+    ref_t = np.tan(xt)
+    # relative error bounded by a few ulp plus the pole's conditioning: d tan / tan = dx (1 + tan^2)/tan
+    cond = (1 + ref_t ** 2) / np.maximum(ref_t, 1e-300) * 2.3e-16
+    assert np.all(np.abs(t - ref_t) <= (6e-16 + cond) * np.maximum(np.abs(ref_t), 1.0))
