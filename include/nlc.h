@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 3
+#define NLC_ABI_VERSION 4
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -91,6 +91,14 @@ int nlc_ilt_rep_inputs(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* p_d
  * -> x_dev (N, d).  HBM-bound streaming kernel for Fourier; algorithmic bytes (2dS+d)*8 per point. */
 int nlc_ilt_reconstruct(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* theta_dev, const double* phi_dev,
                         const double* t_dev, int64_t N, int d, double* x_dev);
+
+/* Backward of nlc_ilt_reconstruct with respect to the representation-function outputs (Fourier only): the
+ * reference trains the rep func THROUGH torchlaplace.laplace_reconstruct by autograd (train_utils.py:388-407 ->
+ * w_nl.py:137-144).  grad_x_dev (N, d) upstream gradient -> grad_theta_dev, grad_phi_dev (N, d, S).  No gradient
+ * with respect to t.  HBM-bound streaming kernel; algorithmic bytes 4dS*8 per point. */
+int nlc_ilt_reconstruct_backward(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* theta_dev,
+                                 const double* phi_dev, const double* t_dev, const double* grad_x_dev, int64_t N,
+                                 int d, double* grad_theta_dev, double* grad_phi_dev);
 
 /* ---- model: NeuralLaplaceModel (w_nl.py:66-145), ReverseGRUEncoder (:14-29),
  *      LaplaceRepresentationFunc (:32-63) ------------------------------------------------------- */

@@ -34,6 +34,7 @@ SYMBOLS = [
     "nlc_device_info",
     "nlc_ilt_rep_inputs",
     "nlc_ilt_reconstruct",
+    "nlc_ilt_reconstruct_backward",
     "nlc_model_blob_size",
     "nlc_set_model",
     "nlc_gru_encode",
@@ -148,6 +149,7 @@ def load_library():
         lib.nlc_device_info.argtypes = [vp, C.c_char_p, i32, P(i32), P(i32), P(dbl)]
         lib.nlc_ilt_rep_inputs.argtypes = [vp, P(IltDesc), vp, vp, i32, i64, i64, i32, vp]
         lib.nlc_ilt_reconstruct.argtypes = [vp, P(IltDesc), vp, vp, vp, i64, i32, vp]
+        lib.nlc_ilt_reconstruct_backward.argtypes = [vp, P(IltDesc), vp, vp, vp, vp, i64, i32, vp, vp]
         lib.nlc_model_blob_size.argtypes = [P(ModelDesc)]
         lib.nlc_model_blob_size.restype = i64
         lib.nlc_set_model.argtypes = [vp, P(ModelDesc), vp, i64]

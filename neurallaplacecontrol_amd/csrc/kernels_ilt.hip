@@ -334,6 +334,91 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ Fourier series, backward
+// x[n,c] = s(t_n) sum_k w_k R(phi_k) cos(theta_k + psi_k),  R(phi) = tan(phi/2 + pi/4) = num/den,  s = e^{gamma t}/T:
+//   d x / d theta_k = -s w_k R sin(theta_k + psi_k)
+//   d x / d phi_k   =  s w_k cos(theta_k + psi_k) / den^2        (R' = (1 + R^2)/2 and num^2 + den^2 = 2)
+// One pass over the same (row, term) stream as the forward kernel: reads theta, phi, writes grad_theta, grad_phi
+// (4 d S * 8 algorithmic bytes per point), the row's upstream gradient times s staged per tile in LDS.
+// No gradient flows to t (the reference's planner and training loop never differentiate the time grid).
+__global__ __launch_bounds__(256) void ilt_fourier_bwd_kernel(const IltBwdArgs a) {
+  extern __shared__ double gs[];  // [rows]
+  const int S = a.S;
+  const int rpp = a.rpp, iters = a.iters, rows = rpp * iters;
+  const int act = rpp * S;
+  const bool active = (int)threadIdx.x < act;
+  const int k = (int)threadIdx.x % S, rloc = (int)threadIdx.x / S;
+  const IltLane L = ilt_lane(k, a.scale);
+  const m::IltTrigK K = ilt_trig_k_sgpr();
+  const int64_t rows_total = a.N * a.d;
+  const int64_t nblk = (rows_total + rows - 1) / rows;
+  constexpr int UB = 8;
+  IltArgs sc{};  // the row scale only reads these
+  sc.alpha = a.alpha;
+  sc.log_tol = a.log_tol;
+  sc.scale = a.scale;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t row0 = blk * rows;
+    const int rows_here = (int)((rows_total - row0 < rows) ? (rows_total - row0) : rows);
+    if ((int)threadIdx.x < rows_here) {
+      const int64_t row = row0 + threadIdx.x;
+      gs[threadIdx.x] = a.gx[row] * ilt_row_scale(sc, a.t[row / a.d]);
+    }
+    __syncthreads();
+    if (active && rloc < rows_here) {
+      const double* __restrict__ tp = a.theta + row0 * S + threadIdx.x;
+      const double* __restrict__ pp = a.phi + row0 * S + threadIdx.x;
+      double* __restrict__ gt = a.gtheta + row0 * S + threadIdx.x;
+      double* __restrict__ gp = a.gphi + row0 * S + threadIdx.x;
+      double th[UB], ph[UB];
+      const int last_i = (rows_here - 1 - rloc) / rpp;
+      auto fetch = [&](int u, int i) {
+        const int ic = i < last_i ? i : last_i;  // past the end: re-read the last valid pass (no branch at the load)
+        th[u] = __builtin_nontemporal_load(tp + (int64_t)act * ic);
+        ph[u] = __builtin_nontemporal_load(pp + (int64_t)act * ic);
+      };
+#pragma unroll
+      for (int u = 0; u < UB; ++u) fetch(u, u);
+      for (int i0 = 0; i0 < iters; i0 += UB) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int i = i0 + u;
+          const int r = rloc + rpp * i;
+          double xt, xp;
+          ilt_args(th[u], ph[u], L.psi, &xt, &xp);
+          fetch(u, i + UB);
+          double num, den, sn, cs;
+          m::tan_parts_short(K, xp, &num, &den);
+          m::sincos_plus_mpio2(K, xt, L.half_m, L.dm, &sn, &cs);
+          const double inv = m::rcp_refined(den);
+          if (r < rows_here) {
+            const double g = gs[r] * L.wk;
+            __builtin_nontemporal_store(-(g * num) * inv * sn, gt + (int64_t)act * i);
+            __builtin_nontemporal_store((g * cs) * inv * inv, gp + (int64_t)act * i);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_ilt_fourier_bwd(const IltBwdArgs& a_in, hipStream_t s) {
+  IltBwdArgs a = a_in;
+  const int64_t rows_total = a.N * a.d;
+  if (rows_total <= 0) return hipSuccess;
+  if (a.S > 256) return hipErrorInvalidValue;
+  a.rpp = 256 / a.S;
+  if (a.rpp > 32) a.rpp = 32;
+  a.iters = 256 / a.rpp / 8 * 8;  // rows = rpp * iters <= 256: one thread per row stages the row's gradient
+  if (a.iters < 8) return hipErrorInvalidValue;
+  const int rows = a.rpp * a.iters;
+  const int64_t nblk = (rows_total + rows - 1) / rows;
+  const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
+  hipLaunchKernelGGL(ilt_fourier_bwd_kernel, dim3(grid), dim3(256), (size_t)rows * sizeof(double), s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ de Hoog, Knight & Stokes
 struct cplx {
   double re, im;

@@ -333,6 +333,24 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
   NLC_GUARD_END(c)
 }
 
+extern "C" int nlc_ilt_reconstruct_backward(nlc_ctx* c, const nlc_ilt_desc* d, const double* theta, const double* phi,
+                                            const double* t, const double* grad_x, int64_t N, int dd,
+                                            double* grad_theta, double* grad_phi) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (int r = check_ilt(c, d)) return r;
+  if (d->algo != NLC_ILT_FOURIER) return fail(c, NLC_ERR_UNSUPPORTED, "backward is implemented for the Fourier ILT only");
+  if (N < 0 || dd < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or d");
+  if (N == 0) return NLC_OK;
+  if (!theta || !phi || !t || !grad_x || !grad_theta || !grad_phi) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  IltBwdArgs a{theta, phi, t, grad_x, grad_theta, grad_phi, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, 0, 0};
+  ProfScope ps(c, "ilt_fourier_bwd_kernel");
+  NLC_HIP(c, launch_ilt_fourier_bwd(a, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
 // =================================================================================== model
 extern "C" int64_t nlc_model_blob_size(const nlc_model_desc* d) { return d ? blob_size(d) : -1; }
 

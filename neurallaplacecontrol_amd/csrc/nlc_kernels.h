@@ -26,6 +26,20 @@ struct IltArgs {
   int dbg;         // 0 normal; timing experiments only: 1 memory-only, 2 arithmetic-only
 };
 hipError_t launch_ilt_fourier(const IltArgs& a, hipStream_t s);
+// backward of the Fourier ILT with respect to theta / phi (training through laplace_reconstruct)
+struct IltBwdArgs {
+  const double* theta;  // (N, d, S)
+  const double* phi;    // (N, d, S)
+  const double* t;      // (N)
+  const double* gx;     // (N, d) upstream gradient
+  double* gtheta;       // (N, d, S)
+  double* gphi;         // (N, d, S)
+  int64_t N;
+  int d, S;
+  double alpha, log_tol, scale;
+  int rpp, iters;  // set by the launcher
+};
+hipError_t launch_ilt_fourier_bwd(const IltBwdArgs& a, hipStream_t s);
 hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s);
 
 struct RepInArgs {

@@ -322,6 +322,36 @@ NLC_HD double cos_plus_mpio2(const IltTrigK& K, double x, double half_m, double 
   __builtin_memcpy(&r, &cb, sizeof(r));
   return r;
 }
+// sin(x + m pi/2) and cos(x + m pi/2) by the same single reduction (backward of the Fourier ILT needs both):
+// sin(y) = y + y z S(z) on |y| <= pi/2, degree 7 in z (approximation error 1.3e-18)
+NLC_HD void sincos_plus_mpio2(const IltTrigK& K, double x, double half_m, double dm, double* sn, double* cs) {
+  const double sh = fma(x, K.inv_pi, half_m) + K.round_shift;
+  const double q = sh - K.round_shift;
+  const double n = fma(2.0, q, -dm);
+  double y = fma(-n, K.pio2_hi, x);
+  y = fma(-n, K.pio2_lo, y);
+  const double z = y * y;
+  double p = fma(K.c2[0], z, K.c2[1]);
+  for (int i = 2; i < 8; ++i) p = fma(p, z, K.c2[i]);
+  const double c = fma(p, z, 1.0);
+  double u = 0x1.89a3f16388edcp-49;
+  u = fma(u, z, -0x1.ae513415aadccp-41);
+  u = fma(u, z, 0x1.6124014cbe2fcp-33);
+  u = fma(u, z, -0x1.ae6455a1a9e7ep-26);
+  u = fma(u, z, 0x1.71de3a54562a8p-19);
+  u = fma(u, z, -0x1.a01a01a018aa6p-13);
+  u = fma(u, z, 0x1.1111111111107p-7);
+  u = fma(u, z, -0x1.5555555555555p-3);
+  const double sv = fma(y * z, u, y);
+  uint64_t sb, cb, vb;
+  __builtin_memcpy(&sb, &sh, sizeof(sb));
+  __builtin_memcpy(&cb, &c, sizeof(cb));
+  __builtin_memcpy(&vb, &sv, sizeof(vb));
+  cb ^= sb << 63;
+  vb ^= sb << 63;
+  __builtin_memcpy(cs, &cb, sizeof(cb));
+  __builtin_memcpy(sn, &vb, sizeof(vb));
+}
 // tan(x) = num/den for x in [0, pi/2] as (cos a + sin a)/(cos a - sin a), a = x - pi/4 (cf. tan_parts_0_halfpi);
 // den is clamped at the value that reproduces the reference's saturated |F|.
 NLC_HD void tan_parts_short(const IltTrigK& K, double x, double* num, double* den) {

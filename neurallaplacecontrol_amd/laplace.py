@@ -5,6 +5,8 @@ Stages, all on the device:
   1. HIP ``nlc_ilt_rep_inputs``  -- contour evaluation s_k(t), Riemann-sphere projection, concat with p
   2. the caller's ``laplace_rep_func`` (any torch callable; PyTorch-ROCm)
   3. HIP ``nlc_ilt_reconstruct`` -- sphere->complex and the Fourier / de Hoog line integral
+     (Fourier: differentiable, ``nlc_ilt_reconstruct_backward`` is its autograd backward, so a representation
+     function trains through it as through torchlaplace)
 
 **Parity unpinned vs upstream torchlaplace** (the package is absent offline): defaults ``alpha``,
 ``tol``, ``scale`` and the ``[theta_s | phi_s | p]`` input order follow SURVEY.md §A.3 and can be
@@ -72,19 +74,10 @@ def rep_func_inputs(p, t, ilt_reconstruction_terms, ilt_algorithm="fourier", opt
     return out, t2
 
 
-def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=None):
-    """theta, phi: (N, d, S) representation-function outputs, t: (N,) -> x (N, d)."""
-    dev = compute_device(theta, phi, t)
-    theta_d, phi_d, t_d = _prep(theta, dev), _prep(phi, dev), _prep(t, dev).reshape(-1)
-    if theta_d.dim() != 3 or theta_d.shape != phi_d.shape:
-        raise ValueError("theta and phi must both be (N, d, S)")
-    N, d, S = theta_d.shape
-    if t_d.numel() != N:
-        raise ValueError("t must have one entry per row of theta/phi")
-    desc = _lib.ilt_desc(ilt_algorithm, S, options)
-    x = torch.empty((N, d), dtype=torch.float64, device=dev)
-    ctx = ctx or default_ctx(dev.index)
-    with torch.cuda.device(dev):
+def _ilt_forward(theta_d, phi_d, t_d, desc, ctx):
+    N, d, _ = theta_d.shape
+    x = torch.empty((N, d), dtype=torch.float64, device=theta_d.device)
+    with torch.cuda.device(theta_d.device):
         ctx.use_torch_stream()
         ctx.check(
             ctx.lib.nlc_ilt_reconstruct(
@@ -92,6 +85,62 @@ def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=No
             )
         )
     return x
+
+
+class _IltFn(torch.autograd.Function):
+    """``nlc_ilt_reconstruct`` with ``nlc_ilt_reconstruct_backward`` as its vector-Jacobian product, so the
+    representation function trains through the HIP line integral as it does through torchlaplace
+    (``train_utils.py:388-407`` -> ``w_nl.py:137-144``).  Fourier ILT only; no gradient with respect to t."""
+
+    @staticmethod
+    def forward(fctx, theta, phi, t_d, desc, ctx):
+        theta_d, phi_d = theta.detach().contiguous(), phi.detach().contiguous()
+        fctx.save_for_backward(theta_d, phi_d, t_d)
+        fctx.desc, fctx.ctx = desc, ctx
+        return _ilt_forward(theta_d, phi_d, t_d, desc, ctx)
+
+    @staticmethod
+    def backward(fctx, grad_x):
+        theta_d, phi_d, t_d = fctx.saved_tensors
+        desc, ctx = fctx.desc, fctx.ctx
+        N, d, _ = theta_d.shape
+        g = grad_x.detach().to(dtype=torch.float64).contiguous()
+        g_theta, g_phi = torch.empty_like(theta_d), torch.empty_like(phi_d)
+        with torch.cuda.device(theta_d.device):
+            ctx.use_torch_stream()
+            ctx.check(
+                ctx.lib.nlc_ilt_reconstruct_backward(
+                    ctx.h, C.byref(desc), _lib.ptr(theta_d), _lib.ptr(phi_d), _lib.ptr(t_d), _lib.ptr(g), N, d,
+                    _lib.ptr(g_theta), _lib.ptr(g_phi),
+                )
+            )
+        return g_theta, g_phi, None, None, None
+
+
+def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=None):
+    """theta, phi: (N, d, S) representation-function outputs, t: (N,) -> x (N, d).
+
+    Differentiable with respect to theta / phi for the Fourier algorithm (HIP backward kernel); with de Hoog the
+    inputs must not require grad."""
+    dev = compute_device(theta, phi, t)
+    needs_grad = torch.is_grad_enabled() and (
+        (torch.is_tensor(theta) and theta.requires_grad) or (torch.is_tensor(phi) and phi.requires_grad)
+    )
+    t_d = _prep(t, dev).reshape(-1)
+    if theta.dim() != 3 or theta.shape != phi.shape:
+        raise ValueError("theta and phi must both be (N, d, S)")
+    N, d, S = theta.shape
+    if t_d.numel() != N:
+        raise ValueError("t must have one entry per row of theta/phi")
+    desc = _lib.ilt_desc(ilt_algorithm, S, options)
+    ctx = ctx or default_ctx(dev.index)
+    if needs_grad:
+        if desc.algo != 0:
+            raise NotImplementedError("autograd through the HIP ILT is implemented for ilt_algorithm='fourier' only")
+        return _IltFn.apply(
+            theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc, ctx
+        )
+    return _ilt_forward(_prep(theta, dev), _prep(phi, dev), t_d, desc, ctx)
 
 
 def laplace_reconstruct(
@@ -121,6 +170,10 @@ def laplace_reconstruct(
         recon_dim = p.shape[1]
     inp, t2 = rep_func_inputs(p, t, S, ilt_algorithm, options)
     B, Tt = t2.shape
+    if torch.is_grad_enabled() and p.requires_grad:
+        # training: the query-point columns are constants, the latent columns must stay in the autograd graph
+        p_dev = p.to(device=inp.device, dtype=torch.float64)
+        inp = torch.cat((inp[..., : 2 * S], p_dev.unsqueeze(1).expand(B, Tt, p_dev.shape[1])), dim=2)
     theta, phi = laplace_rep_func(inp)
     theta = theta.reshape(B * Tt, recon_dim, S)
     phi = phi.reshape(B * Tt, recon_dim, S)

@@ -32,4 +32,12 @@ void nlc_t_tan_short(const double* x, double* y, long n) {
     y[i] = num / den;
   }
 }
+void nlc_t_sin_mpio2(const double* x, double* y, long n) {
+  for (long i = 0; i < n; ++i) {
+    const double dm = (double)(i & 1);
+    double sn, cs;
+    nlc::m::sincos_plus_mpio2(nlc::m::ilt_trig_k(), x[i], 0.5 * dm, dm, &sn, &cs);
+    y[i] = sn;
+  }
+}
 }

@@ -81,6 +81,69 @@ def test_ilt_fourier_many_tiles_per_block(nlc, d, S, N):
     np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("d,S,N", [(5, 17, 1537), (3, 33, 700), (6, 9, 2049), (2, 17, 1), (5, 17, 90_001)])
+def test_ilt_fourier_backward_vs_autograd_of_oracle(nlc, d, S, N):
+    """nlc_ilt_reconstruct_backward against torch autograd through the CPU restatement (float64)."""
+    from oracle import ilt as oilt
+
+    g = torch.Generator().manual_seed(7 * N + S)
+    theta = ((torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi).requires_grad_()
+    phi = ((torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi / 2 * 0.99).requires_grad_()
+    t = torch.rand(N, dtype=torch.float64, generator=g) * 2 + 0.05
+    gx = torch.randn(N, d, dtype=torch.float64, generator=g)
+    for opts in (None, dict(scale=3.0, alpha=1e-2)):
+        ref = oilt.ilt_from_sphere(theta, phi, t, "fourier", opts)
+        rt, rp = torch.autograd.grad(ref, (theta, phi), gx)
+        th_d = theta.detach().cuda().requires_grad_()
+        ph_d = phi.detach().cuda().requires_grad_()
+        got = nlc.ilt_reconstruct(th_d, ph_d, t.cuda(), "fourier", opts)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-9,
+                                   atol=1e-11 * float(ref.abs().max()))
+        gt, gp = torch.autograd.grad(got, (th_d, ph_d), gx.cuda())
+        for a, b in ((gt, rt), (gp, rp)):
+            sc = float(b.abs().max())
+            np.testing.assert_allclose(a.cpu().numpy() / sc, b.numpy() / sc, rtol=1e-9, atol=1e-12)
+
+
+def test_laplace_reconstruct_trains_rep_func_through_hip_ilt(nlc):
+    """Gradients reach the representation function's weights AND the latent p through laplace_reconstruct
+    (the training path of w_nl.py:137-144), equal to autograd through the CPU restatement."""
+    from oracle import ilt as oilt
+
+    torch.manual_seed(3)
+    B, P, d, S = 37, 7, 5, 17
+    lin = torch.nn.Linear(2 * S + P, 2 * d * S).double()
+
+    def make_rep(mod):
+        def rep(i):
+            out = mod(i.reshape(-1, 2 * S + P)).view(-1, 2 * d, S)
+            return torch.tanh(out[:, :d, :]) * np.pi, torch.tanh(out[:, d:, :]) * np.pi / 2
+        return rep
+
+    p = torch.randn(B, P, dtype=torch.float64)
+    t = torch.tensor([0.1, 0.25, 0.7], dtype=torch.float64)
+    p_ref = p.clone().requires_grad_()
+    ref = oilt.laplace_reconstruct(make_rep(lin), p_ref, t, recon_dim=d, ilt_algorithm="fourier",
+                                   ilt_reconstruction_terms=S)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    ref_grads = [lin.weight.grad.clone(), lin.bias.grad.clone(), p_ref.grad.clone()]
+    lin_d = torch.nn.Linear(2 * S + P, 2 * d * S).double().cuda()
+    lin_d.load_state_dict(lin.state_dict())
+    p_d = p.cuda().requires_grad_()
+    got = nlc.laplace_reconstruct(make_rep(lin_d), p_d, t.cuda(), recon_dim=d, ilt_algorithm="fourier",
+                                  ilt_reconstruction_terms=S)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-9, atol=1e-11)
+    (got * w.cuda()).sum().backward()
+    for a, b in zip((lin_d.weight.grad, lin_d.bias.grad, p_d.grad), ref_grads):
+        sc = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy() / sc, b.numpy() / sc, rtol=1e-8, atol=1e-11)
+    with pytest.raises(NotImplementedError):
+        nlc.ilt_reconstruct(torch.zeros(2, 1, 17, dtype=torch.float64, device="cuda", requires_grad=True),
+                            torch.zeros(2, 1, 17, dtype=torch.float64, device="cuda"),
+                            torch.full((2,), 0.1, dtype=torch.float64, device="cuda"), "dehoog")
+
+
 def test_ilt_empty_and_single(nlc):
     z = nlc.ilt_reconstruct(torch.zeros(0, 5, 17).double().cuda(), torch.zeros(0, 5, 17).double().cuda(),
                             torch.zeros(0).double().cuda())

@@ -116,6 +116,9 @@ def test_ilt_short_forms(lib):
     ref = np.where(mm == 0, np.cos(xl), -np.sin(xl))  # cos(x + pi/2) = -sin(x)
     bound = 3e-16 + 1.2e-16 * np.abs(x) / np.pi  # 2-term pi/2: the reduction error grows with the quotient
     assert np.all(np.abs(y - ref.astype(np.float64)) <= bound)
+    ys = call(lib, "nlc_t_sin_mpio2", x)
+    ref_s = np.where(mm == 0, np.sin(xl), np.cos(xl))  # sin(x + pi/2) = cos(x)
+    assert np.all(np.abs(ys - ref_s.astype(np.float64)) <= bound)
     xt = np.linspace(0.0, np.pi / 2, 400001)[:-1]
     t = call(lib, "nlc_t_tan_short", xt)
     ref_t = np.tan(xt)
