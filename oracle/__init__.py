@@ -14,6 +14,8 @@ Parity status
 * MPPI (a1-a4, a11), oracle dynamics, env costs, GRU encoder, representation
   MLP, model plumbing (a5-a8, a10, a12): PINNED against the imported reference
   classes -- see ``tests/golden/make_golden.py`` and the committed fixtures.
+* Delta-t RNN baseline (``rnn_model.py``): PINNED against the reference ``DeltaTRNN``
+  class (``tests/golden/make_golden_rnn.py``, fixtures ``g9_dtrnn_*``).
 * ``laplace_reconstruct`` body (a9): **parity unpinned vs upstream
   torchlaplace** -- the PyPI package ``torchlaplace`` (unpinned in the
   reference's ``requirements.txt:17``) is absent from the build container and
@@ -23,4 +25,4 @@ Parity status
   analytic Laplace pairs and ``mpmath.invertlaplace(method='dehoog')``.
 """
 
-from . import envs, ilt, mppi, nl_model  # noqa: F401
+from . import envs, ilt, mppi, nl_model, rnn_model  # noqa: F401

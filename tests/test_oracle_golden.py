@@ -292,3 +292,27 @@ def test_g8_running_cost_variants_and_terminal_cost(variant, dyn_name, golden_di
         for key, ref in (("action", "action"), ("U", "U_after"), ("cost_total", "cost_total"), ("omega", "omega"),
                          ("states", "states")):
             np.testing.assert_allclose(out[key].numpy(), g[pre + ref], err_msg=pre + key, **TOL)
+
+
+# --------------------------------------------------------------------------- G9: Delta-t RNN baseline (§8f row 4)
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_g9_dtrnn_oracle_matches_reference_class(env, golden_dir):
+    """oracle/rnn_model.py against the real DeltaTRNN (train_utils.py:589-631) and the real MPPIDelay driving it."""
+    from oracle import rnn_model as ornn
+
+    g = np.load(f"{golden_dir}/g9_dtrnn_{env}.npz")
+    sd = load_sd(g, "sd_")
+    obs, window, ts = T(g["fwd_obs"]), T(g["fwd_window"]), T(g["fwd_ts"])
+    np.testing.assert_allclose(ornn.forward(sd, obs, window, ts).numpy(), g["fwd_out"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(
+        ornn.forward(sd, obs, window, ts, normalize=True, normalize_time=False).numpy(), g["raw_out"],
+        rtol=1e-11, atol=1e-13)
+    with pytest.raises(NameError):
+        ornn.forward(sd, obs, window, ts, normalize=False, normalize_time=True)
+    run_steps(g, ornn.make_dynamics(sd), oenvs.RUNNING_COST["oderl-" + env], int(g["nx"]), int(g["nu"]), float(g["A"]))
+    # the synthetic-weight helper reproduces the reference constructor's draw order (GRU, then linear_out)
+    st = onl.ENV_STATS["oderl-" + env]
+    mine = ornn.make_synthetic_state_dict(40, st["d"], st["nu"], int(g["H"]), st["state_std"], [st["act_high"] / 2.0])
+    for k, v in sd.items():
+        if k.startswith(("gru.", "linear_out.", "dt", "state_std", "action_std")):
+            np.testing.assert_allclose(mine[k].numpy(), v.numpy(), rtol=1e-15, atol=0, err_msg=k)
