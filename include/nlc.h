@@ -56,6 +56,8 @@ extern "C" {
 #define NLC_DYN_ORACLE 1 /* oracle.{cartpole,pendulum,acrobot}_dynamics_dt_delay (mppi_with_model.py:129-143) */
 #define NLC_DYN_EXTERNAL 2 /* caller-supplied dynamics/cost callables: the caller runs the horizon loop
                               (mppi_delay.py:271-296) itself between nlc_mppi_rollout and nlc_mppi_weights */
+#define NLC_DYN_DTRNN 3    /* state + DeltaTRNN(state, window, ts_pred): the reference's Delta-t RNN baseline
+                              (train_utils.py:589-631) behind the same harness closure (mppi_with_model.py:103-122) */
 
 typedef struct nlc_ctx nlc_ctx;
 
@@ -130,6 +132,29 @@ int64_t nlc_model_workspace_bytes(nlc_ctx* ctx, int64_t N);
 int nlc_model_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev,
                       int64_t N, int B, double* out_dev, void* ws_dev);
 
+/* ---- baseline model: DeltaTRNN (train_utils.py:589-631; factory :56-74, rnn_hidden_units config.py:43) ------
+ * out, _ = GRU(nin -> hidden, 1 layer, batch_first)(window_n); dx = linear_out(cat(out[:, -1], obs_n, ts_n)). */
+typedef struct {
+  int32_t d;      /* state_dim */
+  int32_t nin;    /* GRU input dim = action_dim (+1 for an encode_obs_time model; forward API only) */
+  int32_t hidden; /* hidden_units: 64, 128 or 160 */
+  /* The caller resolves the reference's branch structure (train_utils.py:618-626; the `else` of the raw-input branch
+   * belongs to `if self.normalize_time`): normalised branch -> the model's buffers and time_div = dt*8; raw branch
+   * (normalize_time False) -> state (0, 1), action (0, 3), time_div 1. */
+  double time_div;
+  double state_mean[NLC_MAX_D], state_std[NLC_MAX_D];
+  double action_mean[NLC_MAX_NIN], action_std[NLC_MAX_NIN];
+} nlc_rnn_desc;
+/* weights_host: float64 blob in the reference's state_dict order:
+ *   gru.weight_ih_l0 (3H,nin) gru.weight_hh_l0 (3H,H) gru.bias_ih_l0 (3H) gru.bias_hh_l0 (3H)
+ *   linear_out.weight (d, H+d+1) linear_out.bias (d) */
+int64_t nlc_rnn_blob_size(const nlc_rnn_desc* desc);
+int nlc_set_rnn_model(nlc_ctx* ctx, const nlc_rnn_desc* desc, const double* weights_host, int64_t n_doubles);
+/* DeltaTRNN.forward: obs_dev (N,d), window_dev (N,B,nin) raw actions, ts_dev (N) raw ts_pred -> out_dev (N,d)
+ * predicted state difference.  ws_dev: N*d doubles of scratch. */
+int nlc_rnn_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev, int64_t N,
+                    int B, double* out_dev, void* ws_dev);
+
 /* ---- planner: MPPIDelay (planners/mppi_delay.py:54-381) ------------------------------------- */
 typedef struct {
   int64_t K;        /* samples owned by THIS ctx (its shard of the population) */
@@ -186,7 +211,9 @@ typedef struct {
 } nlc_mppi_buffers;
 
 /* NLC_DYN_NL: the model's GRU input dim must be nu, or nu+1 for an encode_obs_time model -- the rollout then
- * appends the constant time channel B-1 .. 0 the harness closure builds (mppi_with_model.py:110-119). */
+ * appends the constant time channel B-1 .. 0 the harness closure builds (mppi_with_model.py:110-119).
+ * NLC_DYN_DTRNN: needs nlc_set_rnn_model first; GRU input dim == nu (the closure adds the time channel for
+ * model_name == "nl" only). */
 int nlc_mppi_configure(nlc_ctx* ctx, const nlc_mppi_desc* desc);
 int64_t nlc_mppi_workspace_bytes(nlc_ctx* ctx);
 int nlc_mppi_set_U(nlc_ctx* ctx, const double* U_host); /* (E,T,nu) control sequence(s), :161-164 */

@@ -17,7 +17,7 @@ NLC_MAX_D = 8
 
 ILT_ALGOS = {"fourier": 0, "dehoog": 1}
 ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
-DYN_NL, DYN_ORACLE, DYN_EXTERNAL = 0, 1, 2
+DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN = 0, 1, 2, 3
 
 ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE"}
 
@@ -40,6 +40,9 @@ SYMBOLS = [
     "nlc_gru_encode",
     "nlc_model_workspace_bytes",
     "nlc_model_forward",
+    "nlc_rnn_blob_size",
+    "nlc_set_rnn_model",
+    "nlc_rnn_forward",
     "nlc_mppi_configure",
     "nlc_mppi_workspace_bytes",
     "nlc_mppi_set_U",
@@ -56,6 +59,19 @@ SYMBOLS = [
 
 class IltDesc(C.Structure):
     _fields_ = [("algo", C.c_int32), ("terms", C.c_int32), ("alpha", C.c_double), ("tol", C.c_double), ("scale", C.c_double)]
+
+
+class RnnDesc(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32),
+        ("nin", C.c_int32),
+        ("hidden", C.c_int32),
+        ("time_div", C.c_double),
+        ("state_mean", C.c_double * NLC_MAX_D),
+        ("state_std", C.c_double * NLC_MAX_D),
+        ("action_mean", C.c_double * NLC_MAX_NIN),
+        ("action_std", C.c_double * NLC_MAX_NIN),
+    ]
 
 
 class ModelDesc(C.Structure):
@@ -157,6 +173,10 @@ def load_library():
         lib.nlc_model_workspace_bytes.argtypes = [vp, i64]
         lib.nlc_model_workspace_bytes.restype = i64
         lib.nlc_model_forward.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.nlc_rnn_blob_size.argtypes = [P(RnnDesc)]
+        lib.nlc_rnn_blob_size.restype = i64
+        lib.nlc_set_rnn_model.argtypes = [vp, P(RnnDesc), vp, i64]
+        lib.nlc_rnn_forward.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
         lib.nlc_mppi_configure.argtypes = [vp, P(MppiDesc)]
         lib.nlc_mppi_workspace_bytes.argtypes = [vp]
         lib.nlc_mppi_workspace_bytes.restype = i64

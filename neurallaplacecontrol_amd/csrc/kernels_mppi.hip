@@ -373,6 +373,74 @@ hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ Delta-t RNN baseline: linear_out tail + rollout
+// dx = q + W_out[:, H:H+d] obs_n + W_out[:, H+d] ts_n + b   (train_utils.py:618-631), q = hidden part from rnn_encode_kernel
+__device__ __forceinline__ void rnn_dx(const RnnHead& h, const double (&x)[NLC_MAX_D], const double* q, double tsn,
+                                       double (&dx)[NLC_MAX_D]) {
+  double on[NLC_MAX_D];
+  for (int j = 0; j < h.d; ++j) on[j] = (x[j] - h.mean[j]) / h.std[j];
+  for (int i = 0; i < h.d; ++i) {
+    double acc = q[i];
+    for (int j = 0; j < h.d; ++j) acc += h.Wx[i * h.d + j] * on[j];
+    dx[i] = acc + h.wt[i] * tsn + h.b[i];
+  }
+}
+__global__ __launch_bounds__(256) void rnn_forward_tail_kernel(const RnnForwardArgs a) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.N) return;
+  const int d = a.head.d;
+  double x[NLC_MAX_D], dx[NLC_MAX_D];
+  for (int i = 0; i < d; ++i) x[i] = a.obs[n * d + i];
+  rnn_dx(a.head, x, a.q + n * d, a.ts[n] / a.head.time_div, dx);
+  for (int i = 0; i < d; ++i) a.out[n * d + i] = dx[i];
+}
+hipError_t launch_rnn_forward_tail(const RnnForwardArgs& a, hipStream_t s) {
+  if (a.N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rnn_forward_tail_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// T-step rollout with the harness closure state + model(state, window, ts_pred) (mppi_with_model.py:103-122): one
+// thread per sample; the GRU half of the model is already in q (T, K, d), so a step is a d x d matvec + the cost.
+__global__ __launch_bounds__(256) void rnn_rollout_kernel(const RnnRolloutArgs a) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.K) return;
+  const int d = a.head.d;
+  double x[NLC_MAX_D], dx[NLC_MAX_D];
+  const int64_t e = k / a.Kep;
+  const double* st = a.state0 + (a.state_per_sample ? k : e) * d;
+  const double* U = a.U + e * a.T * a.nu;
+  for (int i = 0; i < d; ++i) x[i] = st[i];
+  const double tsn = a.ts / a.head.time_div;
+  double cost = 0.0, pcost = 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    rnn_dx(a.head, x, a.q + ((int64_t)t * a.K + k) * d, tsn, dx);
+    for (int i = 0; i < d; ++i) x[i] = x[i] + dx[i];
+    double u[NLC_MAX_NU];
+    for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(k * a.T + t) * a.nu + j];
+    if (a.states != nullptr)
+      for (int i = 0; i < d; ++i) a.states[(k * a.T + t) * d + i] = x[i];
+    double pc = 0.0;
+    for (int j = 0; j < a.nu; ++j) {
+      double acj = 0.0;
+      for (int ii = 0; ii < a.nu; ++ii) {
+        double e2 = a.noise[(k * a.T + t) * a.nu + ii];
+        if (a.noise_abs_cost) e2 = fabs(e2);
+        acj += (a.lambda_ * e2) * a.sigma_inv[ii * a.nu + j];
+      }
+      pc += U[t * a.nu + j] * acj;
+    }
+    cost += running_cost_o(a.env, x, u, a.nu);
+    pcost += pc;
+  }
+  a.cost_total[k] = cost + pcost;
+}
+hipError_t launch_rnn_rollout(const RnnRolloutArgs& a, hipStream_t s) {
+  if (a.K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rnn_rollout_kernel, dim3((unsigned)((a.K + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ per-step tail of the staged (de Hoog) planner path
 // x <- x + dx (mppi_with_model.py:120-121), store, running cost and perturbation cost of horizon step t.
 __global__ __launch_bounds__(256) void step_tail_kernel(const StepTailArgs a) {

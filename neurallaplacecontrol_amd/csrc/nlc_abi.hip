@@ -62,6 +62,13 @@ struct nlc_ctx {
   std::vector<double> W1s_host, b1_host;  // for folding the constant sphere inputs at configure time
   int* slot_dev = nullptr;                // (8*nt3) layer-3 slot -> c*S + k (de Hoog path)
 
+  // Delta-t RNN baseline model
+  bool has_rnn = false;
+  nlc_rnn_desc rd{};
+  double* rnn_base = nullptr;  // packed weights (device)
+  RnnArgs rnn{};
+  RnnHead rnn_head{};
+
   // planner
   bool has_mppi = false;
   nlc_mppi_desc pd{};
@@ -243,6 +250,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_flush(c);
   if (c->arena.base) hipFree(c->arena.base);
+  if (c->rnn_base) hipFree(c->rnn_base);
   if (c->slot_dev) hipFree(c->slot_dev);
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
@@ -592,6 +600,115 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
   NLC_GUARD_END(c)
 }
 
+// =================================================================================== Delta-t RNN baseline
+static int64_t rnn_blob_size(const nlc_rnn_desc* d) {
+  const int64_t H = d->hidden;
+  return 3 * H * d->nin + 3 * H * H + 6 * H + (int64_t)d->d * (H + d->d + 1) + d->d;
+}
+extern "C" int64_t nlc_rnn_blob_size(const nlc_rnn_desc* d) { return d ? rnn_blob_size(d) : -1; }
+
+extern "C" int nlc_set_rnn_model(nlc_ctx* c, const nlc_rnn_desc* d, const double* w, int64_t n) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
+  if (d->hidden != 64 && d->hidden != 128 && d->hidden != 160)
+    return fail(c, NLC_ERR_UNSUPPORTED, "DeltaTRNN hidden_units must be 64, 128 or 160");
+  if (d->d < 1 || d->d > NLC_MAX_D) return fail(c, NLC_ERR_UNSUPPORTED, "state_dim must be in 1..8");
+  if (d->nin < 1 || d->nin > NLC_MAX_NIN) return fail(c, NLC_ERR_UNSUPPORTED, "GRU input dim must be in 1..3");
+  if (!(d->time_div != 0.0)) return fail(c, NLC_ERR_BAD_ARG, "time_div must be non-zero");
+  if (n != rnn_blob_size(d)) return fail(c, NLC_ERR_BAD_SHAPE, "weight blob size mismatch");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const int H = d->hidden, dd = d->d, nin = d->nin, F = H + dd + 1;
+  Blob b{w, n};
+  const double* Wih = b.take((int64_t)3 * H * nin);
+  const double* Whh = b.take((int64_t)3 * H * H);
+  const double* bih = b.take(3 * H);
+  const double* bhh = b.take(3 * H);
+  const double* Wo = b.take((int64_t)dd * F);
+  const double* bo = b.take(dd);
+  DeviceArena ar;
+  // input weights with the biases folded into input column 3 (x = [a_0..a_{nin-1}, 0.., 1]), as for the NL encoder
+  std::vector<double> Wihb((size_t)3 * H * 4, 0.0);
+  for (int r = 0; r < 3 * H; ++r) {
+    for (int j = 0; j < nin; ++j) Wihb[(size_t)r * 4 + j] = Wih[(size_t)r * nin + j];
+    Wihb[(size_t)r * 4 + 3] = bih[r] + (r < 2 * H ? bhh[r] : 0.0);
+  }
+  const size_t o_Wih = ar.push(pack_gru_chunked(Wihb.data(), 4, 4, H));
+  const size_t o_Whh = ar.push(pack_gru_chunked(Whh, H, H, H));
+  const size_t o_bhn = ar.push(std::vector<double>(bhh + 2 * H, bhh + 3 * H));
+  const size_t o_Wo = ar.push(pack_A(Wo, F, H, identity_rows(dd)));
+  double* base = nullptr;
+  NLC_HIP(c, hipMalloc((void**)&base, ar.host.size() * sizeof(double)));
+  hipError_t e = hipMemcpy(base, ar.host.data(), ar.host.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    hipFree(base);
+    return fail(c, NLC_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e));
+  }
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->rnn_base) hipFree(c->rnn_base);
+  c->rnn_base = base;
+  c->rd = *d;
+  RnnArgs& R = c->rnn;
+  R = RnnArgs{};
+  R.nin = nin;
+  R.d = dd;
+  for (int j = 0; j < nin; ++j) {
+    R.mean[j] = d->action_mean[j];
+    R.std[j] = d->action_std[j];
+  }
+  R.Wihp = base + o_Wih;
+  R.Whhp = base + o_Whh;
+  R.bhn = base + o_bhn;
+  R.Wop = base + o_Wo;
+  RnnHead& Hd = c->rnn_head;
+  Hd = RnnHead{};
+  Hd.d = dd;
+  for (int i = 0; i < dd; ++i) {
+    for (int j = 0; j < dd; ++j) Hd.Wx[i * dd + j] = Wo[(size_t)i * F + H + j];
+    Hd.wt[i] = Wo[(size_t)i * F + H + dd];
+    Hd.b[i] = bo[i];
+    Hd.mean[i] = d->state_mean[i];
+    Hd.std[i] = d->state_std[i];
+  }
+  Hd.time_div = d->time_div;
+  c->has_rnn = true;
+  if (c->has_mppi && c->pd.dynamics == NLC_DYN_DTRNN) c->has_mppi = false;  // re-configure against the new weights
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_rnn_forward(nlc_ctx* c, const double* obs, const double* window, const double* ts, int64_t N, int B,
+                               double* out, void* ws) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_rnn) return fail(c, NLC_ERR_STATE, "nlc_set_rnn_model has not been called");
+  if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
+  if (N == 0) return NLC_OK;
+  if (!obs || !window || !ts || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  RnnArgs a = c->rnn;
+  a.mode = 0;
+  a.window = window;
+  a.N = N;
+  a.B = B;
+  a.out = (double*)ws;
+  {
+    ProfScope ps(c, "rnn_encode_kernel");
+    NLC_HIP(c, launch_rnn_encode(a, c->rd.hidden, c->stream));
+  }
+  RnnForwardArgs f{};
+  f.head = c->rnn_head;
+  f.N = N;
+  f.obs = obs;
+  f.q = (const double*)ws;
+  f.ts = ts;
+  f.out = out;
+  ProfScope ps(c, "rnn_forward_tail_kernel");
+  NLC_HIP(c, launch_rnn_forward_tail(f, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
 // =================================================================================== planner
 extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if (!c) return NLC_ERR_BAD_ARG;
@@ -609,13 +726,13 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if ((double)E * (double)d->K * d->T * d->nu > 2.0e9)
     return fail(c, NLC_ERR_BAD_SHAPE, "E*K*T*nu exceeds the planner's index range");
   // the env id selects the running cost and the oracle dynamics; with cost_external and NL dynamics nothing needs it
-  const bool env_free = d->cost_external && d->dynamics == NLC_DYN_NL && d->env == -1;
+  const bool env_free = d->cost_external && (d->dynamics == NLC_DYN_NL || d->dynamics == NLC_DYN_DTRNN) && d->env == -1;
   if (!env_free && (d->env < 0 || d->env > 2)) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
   static const int env_d[3] = {5, 3, 6}, env_nu[3] = {1, 1, 2};
   if (!env_free && d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
     return fail(c, NLC_ERR_BAD_SHAPE, "nx / nu do not match the env's trig observation");
   if (d->cost_external && d->dynamics == NLC_DYN_EXTERNAL)
-    return fail(c, NLC_ERR_BAD_ARG, "cost_external needs fused dynamics (NLC_DYN_NL / NLC_DYN_ORACLE)");
+    return fail(c, NLC_ERR_BAD_ARG, "cost_external needs fused dynamics (NLC_DYN_NL / NLC_DYN_ORACLE / NLC_DYN_DTRNN)");
   if (d->dynamics == NLC_DYN_EXTERNAL) {
     // the caller owns dynamics and cost
   } else if (d->dynamics == NLC_DYN_NL) {
@@ -628,6 +745,10 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   } else if (d->dynamics == NLC_DYN_ORACLE) {
     if (d->delay < 0 || d->delay > d->B - 1)
       return fail(c, NLC_ERR_BAD_ARG, "oracle dynamics: delay must be in [0, action_buffer_size-1]");
+  } else if (d->dynamics == NLC_DYN_DTRNN) {
+    if (!c->has_rnn) return fail(c, NLC_ERR_STATE, "Delta-t RNN dynamics need nlc_set_rnn_model first");
+    if (c->rd.d != d->d || c->rd.nin != d->nu)
+      return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
   } else {
     return fail(c, NLC_ERR_UNSUPPORTED, "unknown dynamics id");
   }
@@ -677,7 +798,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 
 namespace {
 struct WsLayout {
-  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, total;
+  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, rq, total;
 };
 WsLayout ws_layout(const nlc_ctx* c) {
   const nlc_mppi_desc& d = c->pd;
@@ -701,6 +822,7 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.fim = take(dh ? KE * d.d * c->S : 0);
   w.dx = take(dh ? KE * d.d : 0);
   w.tconst = take(dh ? 8 : 0);
+  w.rq = take(d.dynamics == NLC_DYN_DTRNN ? KE * d.T * d.d : 0);  // hidden part of linear_out, (T, K, d)
   w.total = off;
   return w;
 }
@@ -988,6 +1110,44 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       }
       t0 += tc;
     }
+  } else if (d.dynamics == NLC_DYN_DTRNN) {
+    RnnArgs g = c->rnn;
+    g.mode = 1;
+    g.perturbed = buf->perturbed;
+    g.abuf = abuf_dev;
+    g.u_scale = d.u_scale;
+    g.T = d.T;
+    g.B = d.B;
+    g.Kep = d.K;
+    g.K = KE;
+    g.N = KE * d.T;
+    g.out = ws + w.rq;
+    {
+      ProfScope ps(c, "rnn_encode_kernel");
+      NLC_HIP(c, launch_rnn_encode(g, c->rd.hidden, c->stream));
+    }
+    RnnRolloutArgs r{};
+    r.head = c->rnn_head;
+    r.K = KE;
+    r.Kep = d.K;
+    r.T = d.T;
+    r.nu = d.nu;
+    r.env = d.cost_external ? -1 : d.env;
+    r.state_per_sample = state_per_sample;
+    r.state0 = state_dev;
+    r.q = ws + w.rq;
+    r.perturbed = buf->perturbed;
+    r.noise = buf->noise;
+    r.U = c->U[c->ucur];
+    for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) r.sigma_inv[i] = d.noise_sigma_inv[i];
+    r.lambda_ = d.lambda_;
+    r.u_scale = d.u_scale;
+    r.ts = d.ts_pred;
+    r.noise_abs_cost = d.noise_abs_cost;
+    r.states = buf->states;
+    r.cost_total = buf->cost_total;
+    ProfScope ps(c, "rnn_rollout_kernel");
+    NLC_HIP(c, launch_rnn_rollout(r, c->stream));
   } else {
     OracleRolloutArgs r{};
     r.K = KE;

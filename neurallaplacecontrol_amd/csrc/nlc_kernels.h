@@ -85,6 +85,63 @@ struct GruArgs {
 };
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s);
 
+// ------------------------------------------------------------------ Delta-t RNN baseline (train_utils.py:589-631)
+// One-layer forward GRU over the action window (hidden H) + the hidden part of linear_out: q = W_out[:, :H] h_last.
+struct RnnArgs {
+  const double* window;     // mode 0: (N, B, nin) raw windows
+  const double* perturbed;  // mode 1: (K, T, nu)
+  const double* abuf;       // mode 1: (E, B, nu)
+  double u_scale;
+  int mode, T;
+  int64_t Kep;  // mode 1: samples per episode
+  int64_t K;    // mode 1: all local samples (E * Kep)
+  int64_t N;    // windows (mode 1: K * T)
+  int B, nin, d;
+  double mean[NLC_MAX_NIN], std[NLC_MAX_NIN];  // (0, 3) on the model's raw-input branch
+  const double* Wihp;  // chunk-packed [GT][1][3][64], biases b_ih (+ b_hh for r, z) folded into column 3
+  const double* Whhp;  // chunk-packed [GT][KS][3][64]
+  const double* bhn;   // (H)
+  const double* Wop;   // [KS][1][64]: rows 0..d-1 of linear_out.weight[:, :H]
+  double* out;         // mode 0: (N, d); mode 1: (T, K, d) -- horizon-major, so the rollout reads it coalesced
+};
+hipError_t launch_rnn_encode(const RnnArgs& a, int hidden, hipStream_t s);
+
+// state part of linear_out + the model's normalisation; small enough to ride in the kernel arguments
+struct RnnHead {
+  int d;
+  double Wx[NLC_MAX_D * NLC_MAX_D];  // linear_out.weight[:, H:H+d], row-major d x d
+  double wt[NLC_MAX_D];              // linear_out.weight[:, H+d]
+  double b[NLC_MAX_D];               // linear_out.bias
+  double mean[NLC_MAX_D], std[NLC_MAX_D];  // (0, 1) on the raw-input branch
+  double time_div;                   // ts is divided by this (dt*8, or 1 on the raw branch)
+};
+struct RnnForwardArgs {  // DeltaTRNN.forward: out = q + Wx obs_n + wt ts_n + b
+  RnnHead head;
+  int64_t N;
+  const double* obs;  // (N, d)
+  const double* q;    // (N, d)
+  const double* ts;   // (N)
+  double* out;        // (N, d)
+};
+hipError_t launch_rnn_forward_tail(const RnnForwardArgs& a, hipStream_t s);
+struct RnnRolloutArgs {  // x <- x + DeltaTRNN(x, window_t, ts_pred), running cost, perturbation cost
+  RnnHead head;
+  int64_t K, Kep;
+  int T, nu, env;  // env: running cost, -1 = none (cost_external)
+  int state_per_sample;
+  const double* state0;
+  const double* q;  // (T, K, d)
+  const double* perturbed;
+  const double* noise;
+  const double* U;
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale, ts;
+  int noise_abs_cost;
+  double* states;
+  double* cost_total;
+};
+hipError_t launch_rnn_rollout(const RnnRolloutArgs& a, hipStream_t s);
+
 // ------------------------------------------------------------------ representation MLP + ILT + rollout
 struct NlNetArgs {
   int d, S, h, nt3;      // nt3 = layer-3 output tiles (theta/phi interleaved slot layout)

@@ -26,7 +26,10 @@ def _check_env(env_name):
 
 
 class NLDynamics:
-    """Neural-Laplace dynamics closure of the harness: ``state + model(state, window, ts_pred)``."""
+    """Learned-model dynamics closure of the harness: ``state + model(state, window, ts_pred)``.
+
+    ``model`` is a :class:`NeuralLaplaceModel` or the Delta-t RNN baseline :class:`DeltaTRNN` (the closure is the
+    same for every learned model, ``mppi_with_model.py:103-122``; only ``model_name == "nl"`` gets the time channel)."""
 
     def __init__(self, model, ts_pred):
         self.model = model
@@ -37,7 +40,8 @@ class NLDynamics:
 
     def __call__(self, state, perturbed_action):
         ts = torch.full((state.shape[0], 1), self.ts_pred, dtype=torch.float64, device=state.device)
-        if self.model.encode_obs_time and perturbed_action.shape[2] == self.model.action_dim:
+        is_nl = getattr(self.model, "_dyn_id", _lib.DYN_NL) == _lib.DYN_NL
+        if is_nl and self.model.encode_obs_time and perturbed_action.shape[2] == self.model.action_dim:
             # the harness closure appends a constant time channel B-1 .. 0 (mppi_with_model.py:110-119)
             B = perturbed_action.shape[1]
             tch = torch.flip(torch.arange(B, device=perturbed_action.device), (0,)).view(1, B, 1)

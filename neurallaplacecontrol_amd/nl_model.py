@@ -97,6 +97,8 @@ def _cme_terms(s_recon_terms):
 
 
 class NeuralLaplaceModel(nn.Module):
+    _dyn_id = _lib.DYN_NL  # rollout the fused planner selects for NLDynamics(model, dt)
+
     def __init__(
         self,
         state_dim,

@@ -153,7 +153,10 @@ class MPPIDelay:
             # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
             # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
             and not (encode_obs_time and not isinstance(dynamics, OracleDynamics))
-            and not (isinstance(dynamics, NLDynamics) and dynamics.model.ilt_algorithm not in ("fourier", "dehoog"))
+            and not (
+                isinstance(dynamics, NLDynamics)
+                and getattr(dynamics.model, "ilt_algorithm", "fourier") not in ("fourier", "dehoog")
+            )
         )
         # fused: the running cost is evaluated inside the rollout kernel as well (EnvCost, no terminal cost)
         self.fused = self.fused_dynamics and isinstance(running_cost, EnvCost) and terminal_state_cost is None
@@ -222,7 +225,7 @@ class MPPIDelay:
         if self.fused_dynamics:
             d.cost_external = int(self.cost_external)
             if isinstance(self.F, NLDynamics):
-                d.dynamics, d.ts_pred = _lib.DYN_NL, self.F.ts_pred
+                d.dynamics, d.ts_pred = self.F.model._dyn_id, self.F.ts_pred  # DYN_NL or DYN_DTRNN
                 d.env = _lib.ENV_IDS[self.running_cost.env_name] if self.fused else -1
             else:
                 if self.fused and self.F.env_name != self.running_cost.env_name:

@@ -1375,3 +1375,109 @@ def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
         part = p._partials.cpu()
         assert [float(act[0]), float(p.cost_total[0]), float(part[0]), float(part[1])] == c_cmds[cmd]
     assert p.U.reshape(-1).tolist() == c_U
+
+
+# --------------------------------------------------------------------------- Delta-t RNN baseline
+def build_rnn(nlc, sd, hidden, normalize=True, normalize_time=True, device="cuda"):
+    d = sd["state_mean"].numel()
+    nu = sd["gru.weight_ih_l0"].shape[1]
+    m = nlc.DeltaTRNN(
+        d, nu, hidden_units=hidden, state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]),
+        action_std=np.array([1.0]), normalize=normalize, normalize_time=normalize_time,
+    ).double()
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_dtrnn_forward_vs_reference_golden(nlc, env):
+    """G9: HIP DeltaTRNN.forward vs the REAL reference class (train_utils.py:589-631), both input branches."""
+    g = np.load(f"{GOLD}/g9_dtrnn_{env}.npz")
+    sd = load_sd(g, "sd_")
+    obs, win, ts = T64(g["fwd_obs"]), T64(g["fwd_window"]), T64(g["fwd_ts"])
+    with torch.no_grad():
+        got = build_rnn(nlc, sd, int(g["H"]))(obs.cuda(), win.cuda(), ts.cuda()).cpu()
+        np.testing.assert_allclose(got.numpy(), g["fwd_out"], **TOL)
+        raw = build_rnn(nlc, sd, int(g["H"]), normalize_time=False)(obs, win, ts)  # CPU inputs -> CPU result
+        assert raw.device.type == "cpu"
+        np.testing.assert_allclose(raw.numpy(), g["raw_out"], **TOL)
+        with pytest.raises(NameError):
+            build_rnn(nlc, sd, int(g["H"]), normalize=False, normalize_time=True)(obs, win, ts)
+    with pytest.raises(NotImplementedError):
+        build_rnn(nlc, sd, int(g["H"]))(obs, win, ts)  # grad mode: inference-only on the HIP path
+
+
+@pytest.mark.parametrize("hidden,B,N", [(64, 4, 1000), (128, 1, 77), (160, 6, 513), (160, 4, 1)])
+def test_dtrnn_forward_vs_oracle_sizes(nlc, hidden, B, N):
+    from oracle import rnn_model as ornn
+
+    d, nu = 6, 2
+    sd = ornn.make_synthetic_state_dict(11, d, nu, hidden, np.linspace(0.7, 2.9, d), [2.5])
+    g = torch.Generator().manual_seed(N)
+    obs = torch.randn(N, d, dtype=torch.float64, generator=g) * 2
+    win = (torch.rand(N, B, nu, dtype=torch.float64, generator=g) * 2 - 1) * 5
+    ts = torch.rand(N, 1, dtype=torch.float64, generator=g) * 0.1 + 0.01
+    ref = ornn.forward(sd, obs, win, ts)
+    with torch.no_grad():
+        got = build_rnn(nlc, sd, hidden)(obs.cuda(), win.cuda(), ts.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **TOL)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_mppi_dtrnn_dynamics_vs_reference_golden(nlc, env):
+    """G9: command() with the Delta-t RNN behind the harness closure vs reference MPPIDelay + reference DeltaTRNN."""
+    g = np.load(f"{GOLD}/g9_dtrnn_{env}.npz")
+    model = build_rnn(nlc, load_sd(g, "sd_"), int(g["H"]))
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["nx"]), int(g["nu"]), float(g["A"])
+
+    def make(U0):
+        return nlc.MPPIDelay(
+            nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-" + env), d, nlc.noise_sigma(nu),
+            num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+            u_scale=A, U_init=U0,
+        )
+
+    check_command_steps(nlc, g, make)
+
+    # the generic path (arbitrary closures calling the HIP model per horizon step) gives the same numbers
+    dyn, cost = nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-" + env)
+
+    def make_generic(U0):
+        return nlc.MPPIDelay(
+            lambda s, a: dyn(s, a), lambda s, u: cost(s, u), d, nlc.noise_sigma(nu), num_samples=K, horizon=T,
+            device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0,
+        )
+
+    with torch.no_grad():
+        check_command_steps(nlc, g, make_generic)
+
+
+def test_mppi_dtrnn_full_horizon_vs_oracle(nlc):
+    """K = 4096, T = 40, 5-row action buffer, device Philox noise replayed through the CPU oracle."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+    from oracle import rnn_model as ornn
+
+    env, K, Tt, B = "oderl-cartpole", 4096, 40, 5
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = ornn.make_synthetic_state_dict(5, d, nu, 160, st["state_std"], [A / 2.0])
+    model = build_rnn(nlc, sd, 160)
+    mppi = nlc.MPPIDelay(
+        nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), num_samples=K, horizon=Tt,
+        device="cuda", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
+        seed=9,
+    )
+    state = oenvs.initial_state(env, seed=1)
+    ab = (torch.rand(B, nu, dtype=torch.float64) - 0.5) * A
+    U0 = mppi.U.cpu().clone()
+    action = mppi.command(state.numpy(), ab)
+    # replay on the CPU: bounding is idempotent, so the bounded noise the device drew serves as the raw draw
+    out = omppi.mppi_command(
+        U0, state, ab, mppi.noise.cpu(), ornn.make_dynamics(sd), oenvs.RUNNING_COST[env], d,
+        torch.inverse(nlc.noise_sigma(nu)), 1.0, A, torch.tensor(-A), torch.tensor(A),
+    )
+    np.testing.assert_allclose(action.cpu().numpy(), out["action"].numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(mppi.cost_total.cpu().numpy(), out["cost_total"].numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(mppi.states.cpu().numpy(), out["states"].numpy(), rtol=1e-8, atol=1e-9)
