@@ -64,6 +64,18 @@ __device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MA
 
 // ------------------------------------------------------------------ one model evaluation
 // p0/p1: layer-1 latent B fragments (index 4s+q).  Returns acc_x: ILT sums, rows = dims (reg r -> dim q+4r).
+// |F| times the component the Fourier phase i^k keeps, as (num * trig, den): even-k groups need cos(theta), odd-k
+// groups sin(theta) = -cos(theta + pi/2).  Short forms of nlc_math.h (one reduction by pi with the quarter turn in
+// the reduction, Chebyshev cosines): 34 FP64 instructions instead of 56 for the fdlibm-kernel pair.
+__device__ __forceinline__ double sphere_term(double theta, double phi, bool odd) {
+  const m::IltTrigK K = m::ilt_trig_k();
+  double num, den;
+  m::tan_parts_short(K, phi / 2.0 + kPi / 4.0, &num, &den);
+  const double c = m::cos_plus_mpio2(K, theta, odd ? 0.5 : 0.0, odd ? 1.0 : 0.0);
+  const double trig = odd ? -c : c;
+  return (num * trig) * m::rcp_refined(den);
+}
+
 // GENERAL_T: sphere coordinates of the per-sample query points enter layer 1 through W1s.
 // FOUT != nullptr-mode (WRITE_F): instead of the Fourier sum, F_k = |F| e^{i theta} of every Laplace term is
 // written to (N, d, S) arrays for the de Hoog kernel (nonlinear in F, cannot be an MFMA).
@@ -164,8 +176,9 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
           fo->fim[fo->row * fo->dS + idx] = rad * sn;
         }
       } else {
-        const double trig = m::cos_quadrant(theta, (g < n.n_even_groups) ? 0 : -1);
-        ax[0] = mfma(cp[g * 64 + lane], (num * trig) * m::rcp_refined(den), ax[0]);
+        (void)num;
+        (void)den;
+        ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
       }
     }
   }
@@ -403,10 +416,7 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
             const int g = 2 * j3[i] + r;
             const double theta = m::tanh_d(o[i][r]) * kPi;
             const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
-            double num, den;
-            m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
-            const double trig = m::cos_quadrant(theta, (g < n.n_even_groups) ? 0 : -1);
-            ax = mfma(cp[g * 64 + lane], (num * trig) * m::rcp_refined(den), ax);
+            ax = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax);
           }
         }
       }
