@@ -32,6 +32,9 @@ import torch  # noqa: E402
 
 ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384, 40, 4, 17, 128, 3.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# newest committed PMC summary (separate rocprofv3 --pmc passes, tools/pmc_summarize.py)
+PMC_JSON = next((p for p in (os.path.join(REPO, "profiles", n) for n in ("r1j_pmc_kernels.json", "r1h_pmc_kernels.json"))
+                 if os.path.exists(p)), os.path.join(REPO, "profiles", "r1j_pmc_kernels.json"))
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
 
 
@@ -204,11 +207,11 @@ def main():
         ms = p["total_ms"] / p["launches"]
         nbytes = N * (2 * d * S_TERMS + d) * 8
         traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, "profiles", "r1h_pmc_kernels.json")
+        pmc = PMC_JSON
         if os.path.exists(pmc):  # PMC passes cannot run inside this process: separate rocprofv3 --pmc runs
             pj = json.load(open(pmc))
             traffic = pj["ilt_fourier"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r1h_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction, same N)"
+            traffic_src = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction, same N)"
         ilt = dict(bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                    algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
@@ -233,9 +236,29 @@ def main():
         ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
                                algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
                                frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               traffic=pj["ilt_dehoog_final"]["hbm_bytes_per_launch"] if os.path.exists(pmc) else None,
-                               traffic_note="mean over S=33 and S=17 launches (profiles/r1h_pmc_kernels.json)")
+                               traffic=pj.get("ilt_dehoog_final", pj.get("ilt_dehoog", {})).get("hbm_bytes_per_launch")
+                               if os.path.exists(pmc) else None,
+                               traffic_note=f"profiles/{os.path.basename(pmc)}")
         del theta, phi
+        # backward of the Fourier ILT (training through laplace_reconstruct): reads theta, phi, writes both gradients
+        theta = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi).requires_grad_()
+        phi = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.99).requires_grad_()
+        gx = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+        for it in range(13):
+            if it == 3:
+                ictx.profile_reset()
+                ictx.profile(True)
+            torch.autograd.grad(nlc.ilt_reconstruct(theta, phi, tt), (theta, phi), gx)
+        torch.cuda.synchronize()
+        ictx.profile(False)
+        p = ictx.profile_read()["ilt_fourier_bwd_kernel"]
+        ms3 = p["total_ms"] / p["launches"]
+        nb3 = N * 4 * d * S_TERMS * 8
+        ilt["backward"] = dict(bound="hbm", kernel="ilt_fourier_bwd_kernel", avg_launch_ms=ms3, points=N,
+                               algorithmic_bytes=nb3, bytes_per_point=4 * d * S_TERMS * 8,
+                               achieved=nb3 / (ms3 * 1e-3) / 1e9, unit="GB/s", frac=nb3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               traffic=pj.get("ilt_fourier_bwd", {}).get("hbm_bytes_per_launch") if os.path.exists(pmc) else None)
+        del theta, phi, gx
 
     if rank != 0:
         if pg is not None:
@@ -250,11 +273,11 @@ def main():
     rk = kernels.get("nl_rollout_kernel", dict(avg_ms=float("nan")))
     gru_tf = gru_flops / (gk["avg_ms"] * 1e-3) / 1e12
     g_traffic, r_traffic, t_src = None, None, None
-    pmc = os.path.join(REPO, "profiles", "r1h_pmc_kernels.json")
+    pmc = PMC_JSON
     if os.path.exists(pmc) and k_local == K_SAMPLES:  # measured at the headline size only
         pj = json.load(open(pmc))
         g_traffic, r_traffic = pj["gru_encode"]["hbm_bytes_per_launch"], pj["nl_rollout"]["hbm_bytes_per_launch"]
-        t_src = "profiles/r1h_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+        t_src = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
     roofline = dict(bound="mfma", achieved=gru_tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=gru_tf / FP64_MFMA_PEAK_TFLOPS, traffic=g_traffic, traffic_source=t_src,
                     algorithmic_hbm_bytes=24 * k_local * HORIZON, kernel="gru_encode_kernel",

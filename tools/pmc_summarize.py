@@ -11,7 +11,8 @@ import glob
 import json
 import sys
 
-KEYS = ("gru_encode", "nl_rollout", "ilt_fourier", "ilt_dehoog", "perturb", "weight_partial", "oracle_rollout", "merge")
+KEYS = ("gru_encode", "nl_rollout", "ilt_fourier_bwd", "ilt_fourier", "ilt_dehoog", "perturb", "weight_partial",
+        "oracle_rollout", "rnn_encode", "rnn_rollout", "merge")
 
 
 def short(name):
