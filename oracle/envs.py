@@ -13,6 +13,7 @@ Oracle dynamics: ``oracle.py:11-86`` (cartpole), ``:89-174`` (acrobot), ``:177-2
 
 import math
 
+import numpy as np
 import torch
 
 ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
@@ -164,3 +165,109 @@ def initial_state(env_name, seed=0):
         st = (torch.rand(4, generator=gen, dtype=torch.float64) - 0.5) * 0.2
         return torch.stack((torch.cos(st[0]), torch.sin(st[0]), torch.cos(st[1]), torch.sin(st[1]), st[2], st[3]))
     raise ValueError(env_name)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The env side of the evaluation loop: one control step of ``step_env`` (mppi_with_model.py:193-216)
+# = get_action (delay buffer, :25-28) + env.integrate_system(2, g, s0) (base_env.py:136-173) + get_obs (:83-89).  With
+# the harness's solver="euler" (overlay.py:39) and ts = [0, dt] the odeint call is one explicit Euler step of
+# torch_rhs on the REDUCED state (angles, not their cos/sin).  Pinned against the real env classes by G10
+# (tests/golden/make_golden_env.py); only "odeint(method='euler') = s + dt * rhs" is restated from torchdiffeq.
+STATE_DIM = {"oderl-cartpole": 4, "oderl-pendulum": 2, "oderl-acrobot": 4}
+
+
+def env_rhs(env_name, s, a, friction=False):
+    """``torch_rhs`` on reduced states s (..., n), actions a (..., nu)."""
+    if env_name == "oderl-cartpole":  # ctcartpole.py:185-237, 4-D branch
+        xd, th, thd = s[..., 1], s[..., 2], s[..., 3]
+        c, sn = torch.cos(th), torch.sin(th)
+        g, fmag, mc, mp, length = 9.8, 3.0, 1.0, 0.1, 1.0
+        mt, pml = mp + mc, mp * length
+        force = torch.clamp(a, min=-fmag, max=fmag)[..., 0] * fmag
+        if friction:
+            temp = (force + pml * thd * thd * sn - 5e-4 * torch.sign(xd)) / mt
+            thacc = (g * sn - c * temp - 2e-6 * thd / pml) / (length * (4.0 / 3.0 - mp * c * c / mt))
+        else:
+            temp = (force + pml * thd * thd * sn) / mt
+            thacc = (g * sn - c * temp) / (length * (4.0 / 3.0 - mp * c * c / mt))
+        xacc = temp - pml * thacc * c / mt
+        return torch.stack([xd, xacc, thd, thacc], -1)
+    if env_name == "oderl-pendulum":  # ctpendulum.py:111-125 (no clamp in the env's rhs)
+        th, thd = s[..., 0], s[..., 1]
+        g, m, l = 10.0, 1.0, 1.0  # noqa: E741
+        return torch.stack([thd, (-3 * g / (2 * l) * torch.sin(th + np.pi) + 3.0 / (m * l**2) * a[..., 0])], -1)
+    if env_name == "oderl-acrobot":  # ctacrobot.py:168-228, fully actuated, 4-D branch (no clamp)
+        th1, th2, d1, d2 = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
+        m1 = m2 = l1 = I1 = I2 = 1.0
+        lc1 = lc2 = 0.5
+        g = 9.8
+        D1 = m1 * lc1**2 + m2 * (l1**2 + lc2**2 + 2 * l1 * lc2 * torch.cos(th2)) + I1 + I2
+        D2 = m2 * (lc2**2 + l1 * lc2 * torch.cos(th2)) + I2
+        phi2 = m2 * lc2 * g * torch.cos(th1 + th2 - math.pi / 2.0)
+        phi1 = (
+            -m2 * l1 * lc2 * d2**2 * torch.sin(th2)
+            - 2 * m2 * l1 * lc2 * d2 * d1 * torch.sin(th2)
+            + (m1 * lc1 + m2 * l1) * g * torch.cos(th1 - math.pi / 2)
+            + phi2
+        )
+        dd2 = (a[..., 0] + D2 / D1 * phi1 - m2 * l1 * lc2 * d1**2 * torch.sin(th2) - phi2) / (m2 * lc2**2 + I2 - D2**2 / D1)
+        dd1 = -(a[..., 1] + D2 * dd2 + phi1) / D1
+        return torch.stack([d1, d2, dd1, dd2], -1)
+    raise ValueError(env_name)
+
+
+def env_obs(env_name, s):
+    """``torch_transform_states``: reduced state -> trig observation."""
+    if env_name == "oderl-cartpole":  # ctcartpole.py:107-129 (length = 1)
+        return torch.stack([s[..., 0], s[..., 1], 1.0 * torch.cos(s[..., 2]), 1.0 * torch.sin(s[..., 2]), s[..., 3]], -1)
+    if env_name == "oderl-pendulum":  # ctpendulum.py:72-78
+        return torch.stack([torch.cos(s[..., 0]), torch.sin(s[..., 0]), s[..., 1]], -1)
+    return torch.stack(  # ctacrobot.py:125-137
+        [torch.cos(s[..., 0]), torch.sin(s[..., 0]), torch.cos(s[..., 1]), torch.sin(s[..., 1]), s[..., 2], s[..., 3]], -1
+    )
+
+
+def env_obs2state(env_name, obs):
+    """``obs2state`` (ctcartpole.py:172-183, ctpendulum.py:104-109, ctacrobot.py:153-166)."""
+    if env_name == "oderl-cartpole":
+        return torch.stack([obs[..., 0], obs[..., 1], trig2angle(obs[..., 2], obs[..., 3]), obs[..., 4]], -1)
+    if env_name == "oderl-pendulum":
+        return torch.stack([trig2angle(obs[..., 0], obs[..., 1]), obs[..., 2]], -1)
+    return torch.stack([trig2angle(obs[..., 0], obs[..., 1]), trig2angle(obs[..., 2], obs[..., 3]), obs[..., 4], obs[..., 5]], -1)
+
+
+def env_reward(env_name, s, a):
+    """``diff_reward(s, a)`` on REDUCED states, as ``integrate_system`` evaluates it (base_env.py:164)."""
+    if env_name == "oderl-cartpole":  # ctcartpole.py:285-346, 4-D branch, swing_up
+        x, xd, th, thd = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
+        e0 = x + 1.0 * torch.sin(th) - 0.0
+        e1 = 1.0 * torch.cos(th) - 1.0
+        return (-(e0 * e0 + e1 * e1) + 0.01 * (-(xd * xd) - thd * thd)) + (-0.01 * (a * a).sum(-1))
+    if env_name == "oderl-pendulum":  # ctpendulum.py:139-155
+        th, thd = s[..., 0], s[..., 1]
+        c, sn = torch.cos(th), torch.sin(th)
+        return (-(1.0**2) * ((1 - c) ** 2 + sn**2) + 0.01 * (-(thd**2))) + (-0.01 * (a * a).sum(-1))
+    th1, th2, v1, v2 = s[..., 0], s[..., 1], s[..., 2], s[..., 3]  # ctacrobot.py:230-255
+    p1x, p1y = -1.0 * torch.cos(th1), 1.0 * torch.sin(th1)
+    p2x, p2y = p1x - 1.0 * torch.cos(th1 + th2), p1y + 1.0 * torch.sin(th1 + th2)
+    state_reward = -((p2x - 1.0 - 1.0) ** 2) - p2y**2
+    return (state_reward + 1e-1 * (-(v1**2) - v2**2)) + (-1e-4 * (a * a).sum(-1))
+
+
+def env_step(env_name, s, a, dt=0.05, friction=False):
+    """One control step on reduced states: (s1, obs1, reward) = Euler step, get_obs, diff_reward(s1, a)."""
+    s1 = s + dt * env_rhs(env_name, s, a, friction)
+    return s1, env_obs(env_name, s1), env_reward(env_name, s1, a)
+
+
+def env_reset(env_name, np_random):
+    """``reset()`` of the three envs (ctcartpole.py:160-170, ctpendulum.py:92-98, ctacrobot.py:148-151): reduced state."""
+    if env_name == "oderl-cartpole":
+        st = np_random.uniform(low=-0.05, high=0.05, size=(4,))
+        st[2] += np.pi
+    elif env_name == "oderl-pendulum":
+        st = np_random.uniform(low=-0.1, high=0.1, size=(2,))
+        st[0] += np.pi
+    else:
+        st = np_random.uniform(low=-0.1, high=0.1, size=(4,))
+    return torch.as_tensor(st, dtype=torch.float64)

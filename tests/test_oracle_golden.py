@@ -316,3 +316,38 @@ def test_g9_dtrnn_oracle_matches_reference_class(env, golden_dir):
     for k, v in sd.items():
         if k.startswith(("gru.", "linear_out.", "dt", "state_std", "action_std")):
             np.testing.assert_allclose(mine[k].numpy(), v.numpy(), rtol=1e-15, atol=0, err_msg=k)
+
+
+# --------------------------------------------------------------------------- G10: env side of the loop (§8f row 3)
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_g10_env_step_oracle_matches_reference_env(env, golden_dir):
+    """oracle/envs.py env_rhs / env_obs / env_reward / env_obs2state / env_reset against the REAL env classes, and the
+    harness's get_action + Euler step closed-loop trace."""
+    g = np.load(f"{golden_dir}/g10_env_{env}.npz")
+    name = "oderl-" + env
+    tol = dict(rtol=1e-12, atol=1e-12)
+    for tag, fr in (("", False), ("fr_", True)):
+        if tag + "s0" not in g.files:
+            continue
+        s0, a = T(g[tag + "s0"]), T(g[tag + "a"])
+        np.testing.assert_allclose(oenvs.env_rhs(name, s0, a, fr).numpy(), g[tag + "rhs"], **tol)
+        s1, obs1, rew = oenvs.env_step(name, s0, a, float(g["dt"]), fr)
+        np.testing.assert_allclose(s1.numpy(), g[tag + "s1"], **tol)
+        np.testing.assert_allclose(obs1.numpy(), g[tag + "obs1"], **tol)
+        np.testing.assert_allclose(rew.numpy(), g[tag + "reward"], **tol)
+        np.testing.assert_allclose(oenvs.env_obs(name, s0).numpy(), g[tag + "obs0"], **tol)
+        np.testing.assert_allclose(oenvs.env_obs2state(name, obs1).numpy(), g[tag + "back"], **tol)
+    # closed-loop trace: delay buffer + step + reward
+    delay, B = int(g["loop_delay"]), int(g["loop_B"])
+    ab = torch.zeros(B, int(g["nu"]), dtype=torch.float64)
+    s = T(g["s0"])[0].clone()
+    for i, act in enumerate(T(g["loop_actions"])):
+        ab, at = omppi.get_action(ab, act, delay)
+        s, obs, rew = oenvs.env_step(name, s, at.clone(), float(g["dt"]))
+        np.testing.assert_allclose(s.numpy(), g["loop_s"][i], **tol)
+        np.testing.assert_allclose(obs.numpy(), g["loop_obs"][i], **tol)
+        np.testing.assert_allclose(float(rew), float(g["loop_rew"][i]), **tol)
+        np.testing.assert_allclose(ab.numpy(), g["loop_ab"][i], **tol)
+    st = oenvs.env_reset(name, np.random.RandomState(5))
+    np.testing.assert_allclose(st.numpy(), g["reset_seed5_state"], rtol=0, atol=0)
+    np.testing.assert_allclose(oenvs.env_obs(name, st).numpy(), g["reset_seed5_obs"], **tol)
