@@ -238,6 +238,21 @@ int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
 int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
                     double* action_host);
 
+/* ---- env side of the evaluation loop: the reference steps ONE env per process on the host,
+ * step_env (mppi_with_model.py:193-216) = get_action (delay buffer, :25-28) + env.integrate_system(2, g, s0)
+ * (base_env.py:136-173; solver "euler" overlay.py:39, ts = [0, dt]: one Euler step of torch_rhs on the reduced
+ * state) + get_obs (:83-89).  Here E independent envs advance on the device, next to a batched planner (E > 1), so a
+ * control step needs no host round trip.
+ *   state_dev (E, n) reduced states (cartpole [x, xdot, theta, thetadot], pendulum [theta, thetadot], acrobot
+ *   [theta1, theta2, v1, v2]), updated in place; action_buffer_dev (E, B, nu) rolled in place, the new action
+ *   appended, row -(delay+1) applied; action_dev (E, nu); obs_dev (E, d) trig observation of the new state;
+ *   reward_dev (E) diff_reward(new state, applied action), may be NULL. */
+int nlc_env_step(nlc_ctx* ctx, int env, int friction, double dt, int delay, int64_t E, int B, int nu,
+                 double* state_dev, double* action_buffer_dev, const double* action_dev, double* obs_dev,
+                 double* reward_dev);
+/* get_obs (base_env.py:83-89): obs_dev (E, d) = torch_transform_states(state_dev (E, n)) */
+int nlc_env_obs(nlc_ctx* ctx, int env, int64_t E, const double* state_dev, double* obs_dev);
+
 /* ---- in-library kernel timing (hipEvent pairs on the launch stream) ------------------------- */
 int nlc_profile_enable(nlc_ctx* ctx, int on);
 int nlc_profile_reset(nlc_ctx* ctx);

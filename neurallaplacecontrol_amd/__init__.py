@@ -12,6 +12,7 @@ All arithmetic runs in hand-written HIP kernels behind the C ABI of ``libnlc_hip
 """
 
 from .envs import EnvCost, NLDynamics, OracleDynamics, initial_state, noise_sigma  # noqa: F401
+from .env_loop import BatchedEnv  # noqa: F401
 from .laplace import ilt_reconstruct, laplace_reconstruct, rep_func_inputs  # noqa: F401
 from .nl_model import LaplaceRepresentationFunc, NeuralLaplaceModel, ReverseGRUEncoder  # noqa: F401
 from .rnn_model import DeltaTRNN  # noqa: F401
@@ -21,6 +22,7 @@ from .planners.mppi_delay import MPPIDelay  # noqa: F401
 __all__ = [
     "MPPIDelay",
     "BatchedMPPIDelay",
+    "BatchedEnv",
     "NeuralLaplaceModel",
     "DeltaTRNN",
     "ReverseGRUEncoder",

@@ -50,6 +50,8 @@ SYMBOLS = [
     "nlc_mppi_rollout",
     "nlc_mppi_weights",
     "nlc_mppi_finish",
+    "nlc_env_step",
+    "nlc_env_obs",
     "nlc_profile_enable",
     "nlc_profile_reset",
     "nlc_profile_count",
@@ -177,6 +179,8 @@ def load_library():
         lib.nlc_rnn_blob_size.restype = i64
         lib.nlc_set_rnn_model.argtypes = [vp, P(RnnDesc), vp, i64]
         lib.nlc_rnn_forward.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.nlc_env_step.argtypes = [vp, i32, i32, dbl, i32, i64, i32, i32, vp, vp, vp, vp, vp]
+        lib.nlc_env_obs.argtypes = [vp, i32, i64, vp, vp]
         lib.nlc_mppi_configure.argtypes = [vp, P(MppiDesc)]
         lib.nlc_mppi_workspace_bytes.argtypes = [vp]
         lib.nlc_mppi_workspace_bytes.restype = i64

@@ -373,6 +373,118 @@ hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ env side of the evaluation loop
+// Reduced-state rhs of the three envs (ctcartpole.py:185-237, ctpendulum.py:111-125, ctacrobot.py:168-228; the 4-D /
+// 2-D branches: explicit angles).  Only cartpole clamps the action inside its rhs.
+__device__ __forceinline__ void env_rhs(int env, const double* s, const double* a, int friction, double* ds) {
+  if (env == NLC_ENV_CARTPOLE) {
+    const double xd = s[1], th = s[2], thd = s[3];
+    const double c = cos(th), sn = sin(th);
+    const double g = 9.8, fmag = 3.0, mc = 1.0, mp = 0.1, len = 1.0;
+    const double mt = mp + mc, pml = mp * len;
+    const double force = clampd(a[0], -fmag, fmag) * fmag;
+    double temp, thacc;
+    if (friction) {
+      const double sg = (xd > 0.0) ? 1.0 : ((xd < 0.0) ? -1.0 : 0.0);
+      temp = (force + pml * thd * thd * sn - 5e-4 * sg) / mt;
+      thacc = (g * sn - c * temp - 2e-6 * thd / pml) / (len * (4.0 / 3.0 - mp * c * c / mt));
+    } else {
+      temp = (force + pml * thd * thd * sn) / mt;
+      thacc = (g * sn - c * temp) / (len * (4.0 / 3.0 - mp * c * c / mt));
+    }
+    ds[0] = xd;
+    ds[1] = temp - pml * thacc * c / mt;
+    ds[2] = thd;
+    ds[3] = thacc;
+  } else if (env == NLC_ENV_PENDULUM) {
+    ds[0] = s[1];
+    ds[1] = -15.0 * sin(s[0] + kPi) + 3.0 * a[0];  // -3g/(2l), 3/(m l^2)
+  } else {
+    const double th1 = s[0], th2 = s[1], d1v = s[2], d2v = s[3];
+    const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
+    const double c2 = cos(th2), s2 = sin(th2);
+    const double D1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
+    const double D2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+    const double phi2 = m2 * lc2 * g * cos(th1 + th2 - kPi / 2.0);
+    const double phi1 = -m2 * l1 * lc2 * (d2v * d2v) * s2 - 2 * m2 * l1 * lc2 * d2v * d1v * s2 +
+                        (m1 * lc1 + m2 * l1) * g * cos(th1 - kPi / 2) + phi2;
+    const double dd2 = (a[0] + D2 / D1 * phi1 - m2 * l1 * lc2 * (d1v * d1v) * s2 - phi2) /
+                       (m2 * (lc2 * lc2) + I2 - (D2 * D2) / D1);
+    ds[0] = d1v;
+    ds[1] = d2v;
+    ds[2] = -(a[1] + D2 * dd2 + phi1) / D1;
+    ds[3] = dd2;
+  }
+}
+// torch_transform_states: reduced state -> trig observation
+__device__ __forceinline__ void env_observe(int env, const double* s, double* o) {
+  if (env == NLC_ENV_CARTPOLE) {
+    o[0] = s[0];
+    o[1] = s[1];
+    o[2] = 1.0 * cos(s[2]);
+    o[3] = 1.0 * sin(s[2]);
+    o[4] = s[3];
+  } else if (env == NLC_ENV_PENDULUM) {
+    o[0] = cos(s[0]);
+    o[1] = sin(s[0]);
+    o[2] = s[1];
+  } else {
+    o[0] = cos(s[0]);
+    o[1] = sin(s[0]);
+    o[2] = cos(s[1]);
+    o[3] = sin(s[1]);
+    o[4] = s[2];
+    o[5] = s[3];
+  }
+}
+// diff_reward(s, a) on the reduced state, as integrate_system evaluates it (base_env.py:164)
+__device__ __forceinline__ double env_reward(int env, const double* s, const double* a, int nu) {
+  double uu = 0.0;
+  for (int j = 0; j < nu; ++j) uu += a[j] * a[j];
+  if (env == NLC_ENV_CARTPOLE) {
+    const double e0 = s[0] + 1.0 * sin(s[2]) - 0.0, e1 = 1.0 * cos(s[2]) - 1.0;
+    return (-(e0 * e0 + e1 * e1) + 0.01 * (-(s[1] * s[1]) - s[3] * s[3])) + (-0.01 * uu);
+  } else if (env == NLC_ENV_PENDULUM) {
+    const double c = cos(s[0]), sn = sin(s[0]);
+    const double om = 1.0 - c;
+    return (-1.0 * (om * om + sn * sn) + 0.01 * (-(s[1] * s[1]))) + (-0.01 * uu);
+  }
+  const double p1x = -1.0 * cos(s[0]), p1y = 1.0 * sin(s[0]);
+  const double p2x = p1x - 1.0 * cos(s[0] + s[1]), p2y = p1y + 1.0 * sin(s[0] + s[1]);
+  const double ex = p2x - 1.0 - 1.0;
+  return ((-(ex * ex) - p2y * p2y) + 1e-1 * (-(s[2] * s[2]) - s[3] * s[3])) + (-1e-4 * uu);
+}
+__global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.E) return;
+  const int n = (a.env == NLC_ENV_PENDULUM) ? 2 : 4;
+  const int d = (a.env == NLC_ENV_CARTPOLE) ? 5 : ((a.env == NLC_ENV_PENDULUM) ? 3 : 6);
+  double s[4], o[6];
+  for (int i = 0; i < n; ++i) s[i] = a.state[e * n + i];
+  if (a.action != nullptr) {
+    // get_action: roll the buffer by one row, append the new action, apply row -(delay + 1)
+    double* ab = a.abuf + e * a.B * a.nu;
+    for (int r = 0; r + 1 < a.B; ++r)
+      for (int j = 0; j < a.nu; ++j) ab[r * a.nu + j] = ab[(r + 1) * a.nu + j];
+    for (int j = 0; j < a.nu; ++j) ab[(a.B - 1) * a.nu + j] = a.action[e * a.nu + j];
+    double at[NLC_MAX_NU], ds[4];
+    for (int j = 0; j < a.nu; ++j) at[j] = ab[(a.B - 1 - a.delay) * a.nu + j];
+    env_rhs(a.env, s, at, a.friction, ds);
+    for (int i = 0; i < n; ++i) {
+      s[i] = s[i] + a.dt * ds[i];  // odeint(method="euler") over ts = [0, dt]
+      a.state[e * n + i] = s[i];
+    }
+    if (a.reward != nullptr) a.reward[e] = env_reward(a.env, s, at, a.nu);
+  }
+  env_observe(a.env, s, o);
+  for (int i = 0; i < d; ++i) a.obs[e * d + i] = o[i];
+}
+hipError_t launch_env_step(const EnvStepArgs& a, hipStream_t s) {
+  if (a.E <= 0) return hipSuccess;
+  hipLaunchKernelGGL(env_step_kernel, dim3((unsigned)((a.E + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ Delta-t RNN baseline: linear_out tail + rollout
 // dx = q + W_out[:, H:H+d] obs_n + W_out[:, H+d] ts_n + b   (train_utils.py:618-631), q = hidden part from rnn_encode_kernel
 __device__ __forceinline__ void rnn_dx(const RnnHead& h, const double (&x)[NLC_MAX_D], const double* q, double tsn,

@@ -600,6 +600,40 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
   NLC_GUARD_END(c)
 }
 
+// =================================================================================== env side of the loop
+extern "C" int nlc_env_step(nlc_ctx* c, int env, int friction, double dt, int delay, int64_t E, int B, int nu,
+                            double* state, double* action_buffer, const double* action, double* obs, double* reward) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  static const int env_nu[3] = {1, 1, 2};
+  if (env < 0 || env > 2) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
+  if (nu != env_nu[env]) return fail(c, NLC_ERR_BAD_SHAPE, "nu does not match the env's action space");
+  if (E < 0 || B < 1 || delay < 0 || delay > B - 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad E / B / delay");
+  if (E == 0) return NLC_OK;
+  if (!state || !action_buffer || !action || !obs) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  EnvStepArgs a{env, friction, B, nu, delay, E, dt, state, action_buffer, action, obs, reward};
+  ProfScope ps(c, "env_step_kernel");
+  NLC_HIP(c, launch_env_step(a, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_env_obs(nlc_ctx* c, int env, int64_t E, const double* state, double* obs) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (env < 0 || env > 2) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
+  if (E < 0) return fail(c, NLC_ERR_BAD_SHAPE, "bad E");
+  if (E == 0) return NLC_OK;
+  if (!state || !obs) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  EnvStepArgs a{env, 0, 1, 1, 0, E, 0.0, const_cast<double*>(state), nullptr, nullptr, obs, nullptr};
+  ProfScope ps(c, "env_step_kernel");
+  NLC_HIP(c, launch_env_step(a, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
 // =================================================================================== Delta-t RNN baseline
 static int64_t rnn_blob_size(const nlc_rnn_desc* d) {
   const int64_t H = d->hidden;

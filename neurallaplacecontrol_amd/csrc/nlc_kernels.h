@@ -251,6 +251,21 @@ struct OracleRolloutArgs {
 };
 hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s);
 
+// ------------------------------------------------------------------ env side of the evaluation loop
+// step_env (mppi_with_model.py:193-216) for E independent envs: get_action (delay buffer, :25-28), one Euler step of
+// the env's torch_rhs on the reduced state (base_env.py:136-173 with solver="euler", ts = [0, dt]), get_obs, reward.
+struct EnvStepArgs {
+  int env, friction, B, nu, delay;
+  int64_t E;
+  double dt;
+  double* state;         // (E, n) reduced state (angles), in/out; NULL action = observation only
+  double* abuf;          // (E, B, nu) in/out: rolled by one row, the new action appended
+  const double* action;  // (E, nu) the planner's (un-delayed) action
+  double* obs;           // (E, d) out: trig observation of the new state
+  double* reward;        // (E) out: diff_reward(new state, applied action); may be NULL
+};
+hipError_t launch_env_step(const EnvStepArgs& a, hipStream_t s);
+
 // ------------------------------------------------------------------ MPPI sampling / weighting
 constexpr int kMaxInlineAbuf = 32;  // action_buffer doubles carried in the kernel arguments (B*nu <= 32)
 struct PerturbArgs {

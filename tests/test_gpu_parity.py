@@ -1481,3 +1481,78 @@ def test_mppi_dtrnn_full_horizon_vs_oracle(nlc):
     np.testing.assert_allclose(action.cpu().numpy(), out["action"].numpy(), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(mppi.cost_total.cpu().numpy(), out["cost_total"].numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(mppi.states.cpu().numpy(), out["states"].numpy(), rtol=1e-8, atol=1e-9)
+
+
+# --------------------------------------------------------------------------- env side of the loop
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_env_step_vs_reference_env_golden(nlc, env):
+    """G10: nlc_env_step / nlc_env_obs vs the REAL env classes (torch_rhs Euler step, torch_transform_states,
+    diff_reward), the harness's get_action delay buffer, and the env's reset stream."""
+    g = np.load(f"{GOLD}/g10_env_{env}.npz")
+    name = "oderl-" + env
+    tol = dict(rtol=1e-11, atol=1e-12)
+    E, dt = int(g["E"]), float(g["dt"])
+    for tag, fr in (("", False), ("fr_", True)):
+        if tag + "s0" not in g.files:
+            continue
+        e = nlc.BatchedEnv(name, E, dt=dt, action_delay=0, action_buffer_size=1, friction=fr)
+        obs0 = e.set_state_(T64(g[tag + "s0"]))
+        np.testing.assert_allclose(obs0.cpu().numpy(), g[tag + "obs0"], **tol)
+        obs1, rew = e.step(T64(g[tag + "a"]).cuda())
+        np.testing.assert_allclose(e.state.cpu().numpy(), g[tag + "s1"], **tol)
+        np.testing.assert_allclose(obs1.cpu().numpy(), g[tag + "obs1"], **tol)
+        np.testing.assert_allclose(rew.cpu().numpy(), g[tag + "reward"], **tol)
+    # closed-loop trace with the delay buffer: three identical envs in one batch
+    delay, B = int(g["loop_delay"]), int(g["loop_B"])
+    e = nlc.BatchedEnv(name, 3, dt=dt, action_delay=delay, action_buffer_size=B)
+    e.set_state_(T64(g["s0"])[0].repeat(3, 1))
+    e.action_buffer.zero_()
+    for i, act in enumerate(T64(g["loop_actions"])):
+        obs, rew = e.step(act.repeat(3, 1))  # host tensor in
+        for k in range(3):
+            np.testing.assert_allclose(e.state[k].cpu().numpy(), g["loop_s"][i], **tol)
+            np.testing.assert_allclose(obs[k].cpu().numpy(), g["loop_obs"][i], **tol)
+            np.testing.assert_allclose(float(rew[k]), float(g["loop_rew"][i]), **tol)
+            np.testing.assert_allclose(e.action_buffer[k].cpu().numpy(), g["loop_ab"][i], **tol)
+    # reset: env 0 of a batch seeded with s draws the stream of a reference env seeded with s
+    e = nlc.BatchedEnv(name, 4, seed=5)
+    np.testing.assert_allclose(e.state[0].cpu().numpy(), g["reset_seed5_state"], rtol=0, atol=0)
+    np.testing.assert_allclose(e.get_obs()[0].cpu().numpy(), g["reset_seed5_obs"], **tol)
+    with pytest.raises(ValueError):
+        nlc.BatchedEnv(name, 2, action_delay=4, action_buffer_size=4)
+
+
+def test_device_closed_loop_matches_host_stepped_loop(nlc):
+    """BatchedMPPIDelay + BatchedEnv entirely on the device vs the same planner stepped through the CPU restatement of
+    the env (oracle/envs.py, pinned by G10): identical actions, states and rewards over 6 control steps."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+
+    env, E, K, Tt, B, delay = "oderl-acrobot", 5, 192, 8, 4, 1
+    nx, nu, A = 6, 2, 5.0
+
+    def planner():
+        return nlc.BatchedMPPIDelay(
+            nlc.OracleDynamics(env, 0.05, delay), nlc.EnvCost(env), nx, nlc.noise_sigma(nu), E, K, Tt, "cuda",
+            lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=3,
+            U_init=torch.zeros(E, Tt, nu, dtype=torch.float64))
+
+    dev = nlc.BatchedEnv(env, E, action_delay=delay, action_buffer_size=B, seed=11)
+    mp_dev, mp_host = planner(), planner()
+    s = dev.state.cpu().clone()
+    ab = torch.zeros(E, B, nu, dtype=torch.float64)
+    obs = dev.get_obs()
+    for _ in range(6):
+        act = mp_dev.command(obs, dev.action_buffer)
+        obs, rew = dev.step(act)
+        # host-stepped twin
+        act_h = mp_host.command(oenvs.env_obs(env, s), ab).cpu()
+        np.testing.assert_allclose(act.cpu().numpy(), act_h.numpy(), rtol=1e-9, atol=1e-10)
+        rews = []
+        for k in range(E):
+            ab[k], at = omppi.get_action(ab[k], act_h[k], delay)
+            s[k], _, r = oenvs.env_step(env, s[k], at.clone(), 0.05)
+            rews.append(float(r))
+        np.testing.assert_allclose(dev.state.cpu().numpy(), s.numpy(), rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(rew.cpu().numpy(), np.array(rews), rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(dev.action_buffer.cpu().numpy(), ab.numpy(), rtol=1e-9, atol=1e-10)
