@@ -16,6 +16,8 @@ Parity status
   classes -- see ``tests/golden/make_golden.py`` and the committed fixtures.
 * Delta-t RNN baseline (``rnn_model.py``): PINNED against the reference ``DeltaTRNN``
   class (``tests/golden/make_golden_rnn.py``, fixtures ``g9_dtrnn_*``).
+* NODE baseline (``node_model.py``): MLP, normalisation, augmentation and planner PINNED against the reference
+  classes (G11); its ``torchdiffeq.odeint`` call is restated (fixed-grid Euler): **parity unpinned for odeint**.
 * ``laplace_reconstruct`` body (a9): **parity unpinned vs upstream
   torchlaplace** -- the PyPI package ``torchlaplace`` (unpinned in the
   reference's ``requirements.txt:17``) is absent from the build container and
@@ -25,4 +27,4 @@ Parity status
   analytic Laplace pairs and ``mpmath.invertlaplace(method='dehoog')``.
 """
 
-from . import envs, ilt, mppi, nl_model, rnn_model  # noqa: F401
+from . import envs, ilt, mppi, nl_model, node_model, rnn_model  # noqa: F401

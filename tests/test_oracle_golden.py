@@ -351,3 +351,29 @@ def test_g10_env_step_oracle_matches_reference_env(env, golden_dir):
     st = oenvs.env_reset(name, np.random.RandomState(5))
     np.testing.assert_allclose(st.numpy(), g["reset_seed5_state"], rtol=0, atol=0)
     np.testing.assert_allclose(oenvs.env_obs(name, st).numpy(), g["reset_seed5_obs"], **tol)
+
+
+# --------------------------------------------------------------------------- G11: NODE baseline (§8f row 4)
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_g11_node_oracle_matches_reference_classes(env, golden_dir):
+    """oracle/node_model.py against the real NODE / xOdeFuncInXAndU classes (odeint = the restated fixed-grid Euler
+    on BOTH sides: parity unpinned for torchdiffeq) and the real MPPIDelay driving them."""
+    from oracle import node_model as onode
+
+    g = np.load(f"{golden_dir}/g11_node_{env}.npz")
+    sd = load_sd(g, "sd_")
+    obs, window = T(g["fwd_obs"]), T(g["fwd_window"])
+    for tag in ("", "t2_"):
+        got = onode.forward(sd, obs, window, T(g[f"fwd_{tag}ts"]))
+        np.testing.assert_allclose(got.numpy(), g[f"fwd_{tag}out"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(onode.ode_func(sd, T(g["func_x"]), window[:, -1, :]).numpy(), g["func_out"],
+                               rtol=1e-11, atol=1e-12)
+    assert onode.euler_substeps(0.125) == [0.05, 0.05, 0.125 - 0.1]
+    assert len(onode.euler_substeps(0.275)) == 6
+    run_steps(g, onode.make_dynamics(sd), oenvs.RUNNING_COST["oderl-" + env], int(g["nx"]), int(g["nu"]), float(g["A"]))
+    st = onl.ENV_STATS["oderl-" + env]
+    mine = onode.make_synthetic_state_dict(50, st["d"], st["nu"], int(g["H"]), int(g["AUG"]), st["state_std"],
+                                           [st["act_high"] / 2.0])
+    for k, v in sd.items():
+        if k.startswith("x_ode_func") or k in ("dt", "state_std", "action_std"):
+            np.testing.assert_allclose(mine[k].numpy(), v.numpy(), rtol=1e-15, atol=0, err_msg=k)
