@@ -58,6 +58,7 @@ extern "C" {
                               (mppi_delay.py:271-296) itself between nlc_mppi_rollout and nlc_mppi_weights */
 #define NLC_DYN_DTRNN 3    /* state + DeltaTRNN(state, window, ts_pred): the reference's Delta-t RNN baseline
                               (train_utils.py:589-631) behind the same harness closure (mppi_with_model.py:103-122) */
+#define NLC_DYN_NODE 4     /* state + NODE(state, window, ts_pred): the neural-ODE baseline (train_utils.py:664-724) */
 
 typedef struct nlc_ctx nlc_ctx;
 
@@ -155,6 +156,30 @@ int nlc_set_rnn_model(nlc_ctx* ctx, const nlc_rnn_desc* desc, const double* weig
 int nlc_rnn_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev, int64_t N,
                     int B, double* out_dev, void* ws_dev);
 
+/* ---- baseline model: NODE (train_utils.py:664-724; ODE function xOdeFuncInXAndU :637-661; factory :101-125;
+ * node_hidden_units 270, node_augment_dim 1, node_method "euler": config.py:40-42).
+ *   x = cat((obs - mean)/std, zeros(augment_dim)); u = window[:, -1, :] (raw);
+ *   out = odeint(f(., u), x, [0, ts_pred[0] / time_div], method="euler", step_size)[-1][:, :d]
+ * torchdiffeq's fixed-grid Euler solver is restated (grid t_k = k*step_size, last point = the end time):
+ * PARITY UNPINNED vs upstream torchdiffeq (absent offline); everything else is pinned against the reference classes. */
+typedef struct {
+  int32_t d;           /* state_dim */
+  int32_t nu;          /* action_dim */
+  int32_t hidden;      /* hidden_units, <= 272 */
+  int32_t augment_dim; /* d + augment_dim <= 8, d + augment_dim + nu <= 12 */
+  double time_div;     /* dt*8 if normalize_time else 1 (train_utils.py:701-702) */
+  double step_size;    /* options["step_size"] = 0.05 (:722) */
+  double state_mean[NLC_MAX_D], state_std[NLC_MAX_D]; /* (0, 1) if !normalize */
+} nlc_node_desc;
+/* weights_host: float64 blob in state_dict order: x_ode_func_in_x_and_u.linear_tanh_stack.{0,2,4}.{weight,bias}:
+ *   (H, d+aug+nu) (H) (H, H) (H) (d+aug, H) (d+aug) */
+int64_t nlc_node_blob_size(const nlc_node_desc* desc);
+int nlc_set_node_model(nlc_ctx* ctx, const nlc_node_desc* desc, const double* weights_host, int64_t n_doubles);
+/* NODE.forward: obs_dev (N,d), action_dev (N,nu) = window[:, -1, :], ts_pred = the FIRST row's raw prediction time
+ * (the reference integrates every row to ts_pred[0], :719) -> out_dev (N,d) integrated normalised state. */
+int nlc_node_forward(nlc_ctx* ctx, const double* obs_dev, const double* action_dev, double ts_pred, int64_t N,
+                     double* out_dev);
+
 /* ---- planner: MPPIDelay (planners/mppi_delay.py:54-381) ------------------------------------- */
 typedef struct {
   int64_t K;        /* samples owned by THIS ctx (its shard of the population) */
@@ -213,7 +238,7 @@ typedef struct {
 /* NLC_DYN_NL: the model's GRU input dim must be nu, or nu+1 for an encode_obs_time model -- the rollout then
  * appends the constant time channel B-1 .. 0 the harness closure builds (mppi_with_model.py:110-119).
  * NLC_DYN_DTRNN: needs nlc_set_rnn_model first; GRU input dim == nu (the closure adds the time channel for
- * model_name == "nl" only). */
+ * model_name == "nl" only).  NLC_DYN_NODE: needs nlc_set_node_model first. */
 int nlc_mppi_configure(nlc_ctx* ctx, const nlc_mppi_desc* desc);
 int64_t nlc_mppi_workspace_bytes(nlc_ctx* ctx);
 int nlc_mppi_set_U(nlc_ctx* ctx, const double* U_host); /* (E,T,nu) control sequence(s), :161-164 */

@@ -5,7 +5,7 @@ Drop-in mirrors of the reference's Python interfaces for this path (SURVEY.md §
     from neurallaplacecontrol_amd import MPPIDelay              # planners/mppi_delay.py:54
     from neurallaplacecontrol_amd import NeuralLaplaceModel     # w_nl.py:66
     from neurallaplacecontrol_amd import laplace_reconstruct    # torchlaplace (external)
-    from neurallaplacecontrol_amd import DeltaTRNN              # train_utils.py:589 (baseline model)
+    from neurallaplacecontrol_amd import DeltaTRNN, NODE        # train_utils.py:589, :664 (baseline models)
 
 All arithmetic runs in hand-written HIP kernels behind the C ABI of ``libnlc_hip.so``
 (``include/nlc.h``); importing the package does not touch the GPU.  There is no CPU fallback.
@@ -15,6 +15,7 @@ from .envs import EnvCost, NLDynamics, OracleDynamics, initial_state, noise_sigm
 from .env_loop import BatchedEnv  # noqa: F401
 from .laplace import ilt_reconstruct, laplace_reconstruct, rep_func_inputs  # noqa: F401
 from .nl_model import LaplaceRepresentationFunc, NeuralLaplaceModel, ReverseGRUEncoder  # noqa: F401
+from .node_model import NODE, xOdeFuncInXAndU  # noqa: F401
 from .rnn_model import DeltaTRNN  # noqa: F401
 from .planners.mppi_batch import BatchedMPPIDelay  # noqa: F401
 from .planners.mppi_delay import MPPIDelay  # noqa: F401
@@ -25,6 +26,7 @@ __all__ = [
     "BatchedEnv",
     "NeuralLaplaceModel",
     "DeltaTRNN",
+    "NODE",
     "ReverseGRUEncoder",
     "LaplaceRepresentationFunc",
     "laplace_reconstruct",

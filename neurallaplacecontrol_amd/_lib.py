@@ -17,7 +17,7 @@ NLC_MAX_D = 8
 
 ILT_ALGOS = {"fourier": 0, "dehoog": 1}
 ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
-DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN = 0, 1, 2, 3
+DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN, DYN_NODE = 0, 1, 2, 3, 4
 
 ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE"}
 
@@ -43,6 +43,9 @@ SYMBOLS = [
     "nlc_rnn_blob_size",
     "nlc_set_rnn_model",
     "nlc_rnn_forward",
+    "nlc_node_blob_size",
+    "nlc_set_node_model",
+    "nlc_node_forward",
     "nlc_mppi_configure",
     "nlc_mppi_workspace_bytes",
     "nlc_mppi_set_U",
@@ -61,6 +64,19 @@ SYMBOLS = [
 
 class IltDesc(C.Structure):
     _fields_ = [("algo", C.c_int32), ("terms", C.c_int32), ("alpha", C.c_double), ("tol", C.c_double), ("scale", C.c_double)]
+
+
+class NodeDesc(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32),
+        ("nu", C.c_int32),
+        ("hidden", C.c_int32),
+        ("augment_dim", C.c_int32),
+        ("time_div", C.c_double),
+        ("step_size", C.c_double),
+        ("state_mean", C.c_double * NLC_MAX_D),
+        ("state_std", C.c_double * NLC_MAX_D),
+    ]
 
 
 class RnnDesc(C.Structure):
@@ -179,6 +195,10 @@ def load_library():
         lib.nlc_rnn_blob_size.restype = i64
         lib.nlc_set_rnn_model.argtypes = [vp, P(RnnDesc), vp, i64]
         lib.nlc_rnn_forward.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.nlc_node_blob_size.argtypes = [P(NodeDesc)]
+        lib.nlc_node_blob_size.restype = i64
+        lib.nlc_set_node_model.argtypes = [vp, P(NodeDesc), vp, i64]
+        lib.nlc_node_forward.argtypes = [vp, vp, vp, dbl, i64, vp]
         lib.nlc_env_step.argtypes = [vp, i32, i32, dbl, i32, i64, i32, i32, vp, vp, vp, vp, vp]
         lib.nlc_env_obs.argtypes = [vp, i32, i64, vp, vp]
         lib.nlc_mppi_configure.argtypes = [vp, P(MppiDesc)]

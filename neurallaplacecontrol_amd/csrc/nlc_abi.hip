@@ -69,6 +69,13 @@ struct nlc_ctx {
   RnnArgs rnn{};
   RnnHead rnn_head{};
 
+  // NODE baseline model
+  bool has_node = false;
+  nlc_node_desc nd{};
+  double* node_base = nullptr;
+  NodeNetArgs node{};
+  int node_ht = 0;
+
   // planner
   bool has_mppi = false;
   nlc_mppi_desc pd{};
@@ -251,6 +258,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   prof_flush(c);
   if (c->arena.base) hipFree(c->arena.base);
   if (c->rnn_base) hipFree(c->rnn_base);
+  if (c->node_base) hipFree(c->node_base);
   if (c->slot_dev) hipFree(c->slot_dev);
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
@@ -744,6 +752,123 @@ extern "C" int nlc_rnn_forward(nlc_ctx* c, const double* obs, const double* wind
 }
 
 // =================================================================================== planner
+// =================================================================================== NODE baseline
+namespace {
+int64_t node_blob_size(const nlc_node_desc* d) {
+  const int64_t H = d->hidden, dy = d->d + d->augment_dim, in = dy + d->nu;
+  return H * in + H + H * H + H + dy * H + dy;
+}
+// step sizes of torchdiffeq's fixed-grid solver over [0, t_end] (restated: oracle/node_model.py::euler_substeps)
+int node_substeps(double t_end, double step, double* h, int max_n) {
+  const int niters = (int)std::ceil(t_end / step + 1.0);
+  if (niters < 2 || niters - 1 > max_n) return -1;
+  double prev = 0.0;
+  for (int i = 1; i < niters; ++i) {
+    const double tk = (i == niters - 1) ? t_end : (double)i * step;
+    h[i - 1] = tk - prev;
+    prev = tk;
+  }
+  return niters - 1;
+}
+}  // namespace
+extern "C" int64_t nlc_node_blob_size(const nlc_node_desc* d) { return d ? node_blob_size(d) : -1; }
+
+extern "C" int nlc_set_node_model(nlc_ctx* c, const nlc_node_desc* d, const double* w, int64_t n) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
+  if (d->hidden < 1 || d->hidden > 272) return fail(c, NLC_ERR_UNSUPPORTED, "NODE hidden_units must be in 1..272");
+  if (d->d < 1 || d->augment_dim < 0 || d->d + d->augment_dim > 8 || d->d > NLC_MAX_D)
+    return fail(c, NLC_ERR_UNSUPPORTED, "state_dim + augment_dim must be <= 8");
+  if (d->nu < 1 || d->nu > NLC_MAX_NU) return fail(c, NLC_ERR_UNSUPPORTED, "nu must be 1 or 2");
+  if (!(d->time_div != 0.0) || !(d->step_size > 0.0)) return fail(c, NLC_ERR_BAD_ARG, "bad time_div / step_size");
+  if (n != node_blob_size(d)) return fail(c, NLC_ERR_BAD_SHAPE, "weight blob size mismatch");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const int H = d->hidden, dy = d->d + d->augment_dim, in = dy + d->nu;
+  const int ht = H <= 64 ? 4 : (H <= 128 ? 8 : 17), Hp = 16 * ht;
+  Blob b{w, n};
+  const double* W1 = b.take((int64_t)H * in);
+  const double* b1 = b.take(H);
+  const double* W2 = b.take((int64_t)H * H);
+  const double* b2 = b.take(H);
+  const double* W3 = b.take((int64_t)dy * H);
+  const double* b3 = b.take(dy);
+  // pad the hidden width to Hp rows / columns with zeros; inputs to 12 columns
+  std::vector<double> W1z((size_t)Hp * 12, 0.0), W2z((size_t)Hp * Hp, 0.0), W3z((size_t)16 * Hp, 0.0), b1z(Hp, 0.0),
+      b2z(Hp, 0.0), b3z(16, 0.0);
+  for (int r = 0; r < H; ++r) {
+    for (int j = 0; j < in; ++j) W1z[(size_t)r * 12 + j] = W1[(size_t)r * in + j];
+    for (int j = 0; j < H; ++j) W2z[(size_t)r * Hp + j] = W2[(size_t)r * H + j];
+    b1z[r] = b1[r];
+    b2z[r] = b2[r];
+  }
+  for (int r = 0; r < dy; ++r) {
+    for (int j = 0; j < H; ++j) W3z[(size_t)r * Hp + j] = W3[(size_t)r * H + j];
+    b3z[r] = b3[r];
+  }
+  DeviceArena ar;
+  const size_t o_W1 = ar.push(pack_A(W1z.data(), 12, 12, identity_rows(Hp)));
+  const size_t o_b1 = ar.push(b1z);
+  const size_t o_W2 = ar.push(pack_A(W2z.data(), Hp, Hp, identity_rows(Hp)));
+  const size_t o_b2 = ar.push(b2z);
+  const size_t o_W3 = ar.push(pack_A(W3z.data(), Hp, Hp, identity_rows(16)));
+  const size_t o_b3 = ar.push(b3z);
+  double* base = nullptr;
+  NLC_HIP(c, hipMalloc((void**)&base, ar.host.size() * sizeof(double)));
+  hipError_t e = hipMemcpy(base, ar.host.data(), ar.host.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    hipFree(base);
+    return fail(c, NLC_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e));
+  }
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->node_base) hipFree(c->node_base);
+  c->node_base = base;
+  c->nd = *d;
+  c->node_ht = ht;
+  NodeNetArgs& N = c->node;
+  N = NodeNetArgs{};
+  N.d = d->d;
+  N.aug = d->augment_dim;
+  N.nu = d->nu;
+  N.W1p = base + o_W1;
+  N.b1 = base + o_b1;
+  N.W2p = base + o_W2;
+  N.b2 = base + o_b2;
+  N.W3p = base + o_W3;
+  N.b3 = base + o_b3;
+  for (int i = 0; i < NLC_MAX_D; ++i) {
+    N.state_mean[i] = i < d->d ? d->state_mean[i] : 0.0;
+    N.state_std[i] = i < d->d ? d->state_std[i] : 1.0;
+  }
+  c->has_node = true;
+  if (c->has_mppi && c->pd.dynamics == NLC_DYN_NODE) c->has_mppi = false;
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+extern "C" int nlc_node_forward(nlc_ctx* c, const double* obs, const double* action, double ts_pred, int64_t N,
+                                double* out) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_node) return fail(c, NLC_ERR_STATE, "nlc_set_node_model has not been called");
+  if (N < 0) return fail(c, NLC_ERR_BAD_SHAPE, "bad N");
+  if (N == 0) return NLC_OK;
+  if (!obs || !action || !out) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  NodeForwardArgs f{};
+  f.net = c->node;
+  f.net.nsub = node_substeps(ts_pred / c->nd.time_div, c->nd.step_size, f.net.hsub, 8);
+  if (f.net.nsub < 0) return fail(c, NLC_ERR_UNSUPPORTED, "prediction time needs more than 8 Euler sub-steps (or is <= 0)");
+  f.N = N;
+  f.obs = obs;
+  f.action = action;
+  f.out = out;
+  ProfScope ps(c, "node_forward_kernel");
+  NLC_HIP(c, launch_node_forward(f, c->node_ht, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
 extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
@@ -760,7 +885,9 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if ((double)E * (double)d->K * d->T * d->nu > 2.0e9)
     return fail(c, NLC_ERR_BAD_SHAPE, "E*K*T*nu exceeds the planner's index range");
   // the env id selects the running cost and the oracle dynamics; with cost_external and NL dynamics nothing needs it
-  const bool env_free = d->cost_external && (d->dynamics == NLC_DYN_NL || d->dynamics == NLC_DYN_DTRNN) && d->env == -1;
+  const bool env_free = d->cost_external &&
+                        (d->dynamics == NLC_DYN_NL || d->dynamics == NLC_DYN_DTRNN || d->dynamics == NLC_DYN_NODE) &&
+                        d->env == -1;
   if (!env_free && (d->env < 0 || d->env > 2)) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
   static const int env_d[3] = {5, 3, 6}, env_nu[3] = {1, 1, 2};
   if (!env_free && d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
@@ -783,6 +910,13 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     if (!c->has_rnn) return fail(c, NLC_ERR_STATE, "Delta-t RNN dynamics need nlc_set_rnn_model first");
     if (c->rd.d != d->d || c->rd.nin != d->nu)
       return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
+  } else if (d->dynamics == NLC_DYN_NODE) {
+    if (!c->has_node) return fail(c, NLC_ERR_STATE, "NODE dynamics need nlc_set_node_model first");
+    if (c->nd.d != d->d || c->nd.nu != d->nu)
+      return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
+    double h[8];
+    if (node_substeps(d->ts_pred / c->nd.time_div, c->nd.step_size, h, 8) < 0)
+      return fail(c, NLC_ERR_UNSUPPORTED, "ts_pred needs more than 8 Euler sub-steps (or is <= 0)");
   } else {
     return fail(c, NLC_ERR_UNSUPPORTED, "unknown dynamics id");
   }
@@ -1144,6 +1278,28 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       }
       t0 += tc;
     }
+  } else if (d.dynamics == NLC_DYN_NODE) {
+    NodeRolloutArgs r{};
+    r.net = c->node;
+    r.net.nsub = node_substeps(d.ts_pred / c->nd.time_div, c->nd.step_size, r.net.hsub, 8);
+    r.K = KE;
+    r.Kep = d.K;
+    r.T = d.T;
+    r.nu = d.nu;
+    r.env = d.cost_external ? -1 : d.env;
+    r.state_per_sample = state_per_sample;
+    r.state0 = state_dev;
+    r.perturbed = buf->perturbed;
+    r.noise = buf->noise;
+    r.U = c->U[c->ucur];
+    for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) r.sigma_inv[i] = d.noise_sigma_inv[i];
+    r.lambda_ = d.lambda_;
+    r.u_scale = d.u_scale;
+    r.noise_abs_cost = d.noise_abs_cost;
+    r.states = buf->states;
+    r.cost_total = buf->cost_total;
+    ProfScope ps(c, "node_rollout_kernel");
+    NLC_HIP(c, launch_node_rollout(r, c->node_ht, c->stream));
   } else if (d.dynamics == NLC_DYN_DTRNN) {
     RnnArgs g = c->rnn;
     g.mode = 1;

@@ -251,6 +251,44 @@ struct OracleRolloutArgs {
 };
 hipError_t launch_oracle_rollout(const OracleRolloutArgs& a, hipStream_t s);
 
+// ------------------------------------------------------------------ NODE baseline (train_utils.py:637-738)
+struct NodeNetArgs {
+  int d, aug, nu;      // state_dim, augment_dim, action_dim: ODE-function input [x (d) | aug | u (nu)], <= 12 entries
+  const double* W1p;   // [3][HT][64]     inputs padded to 12
+  const double* b1;    // (16*HT)         padded with zeros (tanh(0) = 0: padded hidden units contribute nothing)
+  const double* W2p;   // [4*HT][HT][64]
+  const double* b2;    // (16*HT)
+  const double* W3p;   // [4*HT][1][64]   rows 0 .. d+aug-1
+  const double* b3;    // (16)
+  double state_mean[NLC_MAX_D], state_std[NLC_MAX_D];  // (0, 1) if !normalize
+  int nsub;            // Euler sub-steps of the fixed grid over [0, ts_pred / time_div] (step_size 0.05)
+  double hsub[8];
+};
+struct NodeRolloutArgs {
+  NodeNetArgs net;
+  int64_t K, Kep;
+  int T, nu, env;
+  int state_per_sample;
+  const double* state0;
+  const double* perturbed;
+  const double* noise;
+  const double* U;
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale;
+  int noise_abs_cost;
+  double* states;
+  double* cost_total;
+};
+struct NodeForwardArgs {
+  NodeNetArgs net;
+  int64_t N;
+  const double* obs;     // (N, d)
+  const double* action;  // (N, nu): window[:, -1, :]
+  double* out;           // (N, d)
+};
+hipError_t launch_node_rollout(const NodeRolloutArgs& a, int ht, hipStream_t s);
+hipError_t launch_node_forward(const NodeForwardArgs& a, int ht, hipStream_t s);
+
 // ------------------------------------------------------------------ env side of the evaluation loop
 // step_env (mppi_with_model.py:193-216) for E independent envs: get_action (delay buffer, :25-28), one Euler step of
 // the env's torch_rhs on the reduced state (base_env.py:136-173 with solver="euler", ts = [0, dt]), get_obs, reward.

@@ -1556,3 +1556,69 @@ def test_device_closed_loop_matches_host_stepped_loop(nlc):
         np.testing.assert_allclose(dev.state.cpu().numpy(), s.numpy(), rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(rew.cpu().numpy(), np.array(rews), rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(dev.action_buffer.cpu().numpy(), ab.numpy(), rtol=1e-9, atol=1e-10)
+
+
+# --------------------------------------------------------------------------- NODE baseline
+def build_node(nlc, sd, hidden, aug, normalize=True, normalize_time=True, device="cuda"):
+    d = sd["state_mean"].numel()
+    nu = sd["x_ode_func_in_x_and_u.linear_tanh_stack.0.weight"].shape[1] - d - aug
+    m = nlc.NODE(
+        d, nu, d, hidden_units=hidden, state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]),
+        action_std=np.array([1.0]), normalize=normalize, normalize_time=normalize_time, method="euler",
+        augment_dim=aug,
+    ).double()
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_node_forward_vs_reference_golden(nlc, env):
+    """G11: HIP NODE.forward vs the REAL reference classes (odeint = the restated fixed-grid Euler on both sides),
+    three and six Euler sub-steps."""
+    g = np.load(f"{GOLD}/g11_node_{env}.npz")
+    sd = load_sd(g, "sd_")
+    model = build_node(nlc, sd, int(g["H"]), int(g["AUG"]))
+    obs, win = T64(g["fwd_obs"]), T64(g["fwd_window"])
+    with torch.no_grad():
+        for tag in ("", "t2_"):
+            got = model(obs.cuda(), win.cuda(), T64(g[f"fwd_{tag}ts"]).cuda()).cpu()
+            np.testing.assert_allclose(got.numpy(), g[f"fwd_{tag}out"], **TOL)
+        got_cpu = model(obs, win[:, -1, :], T64(g["fwd_ts"]))  # 2-D action input (train_utils.py:712-713), CPU tensors
+        assert got_cpu.device.type == "cpu"
+        np.testing.assert_allclose(got_cpu.numpy(), g["fwd_out"], **TOL)
+
+
+@pytest.mark.parametrize("hidden,aug,N", [(64, 0, 500), (100, 2, 77), (128, 1, 1), (270, 1, 1030)])
+def test_node_forward_vs_oracle_sizes(nlc, hidden, aug, N):
+    from oracle import node_model as onode
+
+    d, nu = 6, 2
+    sd = onode.make_synthetic_state_dict(13, d, nu, hidden, aug, np.linspace(0.7, 2.9, d), [2.5])
+    g = torch.Generator().manual_seed(N)
+    obs = torch.randn(N, d, dtype=torch.float64, generator=g) * 2
+    win = (torch.rand(N, 3, nu, dtype=torch.float64, generator=g) * 2 - 1) * 5
+    ts = torch.full((N, 1), 0.07, dtype=torch.float64)
+    for nt in (True, False):
+        ref = onode.forward(sd, obs, win, ts, normalize=True, normalize_time=nt)
+        with torch.no_grad():
+            got = build_node(nlc, sd, hidden, aug, normalize_time=nt)(obs.cuda(), win.cuda(), ts.cuda()).cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), **TOL)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_mppi_node_dynamics_vs_reference_golden(nlc, env):
+    """G11: command() with the NODE behind the harness closure vs reference MPPIDelay + reference NODE."""
+    g = np.load(f"{GOLD}/g11_node_{env}.npz")
+    model = build_node(nlc, load_sd(g, "sd_"), int(g["H"]), int(g["AUG"]))
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["nx"]), int(g["nu"]), float(g["A"])
+
+    def make(U0):
+        return nlc.MPPIDelay(
+            nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-" + env), d, nlc.noise_sigma(nu),
+            num_samples=K, horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+            u_scale=A, U_init=U0,
+        )
+
+    # the synthetic model is expansive (the reference ADDS the integrated normalised state to the raw state): the
+    # states reach 1e3 within 8 steps and 1-ulp differences grow with them -> relative tolerance on the large entries
+    check_command_steps(nlc, g, make, tol=dict(rtol=1e-8, atol=1e-8))
