@@ -1622,3 +1622,63 @@ def test_mppi_node_dynamics_vs_reference_golden(nlc, env):
     # the synthetic model is expansive (the reference ADDS the integrated normalised state to the raw state): the
     # states reach 1e3 within 8 steps and 1-ulp differences grow with them -> relative tolerance on the large entries
     check_command_steps(nlc, g, make, tol=dict(rtol=1e-8, atol=1e-8))
+
+
+@pytest.mark.parametrize("kind", ["dtrnn", "node"])
+def test_batched_planner_baseline_models_equal_single_planners(nlc, kind):
+    """E episodes with the Delta-t RNN / NODE dynamics: K = 100 makes the 16-sample MFMA tiles straddle episodes;
+    episode e is bit-identical to a single planner fed the same draws."""
+    from oracle import nl_model as onl
+    from oracle import node_model as onode
+    from oracle import rnn_model as ornn
+
+    env, d, nu, A = "oderl-acrobot", 6, 2, 5.0
+    st = onl.ENV_STATS[env]
+    if kind == "dtrnn":
+        model = build_rnn(nlc, ornn.make_synthetic_state_dict(3, d, nu, 64, st["state_std"], [A / 2]), 64)
+    else:
+        model = build_node(nlc, onode.make_synthetic_state_dict(3, d, nu, 100, 1, st["state_std"], [A / 2]), 100, 1)
+    _batched_vs_singles(nlc, lambda: nlc.NLDynamics(model, 0.05), env, E=3, K=100, T=6, n_cmd=2)
+
+
+@pytest.mark.parametrize("kind", ["dtrnn", "node"])
+def test_baseline_models_with_cost_callables_and_weight_updates(nlc, kind):
+    """cost_external next to the baseline-model rollouts (a running_cost closure and a terminal cost keep the fused
+    dynamics), and a load_state_dict between commands is picked up by the planner."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+    from oracle import node_model as onode
+    from oracle import rnn_model as ornn
+
+    env, d, nu, A, K, Tt = "oderl-cartpole", 5, 1, 3.0, 96, 5
+    st = onl.ENV_STATS[env]
+    if kind == "dtrnn":
+        sds = [ornn.make_synthetic_state_dict(s, d, nu, 64, st["state_std"], [A / 2]) for s in (1, 2)]
+        model, dyn_of = build_rnn(nlc, sds[0], 64), ornn.make_dynamics
+    else:
+        sds = [onode.make_synthetic_state_dict(s, d, nu, 64, 1, st["state_std"], [A / 2]) for s in (1, 2)]
+        model, dyn_of = build_node(nlc, sds[0], 64, 1), onode.make_dynamics
+    cost = nlc.EnvCost(env)
+    term = lambda states, actions: 0.1 * (states[:, -1, :] ** 2).sum(-1)  # noqa: E731
+    g = torch.Generator().manual_seed(21)
+    raws = [torch.randn(K, Tt, nu, dtype=torch.float64, generator=g) for _ in range(2)]
+    U0 = torch.randn(Tt, nu, dtype=torch.float64, generator=g) * 0.3
+    state, ab = _state(nlc, env, 2), (torch.rand(4, nu, dtype=torch.float64, generator=g) - 0.5) * A
+    with torch.no_grad():
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), lambda s, u: cost(s, u), d, nlc.noise_sigma(nu), K, Tt, "cpu",
+                          lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(),
+                          terminal_state_cost=term)
+        assert p.cost_external
+        p.noise_dist = _Replay(*[r.clone() for r in raws])
+        U = U0.clone()
+        for i, sd in enumerate(sds):
+            if i:
+                model.load_state_dict(sd)
+            act = p.command(state, ab)
+            ref = omppi.mppi_command(U, state, ab, raws[i], dyn_of(sd), oenvs.RUNNING_COST[env], d,
+                                     torch.inverse(nlc.noise_sigma(nu)), 1.0, A, torch.tensor(-A), torch.tensor(A),
+                                     terminal_state_cost=term)
+            np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(p.cost_total.numpy(), ref["cost_total"].numpy(), rtol=1e-8, atol=1e-8)
+            U = ref["U"].clone()
