@@ -133,12 +133,15 @@ int64_t nlc_model_workspace_bytes(nlc_ctx* ctx, int64_t N);
 int nlc_model_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev,
                       int64_t N, int B, double* out_dev, void* ws_dev);
 
-/* ---- baseline model: DeltaTRNN (train_utils.py:589-631; factory :56-74, rnn_hidden_units config.py:43) ------
+/* ---- baseline models: DeltaTRNN (train_utils.py:589-631; factory :56-74) and RNN (:550-586; factory :77-98);
+ *      rnn_hidden_units config.py:43 ------
  * out, _ = GRU(nin -> hidden, 1 layer, batch_first)(window_n); dx = linear_out(cat(out[:, -1], obs_n, ts_n)). */
 typedef struct {
   int32_t d;      /* state_dim */
   int32_t nin;    /* GRU input dim = action_dim (+1 for an encode_obs_time model; forward API only) */
   int32_t hidden; /* hidden_units: 64, 128 or 160 */
+  int32_t time_input; /* 1: DeltaTRNN (linear_out sees ts); 0: the plain RNN baseline (train_utils.py:550-586), whose
+                       * linear_out is (d, H+d) and which ignores ts_pred */
   /* The caller resolves the reference's branch structure (train_utils.py:618-626; the `else` of the raw-input branch
    * belongs to `if self.normalize_time`): normalised branch -> the model's buffers and time_div = dt*8; raw branch
    * (normalize_time False) -> state (0, 1), action (0, 3), time_div 1. */
@@ -148,7 +151,7 @@ typedef struct {
 } nlc_rnn_desc;
 /* weights_host: float64 blob in the reference's state_dict order:
  *   gru.weight_ih_l0 (3H,nin) gru.weight_hh_l0 (3H,H) gru.bias_ih_l0 (3H) gru.bias_hh_l0 (3H)
- *   linear_out.weight (d, H+d+1) linear_out.bias (d) */
+ *   linear_out.weight (d, H+d+time_input) linear_out.bias (d) */
 int64_t nlc_rnn_blob_size(const nlc_rnn_desc* desc);
 int nlc_set_rnn_model(nlc_ctx* ctx, const nlc_rnn_desc* desc, const double* weights_host, int64_t n_doubles);
 /* DeltaTRNN.forward: obs_dev (N,d), window_dev (N,B,nin) raw actions, ts_dev (N) raw ts_pred -> out_dev (N,d)

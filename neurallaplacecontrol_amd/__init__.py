@@ -16,7 +16,7 @@ from .env_loop import BatchedEnv  # noqa: F401
 from .laplace import ilt_reconstruct, laplace_reconstruct, rep_func_inputs  # noqa: F401
 from .nl_model import LaplaceRepresentationFunc, NeuralLaplaceModel, ReverseGRUEncoder  # noqa: F401
 from .node_model import NODE, xOdeFuncInXAndU  # noqa: F401
-from .rnn_model import DeltaTRNN  # noqa: F401
+from .rnn_model import RNN, DeltaTRNN  # noqa: F401
 from .planners.mppi_batch import BatchedMPPIDelay  # noqa: F401
 from .planners.mppi_delay import MPPIDelay  # noqa: F401
 
@@ -26,6 +26,7 @@ __all__ = [
     "BatchedEnv",
     "NeuralLaplaceModel",
     "DeltaTRNN",
+    "RNN",
     "NODE",
     "ReverseGRUEncoder",
     "LaplaceRepresentationFunc",

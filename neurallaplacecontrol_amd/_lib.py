@@ -84,6 +84,7 @@ class RnnDesc(C.Structure):
         ("d", C.c_int32),
         ("nin", C.c_int32),
         ("hidden", C.c_int32),
+        ("time_input", C.c_int32),
         ("time_div", C.c_double),
         ("state_mean", C.c_double * NLC_MAX_D),
         ("state_std", C.c_double * NLC_MAX_D),

@@ -645,7 +645,7 @@ extern "C" int nlc_env_obs(nlc_ctx* c, int env, int64_t E, const double* state, 
 // =================================================================================== Delta-t RNN baseline
 static int64_t rnn_blob_size(const nlc_rnn_desc* d) {
   const int64_t H = d->hidden;
-  return 3 * H * d->nin + 3 * H * H + 6 * H + (int64_t)d->d * (H + d->d + 1) + d->d;
+  return 3 * H * d->nin + 3 * H * H + 6 * H + (int64_t)d->d * (H + d->d + (d->time_input ? 1 : 0)) + d->d;
 }
 extern "C" int64_t nlc_rnn_blob_size(const nlc_rnn_desc* d) { return d ? rnn_blob_size(d) : -1; }
 
@@ -660,7 +660,7 @@ extern "C" int nlc_set_rnn_model(nlc_ctx* c, const nlc_rnn_desc* d, const double
   if (!(d->time_div != 0.0)) return fail(c, NLC_ERR_BAD_ARG, "time_div must be non-zero");
   if (n != rnn_blob_size(d)) return fail(c, NLC_ERR_BAD_SHAPE, "weight blob size mismatch");
   NLC_HIP(c, hipSetDevice(c->device));
-  const int H = d->hidden, dd = d->d, nin = d->nin, F = H + dd + 1;
+  const int H = d->hidden, dd = d->d, nin = d->nin, F = H + dd + (d->time_input ? 1 : 0);
   Blob b{w, n};
   const double* Wih = b.take((int64_t)3 * H * nin);
   const double* Whh = b.take((int64_t)3 * H * H);
@@ -707,7 +707,7 @@ extern "C" int nlc_set_rnn_model(nlc_ctx* c, const nlc_rnn_desc* d, const double
   Hd.d = dd;
   for (int i = 0; i < dd; ++i) {
     for (int j = 0; j < dd; ++j) Hd.Wx[i * dd + j] = Wo[(size_t)i * F + H + j];
-    Hd.wt[i] = Wo[(size_t)i * F + H + dd];
+    Hd.wt[i] = d->time_input ? Wo[(size_t)i * F + H + dd] : 0.0;
     Hd.b[i] = bo[i];
     Hd.mean[i] = d->state_mean[i];
     Hd.std[i] = d->state_std[i];

@@ -3,6 +3,9 @@ factory ``get_delta_t_rnn_model`` ``:56-74``, ``rnn_hidden_units=160`` ``config.
 arguments, sub-module names and ``state_dict`` keys (``gru.*``, ``linear_out.*``, buffers ``state_mean state_std
 action_mean action_std dt``), so checkpoints written by the reference load unchanged.
 
+The plain ``RNN`` baseline (``train_utils.py:550-586``: the same GRU, ``linear_out`` over ``[h | obs]``, no time input,
+the un-normalised branch tied to ``normalize``) shares the kernels (``nlc_rnn_desc.time_input = 0``).
+
 ``forward`` runs as two HIP launches behind ``nlc_rnn_forward`` (GRU on FP64 matrix cores + hidden part of
 ``linear_out``; then the state/time part); behind ``NLDynamics`` the planner hoists the GRU out of the horizon loop
 (``NLC_DYN_DTRNN``).  Inference only, float64 only, as the harness uses it (``mppi_with_model.py:101,319``).
@@ -92,7 +95,7 @@ class DeltaTRNN(nn.Module):
         ``if self.normalize_time``; normalize=False with normalize_time=True leaves ``batch_obs`` undefined there."""
         d, nin = self.state_dim, self.action_dim + (1 if self.encode_obs_time else 0)
         desc = _lib.RnnDesc()
-        desc.d, desc.nin, desc.hidden = d, nin, self.hidden_units
+        desc.d, desc.nin, desc.hidden, desc.time_input = d, nin, self.hidden_units, 1
         f64 = lambda t: t.detach().to("cpu", torch.float64).reshape(-1)  # noqa: E731
         if self.normalize_time:
             if not self.normalize:
@@ -164,3 +167,63 @@ class DeltaTRNN(nn.Module):
                 )
             )
         return out.to(out_device)
+
+
+class RNN(DeltaTRNN):
+    """Twin of ``train_utils.RNN`` (``:550-586``): ``linear_out(cat(gru(actions)[:, -1], obs))``; ``ts_pred`` is
+    ignored; ``normalize=False`` selects raw observations and actions / 3."""
+
+    def __init__(self, state_dim, action_dim, hidden_units=64, encode_obs_time=False, state_mean=None, state_std=None,
+                 action_mean=None, action_std=None, normalize=False):
+        nn.Module.__init__(self)
+        self.encode_obs_time = encode_obs_time
+        self.state_dim, self.action_dim, self.hidden_units = state_dim, action_dim, hidden_units
+        self.gru = nn.GRU(action_dim, hidden_units, batch_first=True)  # the reference ignores encode_obs_time here
+        self.linear_out = nn.Linear(hidden_units + state_dim, state_dim)
+        self.normalize = normalize
+        self.normalize_time = False
+        self.register_buffer("state_mean", torch.tensor(state_mean))
+        self.register_buffer("state_std", torch.tensor(state_std))
+        self.register_buffer("action_mean", torch.tensor(action_mean))
+        self.register_buffer("action_std", torch.tensor(action_std))
+        self._ctx = None
+        self._key_ts = None
+        self._uploaded_key = None
+
+    @classmethod
+    def from_reference(cls, ref):
+        first = next(ref.parameters())
+        d = ref.linear_out.out_features
+        m = cls(d, ref.gru.input_size, hidden_units=ref.gru.hidden_size, encode_obs_time=bool(ref.encode_obs_time),
+                state_mean=[0.0] * d, state_std=[1.0] * d, action_mean=[0], action_std=[1.0],
+                normalize=ref.normalize).to(device=first.device, dtype=first.dtype)
+        for name in ("state_mean", "state_std", "action_mean", "action_std"):
+            m.register_buffer(name, getattr(ref, name).detach().clone())
+        m.load_state_dict(ref.state_dict())
+        m.train(ref.training)
+        return m
+
+    def model_desc(self):
+        d, nin = self.state_dim, self.action_dim
+        desc = _lib.RnnDesc()
+        desc.d, desc.nin, desc.hidden, desc.time_input = d, nin, self.hidden_units, 0
+        desc.time_div = 1.0
+        f64 = lambda t: t.detach().to("cpu", torch.float64).reshape(-1)  # noqa: E731
+        if self.normalize:
+            sm, ss = f64(self.state_mean), f64(self.state_std)
+            am = f64(self.action_mean).expand(nin) if self.action_mean.numel() == 1 else f64(self.action_mean)
+            a_s = f64(self.action_std).expand(nin) if self.action_std.numel() == 1 else f64(self.action_std)
+            if am.numel() != nin or a_s.numel() != nin or sm.numel() != d or ss.numel() != d:
+                raise ValueError("normalisation buffers do not broadcast against the model's input dims")
+        else:
+            sm, ss = torch.zeros(d, dtype=torch.float64), torch.ones(d, dtype=torch.float64)
+            am, a_s = torch.zeros(nin, dtype=torch.float64), torch.full((nin,), 3.0, dtype=torch.float64)
+        for i in range(d):
+            desc.state_mean[i], desc.state_std[i] = float(sm[i]), float(ss[i])
+        for i in range(nin):
+            desc.action_mean[i], desc.action_std[i] = float(am[i]), float(a_s[i])
+        return desc
+
+    def forward(self, in_batch_obs, in_batch_action, _):
+        ts = torch.zeros(in_batch_obs.shape[0], dtype=torch.float64)  # unused by the model (time_input = 0)
+        return super().forward(in_batch_obs, in_batch_action, ts)

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 
 def make_synthetic_state_dict(seed=0, d=5, nu=1, hidden=160, state_std=None, action_std=None, dt=0.05,
-                              out_scale=0.2):
+                              out_scale=0.2, time_input=True):
     """Seeded synthetic weights in the reference constructor's order (GRU, then linear_out: train_utils.py:610-613).
 
     ``out_scale`` shrinks ``linear_out`` ("trained-like": a model that predicts small state differences), so a
@@ -35,7 +35,7 @@ def make_synthetic_state_dict(seed=0, d=5, nu=1, hidden=160, state_std=None, act
     gen_state = torch.random.get_rng_state()
     torch.manual_seed(seed)
     gru = nn.GRU(nu, hidden, batch_first=True)
-    lin = nn.Linear(hidden + d + 1, d)
+    lin = nn.Linear(hidden + d + (1 if time_input else 0), d)  # the plain RNN baseline has no time input
     torch.random.set_rng_state(gen_state)
     sd = {f"gru.{k}": v for k, v in gru.state_dict().items()}
     sd["linear_out.weight"] = lin.weight
@@ -88,6 +88,27 @@ def forward(sd, obs, window, ts_pred, normalize=True, normalize_time=True):
     h = gru_forward_last(sd, batch_action)
     feat = torch.cat((h, batch_obs, ts), dim=1)
     return feat @ sd["linear_out.weight"].T + sd["linear_out.bias"]
+
+
+def forward_rnn(sd, obs, window, normalize=True):
+    """``RNN.forward`` (train_utils.py:577-586): the plain baseline -- no time input, ``linear_out`` is (d, H+d), the
+    raw-input branch belongs to ``normalize``."""
+    obs, window = obs.to(torch.float64), window.to(torch.float64)
+    if normalize:
+        batch_obs = (obs - sd["state_mean"]) / sd["state_std"]
+        batch_action = (window - sd["action_mean"]) / sd["action_std"]
+    else:
+        batch_obs = obs
+        batch_action = window / 3.0
+    h = gru_forward_last(sd, batch_action)
+    return torch.cat((h, batch_obs), dim=1) @ sd["linear_out.weight"].T + sd["linear_out.bias"]
+
+
+def make_dynamics_rnn(sd, normalize=True):
+    def dynamics(state, window):
+        return state + forward_rnn(sd, state, window, normalize)
+
+    return dynamics
 
 
 def make_dynamics(sd, dt=0.05, normalize=True, normalize_time=True):

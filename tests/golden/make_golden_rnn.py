@@ -13,6 +13,8 @@ Fixture contents per env (cartpole, pendulum, acrobot):
   sd_*                  the model's state_dict (reference constructor under torch.manual_seed, linear_out scaled)
   fwd_obs/window/ts/out DeltaTRNN.forward on random inputs, normalize=normalize_time=True
   raw_out               the same inputs through a normalize_time=False model (raw obs, action / 3, raw ts)
+  rnnsd_*, rnn_out, rnn_raw_out   the plain RNN baseline (train_utils.py:550-586, hidden 64) on the same inputs,
+                        normalize=True / False
   s{0,1}_*              two consecutive reference MPPIDelay.command() calls with the model as dynamics
 """
 
@@ -46,6 +48,7 @@ def load_reference_class(name):
 def main():
     MPPIDelay, _w_nl, envs, _dyn = mg.load_reference_modules()
     DeltaTRNN = load_reference_class("DeltaTRNN")
+    RNN = load_reference_class("RNN")
     K, T, B, H = 64, 8, 4, 160
     for env_name, mk in envs.items():
         env = mk()
@@ -103,6 +106,23 @@ def main():
             state = mppi.states[0, 0].clone()
             action_buffer = torch.roll(action_buffer, -1, dims=0)
             action_buffer[-1] = torch.as_tensor(c["action"])
+        # the plain RNN baseline (train_utils.py:550-586): forward on both branches
+        def build_rnn(normalize, seed):
+            torch.manual_seed(seed)
+            m = RNN(d, nu, hidden_units=64, encode_obs_time=False, state_mean=np.zeros(d),
+                    state_std=np.array(st["state_std"]), action_mean=np.array([0] * 1), action_std=np.array([A / 2.0]),
+                    normalize=normalize).double()
+            with torch.no_grad():
+                m.linear_out.weight.mul_(0.2)
+                m.linear_out.bias.mul_(0.2)
+            return m
+
+        rnn = build_rnn(True, 43)
+        out.update({f"rnnsd_{k}": mg.np_(v) for k, v in rnn.state_dict().items()})
+        with torch.no_grad():
+            out["rnn_out"] = mg.np_(rnn(obs, window, ts))
+            out["rnn_raw_out"] = mg.np_(build_rnn(False, 43)(obs, window, ts))
+
         np.savez_compressed(f"{HERE}/g9_dtrnn_{env_name.split('-')[1]}.npz", K=K, T=T, B=B, H=H, nx=d, nu=nu, A=A, **out)
         print("g9", env_name, "action", out["s1_action"], "max |dx|", np.abs(out["fwd_out"]).max())
 

@@ -1407,6 +1407,43 @@ def test_dtrnn_forward_vs_reference_golden(nlc, env):
         build_rnn(nlc, sd, int(g["H"]))(obs, win, ts)  # grad mode: inference-only on the HIP path
 
 
+@pytest.mark.parametrize("env", ["cartpole", "acrobot"])
+def test_plain_rnn_baseline_vs_reference_golden(nlc, env):
+    """G9: the plain RNN baseline (train_utils.py:550-586) vs the REAL reference class on both input branches, and
+    behind the planner vs the CPU oracle."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import rnn_model as ornn
+
+    g = np.load(f"{GOLD}/g9_dtrnn_{env}.npz")
+    sd = load_sd(g, "rnnsd_")
+    d, nu, A = int(g["nx"]), int(g["nu"]), float(g["A"])
+    obs, win, ts = T64(g["fwd_obs"]), T64(g["fwd_window"]), T64(g["fwd_ts"])
+
+    def build(normalize):
+        m = nlc.RNN(d, nu, hidden_units=64, state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]),
+                    action_std=np.array([1.0]), normalize=normalize).double()
+        m.load_state_dict(sd)
+        return m.cuda()
+
+    with torch.no_grad():
+        np.testing.assert_allclose(build(True)(obs.cuda(), win.cuda(), ts.cuda()).cpu().numpy(), g["rnn_out"], **TOL)
+        np.testing.assert_allclose(build(False)(obs, win, ts).numpy(), g["rnn_raw_out"], **TOL)
+    K, Tt = 80, 6
+    gen = torch.Generator().manual_seed(31)
+    raw = torch.randn(K, Tt, nu, dtype=torch.float64, generator=gen)
+    U0 = torch.randn(Tt, nu, dtype=torch.float64, generator=gen) * 0.3
+    state, ab = T64(g["s0_state"]), T64(g["s0_action_buffer"])
+    p = nlc.MPPIDelay(nlc.NLDynamics(build(True), 0.05), nlc.EnvCost("oderl-" + env), d, nlc.noise_sigma(nu), K, Tt,
+                      "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+    p.noise_dist = _Replay(raw.clone())
+    act = p.command(state, ab)
+    ref = omppi.mppi_command(U0.clone(), state, ab, raw, ornn.make_dynamics_rnn(sd), oenvs.RUNNING_COST["oderl-" + env],
+                             d, torch.inverse(nlc.noise_sigma(nu)), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), **TOL)
+    np.testing.assert_allclose(p.states.numpy(), ref["states"].numpy(), **TOL)
+
+
 @pytest.mark.parametrize("hidden,B,N", [(64, 4, 1000), (128, 1, 77), (160, 6, 513), (160, 4, 1)])
 def test_dtrnn_forward_vs_oracle_sizes(nlc, hidden, B, N):
     from oracle import rnn_model as ornn

@@ -310,6 +310,11 @@ def test_g9_dtrnn_oracle_matches_reference_class(env, golden_dir):
     with pytest.raises(NameError):
         ornn.forward(sd, obs, window, ts, normalize=False, normalize_time=True)
     run_steps(g, ornn.make_dynamics(sd), oenvs.RUNNING_COST["oderl-" + env], int(g["nx"]), int(g["nu"]), float(g["A"]))
+    # the plain RNN baseline (train_utils.py:550-586)
+    rsd = load_sd(g, "rnnsd_")
+    np.testing.assert_allclose(ornn.forward_rnn(rsd, obs, window).numpy(), g["rnn_out"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(ornn.forward_rnn(rsd, obs, window, normalize=False).numpy(), g["rnn_raw_out"],
+                               rtol=1e-11, atol=1e-13)
     # the synthetic-weight helper reproduces the reference constructor's draw order (GRU, then linear_out)
     st = onl.ENV_STATS["oderl-" + env]
     mine = ornn.make_synthetic_state_dict(40, st["d"], st["nu"], int(g["H"]), st["state_std"], [st["act_high"] / 2.0])
