@@ -13,14 +13,10 @@
 // Roofline: FP64 MFMA.  Per 16 samples and Euler sub-step: 3 HT + 4 HT^2 + 4 HT MFMAs (HT = ceil(H/16) = 17 for
 // H = 270: 1275 MFMAs of 2048 flop); three sub-steps per horizon step at the harness's dt.
 #include "nlc_device.h"
+#include "nlc_envcost.h"
 #include "nlc_kernels.h"
 
 namespace nlc {
-
-namespace {
-__device__ __forceinline__ double running_cost_n(int env, const double (&x)[NLC_MAX_D], const double (&u)[NLC_MAX_NU],
-                                                 int nu);
-}
 
 // One evaluation of the ODE function for the wave's 16 samples.  in0/in1/in2: layer-1 B fragments (input index 4s+q
 // of [y (d+aug) | u (nu)]).  Returns the output tile: register r of lane group q = row 4r + q of f.
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(256) void node_rollout_kernel(const NodeRolloutArgs
       }
       pc += a.U[uoff + t * a.nu + j] * acj;
     }
-    cost += running_cost_n(a.env, xs, u, a.nu);
+    cost += running_cost(a.env, xs, u, a.nu);
     pcost += pc;
   }
   if (valid && q == 0) a.cost_total[k] = cost + pcost;
@@ -161,41 +157,6 @@ __global__ __launch_bounds__(256) void node_forward_kernel(const NodeForwardArgs
     if (i1 < d) a.out[r * d + i1] = y1;
   }
 }
-
-namespace {
-// env running costs on the trig observation (same formulas as kernels_nl.hip / kernels_mppi.hip;
-// mppi_with_model.py:163-164 -> ctcartpole.py:303-346, ctpendulum.py:139-155, ctacrobot.py:233-255)
-__device__ __forceinline__ double trig2angle_n(double c, double s) {
-  const double C = c * c + s * s;
-  c = c / C;
-  s = s / C;
-  return atan2(s / C, c / C);
-}
-__device__ __forceinline__ double running_cost_n(int env, const double (&x)[NLC_MAX_D], const double (&u)[NLC_MAX_NU],
-                                                 int nu) {
-  if (env < 0) return 0.0;
-  double uu = 0.0;
-  for (int j = 0; j < nu; ++j) uu += u[j] * u[j];
-  if (env == NLC_ENV_CARTPOLE) {
-    const double e0 = x[0] + x[3] - 0.0, e1 = x[2] - 1.0;
-    const double sr = -(e0 * e0 + e1 * e1);
-    const double vr = -(x[1] * x[1]) - x[4] * x[4];
-    return -((sr + 0.01 * vr) + (-0.01 * uu));
-  } else if (env == NLC_ENV_PENDULUM) {
-    const double om = 1.0 - x[0];
-    const double sr = -(om * om + x[1] * x[1]);
-    const double vr = -(x[2] * x[2]);
-    return -((sr + 0.01 * vr) + (-0.01 * uu));
-  }
-  const double th1 = trig2angle_n(x[0], x[1]), th2 = trig2angle_n(x[2], x[3]);
-  const double vr = -(x[4] * x[4]) - x[5] * x[5];
-  const double p1x = -cos(th1), p1y = sin(th1);
-  const double p2x = p1x - cos(th1 + th2), p2y = p1y + sin(th1 + th2);
-  const double ex = p2x - 1.0 - 1.0;
-  const double sr = -(ex * ex) - p2y * p2y;
-  return -((sr + 1e-1 * vr) + (-1e-4 * uu));
-}
-}  // namespace
 
 hipError_t launch_node_rollout(const NodeRolloutArgs& a, int ht, hipStream_t s) {
   if (a.K <= 0) return hipSuccess;

@@ -98,7 +98,7 @@ def test_ilt_fourier_backward_vs_autograd_of_oracle(nlc, d, S, N):
         ph_d = phi.detach().cuda().requires_grad_()
         got = nlc.ilt_reconstruct(th_d, ph_d, t.cuda(), "fourier", opts)
         np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-9,
-                                   atol=1e-11 * float(ref.abs().max()))
+                                   atol=1e-11 * float(ref.detach().abs().max()))
         gt, gp = torch.autograd.grad(got, (th_d, ph_d), gx.cuda())
         for a, b in ((gt, rt), (gp, rp)):
             sc = float(b.abs().max())
@@ -1719,3 +1719,43 @@ def test_baseline_models_with_cost_callables_and_weight_updates(nlc, kind):
             np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-8, atol=1e-9)
             np.testing.assert_allclose(p.cost_total.numpy(), ref["cost_total"].numpy(), rtol=1e-8, atol=1e-8)
             U = ref["U"].clone()
+
+
+@pytest.mark.parametrize("kind,K,Tt,B", [("dtrnn", 17, 1, 1), ("dtrnn", 130, 3, 6), ("node", 17, 1, 1), ("node", 130, 3, 6),
+                                         ("rnn", 33, 2, 2)])
+def test_baseline_planners_edge_shapes_vs_oracle(nlc, kind, K, Tt, B):
+    """Ragged K (below / across one 16-sample tile), T = 1, one-row and six-row action buffers, nu = 2."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+    from oracle import node_model as onode
+    from oracle import rnn_model as ornn
+
+    env, d, nu, A = "oderl-acrobot", 6, 2, 5.0
+    st = onl.ENV_STATS[env]
+    if kind == "dtrnn":
+        sd = ornn.make_synthetic_state_dict(8, d, nu, 128, st["state_std"], [A / 2])
+        model, dyn = build_rnn(nlc, sd, 128), ornn.make_dynamics(sd)
+    elif kind == "rnn":
+        sd = ornn.make_synthetic_state_dict(8, d, nu, 64, st["state_std"], [A / 2], time_input=False)
+        model = nlc.RNN(d, nu, hidden_units=64, state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]),
+                        action_std=np.array([1.0]), normalize=True).double()
+        model.load_state_dict({k: v for k, v in sd.items() if k != "dt"})
+        model, dyn = model.cuda(), ornn.make_dynamics_rnn(sd)
+    else:
+        sd = onode.make_synthetic_state_dict(8, d, nu, 128, 1, st["state_std"], [A / 2])
+        model, dyn = build_node(nlc, sd, 128, 1), onode.make_dynamics(sd)
+    g = torch.Generator().manual_seed(K * 7 + B)
+    raw = torch.randn(K, Tt, nu, dtype=torch.float64, generator=g) @ torch.linalg.cholesky(nlc.noise_sigma(nu)).T
+    U0 = torch.randn(Tt, nu, dtype=torch.float64, generator=g) * 0.3
+    state = _state(nlc, env, 3)
+    ab = (torch.rand(B, nu, dtype=torch.float64, generator=g) - 0.5) * A
+    p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, Tt, "cpu", lambda_=1.0,
+                      u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+    p.noise_dist = _Replay(raw.clone())
+    act = p.command(state, ab)
+    ref = omppi.mppi_command(U0.clone(), state, ab, raw, dyn, oenvs.RUNNING_COST[env], d,
+                             torch.inverse(nlc.noise_sigma(nu)), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), **TOL)
+    np.testing.assert_allclose(p.cost_total.numpy(), ref["cost_total"].numpy(), **TOL)
+    np.testing.assert_allclose(p.states.numpy(), ref["states"].numpy(), **TOL)
