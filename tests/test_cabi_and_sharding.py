@@ -41,7 +41,8 @@ def test_struct_layouts_match_header():
     src = r"""
     #include <stdio.h>
     #include "nlc.h"
-    int main(){ printf("%zu %zu %zu %zu\n", sizeof(nlc_ilt_desc), sizeof(nlc_model_desc), sizeof(nlc_mppi_desc), sizeof(nlc_mppi_buffers)); return 0; }
+    int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(nlc_ilt_desc), sizeof(nlc_model_desc), sizeof(nlc_mppi_desc),
+                       sizeof(nlc_mppi_buffers), sizeof(nlc_rnn_desc), sizeof(nlc_node_desc)); return 0; }
     """
     import tempfile
 
@@ -49,7 +50,8 @@ def test_struct_layouts_match_header():
         open(os.path.join(td, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), "-o", os.path.join(td, "s"), os.path.join(td, "s.c")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
-    assert sizes == [C.sizeof(_lib.IltDesc), C.sizeof(_lib.ModelDesc), C.sizeof(_lib.MppiDesc), C.sizeof(_lib.MppiBuffers)]
+    assert sizes == [C.sizeof(_lib.IltDesc), C.sizeof(_lib.ModelDesc), C.sizeof(_lib.MppiDesc), C.sizeof(_lib.MppiBuffers),
+                     C.sizeof(_lib.RnnDesc), C.sizeof(_lib.NodeDesc)]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
@@ -68,6 +70,17 @@ def test_fails_loudly_without_gpu(lib):
         nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum"), nlc.EnvCost("oderl-pendulum"), 3, nlc.noise_sigma(1), 8, 4)
     with pytest.raises(_lib.NlcError):
         _lib.Ctx(0)
+    with pytest.raises(RuntimeError):
+        nlc.BatchedEnv("oderl-cartpole", 4)
+    d = 3
+    for model in (
+        nlc.DeltaTRNN(d, 1, hidden_units=64, state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]),
+                      action_std=np.array([1.0]), normalize=True, normalize_time=True).double(),
+        nlc.NODE(d, 1, d, hidden_units=64, state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]),
+                 action_std=np.array([1.0]), normalize=True, normalize_time=True, augment_dim=1).double(),
+    ):
+        with torch.no_grad(), pytest.raises(RuntimeError):  # no CPU fallback behind the model mirrors either
+            model(torch.zeros(2, d).double(), torch.zeros(2, 4, 1).double(), torch.full((2, 1), 0.05).double())
 
 
 def test_product_does_not_import_oracle():
