@@ -313,7 +313,10 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   if (a.iters < 8) return hipErrorInvalidValue;
   const int rows = a.rpp * a.iters;
   const int64_t nblk = (rows_total + rows - 1) / rows;
-  const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
+  // persistent grid: 1024-4096 blocks measure the same within run-to-run noise (NLC_ILT_GRID: experiments)
+  int64_t cap = 2048;
+  if (const char* ev = std::getenv("NLC_ILT_GRID")) cap = std::atoll(ev) > 0 ? std::atoll(ev) : cap;
+  const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
   const size_t shmem = (size_t)rows * SP * sizeof(double);
   a.dbg = 0;
   if (const char* ev = std::getenv("NLC_ILT_DBG")) a.dbg = std::atoi(ev);  // 1 memory-only, 2 arithmetic-only (timing)
