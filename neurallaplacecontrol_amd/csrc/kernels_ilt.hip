@@ -314,12 +314,18 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   const int rows = a.rpp * a.iters;
   const int64_t nblk = (rows_total + rows - 1) / rows;
   // persistent grid: 1024-4096 blocks measure the same within run-to-run noise (NLC_ILT_GRID: experiments)
-  int64_t cap = 2048;
-  if (const char* ev = std::getenv("NLC_ILT_GRID")) cap = std::atoll(ev) > 0 ? std::atoll(ev) : cap;
+  static const int64_t cap = [] {  // read once: no getenv on the launch path
+    const char* ev = std::getenv("NLC_ILT_GRID");
+    return (ev && std::atoll(ev) > 0) ? (int64_t)std::atoll(ev) : (int64_t)2048;
+  }();
   const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
   const size_t shmem = (size_t)rows * SP * sizeof(double);
   a.dbg = 0;
-  if (const char* ev = std::getenv("NLC_ILT_DBG")) a.dbg = std::atoi(ev);  // 1 memory-only, 2 arithmetic-only (timing)
+  static const int dbg_env = [] {  // 1 memory-only, 2 arithmetic-only (timing experiments); read once
+    const char* ev = std::getenv("NLC_ILT_DBG");
+    return ev ? std::atoi(ev) : 0;
+  }();
+  a.dbg = dbg_env;
 #define NLC_ILT_LAUNCH(D)                                                                              \
   switch (a.iters) {                                                                                   \
     case 8: hipLaunchKernelGGL((ilt_fourier_kernel<D, 8>), dim3(grid), dim3(256), shmem, s, a); break;   \

@@ -335,7 +335,6 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
   if (!theta || !phi || !t || !x) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
   IltArgs a{theta, phi, t, x, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr, 1.0, 1, 0, 0, 0};
-  if (const char* ev = std::getenv("NLC_ILT_DBG")) a.dbg = std::atoi(ev);  // timing experiments only (IltArgs.dbg)
   if (d->algo == NLC_ILT_FOURIER) {
     ProfScope ps(c, "ilt_fourier_kernel");
     NLC_HIP(c, launch_ilt_fourier(a, c->stream));
@@ -1236,7 +1235,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       return d.cost_external ? NLC_OK : run_weights(c, buf);
     }
     // NLC_ROLLOUT_VARIANT=1|2 pins the wave-per-tile / latency-split kernel (tests, experiments); default auto
-    int variant = 0;
+    int variant = 0;  // (read per command: the GPU tests switch it inside one process)
     if (const char* ev = std::getenv("NLC_ROLLOUT_VARIANT")) variant = std::atoi(ev);
     // Horizon chunking (experiment knob, OFF by default): NLC_HORIZON_CHUNKS=n cuts the horizon into n chunks and
     // runs the GRU encode of chunk c+1 on the ctx's side stream while the rollout of chunk c runs on the main
