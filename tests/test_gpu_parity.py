@@ -991,8 +991,15 @@ model = n.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=17, ilt_a
                              normalize=True, normalize_time=True).double()
 model.load_state_dict(sd)
 model = model.cuda()
+kw = dict(state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]),
+          normalize=True, normalize_time=True)
+rnn = n.DeltaTRNN(d, nu, hidden_units=64, **kw).double()
+rnn.load_state_dict(torch.load(os.path.join(sys.argv[2], "sd_rnn.pt")))
+node = n.NODE(d, nu, d, hidden_units=64, augment_dim=1, **kw).double()
+node.load_state_dict(torch.load(os.path.join(sys.argv[2], "sd_node.pt")))
 out = {}
-for name, dyn in (("nl", n.NLDynamics(model, 0.05)), ("oracle", n.OracleDynamics("oderl-cartpole", 0.05, 2))):
+for name, dyn in (("nl", n.NLDynamics(model, 0.05)), ("oracle", n.OracleDynamics("oderl-cartpole", 0.05, 2)),
+                  ("dtrnn", n.NLDynamics(rnn.cuda(), 0.05)), ("node", n.NLDynamics(node.cuda(), 0.05))):
     p = n.MPPIDelay(dyn, n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
                     u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
                     noise_rng="philox", seed=21, process_group=dist.group.WORLD)
@@ -1020,6 +1027,13 @@ def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
     st = onl.ENV_STATS["oderl-cartpole"]
     sd = onl.make_synthetic_state_dict(8, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
     torch.save(sd, tmp_path / "sd.pt")
+    from oracle import node_model as onode
+    from oracle import rnn_model as ornn
+
+    sd_rnn = ornn.make_synthetic_state_dict(8, d, nu, 64, st["state_std"], [A / 2])
+    sd_node = onode.make_synthetic_state_dict(8, d, nu, 64, 1, st["state_std"], [A / 2])
+    torch.save(sd_rnn, tmp_path / "sd_rnn.pt")
+    torch.save(sd_node, tmp_path / "sd_node.pt")
     script = tmp_path / "worker.py"
     script.write_text(_TWO_RANK_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
@@ -1029,7 +1043,9 @@ def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     model = build_model(nlc, sd)
     state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
-    for name, dyn in (("nl", nlc.NLDynamics(model, 0.05)), ("oracle", nlc.OracleDynamics("oderl-cartpole", 0.05, 2))):
+    for name, dyn in (("nl", nlc.NLDynamics(model, 0.05)), ("oracle", nlc.OracleDynamics("oderl-cartpole", 0.05, 2)),
+                      ("dtrnn", nlc.NLDynamics(build_rnn(nlc, sd_rnn, 64), 0.05)),
+                      ("node", nlc.NLDynamics(build_node(nlc, sd_node, 64, 1), 0.05))):
         assert torch.equal(r0[name]["acts"], r1[name]["acts"]) and torch.equal(r0[name]["U"], r1[name]["U"])
         p = nlc.MPPIDelay(dyn, nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
                           u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
