@@ -33,7 +33,7 @@ import torch  # noqa: E402
 ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384, 40, 4, 17, 128, 3.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # newest committed PMC summary (separate rocprofv3 --pmc passes, tools/pmc_summarize.py)
-PMC_JSON = next((p for p in (os.path.join(REPO, "profiles", n) for n in ("r1j_pmc_kernels.json", "r1h_pmc_kernels.json"))
+PMC_JSON = next((p for p in (os.path.join(REPO, "profiles", n) for n in ("r1k_pmc_kernels.json", "r1j_pmc_kernels.json", "r1h_pmc_kernels.json"))
                  if os.path.exists(p)), os.path.join(REPO, "profiles", "r1j_pmc_kernels.json"))
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
 
