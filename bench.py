@@ -124,6 +124,12 @@ def main():
     ap.add_argument("--samples", type=int, default=K_SAMPLES,
                     help="override K (experiments only; the headline metric is quoted at the default 16384)")
     args = ap.parse_args()
+    # stdout carries exactly ONE JSON line (driver contract).  Libraries write there too -- RCCL prints its
+    # NCCL_DEBUG=VERSION banner (set by the box image) to stdout at communicator creation -- so everything else this
+    # process and its libraries print goes to stderr, and the result line is written to the saved stdout at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -315,7 +321,8 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
     if K_total != K_SAMPLES:
         out["config"]["workload"] += f" -- EXPERIMENT with K={K_total}, not the headline configuration"
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     if pg is not None:
         dist.destroy_process_group()
 
