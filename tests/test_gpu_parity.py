@@ -144,6 +144,34 @@ def test_laplace_reconstruct_trains_rep_func_through_hip_ilt(nlc):
                             torch.full((2,), 0.1, dtype=torch.float64, device="cuda"), "dehoog")
 
 
+def test_ilt_fourier_full_bench_size_vs_oracle(nlc):
+    """The stand-alone kernel at the bench's N = K*T = 655 360 points (d = 5, S = 17), forward and backward, against the
+    CPU restatement on the same inputs (forward on every point; the gradient check on a checksum <g, x> = sum g x)."""
+    from oracle import ilt as oilt
+
+    N, d, S = 16384 * 40, 5, 17
+    g = torch.Generator().manual_seed(99)
+    theta = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi / 2 * 0.99
+    t = torch.full((N,), 0.125, dtype=torch.float64)
+    gx = torch.randn(N, d, dtype=torch.float64, generator=g)
+    ref = oilt.ilt_from_sphere(theta, phi, t, "fourier", None)
+    th_d, ph_d = theta.cuda().requires_grad_(), phi.cuda().requires_grad_()
+    got = nlc.ilt_reconstruct(th_d, ph_d, t.cuda(), "fourier", None)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.detach().cpu().numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
+    gt, gp = torch.autograd.grad(got, (th_d, ph_d), gx.cuda())
+    # directional derivative of <gx, x> along a random direction, by central differences of the ORACLE
+    dth = torch.randn(theta.shape, dtype=torch.float64, generator=g)
+    dph = torch.randn(phi.shape, dtype=torch.float64, generator=g) * 0.1
+    eps = 1e-6
+    fp = (oilt.ilt_from_sphere(theta + eps * dth, phi + eps * dph, t, "fourier", None) * gx).sum()
+    fm = (oilt.ilt_from_sphere(theta - eps * dth, phi - eps * dph, t, "fourier", None) * gx).sum()
+    fd = float((fp - fm) / (2 * eps))
+    an = float((gt.cpu() * dth).sum() + (gp.cpu() * dph).sum())
+    assert abs(fd - an) <= 1e-6 * max(abs(fd), abs(an), 1.0), (fd, an)
+
+
 def test_ilt_empty_and_single(nlc):
     z = nlc.ilt_reconstruct(torch.zeros(0, 5, 17).double().cuda(), torch.zeros(0, 5, 17).double().cuda(),
                             torch.zeros(0).double().cuda())
