@@ -1601,6 +1601,18 @@ def test_env_step_vs_reference_env_golden(nlc, env):
     np.testing.assert_allclose(e.get_obs()[0].cpu().numpy(), g["reset_seed5_obs"], **tol)
     with pytest.raises(ValueError):
         nlc.BatchedEnv(name, 2, action_delay=4, action_buffer_size=4)
+    # per-episode reset: only the listed env is re-drawn (continuing ITS stream) and gets a zeroed action buffer
+    e.step(torch.ones(4, int(g["nu"]), dtype=torch.float64))
+    before_s, before_ab = e.state.clone(), e.action_buffer.clone()
+    e.reset([2])
+    keep = [0, 1, 3]
+    assert torch.equal(e.state[keep], before_s[keep]) and torch.equal(e.action_buffer[keep], before_ab[keep])
+    assert not torch.equal(e.state[2], before_s[2]) and float(e.action_buffer[2].abs().max()) == 0.0
+    from oracle import envs as oenvs
+
+    rs = np.random.RandomState(5 + 2)
+    oenvs.env_reset(name, rs)  # the constructor's draw
+    np.testing.assert_allclose(e.state[2].cpu().numpy(), oenvs.env_reset(name, rs).numpy(), rtol=0, atol=0)
 
 
 def test_device_closed_loop_matches_host_stepped_loop(nlc):
