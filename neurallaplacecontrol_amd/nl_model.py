@@ -7,9 +7,10 @@ action_std dt``: reference ``w_nl.py:14-115``), so checkpoints written by the re
 
 ``NeuralLaplaceModel.forward`` (reference ``w_nl.py:117-145``) runs as two HIP launches behind
 ``nlc_model_forward``: the GRU encoder on FP64 matrix cores, then representation MLP + sphere map +
-Fourier ILT fused (the (N, 2dS) theta/phi tensor never reaches HBM).  Inference only, float64 only
-(the reference harness calls ``model.double()`` under ``torch.no_grad()``:
-``mppi_with_model.py:101,319``).
+Fourier ILT fused (the (N, 2dS) theta/phi tensor never reaches HBM), float64 only (the reference harness calls
+``model.double()`` under ``torch.no_grad()``: ``mppi_with_model.py:101,319``).  In grad mode (training,
+``train_utils.py:388-407``) ``forward`` runs the reference's op sequence with the GRU / MLP on PyTorch-ROCm and the
+line integral -- forward and backward -- in HIP, so the class is trainable on the GPU without torchlaplace.
 """
 
 import copy
@@ -270,7 +271,39 @@ class NeuralLaplaceModel(nn.Module):
             ctx.check(ctx.lib.nlc_gru_encode(ctx.h, _lib.ptr(win), N, B, _lib.ptr(out)))
         return out
 
+    def _forward_train(self, in_batch_obs, in_batch_action, ts_pred):
+        """Grad-mode forward (the reference trains through ``model(...)``, ``train_utils.py:388-407``): the op sequence of
+        ``w_nl.py:117-145`` with the GRU encoder and the representation MLP on PyTorch-ROCm (their backward is
+        autograd's) and the line integral in HIP, forward AND backward (``nlc_ilt_reconstruct_backward``)."""
+        if self.ilt_algorithm != "fourier":
+            raise NotImplementedError("training through the HIP ILT is implemented for ilt_algorithm='fourier' only")
+        dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
+        if next(self.parameters()).device != dev:
+            raise RuntimeError("training forward: move the model to the GPU first (model.to('cuda'))")
+        obs = in_batch_obs.to(dev, torch.float64)
+        act = in_batch_action.to(dev, torch.float64)
+        ts = torch.as_tensor(ts_pred).to(dev, torch.float64)
+        if self.normalize:
+            batch_obs = (obs - self.state_mean) / self.state_std
+            batch_action = (act - self.action_mean) / self.action_std
+            if self.normalize_time:
+                ts = ts / (self.dt * 8.0)
+        else:
+            batch_obs = obs
+            batch_action = act / 3.0
+        if batch_action.dim() == 2:
+            batch_action = batch_action.unsqueeze(1)
+        p = torch.cat((batch_obs, self.action_encoder(batch_action)), dim=1)
+        return torch.squeeze(
+            laplace_reconstruct(
+                self.laplace_rep_func, p, ts, recon_dim=self.output_dim, ilt_algorithm=self.ilt_algorithm,
+                ilt_reconstruction_terms=self.s_recon_terms, options=self.ilt_options,
+            )
+        ).to(in_batch_obs.device)
+
     def forward(self, in_batch_obs, in_batch_action, ts_pred):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(in_batch_obs, in_batch_action, ts_pred)
         self._no_grad_only()
         out_device = in_batch_obs.device
         dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))

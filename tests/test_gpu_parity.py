@@ -312,10 +312,53 @@ def test_model_requires_no_grad_and_double(nlc):
     st = onl.ENV_STATS["oderl-cartpole"]
     sd = onl.make_synthetic_state_dict(0, 5, 1, 128, 17, st["state_std"], [1.5])
     model = build_model(nlc, sd)
-    with pytest.raises(NotImplementedError):
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    with pytest.raises(NotImplementedError):  # grad mode with nothing to train: the fused path is inference-only
         model(torch.zeros(2, 5).double().cuda(), torch.zeros(2, 4, 1).double().cuda(), torch.ones(2, 1).double().cuda())
     with torch.no_grad(), pytest.raises(NotImplementedError):
         model.float()(torch.zeros(2, 5).cuda(), torch.zeros(2, 4, 1).cuda(), torch.ones(2, 1).cuda())
+
+
+@pytest.mark.parametrize("env", ["cartpole", "acrobot"])
+def test_model_trains_through_hip_ilt(nlc, env):
+    """Grad-mode forward (train_utils.py:388-407 trains through model(...)): GRU / MLP on PyTorch-ROCm, line integral
+    forward AND backward in HIP.  Output and every parameter gradient equal autograd through the CPU restatement."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-" + env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(3, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    g = torch.Generator().manual_seed(17)
+    N = 203
+    obs = torch.randn(N, d, dtype=torch.float64, generator=g) * torch.tensor(st["state_std"])
+    win = (torch.rand(N, 4, nu, dtype=torch.float64, generator=g) * 2 - 1) * A
+    ts = torch.rand(N, 1, dtype=torch.float64, generator=g) * 0.08 + 0.02
+    target = torch.randn(N, d, dtype=torch.float64, generator=g)
+    # oracle side: the state_dict tensors as leaves
+    names = [k for k in sd if k.startswith(("action_encoder.", "laplace_rep_func."))]
+    leaves = {k: (v.clone().requires_grad_() if k in names else v) for k, v in sd.items()}
+    ref = onl.nl_forward(leaves, obs, win, ts, S=17)
+    ((ref - target) ** 2).mean().backward()
+    model = build_model(nlc, sd)
+    model.train()
+    got = model(obs.cuda(), win.cuda(), ts.cuda())
+    assert got.requires_grad
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-8, atol=1e-10)
+    ((got - target.cuda()) ** 2).mean().backward()
+    for k, p_ in model.named_parameters():
+        ref_g = leaves[k].grad
+        sc = float(ref_g.abs().max()) + 1e-300
+        np.testing.assert_allclose(p_.grad.cpu().numpy() / sc, ref_g.numpy() / sc, rtol=1e-7, atol=1e-9, err_msg=k)
+    # one optimiser step changes the weights; the planner's fused (inference) path picks them up
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    opt.step()
+    with torch.no_grad():
+        after = model(obs.cuda(), win.cuda(), ts.cuda())
+    assert not torch.allclose(after, got.detach())
+    with torch.no_grad():
+        twin = build_model(nlc, {k: v.detach().cpu() for k, v in model.state_dict().items()})(obs.cuda(), win.cuda(), ts.cuda())
+    np.testing.assert_allclose(after.cpu().numpy(), twin.cpu().numpy(), rtol=1e-12, atol=1e-14)
 
 
 # --------------------------------------------------------------------------- planner (a1-a4, a10-a12)
