@@ -7,7 +7,8 @@ action_mean action_std dt``), so checkpoints written by the reference load uncha
 ``forward`` is one HIP launch (``nlc_node_forward``): the ODE function's three layers on FP64 matrix cores inside the
 fixed-grid Euler loop; behind ``NLDynamics`` the planner runs it inside the horizon loop (``NLC_DYN_NODE``).
 ``torchdiffeq.odeint(method="euler", options={"step_size": 0.05})`` is restated (grid ``k * step_size``, last point =
-the end time): **parity unpinned vs upstream torchdiffeq**, which is absent offline.  Inference only, float64 only.
+the end time): **parity unpinned vs upstream torchdiffeq**, which is absent offline.  The HIP path is inference-only
+and float64; in grad mode ``forward`` is the same op sequence in torch ops on PyTorch-ROCm (trainable).
 """
 
 import ctypes as C
@@ -164,7 +165,36 @@ class NODE(nn.Module):
             self._uploaded_key = self.upload(self._ctx)
         return self._ctx
 
+    def _forward_train(self, in_batch_obs, in_batch_action, ts_pred):
+        """Grad-mode forward for training: the reference's op sequence (``train_utils.py:696-724``) with the restated
+        fixed-grid Euler ``odeint`` in torch ops on PyTorch-ROCm; the HIP kernels serve inference / planning."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":  # no CPU path in this package, training included
+            raise RuntimeError("training forward: move the model to the GPU first (model.to('cuda'))")
+        obs, act = in_batch_obs.to(dev), in_batch_action.to(dev)
+        desc = self.model_desc()
+        d = self.state_dim
+        sm = torch.tensor(list(desc.state_mean)[:d], dtype=obs.dtype, device=dev)
+        ss = torch.tensor(list(desc.state_std)[:d], dtype=obs.dtype, device=dev)
+        x = (obs - sm) / ss
+        if self.augment_dim > 0:
+            x = torch.cat([x, torch.zeros(obs.shape[0], self.augment_dim, dtype=obs.dtype, device=dev)], 1)
+        if act.dim() == 2:
+            act = act.unsqueeze(1)
+        self.x_ode_func_in_x_and_u.update_u(act[:, -1, :])
+        t_end = float(torch.as_tensor(ts_pred).reshape(-1)[0]) / desc.time_div
+        import math
+
+        niters = int(math.ceil(t_end / self.step_size + 1))
+        grid = [k * self.step_size for k in range(niters)]
+        grid[-1] = t_end
+        for k in range(niters - 1):
+            x = x + (grid[k + 1] - grid[k]) * self.x_ode_func_in_x_and_u(None, x)
+        return x[:, : x.shape[-1] - self.augment_dim].to(in_batch_obs.device)
+
     def forward(self, in_batch_obs, in_batch_action, ts_pred):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(in_batch_obs, in_batch_action, ts_pred)
         if torch.is_grad_enabled():
             raise NotImplementedError(
                 "neurallaplacecontrol_amd.NODE is inference-only on the HIP path: wrap the call in torch.no_grad() "

@@ -8,7 +8,8 @@ the un-normalised branch tied to ``normalize``) shares the kernels (``nlc_rnn_de
 
 ``forward`` runs as two HIP launches behind ``nlc_rnn_forward`` (GRU on FP64 matrix cores + hidden part of
 ``linear_out``; then the state/time part); behind ``NLDynamics`` the planner hoists the GRU out of the horizon loop
-(``NLC_DYN_DTRNN``).  Inference only, float64 only, as the harness uses it (``mppi_with_model.py:101,319``).
+(``NLC_DYN_DTRNN``).  The HIP path is inference-only and float64, as the harness uses it
+(``mppi_with_model.py:101,319``); in grad mode ``forward`` is the same op sequence on PyTorch-ROCm (trainable).
 """
 
 import ctypes as C
@@ -142,7 +143,28 @@ class DeltaTRNN(nn.Module):
             self._uploaded_key = self.upload(self._ctx)
         return self._ctx
 
+    def _forward_train(self, in_batch_obs, in_batch_action, ts_pred):
+        """Grad-mode forward for training (``train_utils.py:388-407``): the reference's op sequence (``:618-631``) on
+        PyTorch-ROCm modules; the HIP kernels serve inference / planning."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":  # no CPU path in this package, training included
+            raise RuntimeError("training forward: move the model to the GPU first (model.to('cuda'))")
+        obs, act = in_batch_obs.to(dev), in_batch_action.to(dev)
+        desc = self.model_desc()  # resolves (and rejects) the reference's normalisation branches
+        d, nin = self.state_dim, desc.nin
+        sm = torch.tensor(list(desc.state_mean)[:d], dtype=obs.dtype, device=dev)
+        ss = torch.tensor(list(desc.state_std)[:d], dtype=obs.dtype, device=dev)
+        am = torch.tensor(list(desc.action_mean)[:nin], dtype=obs.dtype, device=dev)
+        a_s = torch.tensor(list(desc.action_std)[:nin], dtype=obs.dtype, device=dev)
+        out, _ = self.gru((act - am) / a_s)
+        feats = [out[:, -1, :], (obs - sm) / ss]
+        if desc.time_input:
+            feats.append(torch.as_tensor(ts_pred).to(dev, obs.dtype).reshape(obs.shape[0], 1) / desc.time_div)
+        return self.linear_out(torch.cat(feats, dim=1)).to(in_batch_obs.device)
+
     def forward(self, in_batch_obs, in_batch_action, ts_pred):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(in_batch_obs, in_batch_action, ts_pred)
         if torch.is_grad_enabled():
             raise NotImplementedError(
                 "neurallaplacecontrol_amd.DeltaTRNN is inference-only on the HIP path: wrap the call in "

@@ -81,6 +81,8 @@ def test_fails_loudly_without_gpu(lib):
     ):
         with torch.no_grad(), pytest.raises(RuntimeError):  # no CPU fallback behind the model mirrors either
             model(torch.zeros(2, d).double(), torch.zeros(2, 4, 1).double(), torch.full((2, 1), 0.05).double())
+        with pytest.raises(RuntimeError):  # ... nor in grad mode (training forward needs the GPU as well)
+            model(torch.zeros(2, d).double(), torch.zeros(2, 4, 1).double(), torch.full((2, 1), 0.05).double())
 
 
 def test_product_does_not_import_oracle():

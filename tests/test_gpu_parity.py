@@ -1490,8 +1490,24 @@ def test_dtrnn_forward_vs_reference_golden(nlc, env):
         np.testing.assert_allclose(raw.numpy(), g["raw_out"], **TOL)
         with pytest.raises(NameError):
             build_rnn(nlc, sd, int(g["H"]), normalize=False, normalize_time=True)(obs, win, ts)
+    frozen = build_rnn(nlc, sd, int(g["H"]))
+    for p_ in frozen.parameters():
+        p_.requires_grad_(False)
     with pytest.raises(NotImplementedError):
-        build_rnn(nlc, sd, int(g["H"]))(obs, win, ts)  # grad mode: inference-only on the HIP path
+        frozen(obs, win, ts)  # grad mode with nothing to train: the HIP path is inference-only
+    # grad mode with trainable parameters: the same op sequence on PyTorch-ROCm, gradients = autograd of the oracle
+    from oracle import rnn_model as ornn
+
+    leaves = {k: (v.clone().requires_grad_() if k.startswith(("gru.", "linear_out.")) else v) for k, v in sd.items()}
+    ref = ornn.forward(leaves, obs, win, ts)
+    ref.square().sum().backward()
+    m = build_rnn(nlc, sd, int(g["H"]))
+    out = m(obs.cuda(), win.cuda(), ts.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["fwd_out"], **TOL)
+    out.square().sum().backward()
+    for k, p_ in m.named_parameters():
+        sc = float(leaves[k].grad.abs().max()) + 1e-300
+        np.testing.assert_allclose(p_.grad.cpu().numpy() / sc, leaves[k].grad.numpy() / sc, rtol=1e-7, atol=1e-9, err_msg=k)
 
 
 @pytest.mark.parametrize("env", ["cartpole", "acrobot"])
@@ -1722,6 +1738,18 @@ def test_node_forward_vs_reference_golden(nlc, env):
         got_cpu = model(obs, win[:, -1, :], T64(g["fwd_ts"]))  # 2-D action input (train_utils.py:712-713), CPU tensors
         assert got_cpu.device.type == "cpu"
         np.testing.assert_allclose(got_cpu.numpy(), g["fwd_out"], **TOL)
+    # grad mode: torch-op Euler loop on PyTorch-ROCm; output and gradients = autograd of the oracle
+    from oracle import node_model as onode
+
+    leaves = {k: (v.clone().requires_grad_() if k.startswith("x_ode_func") else v) for k, v in sd.items()}
+    ref = onode.forward(leaves, obs, win, T64(g["fwd_ts"]))
+    ref.square().sum().backward()
+    out = model(obs.cuda(), win.cuda(), T64(g["fwd_ts"]).cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["fwd_out"], **TOL)
+    out.square().sum().backward()
+    for k, p_ in model.named_parameters():
+        sc = float(leaves[k].grad.abs().max()) + 1e-300
+        np.testing.assert_allclose(p_.grad.cpu().numpy() / sc, leaves[k].grad.numpy() / sc, rtol=1e-7, atol=1e-9, err_msg=k)
 
 
 @pytest.mark.parametrize("hidden,aug,N", [(64, 0, 500), (100, 2, 77), (128, 1, 1), (270, 1, 1030)])
