@@ -1,5 +1,5 @@
-/* Plain-C client of include/nlc.h: one MPPI command with oracle cartpole dynamics, device buffers from the HIP
- * runtime's C API, no Python and no torch.  Prints the action, the first cost and beta/eta so the GPU test can
+/* Plain-C client of include/nlc.h: MPPI commands with oracle cartpole dynamics, one env step, and the Fourier line
+ * integral with its backward; device buffers from the HIP runtime's C API, no Python and no torch.  Prints the action, the first cost and beta/eta so the GPU test can
  * compare them with the Python mirror driving the same library (device Philox noise, same seed and counter).
  *   gcc -std=c99 cabi_client.c -I include -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L<libdir> -lnlc_hip
  *       -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,<libdir> -Wl,-rpath,/opt/rocm/lib -lm -o cabi_client */
@@ -64,6 +64,50 @@ int main(void) {
   }
   CHECK(nlc_mppi_get_U(ctx, U));
   for (int t = 0; t < T; ++t) printf("%.17g%c", U[t], t + 1 < T ? ' ' : '\n');
+
+  /* env side of the loop: two envs, one control step (delay 1, 3-row action buffers) */
+  {
+    double st[8] = {0.1, -0.2, 3.0, 0.5, -0.3, 0.4, 2.5, -1.0}, ab[6] = {0.5, 1.0, -2.0, 0.25, -0.5, 1.5};
+    double act[2] = {2.0, -1.0}, obs[10], rew[2];
+    double *st_d = dev_alloc(8), *ab_d = dev_alloc(6), *act_d = dev_alloc(2), *obs_d = dev_alloc(10), *rew_d = dev_alloc(2);
+    hipMemcpy(st_d, st, sizeof(st), hipMemcpyHostToDevice);
+    hipMemcpy(ab_d, ab, sizeof(ab), hipMemcpyHostToDevice);
+    hipMemcpy(act_d, act, sizeof(act), hipMemcpyHostToDevice);
+    CHECK(nlc_env_step(ctx, NLC_ENV_CARTPOLE, 0, 0.05, 1, 2, 3, 1, st_d, ab_d, act_d, obs_d, rew_d));
+    CHECK(nlc_synchronize(ctx));
+    hipMemcpy(obs, obs_d, sizeof(obs), hipMemcpyDeviceToHost);
+    hipMemcpy(rew, rew_d, sizeof(rew), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 10; ++i) printf("%.17g ", obs[i]);
+    printf("%.17g %.17g\n", rew[0], rew[1]);
+  }
+  /* torchlaplace.laplace_reconstruct line integral and its backward: 3 points, d = 2, S = 17 */
+  {
+    enum { N = 3, D = 2, S = 17 };
+    double th[N * D * S], ph[N * D * S], tt[N] = {0.1, 0.125, 0.3}, gx[N * D], x[N * D], gth[N * D * S], gph[N * D * S];
+    for (int i = 0; i < N * D * S; ++i) {
+      th[i] = 3.0 * ((i * 37) % 101) / 101.0 - 1.5;
+      ph[i] = 1.2 * ((i * 53) % 97) / 97.0 - 0.6;
+    }
+    for (int i = 0; i < N * D; ++i) gx[i] = 1.0 + 0.5 * i;
+    double *th_d = dev_alloc(N * D * S), *ph_d = dev_alloc(N * D * S), *t_d = dev_alloc(N), *gx_d = dev_alloc(N * D);
+    double *x_d = dev_alloc(N * D), *gth_d = dev_alloc(N * D * S), *gph_d = dev_alloc(N * D * S);
+    hipMemcpy(th_d, th, sizeof(th), hipMemcpyHostToDevice);
+    hipMemcpy(ph_d, ph, sizeof(ph), hipMemcpyHostToDevice);
+    hipMemcpy(t_d, tt, sizeof(tt), hipMemcpyHostToDevice);
+    hipMemcpy(gx_d, gx, sizeof(gx), hipMemcpyHostToDevice);
+    nlc_ilt_desc il;
+    il.algo = NLC_ILT_FOURIER; il.terms = S; il.alpha = 1e-3; il.tol = 1e-2; il.scale = 2.0;
+    CHECK(nlc_ilt_reconstruct(ctx, &il, th_d, ph_d, t_d, N, D, x_d));
+    CHECK(nlc_ilt_reconstruct_backward(ctx, &il, th_d, ph_d, t_d, gx_d, N, D, gth_d, gph_d));
+    CHECK(nlc_synchronize(ctx));
+    hipMemcpy(x, x_d, sizeof(x), hipMemcpyDeviceToHost);
+    hipMemcpy(gth, gth_d, sizeof(gth), hipMemcpyDeviceToHost);
+    hipMemcpy(gph, gph_d, sizeof(gph), hipMemcpyDeviceToHost);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < N * D * S; ++i) { s1 += gth[i] * (1 + i % 3); s2 += gph[i] * (1 + i % 5); }
+    for (int i = 0; i < N * D; ++i) printf("%.17g ", x[i]);
+    printf("%.17g %.17g\n", s1, s2);
+  }
   nlc_destroy(ctx);
   return 0;
 }

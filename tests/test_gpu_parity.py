@@ -1462,6 +1462,27 @@ def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
         part = p._partials.cpu()
         assert [float(act[0]), float(p.cost_total[0]), float(part[0]), float(part[1])] == c_cmds[cmd]
     assert p.U.reshape(-1).tolist() == c_U
+    # env step through the C client == through BatchedEnv
+    c_env = [float(x) for x in lines[3].split()]
+    e = nlc.BatchedEnv("oderl-cartpole", 2, dt=0.05, action_delay=1, action_buffer_size=3)
+    e.set_state_(torch.tensor([[0.1, -0.2, 3.0, 0.5], [-0.3, 0.4, 2.5, -1.0]], dtype=torch.float64))
+    e.action_buffer.copy_(torch.tensor([0.5, 1.0, -2.0, 0.25, -0.5, 1.5], dtype=torch.float64).view(2, 3, 1))
+    obs, rew = e.step(torch.tensor([[2.0], [-1.0]], dtype=torch.float64))
+    assert obs.cpu().reshape(-1).tolist() + rew.cpu().tolist() == c_env
+    # ILT forward / backward through the C client == through the Python mirror's autograd
+    c_ilt = [float(x) for x in lines[4].split()]
+    N, D, S = 3, 2, 17
+    i = torch.arange(N * D * S, dtype=torch.float64)
+    th = (3.0 * ((i * 37) % 101) / 101.0 - 1.5).view(N, D, S).cuda().requires_grad_()
+    ph = (1.2 * ((i * 53) % 97) / 97.0 - 0.6).view(N, D, S).cuda().requires_grad_()
+    x = nlc.ilt_reconstruct(th, ph, torch.tensor([0.1, 0.125, 0.3], dtype=torch.float64).cuda())
+    gx = (1.0 + 0.5 * torch.arange(N * D, dtype=torch.float64)).view(N, D).cuda()
+    gt, gp = torch.autograd.grad(x, (th, ph), gx)
+    w1 = (1 + torch.arange(N * D * S) % 3).double().cuda()
+    w2 = (1 + torch.arange(N * D * S) % 5).double().cuda()
+    np.testing.assert_allclose(x.detach().cpu().reshape(-1).numpy(), c_ilt[: N * D], rtol=0, atol=0)
+    np.testing.assert_allclose([float((gt.reshape(-1) * w1).sum()), float((gp.reshape(-1) * w2).sum())], c_ilt[N * D:],
+                               rtol=1e-13)
 
 
 # --------------------------------------------------------------------------- Delta-t RNN baseline
