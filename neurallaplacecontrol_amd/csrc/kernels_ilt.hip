@@ -204,13 +204,13 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
       const int64_t n0 = row0 / a.d;  // wave-uniform
       const unsigned xr = (unsigned)(row0 - n0 * a.d) + (unsigned)tid_row;
       const double t_row = a.t[n0 + xr / (unsigned)a.d];  // 32-bit division, once per tile
-      // successor tile of this block; without one the refills (values unused) all aim at ONE cache line of the
+      // successor tile of this block; without one the refills (values unused) all aim at ONE element of the
       // input -- re-reading this tile instead cost 32 KB of HBM reads per block, +9 % traffic (PMC FETCH_SIZE)
       const int64_t nxt = blk + gridDim.x;
       const bool has_next = nxt < nfull;
       const int64_t actn = has_next ? act : 0;
-      const double* __restrict__ tn = has_next ? tp + (int64_t)gridDim.x * rows * S : a.theta + (threadIdx.x & 7);
-      const double* __restrict__ pn = has_next ? pp + (int64_t)gridDim.x * rows * S : a.phi + (threadIdx.x & 7);
+      const double* __restrict__ tn = has_next ? tp + (int64_t)gridDim.x * rows * S : a.theta;  // element 0: always valid
+      const double* __restrict__ pn = has_next ? pp + (int64_t)gridDim.x * rows * S : a.phi;
 #pragma unroll
       for (int i = 0; i < ITERS; ++i) {
         const int u = i % UB;
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void ilt_fourier_bwd_kernel(const IltBwdArgs a
       double* __restrict__ gp = a.gphi + row0 * S + threadIdx.x;
       double th[UB], ph[UB];
       const int last_i = (rows_here - 1 - rloc) / rpp;
-      const double* __restrict__ td = a.theta + (threadIdx.x & 7);  // one cache line for the passes past the end:
-      const double* __restrict__ pd = a.phi + (threadIdx.x & 7);    // no branch at the load, no wasted HBM reads
+      const double* __restrict__ td = a.theta;  // element 0 (always valid) for the passes past the end:
+      const double* __restrict__ pd = a.phi;    // no branch at the load, no wasted HBM reads
       auto fetch = [&](int u, int i) {
         const bool in = i <= last_i;
         th[u] = __builtin_nontemporal_load(in ? tp + (int64_t)act * i : td);

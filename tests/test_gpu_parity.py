@@ -81,7 +81,8 @@ def test_ilt_fourier_many_tiles_per_block(nlc, d, S, N):
     np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("d,S,N", [(5, 17, 1537), (3, 33, 700), (6, 9, 2049), (2, 17, 1), (5, 17, 90_001)])
+@pytest.mark.parametrize("d,S,N", [(5, 17, 1537), (3, 33, 700), (6, 9, 2049), (2, 17, 1), (5, 17, 90_001), (1, 3, 1),
+                                   (1, 2, 2)])
 def test_ilt_fourier_backward_vs_autograd_of_oracle(nlc, d, S, N):
     """nlc_ilt_reconstruct_backward against torch autograd through the CPU restatement (float64)."""
     from oracle import ilt as oilt
