@@ -192,6 +192,15 @@ int64_t blob_size(const nlc_model_desc* d) {
          h * h + h + 2 * d->d * S * h + 2 * d->d * S;
 }
 
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain (unregistered) host memory: not an error for us
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice;
+}
+
 void sphere_inputs(const nlc_ilt_desc& ilt, double tn, std::vector<double>& sph) {
   // [theta_s(0..S-1) | phi_s(0..S-1)] of s_k = gamma + i pi k / T
   const int S = ilt.terms;
@@ -925,8 +934,11 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     if (c->U[i]) hipFree(c->U[i]);
     c->U[i] = nullptr;
     NLC_HIP(c, hipMalloc((void**)&c->U[i], un * sizeof(double)));
-    NLC_HIP(c, hipMemset(c->U[i], 0, un * sizeof(double)));
+    // on the ctx's stream and waited for below: hipMemset runs asynchronously on the NULL stream, which is not
+    // ordered against a non-blocking stream -- it could land after the nlc_mppi_set_U copy that follows configure
+    NLC_HIP(c, hipMemsetAsync(c->U[i], 0, un * sizeof(double), c->stream));
   }
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
   c->ucur = 0;
   if (c->small) hipFree(c->small);
   c->small = nullptr;
@@ -1069,6 +1081,8 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     NLC_HIP(c, hipMemcpyAsync(state_dev, state, ns * sizeof(double), hipMemcpyDefault, c->stream));
     NLC_HIP(c, hipMemcpyAsync(abuf_dev, abuf_host, (size_t)d.E * d.B * d.nu * sizeof(double), hipMemcpyDefault,
                               c->stream));
+    // a caller-owned HOST buffer may be a temporary: the copies out of it must have completed before we return
+    if (!is_device_ptr(state) || !is_device_ptr(abuf_host)) NLC_HIP(c, hipStreamSynchronize(c->stream));
   } else if (!external && !state_per_sample && d.B * d.nu <= kMaxInlineAbuf) {
     inline_inputs = true;  // state and action_buffer travel in the shift kernel's arguments (below)
   } else if (!external) {
@@ -1079,7 +1093,9 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     double* pin_abuf = c->pinned + d.d;
     std::memcpy(pin_abuf, abuf_host, (size_t)d.B * d.nu * sizeof(double));
     if (state_per_sample) {
+      // (K, d) from caller-owned pageable memory: wait for the copy, the source may be a temporary
       NLC_HIP(c, hipMemcpyAsync(state_dev, state, (size_t)d.K * d.d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      NLC_HIP(c, hipStreamSynchronize(c->stream));
     } else {
       std::memcpy(pin_state, state, (size_t)d.d * sizeof(double));
       NLC_HIP(c, hipMemcpyAsync(state_dev, pin_state, (size_t)d.d * sizeof(double), hipMemcpyHostToDevice, c->stream));

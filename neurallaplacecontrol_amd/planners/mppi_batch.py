@@ -63,7 +63,9 @@ class BatchedMPPIDelay(MPPIDelay):
                 t = t.to(self.cd)
             return t.contiguous()
 
-        self._ensure_configured(ab.shape[1])
+        with torch.cuda.device(self.cd):
+            self.ctx.use_torch_stream()  # (re)configuration uploads are ordered on the command's stream
+            self._ensure_configured(ab.shape[1])
         if self.encode_obs_time and ab.shape[2] == nu + 1:
             ab = ab[:, :, :nu]  # drop the time-stamp column (mppi_delay.py:262-264)
         if ab.shape[2] != nu:

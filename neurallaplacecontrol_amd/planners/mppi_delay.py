@@ -340,11 +340,11 @@ class MPPIDelay:
         ab = torch.as_tensor(action_buffer).detach().to("cpu", torch.float64).contiguous()
         if ab.dim() != 2:
             raise ValueError("action_buffer must be (B, nu)")
-        self._ensure_configured(ab.shape[0])
         lib, ctx = self.ctx.lib, self.ctx
         rng = 1 if self.noise_rng == "philox" else 0
         with torch.cuda.device(self.cd):
-            ctx.use_torch_stream()
+            ctx.use_torch_stream()  # before any (re)configuration: its uploads are ordered on this stream too
+            self._ensure_configured(ab.shape[0])
             if not rng:
                 # K x T x nu draw on `device`, same generator consumption as the reference (:319)
                 raw = self.noise_dist.sample((self.K, self.T))
