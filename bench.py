@@ -12,15 +12,20 @@ Noise is drawn on the device (Philox) so every input of the timed region is HBM-
 SAME K=16384 population is sharded over the ranks (strong scaling, as the metric is worded) and each
 command() does one RCCL all-gather of 2+T*nu doubles.
 
-Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel: the FP64-MFMA
-GRU encoder), ``roofline_ilt`` (stand-alone Fourier ILT kernel, HBM-bound; ``dehoog33`` inside it is the de Hoog
-kernel of the ILT ablation) and ``cpu_baseline`` (the CPU
-oracle = reference op sequence, timed on this host's cores; rank 0, N=1 only).
+The K timed steps run WITHOUT the library's per-launch event profiling; a second, untimed pass of the same steps
+with profiling on gives the per-kernel averages the roofline uses (hipEvent pairs on the launch stream).
+
+Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel: the FP64-MFMA GRU
+encoder at the headline size, the fused one-launch planner body on a small shard), ``roofline_ilt`` (stand-alone
+Fourier ILT kernel, HBM-bound; ``dehoog33`` / ``backward`` inside it) and ``cpu_baseline`` (the CPU oracle =
+reference op sequence, timed on this host's cores; rank 0, N=1 only).
 """
 
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,10 +37,43 @@ import torch  # noqa: E402
 
 ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384, 40, 4, 17, 128, 3.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# newest committed PMC summary (separate rocprofv3 --pmc passes, tools/pmc_summarize.py)
-PMC_JSON = next((p for p in (os.path.join(REPO, "profiles", n) for n in ("r1k_pmc_kernels.json", "r1j_pmc_kernels.json", "r1h_pmc_kernels.json"))
-                 if os.path.exists(p)), os.path.join(REPO, "profiles", "r1j_pmc_kernels.json"))
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
+# newest committed PMC summary (separate rocprofv3 --pmc passes: tools/collect_profiles.sh + tools/pmc_summarize.py)
+PMC_CANDIDATES = ("r2_pmc_kernels.json", "r1k_pmc_kernels.json")
+# library kernel (nlc_profile_read name) -> key of the PMC summary; the summary's "_meta.kernel_names" must list a
+# rocprof kernel name containing the library name, or the traffic figure belongs to some other build
+PMC_KEYS = {"gru_encode_kernel": "gru_encode", "nl_rollout_kernel": "nl_rollout", "ilt_fourier_kernel": "ilt_fourier",
+            "ilt_dehoog_kernel": "ilt_dehoog", "ilt_fourier_bwd_kernel": "ilt_fourier_bwd",
+            "nl_plan_fused_kernel": "nl_plan_fused"}
+
+
+def load_pmc():
+    for name in PMC_CANDIDATES:
+        p = os.path.join(REPO, "profiles", name)
+        if os.path.exists(p):
+            return name, json.load(open(p))
+    return None, None
+
+
+def pmc_traffic(pmc_name, pj, lib_kernel):
+    """HBM bytes per launch of `lib_kernel` from the committed PMC summary, with its provenance; (None, None) if the
+    summary has no such kernel.  A summary that names kernels this library does not have is a stale file: fail loudly."""
+    if pj is None:
+        return None, None
+    key = PMC_KEYS[lib_kernel]
+    if key not in pj:
+        return None, None
+    meta = pj.get("_meta")
+    if meta is not None:
+        names = meta.get("kernel_names", {}).get(key, [])
+        if not any(lib_kernel in n for n in names):
+            raise RuntimeError(f"profiles/{pmc_name}: entry {key!r} was collected from kernels {names}, none of which is "
+                               f"the library's {lib_kernel!r} -- stale PMC summary, re-run tools/collect_profiles.sh")
+        src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 "
+               f"correction; collected at commit {meta.get('commit', '?')} on {meta.get('device', '?')}, {meta.get('date', '?')})")
+    else:
+        src = f"profiles/{pmc_name} (round-1 summary without provenance record; rocprofv3 --pmc, FETCH x2 gfx950 correction)"
+    return pj[key].get("hbm_bytes_per_launch"), src
 
 
 def synthetic_state_dict(d, nu, S, seed=0):
@@ -58,60 +96,136 @@ def synthetic_state_dict(d, nu, S, seed=0):
     return model
 
 
-def flops_gru_per_window(g, nin_pad, B):
-    # MFMAs issued per 16 windows (kernels_gru.hip header) * 2048 flop / 16
+# ---- flop accounting.  "issued" = MFMAs the kernel executes x 2048 flop (padded tiles included);
+# "needed" = the algorithm's multiply-adds (SURVEY §8d formulas, with the W_hh h0 = 0 products the kernel skips removed)
+def flops_gru_issued_per_window(g, B):
     MT, KS = 3 * g // 16, g // 4
     mfma = B * MT + (B - 1) * KS * MT + B * KS * MT + (B - 1) * KS * MT + KS
     return mfma * 2048 / 16
 
 
-def flops_rollout_per_sample_step(h, nt3):
+def flops_gru_needed_per_window(g, nin, B):
+    return B * 2 * 3 * g * nin + (B - 1) * 2 * 3 * g * g + B * 2 * 3 * g * g + (B - 1) * 2 * 3 * g * g + 2 * g * 2
+
+
+def flops_rollout_issued_per_sample_step(h, nt3):
     HT, KS = h // 16, h // 4
     mfma = (2 + KS) * HT + KS * nt3 + 2 * nt3
     return mfma * 2048 / 16
 
 
-def cpu_baseline(sd, d, nu, budget_s=12.0):
-    """Oracle (torch-CPU float64, aten::gru like the reference) timed on this host; bounded sample."""
+def flops_rollout_needed_per_sample_step(h, d, S):
+    P = d + 2  # the 2S constant sphere inputs are folded into the layer-1 bias
+    return 2 * (P * h + h * h + 2 * d * S * h) + 2 * d * S
+
+
+def host_cpu_info():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical
+    return dict(model=model, physical_cores=len(cores) or logical, logical_cpus=logical, usable_cpus=usable)
+
+
+def cpu_baseline(sd, d, nu, budget_s=30.0):
+    """Oracle (torch-CPU float64, aten::gru like the reference) timed on this host over the same region as the GPU
+    step (mppi_with_model.py:257-259).  SURVEY §8d: warm-up, median of >= 3, 1 thread and all physical cores stated."""
     from oracle import envs as oenvs
     from oracle import mppi as omppi
     from oracle import nl_model as onl
 
-    K, T = K_SAMPLES, HORIZON
+    T = HORIZON
     tg = onl.TorchGRUModel(sd, nu)
-    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
-
-    def dynamics(state, window):
-        return state + tg.forward(state, window, ts, S=S_TERMS).view(state.shape)
-
     sig = torch.ones((nu, nu), dtype=torch.double) * 0.5 + torch.eye(nu, dtype=torch.double) * 0.5
-    torch.manual_seed(0)
-    mppi = omppi.MPPIOracle(dynamics, oenvs.RUNNING_COST[ENV], d, sig, K, T, 1.0, torch.tensor(-A_HIGH),
-                            torch.tensor(A_HIGH), A_HIGH)
     state, ab = oenvs.initial_state(ENV), torch.zeros(ABUF, nu, dtype=torch.float64)
-    # torch's default (one thread per core) is far from the best setting for these small FP64 ops on a
-    # many-core host (128 threads: ~42 s per command on the MI355X box); sweep a few thread counts within
-    # the time budget and report the best, i.e. the strongest CPU baseline
-    ncores = os.cpu_count() or 1
+    info = host_cpu_info()
     default_threads = torch.get_num_threads()
-    best, tried = None, []
-    t_start = time.perf_counter()
-    with torch.no_grad():
-        for nt in [c for c in (16, 8, 32) if c <= ncores] or [ncores]:
-            if tried and time.perf_counter() - t_start > budget_s:
-                break
-            torch.set_num_threads(nt)
+
+    def make(K):
+        ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+
+        def dynamics(st, window):
+            return st + tg.forward(st, window, ts, S=S_TERMS).view(st.shape)
+
+        torch.manual_seed(0)
+        return omppi.MPPIOracle(dynamics, oenvs.RUNNING_COST[ENV], d, sig, K, T, 1.0, torch.tensor(-A_HIGH),
+                                torch.tensor(A_HIGH), A_HIGH)
+
+    def timed(mppi, n):
+        out = []
+        for _ in range(n):
             t0 = time.perf_counter()
             mppi.command(state, ab)
-            el = time.perf_counter() - t0
-            tried.append((nt, el))
-            if best is None or el < best[1]:
-                best = (nt, el)
+            out.append(time.perf_counter() - t0)
+        return out
+
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        # 1. thread-count sweep on a 1/8 population (warm-up + one command each): torch's default of one thread per
+        #    logical CPU is far from the best setting for these small FP64 ops on a many-core host
+        K8 = K_SAMPLES // 8
+        small = make(K8)
+        limit = info["usable_cpus"]
+        cand = sorted({c for c in (8, 16, 32, info["physical_cores"]) if c <= limit} or {limit})
+        sweep = []
+        for nt in cand:
+            torch.set_num_threads(nt)
+            timed(small, 1)
+            sweep.append((nt, timed(small, 1)[0]))
+        best_nt = min(sweep, key=lambda x: x[1])[0]
+        # 2. the reported figure: full population, best thread count, one warm-up, median of >= 3
+        torch.set_num_threads(best_nt)
+        full = make(K_SAMPLES)
+        warm = timed(full, 1)[0]
+        n_rep = 3
+        if warm * 6 < budget_s - (time.perf_counter() - t_start):
+            n_rep = 5
+        reps = timed(full, n_rep)
+        med = statistics.median(reps)
+        # 3. single figures for 1 thread and for all physical cores, time-boxed on the 1/8 population and scaled by 8
+        #    (the work is linear in K; at 1/8 the per-op overheads weigh more, so the extrapolation favours neither)
+        torch.set_num_threads(1)
+        timed(small, 1)
+        one = timed(small, 1)[0] * 8.0
+        allc = dict(sweep).get(info["physical_cores"])
+        allc = allc * 8.0 if allc is not None else None
     torch.set_num_threads(default_threads)
-    return dict(value=1.0 / best[1], unit="planning steps/s", cores=best[0], kind="port",
-                sample=f"one full command() of the same workload (K={K}, T={T}) per thread count "
-                       f"{[(n, round(e, 2)) for n, e in tried]} (threads, seconds); best reported; host has {ncores} "
-                       f"logical cores; torch {torch.__version__} CPU float64, aten::gru encoder as in the reference")
+    return dict(
+        value=1.0 / med, unit="planning steps/s", cores=best_nt, kind="port",
+        sample=(f"full workload (K={K_SAMPLES}, T={T}): 1 warm-up + median of {n_rep} command() calls at {best_nt} threads "
+                f"(runs {[round(r, 2) for r in reps]} s, warm-up {warm:.2f} s); thread count picked by a sweep on K={K8}: "
+                f"{[(n, round(e, 3)) for n, e in sweep]} (threads, s)"),
+        cpu_model=info["model"], physical_cores=info["physical_cores"], logical_cpus=info["logical_cpus"],
+        usable_cpus=info["usable_cpus"],
+        one_thread=dict(value=1.0 / one, seconds_per_command=one, note=f"extrapolated x8 from K={K8}"),
+        all_physical_cores=(dict(value=1.0 / allc, seconds_per_command=allc, threads=info["physical_cores"],
+                                 note=f"extrapolated x8 from K={K8}") if allc else None),
+        torch=torch.__version__, oracle="oracle/ (torch-CPU float64, aten::gru encoder as in the reference)",
+    )
+
+
+def git_commit():
+    try:
+        return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return os.environ.get("NLC_COMMIT")  # the GPU box gets a snapshot without .git
 
 
 def main():
@@ -120,7 +234,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
     ap.add_argument("--samples", type=int, default=K_SAMPLES,
                     help="override K (experiments only; the headline metric is quoted at the default 16384)")
     args = ap.parse_args()
@@ -175,24 +290,30 @@ def main():
 
     for _ in range(args.warmup):
         abuf = step(abuf)
-    planner.ctx.profile_reset()
-    planner.ctx.profile(True)  # hipEvent pairs around every launch, on the launch stream
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         abuf = step(abuf)
     fence()
     elapsed = time.perf_counter() - t0
-    planner.ctx.profile(False)
-    prof = planner.ctx.profile_read()
     if pg is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # second, untimed pass: the same steps with hipEvent pairs around every launch (on the launch stream)
+    planner.ctx.profile_reset()
+    planner.ctx.profile(True)
+    for _ in range(args.steps):
+        abuf = step(abuf)
+    fence()
+    planner.ctx.profile(False)
+    prof = planner.ctx.profile_read()
+
+    pmc_name, pj = load_pmc()
 
     # ---- stand-alone ILT kernel at N = K*T points (the BASELINE 'ILT GB/s vs HBM peak' figure)
     ilt = None
-    if rank == 0:
+    if rank == 0 and not args.no_ilt:
         N = K_SAMPLES * HORIZON
         g = torch.Generator(device="cuda").manual_seed(1)
         theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
@@ -212,12 +333,7 @@ def main():
         p = ictx.profile_read()["ilt_fourier_kernel"]
         ms = p["total_ms"] / p["launches"]
         nbytes = N * (2 * d * S_TERMS + d) * 8
-        traffic, traffic_src = None, None
-        pmc = PMC_JSON
-        if os.path.exists(pmc):  # PMC passes cannot run inside this process: separate rocprofv3 --pmc runs
-            pj = json.load(open(pmc))
-            traffic = pj["ilt_fourier"]["hbm_bytes_per_launch"]
-            traffic_src = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction, same N)"
+        traffic, traffic_src = pmc_traffic(pmc_name, pj, "ilt_fourier_kernel")
         ilt = dict(bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                    algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
@@ -239,12 +355,10 @@ def main():
         p = ictx.profile_read()["ilt_dehoog_kernel"]
         ms2 = p["total_ms"] / p["launches"]
         nb2 = N * (2 * d * S2 + d) * 8
+        tr2, tr2_src = pmc_traffic(pmc_name, pj, "ilt_dehoog_kernel")
         ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
                                algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
-                               frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               traffic=pj.get("ilt_dehoog_final", pj.get("ilt_dehoog", {})).get("hbm_bytes_per_launch")
-                               if os.path.exists(pmc) else None,
-                               traffic_note=f"profiles/{os.path.basename(pmc)}")
+                               frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=tr2, traffic_source=tr2_src)
         del theta, phi
         # backward of the Fourier ILT (training through laplace_reconstruct): reads theta, phi, writes both gradients
         theta = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi).requires_grad_()
@@ -260,10 +374,11 @@ def main():
         p = ictx.profile_read()["ilt_fourier_bwd_kernel"]
         ms3 = p["total_ms"] / p["launches"]
         nb3 = N * 4 * d * S_TERMS * 8
+        tr3, tr3_src = pmc_traffic(pmc_name, pj, "ilt_fourier_bwd_kernel")
         ilt["backward"] = dict(bound="hbm", kernel="ilt_fourier_bwd_kernel", avg_launch_ms=ms3, points=N,
                                algorithmic_bytes=nb3, bytes_per_point=4 * d * S_TERMS * 8,
                                achieved=nb3 / (ms3 * 1e-3) / 1e9, unit="GB/s", frac=nb3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               traffic=pj.get("ilt_fourier_bwd", {}).get("hbm_bytes_per_launch") if os.path.exists(pmc) else None)
+                               traffic=tr3, traffic_source=tr3_src)
         del theta, phi, gx
 
     if rank != 0:
@@ -273,31 +388,41 @@ def main():
 
     kernels = {k: dict(avg_ms=v["total_ms"] / max(v["launches"], 1), launches=v["launches"]) for k, v in prof.items()}
     k_local = K_total // world
-    gru_flops = flops_gru_per_window(HIDDEN // 2, 4, ABUF) * k_local * HORIZON
-    roll_flops = flops_rollout_per_sample_step(HIDDEN, 11) * k_local * HORIZON  # nt3 = 11 tiles for d=5, S=17
-    gk = kernels.get("gru_encode_kernel", dict(avg_ms=float("nan")))
-    rk = kernels.get("nl_rollout_kernel", dict(avg_ms=float("nan")))
-    gru_tf = gru_flops / (gk["avg_ms"] * 1e-3) / 1e12
-    g_traffic, r_traffic, t_src = None, None, None
-    pmc = PMC_JSON
-    if os.path.exists(pmc) and k_local == K_SAMPLES:  # measured at the headline size only
-        pj = json.load(open(pmc))
-        g_traffic, r_traffic = pj["gru_encode"]["hbm_bytes_per_launch"], pj["nl_rollout"]["hbm_bytes_per_launch"]
-        t_src = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
-    roofline = dict(bound="mfma", achieved=gru_tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=gru_tf / FP64_MFMA_PEAK_TFLOPS, traffic=g_traffic, traffic_source=t_src,
-                    algorithmic_hbm_bytes=24 * k_local * HORIZON, kernel="gru_encode_kernel",
-                    avg_launch_ms=gk["avg_ms"], flops_per_launch=gru_flops,
-                    also=dict(kernel="nl_rollout_kernel", avg_launch_ms=rk["avg_ms"], flops_per_launch=roll_flops,
-                              traffic=r_traffic,
-                              achieved=roll_flops / (rk["avg_ms"] * 1e-3) / 1e12,
-                              frac=roll_flops / (rk["avg_ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS))
+    windows = k_local * HORIZON
+    g_hidden = HIDDEN // 2
+    gru_need = flops_gru_needed_per_window(g_hidden, nu, ABUF) * windows
+    gru_iss = flops_gru_issued_per_window(g_hidden, ABUF) * windows
+    roll_need = flops_rollout_needed_per_sample_step(HIDDEN, d, S_TERMS) * windows
+    roll_iss = flops_rollout_issued_per_sample_step(HIDDEN, 11) * windows  # nt3 = 11 layer-3 tiles for d=5, S=17
+
+    def mfma_entry(kernel, need, issued, alg_bytes):
+        k = kernels[kernel]
+        sec = k["avg_ms"] * 1e-3
+        traffic, src = (pmc_traffic(pmc_name, pj, kernel) if k_local == K_SAMPLES else (None, None))
+        return dict(bound="mfma", achieved=need / sec / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=need / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, traffic=traffic, traffic_source=src,
+                    kernel=kernel, avg_launch_ms=k["avg_ms"], flops_per_launch=need,
+                    issued_flops_per_launch=issued, frac_issued=issued / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                    algorithmic_hbm_bytes=alg_bytes,
+                    note="achieved/frac count the algorithm's flops (SURVEY 8d, W_hh h0 = 0 products skipped); "
+                         "frac_issued counts the MFMAs the kernel executes (16-wide tile padding included)")
+
+    if "nl_plan_fused_kernel" in kernels:
+        # small shard: GRU encode and split rollout are roles of ONE launch (kernels_fused.hip)
+        roofline = mfma_entry("nl_plan_fused_kernel", gru_need + roll_need, gru_iss + roll_iss,
+                              (8 * nu + 16 + 16 + 8 * (2 * nu + d)) * windows)
+    else:
+        roofline = mfma_entry("gru_encode_kernel", gru_need, gru_iss, (8 * nu + 16) * windows)
+        roofline["also"] = mfma_entry("nl_rollout_kernel", roll_need, roll_iss, (16 + 8 * (2 * nu + d)) * windows)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_cpu, d, nu, args.cpu_budget)
     info = planner.ctx.device_info()
+    workload = (f"oderl-cartpole (nx=5, nu=1), K={K_total} MPPI samples sharded over the ranks, H={HORIZON}, "
+                f"action_buffer_size={ABUF}, NL dynamics h={HIDDEN} S={S_TERMS} fourier ILT")
+    workload += " (BASELINE configs[1])" if K_total == K_SAMPLES else " -- EXPERIMENT: not the headline population of 16384"
     out = dict(
-        metric="MPPI planning steps/sec (16384 samples, H=40)",
+        metric=f"MPPI planning steps/sec ({K_total} samples, H={HORIZON})",
         value=args.steps / elapsed,
         unit="planning steps/s",
         n_gpus=world,
@@ -309,18 +434,16 @@ def main():
         vs_baseline=None,
         dtype="f64",
         data="synthetic",
-        config=dict(workload="oderl-cartpole (nx=5, nu=1), K=16384 MPPI samples sharded over the ranks, H=40, "
-                             "action_buffer_size=4, NL dynamics h=128 S=17 fourier ILT (BASELINE configs[1])",
-                    samples_per_gpu=k_local, noise="device Philox4x32-10", device=info["name"]),
+        config=dict(workload=workload, samples_per_gpu=k_local, noise="device Philox4x32-10", device=info["name"],
+                    commit=git_commit()),
         roofline=roofline,
         roofline_ilt=ilt,
         cpu_baseline=cpu,
         kernels_avg_ms=kernels,
+        kernels_note="per-launch hipEvent averages from a second, untimed pass of the same steps",
     )
     if cpu:
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
-    if K_total != K_SAMPLES:
-        out["config"]["workload"] += f" -- EXPERIMENT with K={K_total}, not the headline configuration"
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     if pg is not None:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 4
+#define NLC_ABI_VERSION 5
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -71,6 +71,15 @@ const char* nlc_last_error(const nlc_ctx* ctx); /* ctx may be NULL: error of the
  * is what torch.cuda.current_stream().cuda_stream reports for torch's default stream. */
 int nlc_set_stream(nlc_ctx* ctx, void* hip_stream);
 int nlc_synchronize(nlc_ctx* ctx);
+/* Planner tuning knobs (none changes a result beyond last-bit rounding of the reductions they do not touch; they pick
+ * which hand-written rollout body a command of NLC_DYN_NL / Fourier runs):
+ *   "rollout_variant"    0 auto (default) | 1 one wavefront per 16-sample tile | 2 latency-split, one workgroup per tile
+ *                        | 3 fused one-launch body (GRU encode + split rollout as roles of one persistent grid)
+ *   "fused_max_samples"  auto picks the fused body up to this many local samples (default 2048: one GPU's shard of
+ *                        BASELINE configs[1] at 8 GPUs; at 4096 the two-launch path measured faster)
+ *   "fused_roll_cap"     rollout workgroups the fused body starts right away, one per CU (0 = auto: half the CUs)
+ * Unknown names / out-of-range values: NLC_ERR_BAD_ARG. */
+int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
 /* device properties the bench reports next to its roofline numbers */
 int nlc_device_info(nlc_ctx* ctx, char* name, int name_len, int* num_cus, int* clock_mhz, double* hbm_gib);
 
@@ -132,6 +141,11 @@ int nlc_gru_encode(nlc_ctx* ctx, const double* window_dev, int64_t N, int B, dou
 int64_t nlc_model_workspace_bytes(nlc_ctx* ctx, int64_t N);
 int nlc_model_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev,
                       int64_t N, int B, double* out_dev, void* ws_dev);
+/* a8 alone: LaplaceRepresentationFunc.forward (w_nl.py:55-63) on N explicit input rows
+ * rep_in_dev (N, 2S + d + 2) = [theta_s (S) | phi_s (S) | latent p (d+2)] -- whatever sphere coordinates the caller
+ * supplies, as torchlaplace hands them to the module -- -> theta_dev, phi_dev (N, d, S) with theta = pi tanh(.),
+ * phi = (pi/2) tanh(.) (:59-62).  Same MFMA kernel as the de Hoog path's representation stage. */
+int nlc_rep_func(nlc_ctx* ctx, const double* rep_in_dev, int64_t N, double* theta_dev, double* phi_dev);
 
 /* ---- baseline models: DeltaTRNN (train_utils.py:589-631; factory :56-74) and RNN (:550-586; factory :77-98);
  *      rnn_hidden_units config.py:43 ------

@@ -22,6 +22,8 @@ DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN, DYN_NODE = 0, 1, 2, 3, 4
 ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnlc_hip.so")
+# tools/ only (A/B builds of one kernel on one box, tools/ab_cmd.sh): another build of the SAME library
+LIB_PATH = os.environ.get("NLC_LIB_PATH", LIB_PATH)
 
 # every symbol include/nlc.h declares (tests check the built library exports them all)
 SYMBOLS = [
@@ -30,6 +32,7 @@ SYMBOLS = [
     "nlc_destroy",
     "nlc_last_error",
     "nlc_set_stream",
+    "nlc_set_option",
     "nlc_synchronize",
     "nlc_device_info",
     "nlc_ilt_rep_inputs",
@@ -40,6 +43,7 @@ SYMBOLS = [
     "nlc_gru_encode",
     "nlc_model_workspace_bytes",
     "nlc_model_forward",
+    "nlc_rep_func",
     "nlc_rnn_blob_size",
     "nlc_set_rnn_model",
     "nlc_rnn_forward",
@@ -202,6 +206,8 @@ def load_library():
         lib.nlc_node_forward.argtypes = [vp, vp, vp, dbl, i64, vp]
         lib.nlc_env_step.argtypes = [vp, i32, i32, dbl, i32, i64, i32, i32, vp, vp, vp, vp, vp]
         lib.nlc_env_obs.argtypes = [vp, i32, i64, vp, vp]
+        lib.nlc_rep_func.argtypes = [vp, vp, i64, vp, vp]
+        lib.nlc_set_option.argtypes = [vp, C.c_char_p, dbl]
         lib.nlc_mppi_configure.argtypes = [vp, P(MppiDesc)]
         lib.nlc_mppi_workspace_bytes.argtypes = [vp]
         lib.nlc_mppi_workspace_bytes.restype = i64
@@ -248,6 +254,10 @@ class Ctx:
 
         s = torch.cuda.current_stream(self.device_index).cuda_stream
         self.check(self.lib.nlc_set_stream(self.h, C.c_void_p(s)))
+
+    def set_option(self, name, value):
+        """Planner tuning knob of ``include/nlc.h`` (``nlc_set_option``)."""
+        self.check(self.lib.nlc_set_option(self.h, name.encode(), float(value)))
 
     def device_info(self):
         name = C.create_string_buffer(128)

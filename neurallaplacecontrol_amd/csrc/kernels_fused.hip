@@ -1,0 +1,283 @@
+// One-launch planner body for SMALL populations (one GPU's K/G shard of BASELINE configs[1]): the hoisted GRU encode
+// (w_nl.py:14-29, one 16-window tile per wavefront) and the latency-split T-step rollout (planners/mppi_delay.py:271-296,
+// one 16-sample tile per workgroup) run as ROLES of the same persistent grid instead of two back-to-back launches.
+//
+// Why: at K = 2048 the split rollout is 128 workgroups walking 40 strictly sequential horizon steps (0.40 ms) while
+// the other half of the chip idles, after the encode (0.42 ms, throughput-bound on the whole chip) has run alone.
+// Here the rollout of a tile starts as soon as the latents of its FIRST horizon step exist and the encoder waves keep
+// every other SIMD (and the rollout workgroups' own idle issue slots, at lower wave priority) busy.
+//
+// Grid: 2 workgroups of 256 threads per CU, all co-resident (the host sizes the grid from the device's CU count and
+// this kernel's occupancy).  Roles are taken at run time and do NOT depend on dispatch order or placement for
+// correctness (only for speed):
+//   * census: the first workgroup to arrive on a CU (s_getreg HW_ID / XCC_ID -> per-CU counter) may take a rollout tile
+//     from the rollout ticket, so rollout workgroups sit on distinct CUs, at most roll_cap of them start right away;
+//   * everybody else takes encoder tiles from the encoder ticket, in horizon-major order (all tiles of step t before
+//     step t+1), one tile per wavefront, and publishes each tile's latents;
+//   * when the encoder ticket runs dry the workgroup drains what is left of the rollout ticket.
+// An encoder never waits for anything, so the grid drains even if a rollout workgroup had to give up (bounded spins).
+//
+// Hand-off of a tile's latents (256 B, (T, K, 2) horizon-major so a tile is two whole 128-B lines), following
+// cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "inter-workgroup visibility" (third row of the sc1 table):
+//   producer wave: 8-B write-through (sc1) stores of the whole lines by ONE store instruction, s_waitcnt vmcnt(0),
+//                  then ONE lane's agent-scope atomic add on the tile's flag word;
+//   consumer:      ONE wave polls the flag with relaxed agent loads (global_load_dword sc1), a workgroup barrier, then
+//                  EVERY load of the latents is a 16-B buffer_load ... sc1 (bypasses the CU's L1; no acquire fence).
+// All polled words are zeroed by the command's perturb kernel (launched before this one on the same stream).
+#include "nlc_device.h"
+#include "nlc_gru_tile.h"
+#include "nlc_kernels.h"
+#include "nlc_rollout.h"
+
+namespace nlc {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+#define NLC_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// Diagnostics (progress counters, timeline stamps) are compiled in only with -DNLC_FUSED_TRACE=1 (tools/fused_debug.py):
+// 5120 encoder tiles x 3 same-address device-scope atomics were themselves a bottleneck of the launch.
+#ifndef NLC_FUSED_TRACE
+#define NLC_FUSED_TRACE 0
+#endif
+// timeline stamps: every lane of the calling wave issues the same atomic max
+__device__ __forceinline__ void stamp_max(unsigned* w, bool complement) {
+  if (!NLC_FUSED_TRACE) return;
+  const unsigned t = (unsigned)__builtin_amdgcn_s_memrealtime();
+  __hip_atomic_fetch_max(w, complement ? ~t : t, NLC_RLX_AGENT);
+}
+// GRU latents published by encoder workgroups of this launch (see the file header for the protocol)
+struct PaHandoff {
+  __amdgpu_buffer_rsrc_t rsrc;  // over paT (T, K, 2)
+  int64_t K;
+  const unsigned* flags;  // (T, ntk)
+  int ntk, tile, T;
+  unsigned* sync;           // device copy of the give-up code
+  unsigned* timeout_host;   // pinned host word the planner checks after the command
+  double cur0, cur1, nxt0, nxt1;
+  int ready_upto;  // polling wave: flags of steps < ready_upto have been seen set
+  static constexpr int kPollWave = 3;        // the wave with the fewest layer-3 tiles
+  static constexpr unsigned kSpinLimit = 1u << 18;  // ~1 s of polling, then give up (never hang the GPU)
+
+  __device__ __forceinline__ void load(int t, int64_t kc, double* a0, double* a1) const {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((int64_t)t * K + kc) * 16), 0, /*sc1*/ 16);
+    *a0 = __builtin_bit_cast(double, ((unsigned long long)v.y << 32) | v.x);
+    *a1 = __builtin_bit_cast(double, ((unsigned long long)v.w << 32) | v.z);
+  }
+  // Polling wave: wait until the flag of step t_first is set.  The FIRST look is one 64-lane gather over the flags of
+  // the next steps (usually the encoders are ahead and this is the only load for many steps); while waiting only ONE
+  // word is polled, with growing sleeps -- 128 workgroups gathering 40 lines each every microsecond was measurable as
+  // lost L2 bandwidth for the encoder waves' weight streams.
+  __device__ __forceinline__ void wait(int t_first, int t_end, int lane) {
+    unsigned naps = 0;
+    for (unsigned spins = 0;; ++spins) {
+      const int tt = t_first + ((spins == 0 || naps == 0) ? lane : 0);
+      unsigned f = 0;
+      if (tt < t_end && (naps == 0 || lane == 0)) f = __hip_atomic_load(flags + (int64_t)tt * ntk + tile, NLC_RLX_AGENT);
+      const unsigned long long ready = __ballot(f != 0);
+      const int cnt = (~ready == 0ull) ? 64 : __builtin_ctzll(~ready);
+      if (cnt >= 1) {
+        ready_upto = t_first + cnt;
+        return;
+      }
+      if (spins > kSpinLimit) {
+        // (every lane stores the same word: no lane-divergent branch inside the polling loop)
+        __hip_atomic_store(sync + kFusedTimeout, 1u + (unsigned)t_first, NLC_RLX_AGENT);
+        __hip_atomic_store(timeout_host, 1u + (unsigned)t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ready_upto = t_end;  // stop polling: the command is lost, the grid must still drain
+        return;
+      }
+      naps = naps < 4 ? naps + 1 : 4;
+      if (naps == 1) __builtin_amdgcn_s_sleep(16);
+      else if (naps == 2) __builtin_amdgcn_s_sleep(32);
+      else __builtin_amdgcn_s_sleep(64);  // ~2 us
+    }
+  }
+  __device__ __forceinline__ void begin(int t0, int wv, int lane, int64_t kc) {
+    if (wv == kPollWave) {
+      wait(t0, T, lane);
+      stamp_max(sync + kFusedTimeRollBeginFirst, true);
+      stamp_max(sync + kFusedTimeRollBeginLast, false);
+    }
+    __syncthreads();
+    load(t0, kc, &cur0, &cur1);
+  }
+  __device__ __forceinline__ void after_barrier1(int t, int t_end, int wv, int lane) {
+    if (wv == kPollWave && t + 1 < t_end && t + 1 >= ready_upto) wait(t + 1, t_end, lane);
+  }
+  __device__ __forceinline__ void after_barrier2(int t, int t_end, int64_t kc) {
+    if (t + 1 < t_end) load(t + 1, kc, &nxt0, &nxt1);
+  }
+  __device__ __forceinline__ void advance() {
+    cur0 = nxt0;
+    cur1 = nxt1;
+  }
+};
+
+// Wave-level atomics in UNIFORM control flow: every lane executes the atomic, lane 0 adds 1 and the others add 0 (the
+// compiler's atomic optimiser folds the 64 same-address adds into one).  Not `if (lane == 0) atomic...` inside the
+// persistent loop: a lane-divergent branch next to the loop's back edge lets ROCm 7.2 peel lanes 1..63 into a loop of
+// their own that re-reads the ticket lane 0 has not drawn yet and never ends (seen in the ISA and as a hung launch).
+__device__ __forceinline__ unsigned wave_ticket(unsigned* ctr, int lane) {
+  const unsigned old = __hip_atomic_fetch_add(ctr, lane == 0 ? 1u : 0u, NLC_RLX_AGENT);
+  return __builtin_amdgcn_readfirstlane(old);  // lane 0 added first: it holds the pre-add value
+}
+__device__ __forceinline__ void wave_add_one(unsigned* ctr, int lane) {
+  __hip_atomic_fetch_add(ctr, lane == 0 ? 1u : 0u, NLC_RLX_AGENT);
+}
+
+// Each role reads the kernel arguments through its OWN laundered copy of the kernel-argument segment pointer (the one
+// by-value argument sits at offset 0 of that segment).  Read the ordinary way, the scalar loads of every field either
+// role touches are hoisted to the top of the kernel and kept live across both roles: 1500 SGPR spills into VGPR lanes
+// (v_readlane / v_writelane + s_nop in the encoder's GEMM loops) and an encoder role 1.5x slower than the stand-alone
+// gru_encode_kernel.  Behind the asm statement the loads stay inside the role.
+// Tried and dropped: non-inlined role functions reading the segment pointer, and an address-space cast of the by-value
+// argument's address (both read address 0 on the MI355X); a copy of the block in global memory read through the
+// constant cache (correct, but every scalar load of it crawls: 13 ms per launch instead of 0.8).
+typedef const __attribute__((address_space(4))) FusedArgs* fused_args_cptr;
+__device__ __forceinline__ fused_args_cptr role_args() {
+  fused_args_cptr p = (fused_args_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+template <int HT, int NT3>
+__device__ __forceinline__ void fused_rollout(int tile, double* smem) {
+  constexpr int KS = HT * 4;
+  const FusedArgs& a = *(const FusedArgs*)role_args();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  PaHandoff src;
+  src.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.r.pa, 0, 0x7fffffff, 0x00020000);
+  src.K = a.r.K;
+  src.flags = a.ctl.sync + kFusedFlags;
+  src.ntk = a.ctl.ntk;
+  src.tile = tile;
+  src.T = a.r.T;
+  src.sync = a.ctl.sync;
+  src.timeout_host = a.ctl.timeout_host;
+  src.ready_upto = 0;
+  // the sequential chain is the command's critical path: its waves win the issue arbitration on their SIMDs
+  if (NLC_FUSED_TRACE && wv == 0) wave_add_one(a.ctl.sync + kFusedStatRollStart, lane);
+  __builtin_amdgcn_s_setprio(3);
+  rollout_split_tile<HT, NT3>(a.r, (int64_t)tile, src, smem, smem + KS * 64, smem + 2 * KS * 64);
+  __builtin_amdgcn_s_setprio(0);
+  if (wv == 0) {
+    if (NLC_FUSED_TRACE) wave_add_one(a.ctl.sync + kFusedStatRollDone, lane);
+    stamp_max(a.ctl.sync + kFusedTimeRollEndFirst, true);
+    stamp_max(a.ctl.sync + kFusedTimeRollEndLast, false);
+  }
+}
+
+// Encoder role: this wavefront draws encoder tiles (ticket order = horizon-major) until the ticket is spent.
+template <int G>
+__device__ __forceinline__ void fused_encode(double* smem) {
+  constexpr int KSG = G / 4;
+  const FusedArgs& a = *(const FusedArgs*)role_args();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  unsigned* sync = a.ctl.sync;
+  double* H0 = smem + (size_t)wv * 2 * KSG * 64;
+  double* H1 = H0 + KSG * 64;
+  for (;;) {
+    const unsigned i = wave_ticket(sync + kFusedEncTicket, lane);
+    if (i >= (unsigned)a.ctl.n_enc) break;
+    const int t = (int)(i / (unsigned)a.ctl.ntk), j = (int)(i - (unsigned)t * (unsigned)a.ctl.ntk);
+    const int64_t k = (int64_t)j * 16 + c;
+    const bool valid = k < a.r.K;
+    const int64_t kk = valid ? k : a.r.K - 1;
+    const double o = gru_encode_tile<G>(a.g, lane, 0, kk, t, H0, H1);
+    if (valid && q < 2) {
+      unsigned long long* dst = (unsigned long long*)(a.r.pa + ((int64_t)t * a.r.K + k) * 2 + q);
+      __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, o), NLC_RLX_AGENT);  // global_store_dwordx2 sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left this wave
+    wave_add_one(sync + kFusedFlags + i, lane);
+    if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEncDone, lane);
+    stamp_max(sync + kFusedTimeEncLast, false);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int HT, int NT3, int G>
+__global__ __launch_bounds__(256, 2) void nl_plan_fused_kernel(const FusedArgs av) {
+  const FusedCtl& a = av.ctl;  // role assignment; the roles read av through role_args()
+  constexpr int KSG = G / 4;  // GRU k-steps
+  constexpr int KS = HT * 4;  // representation-MLP k-steps
+  constexpr int kGruDoubles = 4 * 2 * KSG * 64, kRollDoubles = 2 * KS * 64 + 8 * 64;
+  __shared__ double smem[kGruDoubles > kRollDoubles ? kGruDoubles : kRollDoubles];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned* sync = a.sync;
+  int* s_tile = reinterpret_cast<int*>(smem);  // broadcast slot (inside wave 0's GRU region / the rollout's H1)
+
+  // ---- census (wave 0, wave-uniform control flow: see wave_ticket): the FIRST workgroup to arrive on a CU may take a
+  // rollout tile, so rollout workgroups sit on distinct CUs (two on one CU walk their chains at 19 us per horizon step
+  // instead of 10.7: measured, profiles/r2_fused_small_shard.md)
+  if (wv == 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID [3:0]
+    const unsigned cu = ((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu);
+    int tile = -1;
+    if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEntered, lane);
+    stamp_max(sync + kFusedTimeEntry, true);
+    const unsigned nth = wave_ticket(sync + kFusedCuOcc + cu, lane);
+    if (nth == 0) {  // wave-uniform
+      const unsigned tk = wave_ticket(sync + kFusedRollTicket, lane);
+      if (tk < (unsigned)a.roll_cap && tk < (unsigned)a.ntk) {
+        tile = (int)tk;
+      } else {
+        // a ticket beyond roll_cap is handed back so the drain phase below still sees every tile
+        __hip_atomic_fetch_add(sync + kFusedRollTicket, lane == 0 ? (unsigned)-1 : 0u, NLC_RLX_AGENT);
+      }
+    }
+    *s_tile = tile;  // every lane of wave 0 stores the same word
+  }
+  __syncthreads();
+  int tile = *s_tile;
+  __syncthreads();
+
+  if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);
+
+  // ---- encoder role: one tile (horizon step t, samples 16 j .. 16 j + 15) per wavefront and ticket
+  __syncthreads();  // (a rollout may just have finished in this LDS)
+  fused_encode<G>(smem);
+
+  // ---- drain: rollout tiles nobody has taken yet (K/16 > roll_cap, or fewer CUs than the host assumed)
+  for (;;) {
+    __syncthreads();
+    if (wv == 0) {
+      const unsigned tk = wave_ticket(sync + kFusedRollTicket, lane);
+      *s_tile = tk < (unsigned)a.ntk ? (int)tk : -1;
+    }
+    __syncthreads();
+    tile = *s_tile;
+    __syncthreads();
+    if (tile < 0) break;
+    fused_rollout<HT, NT3>(tile, smem);
+  }
+  if (NLC_FUSED_TRACE && wv == 0) wave_add_one(sync + kFusedStatExited, lane);
+}
+
+hipError_t fused_max_resident_blocks(int* blocks_per_cu) {
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)nl_plan_fused_kernel<8, 11, 64>, 256, 0);
+}
+
+hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, hipStream_t s) {
+  if (a.r.K <= 0) return hipSuccess;
+  if (a.r.net.h != 128 || g != 64) return hipErrorInvalidValue;
+  switch (a.r.net.nt3) {
+#define X(N)                                                                                          \
+  case N:                                                                                             \
+    hipLaunchKernelGGL((nl_plan_fused_kernel<8, N, 64>), dim3(grid), dim3(256), 0, s, a);         \
+    break;
+    X(7) X(9) X(11) X(13) X(17) X(21)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace nlc

@@ -34,6 +34,8 @@ hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s) {
 // Episode e of a batched planner continues the index space at e * K_global (e == 0: the single planner's stream).
 __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
   const int64_t total = a.K * a.T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_zero_words; i += (int64_t)gridDim.x * blockDim.x)
+    a.zero_words[i] = 0u;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = idx / a.T;

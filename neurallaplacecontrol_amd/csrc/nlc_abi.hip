@@ -94,8 +94,12 @@ struct nlc_ctx {
   double* pinned = nullptr;
   size_t pinned_n = 0;
   hipEvent_t stage_ev = nullptr;  // recorded after the staged H2D copies of a command
-  hipEvent_t ev_start = nullptr;  // horizon-chunk overlap: perturbation done (main stream)
-  hipEvent_t ev_chunk[8] = {};    // GRU latents of chunk c ready (side stream)
+  // planner options (nlc_set_option)
+  int opt_rollout_variant = 0;          // 0 auto, 1 wave-per-tile, 2 latency-split (two launches), 3 fused one-launch body
+  int opt_fused_roll_cap = 0;           // 0 auto (half the CUs)
+  int64_t opt_fused_max_samples = 2048; // auto: populations up to this size take the fused body (measured: 4096 is slower)
+  int fused_blocks_per_cu = -1;         // occupancy of the fused kernel (queried once)
+  bool fused_lost = false;              // a fused command gave up (hand-off timeout): reported by the next call
 };
 
 namespace {
@@ -275,9 +279,6 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   if (c->small) hipFree(c->small);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->stage_ev) hipEventDestroy(c->stage_ev);
-  if (c->ev_start) hipEventDestroy(c->ev_start);
-  for (hipEvent_t e : c->ev_chunk)
-    if (e) hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   hipStreamDestroy(c->own_stream);
   delete c;
@@ -288,6 +289,25 @@ extern "C" const char* nlc_last_error(const nlc_ctx* c) { return c ? c->err.c_st
 extern "C" int nlc_set_stream(nlc_ctx* c, void* s) {
   if (!c) return NLC_ERR_BAD_ARG;
   c->stream = (hipStream_t)s;
+  return NLC_OK;
+}
+
+extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (!name) return fail(c, NLC_ERR_BAD_ARG, "NULL option name");
+  const std::string n(name);
+  if (n == "rollout_variant") {
+    if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
+    c->opt_rollout_variant = (int)value;
+  } else if (n == "fused_roll_cap") {
+    if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_roll_cap must be >= 0 (0 = auto)");
+    c->opt_fused_roll_cap = (int)value;
+  } else if (n == "fused_max_samples") {
+    if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_max_samples must be >= 0");
+    c->opt_fused_max_samples = (int64_t)value;
+  } else {
+    return fail(c, NLC_ERR_BAD_ARG, "unknown option: " + n);
+  }
   return NLC_OK;
 }
 
@@ -583,6 +603,7 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
     rf.net = c->net;
     rf.N = N;
     rf.obs = obs;
+    rf.obs_stride = c->md.d;
     rf.obs_per_sample = 1;
     rf.pa = pa;
     rf.pa_stride = 2;
@@ -612,6 +633,42 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
     ProfScope ps(c, "nl_forward_kernel");
     NLC_HIP(c, launch_nl_forward(f, c->stream));
   }
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
+// LaplaceRepresentationFunc.forward (w_nl.py:55-63) on explicit input rows [theta_s (S) | phi_s (S) | p (d+2)]
+extern "C" int nlc_rep_func(nlc_ctx* c, const double* rep_in, int64_t N, double* theta, double* phi) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
+  if (N < 0) return fail(c, NLC_ERR_BAD_SHAPE, "bad N");
+  if (N == 0) return NLC_OK;
+  if (!rep_in || !theta || !phi) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const int64_t row = 2 * (int64_t)c->S + c->P;
+  RepFuncArgs rf{};
+  rf.net = c->net;
+  for (int i = 0; i < NLC_MAX_D; ++i) {  // the rows hold the latent p as the module sees it: no normalisation
+    rf.net.state_mean[i] = 0.0;
+    rf.net.state_std[i] = 1.0;
+  }
+  rf.N = N;
+  rf.obs = rep_in + 2 * c->S;
+  rf.obs_stride = row;
+  rf.obs_per_sample = 1;
+  rf.Kep = 1;
+  rf.pa = rep_in + 2 * c->S + c->md.d;
+  rf.pa_stride = row;
+  rf.general_t = 1;
+  rf.slot = c->slot_dev;
+  rf.fre = theta;
+  rf.fim = phi;
+  rf.sph = rep_in;
+  rf.sph_stride = row;
+  rf.write_angles = 1;
+  ProfScope ps(c, "nl_repfunc_kernel");
+  NLC_HIP(c, launch_nl_repfunc(rf, c->stream));
   return NLC_OK;
   NLC_GUARD_END(c)
 }
@@ -950,6 +1007,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     NLC_HIP(c, hipHostMalloc((void**)&c->pinned, pin_need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     c->pinned_n = pin_need;
   }
+  std::memset(c->pinned, 0, c->pinned_n * sizeof(double));
   c->pd = *d;
   c->pd.E = E;
   c->nblk = (int)((d->K + kWeightBlockSamples - 1) / kWeightBlockSamples);
@@ -977,7 +1035,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 
 namespace {
 struct WsLayout {
-  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, rq, total;
+  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, rq, sync, total;
 };
 WsLayout ws_layout(const nlc_ctx* c) {
   const nlc_mppi_desc& d = c->pd;
@@ -1002,10 +1060,24 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.dx = take(dh ? KE * d.d : 0);
   w.tconst = take(dh ? 8 : 0);
   w.rq = take(d.dynamics == NLC_DYN_DTRNN ? KE * d.T * d.d : 0);  // hidden part of linear_out, (T, K, d)
+  // fused one-launch planner body: tickets, per-CU census, one flag word per encoder tile (unsigned words)
+  w.sync = take(d.dynamics == NLC_DYN_NL && !dh ? (fused_sync_words(d.T, (int64_t)KE) + 1) / 2 : 0);
   w.total = off;
   return w;
 }
 }  // namespace
+
+// pinned host word a rollout workgroup of the fused planner body sets when it gives up waiting for an encoder tile
+static double* fused_timeout_word(nlc_ctx* c) {
+  const nlc_mppi_desc& d = c->pd;
+  return c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu + (size_t)d.E * d.T * d.nu;
+}
+static bool fused_gave_up(nlc_ctx* c) {
+  unsigned* w = reinterpret_cast<unsigned*>(fused_timeout_word(c));
+  if (*w == 0u) return false;
+  *w = 0u;
+  return true;
+}
 
 static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   const nlc_mppi_desc& d = c->pd;
@@ -1068,6 +1140,8 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
   if (d.cost_external && !buf->states) return fail(c, NLC_ERR_BAD_ARG, "cost_external needs buf->states");
   NLC_HIP(c, hipSetDevice(c->device));
+  if (fused_gave_up(c))  // (a device-resident caller never synchronised inside nlc_mppi_finish)
+    return fail(c, NLC_ERR_HIP, "fused planner body: the PREVIOUS command timed out waiting for GRU latents");
   const WsLayout w = ws_layout(c);
   double* ws = (double*)buf->workspace;
   double* state_dev = ws + w.state0;
@@ -1131,6 +1205,11 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) p.chol[i] = d.noise_chol[i];
   p.seed = seed;
   p.counter = counter;
+  if (d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_DEHOOG) {
+    // the fused planner body's tickets / census / flags start every command at zero
+    p.zero_words = reinterpret_cast<unsigned*>(ws + w.sync);
+    p.n_zero_words = (int64_t)fused_sync_words(d.T, KE);
+  }
   if (inline_inputs) {
     p.n_state_in = d.d;
     p.n_abuf_in = d.B * d.nu;
@@ -1139,15 +1218,21 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     std::memcpy(p.state_in, state, (size_t)d.d * sizeof(double));
     std::memcpy(p.abuf_in, abuf_host, (size_t)d.B * d.nu * sizeof(double));
   }
-  {
-    ProfScope ps(c, "shift_U_kernel");
-    NLC_HIP(c, launch_shift_U(p, c->stream));
-  }
-  c->ucur ^= 1;
-  {
+  c->ucur ^= 1;  // from here on c->U[c->ucur] is the shifted sequence the two kernels below produce
+  // (a lambda: the fused planner body's argument block rides to the device in the perturb kernel's arguments, so that
+  // path fills p.blob first)
+  auto launch_shift_perturb = [&]() -> int {
+    {
+      ProfScope ps(c, "shift_U_kernel");
+      NLC_HIP(c, launch_shift_U(p, c->stream));
+    }
     ProfScope ps(c, "perturb_kernel");
     NLC_HIP(c, launch_perturb(p, c->stream));
-  }
+    return NLC_OK;
+  };
+  const bool nl_fourier = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_DEHOOG;
+  if (!nl_fourier)
+    if (int rc = launch_shift_perturb()) return rc;
   if (external) return NLC_OK;  // the caller runs the horizon loop, then nlc_mppi_weights
   if (d.dynamics == NLC_DYN_NL) {
     double* pa = ws + w.pa;
@@ -1200,6 +1285,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       RepFuncArgs rf{};
       rf.net = r.net;
       rf.N = KE;
+      rf.obs_stride = d.d;
       rf.Kep = d.K;
       rf.pa_stride = (int64_t)d.T * 2;
       rf.tn = c->tn;
@@ -1250,48 +1336,54 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       }
       return d.cost_external ? NLC_OK : run_weights(c, buf);
     }
-    // NLC_ROLLOUT_VARIANT=1|2 pins the wave-per-tile / latency-split kernel (tests, experiments); default auto
-    int variant = 0;  // (read per command: the GPU tests switch it inside one process)
-    if (const char* ev = std::getenv("NLC_ROLLOUT_VARIANT")) variant = std::atoi(ev);
-    // Horizon chunking (experiment knob, OFF by default): NLC_HORIZON_CHUNKS=n cuts the horizon into n chunks and
-    // runs the GRU encode of chunk c+1 on the ctx's side stream while the rollout of chunk c runs on the main
-    // stream, so the encoder could fill the CUs a small shard's rollout leaves idle.  Measured on MI355X at
-    // K = 2048 / 4096 / 8192: 0.98 / 1.43 / 2.55 ms unchunked vs 1.04 / 1.54 / 2.65 ms with 4 chunks -- the
-    // co-running kernels slow each other down by more than the overlap buys, so the default stays 1.
-    int chunks = 1;
-    if (const char* ev = std::getenv("NLC_HORIZON_CHUNKS")) chunks = std::atoi(ev);
-    if (chunks < 1) chunks = 1;
-    if (chunks > 8) chunks = 8;
-    if (chunks > d.T) chunks = d.T;
-    hipStream_t side = (chunks > 1) ? c->own_stream : c->stream;
-    if (chunks > 1) {
-      if (!c->ev_start) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
-      NLC_HIP(c, hipEventRecord(c->ev_start, c->stream));
-      NLC_HIP(c, hipStreamWaitEvent(side, c->ev_start, 0));
-    }
-    const int base = d.T / chunks, extra = d.T % chunks;
-    int t0 = 0;
-    for (int ci = 0; ci < chunks; ++ci) {
-      const int tc = base + (ci < extra ? 1 : 0);
-      g.t0 = t0;
-      g.Tc = tc;
-      g.N = KE * tc;
+    // rollout_variant (nlc_set_option): 0 auto, 1 wave-per-tile, 2 latency-split, 3 fused one-launch body
+    int variant = c->opt_rollout_variant;
+    const bool fused_ok = c->g == 64 && c->net.nt3 <= 21 && KE * d.T * 16 < (int64_t)1 << 31;
+    if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
+    if (variant == 0 && fused_ok && KE <= c->opt_fused_max_samples) variant = 3;
+    if (variant == 3) {
+      if (c->fused_blocks_per_cu < 0) {
+        int bpc = 0;
+        NLC_HIP(c, fused_max_resident_blocks(&bpc));
+        c->fused_blocks_per_cu = bpc;
+      }
+      const int bpc = c->fused_blocks_per_cu < 2 ? c->fused_blocks_per_cu : 2;
+      if (bpc < 1) return fail(c, NLC_ERR_HIP, "fused planner body: kernel does not fit a CU");
+      const int ncu = c->prop.multiProcessorCount;
+      FusedArgs f{};
+      f.r = r;
+      f.r.t_begin = 0;
+      f.r.t_end = d.T;
+      f.g = g;
+      f.g.t0 = 0;
+      f.g.Tc = d.T;
+      f.g.N = KE * d.T;
+      FusedCtl& fc = f.ctl;
+      fc.sync = reinterpret_cast<unsigned*>(ws + w.sync);
+      fc.timeout_host = reinterpret_cast<unsigned*>(fused_timeout_word(c));
+      fc.ntk = (int)((KE + 15) / 16);
+      fc.n_enc = fc.ntk * d.T;
+      // rollout workgroups start one per CU on the first CUs to arrive; by default on half the CUs at most
+      fc.roll_cap = c->opt_fused_roll_cap > 0 ? c->opt_fused_roll_cap : (ncu / 2 > 0 ? ncu / 2 : 1);
+      if (fc.roll_cap > fc.ntk) fc.roll_cap = fc.ntk;
+      if (int rc = launch_shift_perturb()) return rc;
+      // every workgroup must be resident at once: a rollout workgroup waits for encoder workgroups of the same launch
+      const unsigned grid = (unsigned)(ncu * bpc);
+      ProfScope ps(c, "nl_plan_fused_kernel");
+      NLC_HIP(c, launch_nl_plan_fused(f, c->g, grid, c->stream));
+    } else {
+      if (int rc = launch_shift_perturb()) return rc;
+      g.t0 = 0;
+      g.Tc = d.T;
+      g.N = KE * d.T;
       {
-        ProfScope ps(c, "gru_encode_kernel", side, true);
-        NLC_HIP(c, launch_gru_encode(g, c->g, side));
+        ProfScope ps(c, "gru_encode_kernel");
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
       }
-      if (chunks > 1) {
-        if (!c->ev_chunk[ci]) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_chunk[ci], hipEventDisableTiming));
-        NLC_HIP(c, hipEventRecord(c->ev_chunk[ci], side));
-        NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_chunk[ci], 0));
-      }
-      r.t_begin = t0;
-      r.t_end = t0 + tc;
-      {
-        ProfScope ps(c, "nl_rollout_kernel");
-        NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
-      }
-      t0 += tc;
+      r.t_begin = 0;
+      r.t_end = d.T;
+      ProfScope ps(c, "nl_rollout_kernel");
+      NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
     }
   } else if (d.dynamics == NLC_DYN_NODE) {
     NodeRolloutArgs r{};
@@ -1433,6 +1525,8 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   if (action_host) {
     const size_t na = (size_t)d.E * d.u_per_command * d.nu;
     NLC_HIP(c, hipStreamSynchronize(c->stream));
+    if (fused_gave_up(c))
+      return fail(c, NLC_ERR_HIP, "fused planner body: a rollout workgroup timed out waiting for GRU latents; command lost");
     std::memcpy(action_host, pin_act, na * sizeof(double));
   }
   return NLC_OK;

@@ -1,0 +1,211 @@
+// One 16-window tile of the ReverseGRUEncoder (w_nl.py:14-29) on FP64 matrix cores: chunked gate GEMMs, two-wide
+// gate math and the tile body shared by gru_encode_kernel (kernels_gru.hip) and the fused planner kernel
+// (kernels_fused.hip).  See kernels_gru.hip for the dataflow and the roofline.
+#pragma once
+#include "nlc_device.h"
+#include "nlc_kernels.h"
+
+namespace nlc {
+
+// (Measured on MI355X, cfg2, round 1: gates replaced by plain FMAs -> 2.65 ms vs 3.43 ms, i.e. MFMA + weight
+// streaming 2.65 ms, gate transcendentals 0.8 ms; a two-k-step fragment prefetch changed nothing: loads are hidden.)
+// Gate GEMMs are processed in CHUNKS of one 16-feature tile per gate (r_j, z_j, n_j): only four accumulator
+// tiles are live at a time instead of sixteen, which keeps the kernel under 256 VGPRs -> two waves per SIMD,
+// so one wave's gate transcendentals (FP64 VALU) overlap the other wave's MFMAs.
+// Chunk-packed weights: Wc[((j*KS + ks)*3 + g)*64 + lane], g in {r, z, n}: row g*G + 16 j + (lane & 15).
+template <int KS>
+__device__ __forceinline__ void chunk_gemm(v4d& c0, v4d& c1, v4d& c2, const double* __restrict__ wc, int lane,
+                                           const double* __restrict__ hb) {
+  // hb: this wave's hidden-state image in LDS, hb[ks*64 + lane] = B fragment of k-step ks (written by the same lane)
+  double a_cur[3], a_nxt[3];
+  gptr p = opaque(wc);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) a_cur[g] = p[g * 64 + lane];
+  double b_cur = hb[lane], b_nxt = 0.0;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+      p = opaque(p + 3 * 64);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) a_nxt[g] = p[g * 64 + lane];
+      b_nxt = hb[(ks + 1) * 64 + lane];
+    }
+    c0 = mfma(a_cur[0], b_cur, c0);
+    c1 = mfma(a_cur[1], b_cur, c1);
+    c2 = mfma(a_cur[2], b_cur, c2);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) a_cur[g] = a_nxt[g];
+    b_cur = b_nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- two-wide gate math: the r/z sigmoids and the n tanh of TWO hidden units are evaluated in lockstep (clang
+// ext-vector arithmetic = two independent FP64 instruction streams), so each wave issues two dependent chains
+// instead of one and the FP64 VALU latency is covered without relying on the partner wave.
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2d fma2(v2d a, v2d b, v2d c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2d splat2(double x) { return v2d{x, x}; }
+__device__ __forceinline__ v2d rcp_refined2(v2d d) {
+  // v_rcp_f64 (~2^-24) + one cubic step r (1 + e + e^2), e = 1 - d r: 3 FMAs, <= 1 ulp (tools/rcp_probe.hip)
+  const v2d r = {__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
+  const v2d e = fma2(-d, r, splat2(1.0));
+  return fma2(r, fma2(e, e, e), r);
+}
+__device__ __forceinline__ v2d expm1_poly2(v2d r) {
+  v2d q = splat2(0x1.af38a9b0ec855p-26);
+  q = fma2(q, r, splat2(0x1.289185613a3d6p-22));
+  q = fma2(q, r, splat2(0x1.71de0dae63bb3p-19));
+  q = fma2(q, r, splat2(0x1.a019b90d2ae7ap-16));
+  q = fma2(q, r, splat2(0x1.a01a01a7c41d5p-13));
+  q = fma2(q, r, splat2(0x1.6c16c1788bd90p-10));
+  q = fma2(q, r, splat2(0x1.11111111109b3p-7));
+  q = fma2(q, r, splat2(0x1.5555555553d63p-5));
+  q = fma2(q, r, splat2(0x1.5555555555556p-3));
+  q = fma2(q, r, splat2(0x1.0000000000001p-1));
+  return fma2(q * r, r, r);
+}
+__device__ __forceinline__ v2d exp_reduce2(v2d y, v2i* n) {
+  // round-to-nearest by the 1.5 * 2^52 shift; the integer is the low word of the shifted sum (no v_rndne / v_cvt)
+  const v2d sh = fma2(y, splat2(1.44269504088896338700e+00), splat2(6755399441055744.0));
+  const v2d fn = sh - splat2(6755399441055744.0);
+  v2d r = fma2(-fn, splat2(6.93147180369123816490e-01), y);
+  r = fma2(-fn, splat2(1.90821492927058770002e-10), r);
+  *n = v2i{__double2loint(sh.x), __double2loint(sh.y)};
+  return r;
+}
+// 1 + e^{-x} for either sign (e^{-x} >= 0, nothing cancels).  The argument is clamped to +-350 so that the product
+// of two such terms stays finite (below -350 the true sigmoid is < 1e-152 and this returns ~1e-152).
+__device__ __forceinline__ v2d one_plus_exp_neg2(v2d x) {
+  const v2d y = __builtin_elementwise_min(__builtin_elementwise_max(-x, splat2(-350.0)), splat2(350.0));
+  v2i n;
+  const v2d r = exp_reduce2(y, &n);
+  const v2d p = splat2(1.0) + expm1_poly2(r);
+  const v2d e = {ldexp(p.x, n.x), ldexp(p.y, n.y)};
+  return splat2(1.0) + e;
+}
+// the reset and update gates share ONE reciprocal: sigmoid(a) = B / (A B), sigmoid(b) = A / (A B) with
+// A = 1 + e^{-a}, B = 1 + e^{-b}  (three multiplies instead of a second v_rcp_f64 + refinement)
+__device__ __forceinline__ void sigmoid_pair2(v2d a, v2d b, v2d* sa, v2d* sb) {
+  const v2d A = one_plus_exp_neg2(a), B = one_plus_exp_neg2(b);
+  const v2d R = rcp_refined2(A * B);
+  *sa = B * R;
+  *sb = A * R;
+}
+__device__ __forceinline__ v2d tanh2(v2d x) {
+  const v2d y = __builtin_elementwise_max(-2.0 * __builtin_elementwise_abs(x), splat2(-745.0));
+  v2i n;
+  const v2d r = exp_reduce2(y, &n);
+  const v2d p = expm1_poly2(r);
+  const v2d two_n = {ldexp(1.0, n.x), ldexp(1.0, n.y)};
+  const v2d em = fma2(two_n, p, two_n - splat2(1.0));
+  const v2d t = -em * rcp_refined2(splat2(2.0) + em);
+  return __builtin_elementwise_copysign(t, x);
+}
+
+__device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d& ain, const v4d& ahn, const v4d& hold) {
+  v4d hnew;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const v2d r2 = half ? ar.zw : ar.xy, z2 = half ? az.zw : az.xy, in2 = half ? ain.zw : ain.xy;
+    const v2d hn2 = half ? ahn.zw : ahn.xy, ho2 = half ? hold.zw : hold.xy;
+    v2d rg, zg;
+    sigmoid_pair2(r2, z2, &rg, &zg);
+    const v2d ng = tanh2(fma2(rg, hn2, in2));
+    const v2d hv = fma2(zg, ho2 - ng, ng);  // (h - n) z + n, the form aten's gru_cell evaluates (= (1-z) n + z h)
+    if (half) {
+      hnew.zw = hv;
+    } else {
+      hnew.xy = hv;
+    }
+  }
+  return hnew;
+}
+
+// One wavefront encodes the 16 windows its lanes' columns name.  Mode 0: window row `wc` of the explicit (N, B, nin)
+// tensor; mode 1: window (kk, tt) of the MPPI history.  H0 / H1: this wave's hidden-state images in LDS (KS*64 doubles
+// each, every entry written and read by the same lane: no barrier).  Returns linear_out row q (valid for q < 2).
+template <int G>
+__device__ __forceinline__ double gru_encode_tile(const GruArgs& a, int lane, int64_t wc, int64_t kk, int tt,
+                                                  double* __restrict__ H0, double* __restrict__ H1) {
+  constexpr int GT = G / 16;   // tiles per gate = chunks
+  constexpr int KS = G / 4;    // k-steps over the hidden dimension
+  const int q = lane >> 4;
+  // per-lane input normalisation constants (lane q feeds input dim q; q == 3 feeds the bias column)
+  double in_mean = 0.0, in_std = 1.0;
+  if (q < a.nin) {
+    in_mean = a.mean[q];
+    in_std = a.std[q];
+  }
+  const int ab_off = (a.mode == 1) ? (int)(kk / a.Kep) * a.B : 0;  // this sample's episode block of action_buffer
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    H0[ks * 64 + lane] = 0.0;
+    H1[ks * 64 + lane] = 0.0;
+  }
+  v4d hn[GT];
+
+  for (int s = 0; s < a.B; ++s) {
+    // reversed time: GRU step s consumes window element B-1-s  (torch.flip, w_nl.py:27)
+    const int j_win = a.B - 1 - s;
+    double xin = 0.0;
+    if (q < a.nin) {
+      double raw;
+      if (a.mode == 0) {
+        raw = a.window[(wc * a.B + j_win) * a.nin + q];
+      } else {
+        const int i = tt + j_win;
+        if (q < a.nact)
+          raw = (i < a.B - 1) ? a.abuf[(ab_off + 1 + i) * a.nact + q]
+                              : a.u_scale * a.perturbed[(kk * a.T + (i - (a.B - 1))) * a.nact + q];
+        else
+          raw = (double)(a.B - 1 - j_win);  // encode_obs_time model: the harness's constant time channel
+      }
+      xin = (raw - in_mean) / in_std;
+    } else if (q == 3) {
+      xin = 1.0;  // bias column of the packed W_ih0
+    }
+    // ---------------- layer 0: input side is one k-step (K = nin padded to 4, bias folded into column 3)
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
+      v4d ar = mfma(wp[lane], xin, splat(0.0));
+      v4d az = mfma(wp[64 + lane], xin, splat(0.0));
+      v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
+      v4d ahn = load_bias_tile(a.bhn0, j, q);
+      if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, H0);
+      const v4d hold = {H0[(4 * j + 0) * 64 + lane], H0[(4 * j + 1) * 64 + lane], H0[(4 * j + 2) * 64 + lane],
+                        H0[(4 * j + 3) * 64 + lane]};
+      hn[j] = gru_gates(ar, az, ain, ahn, hold);
+    }
+#pragma unroll
+    for (int j = 0; j < GT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H0[(4 * j + r) * 64 + lane] = hn[j][r];
+    // ---------------- layer 1
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      v4d ar = load_bias_tile(a.brz1, j, q);
+      v4d az = load_bias_tile(a.brz1, GT + j, q);
+      v4d ain = load_bias_tile(a.bin1, j, q);
+      v4d ahn = load_bias_tile(a.bhn1, j, q);
+      chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, H0);
+      if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, H1);
+      const v4d hold = {H1[(4 * j + 0) * 64 + lane], H1[(4 * j + 1) * 64 + lane], H1[(4 * j + 2) * 64 + lane],
+                        H1[(4 * j + 3) * 64 + lane]};
+      hn[j] = gru_gates(ar, az, ain, ahn, hold);
+    }
+#pragma unroll
+    for (int j = 0; j < GT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1[(4 * j + r) * 64 + lane] = hn[j][r];
+  }
+  // ---------------- linear_out (2 x g): rows 0,1 of one output tile
+  v4d o[1];
+  o[0] = splat(0.0);
+  gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return H1[ks * 64 + lane]; });
+  return o[0][0] + a.bo[q < 2 ? q : 0];
+}
+
+}  // namespace nlc

@@ -184,6 +184,35 @@ struct RolloutArgs {
 };
 hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s, int force_variant = 0);
 
+// One-launch planner body for small populations (kernels_fused.hip): GRU encode + split rollout as roles of one grid.
+// `sync` is a block of unsigned words the command's perturb kernel zeroes:
+constexpr int kFusedEncTicket = 0, kFusedRollTicket = 1, kFusedTimeout = 2;
+// progress counters (diagnostics; one relaxed atomic add each): workgroups entered / rollout tiles started / finished /
+// encoder tiles published / workgroups exited
+constexpr int kFusedStatEntered = 4, kFusedStatRollStart = 5, kFusedStatRollDone = 6, kFusedStatEncDone = 7, kFusedStatExited = 8;
+// timeline (low 32 bits of the 100 MHz s_memrealtime counter; "first" values are stored complemented so that the zeroed
+// word works with atomic max): first entry, first / last rollout past its first hand-off, first / last rollout done,
+// last encoder tile published
+constexpr int kFusedTimeEntry = 9, kFusedTimeRollBeginFirst = 10, kFusedTimeRollBeginLast = 11, kFusedTimeRollEndFirst = 12,
+              kFusedTimeRollEndLast = 13, kFusedTimeEncLast = 14;
+constexpr int kFusedCuOcc = 16;              // 2048 per-CU arrival counters (XCC_ID << 8 | SE/SH/CU id)
+constexpr int kFusedFlags = 16 + 2048;       // (T, ntk) one word per encoder tile
+inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)T * (size_t)((K + 15) / 16); }
+struct FusedCtl {   // role assignment; passed to the kernel by value
+  unsigned* sync;
+  unsigned* timeout_host;  // pinned host word: non-zero = a rollout workgroup gave up waiting (command lost)
+  int ntk;         // 16-sample tiles per horizon step
+  int n_enc;       // T * ntk encoder tiles
+  int roll_cap;    // rollout workgroups that start right away (one per CU); the other tiles drain after the encoders
+};
+struct FusedArgs {   // the kernel's one by-value argument
+  RolloutArgs r;   // r.pa: the (T, K, 2) HORIZON-major latent tensor (written and read inside the launch)
+  GruArgs g;       // mode 1 fields filled in; g.out unused
+  FusedCtl ctl;
+};
+hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, hipStream_t s);
+hipError_t fused_max_resident_blocks(int* blocks_per_cu);
+
 struct ForwardArgs {
   NlNetArgs net;
   int64_t N;
@@ -199,6 +228,7 @@ struct RepFuncArgs {
   NlNetArgs net;
   int64_t N;
   const double* obs;  // (N, d), or (E, d) rows broadcast over the Kep samples of each episode
+  int64_t obs_stride; // doubles between obs rows (d for a dense tensor)
   int obs_per_sample;
   int64_t Kep;
   const double* pa;   // GRU latents, row n at pa + n*pa_stride
@@ -209,6 +239,11 @@ struct RepFuncArgs {
   const int* slot;    // (8*nt3) slot -> c*S + k or -1
   double* fre;        // (N, d, S)
   double* fim;
+  // LaplaceRepresentationFunc.forward on explicit input rows (general_t only): sphere inputs [theta_s | phi_s] of row n at
+  // sph + n * sph_stride (NULL: computed from ts); write_angles: store the module's (theta, phi) instead of F (re, im)
+  const double* sph;
+  int64_t sph_stride;
+  int write_angles;
 };
 hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s);
 
@@ -326,6 +361,9 @@ struct PerturbArgs {
   double* abuf_dst;
   double state_in[NLC_MAX_D];
   double abuf_in[kMaxInlineAbuf];
+  // words the perturb kernel zeroes for a later kernel of the same command (the fused planner's sync block)
+  unsigned* zero_words;
+  int64_t n_zero_words;
 };
 hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s);
 hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s);

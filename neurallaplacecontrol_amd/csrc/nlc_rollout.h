@@ -1,0 +1,374 @@
+// Device code shared by the rollout kernels (kernels_nl.hip) and the fused planner kernel (kernels_fused.hip):
+// one evaluation of the representation MLP + sphere->complex + Fourier ILT (nl_eval), and the latency-split T-step
+// rollout of one 16-sample tile by the four waves of a workgroup (rollout_split_tile).  Reference call sites and the
+// dataflow are described at the top of kernels_nl.hip.
+#pragma once
+#include "nlc_device.h"
+#include "nlc_envcost.h"
+#include "nlc_kernels.h"
+
+namespace nlc {
+
+// ------------------------------------------------------------------ one model evaluation
+// p0/p1: layer-1 latent B fragments (index 4s+q).  Returns acc_x: ILT sums, rows = dims (reg r -> dim q+4r).
+// |F| times the component the Fourier phase i^k keeps, as (num * trig, den): even-k groups need cos(theta), odd-k
+// groups sin(theta) = -cos(theta + pi/2).  Short forms of nlc_math.h (one reduction by pi with the quarter turn in
+// the reduction, Chebyshev cosines): 34 FP64 instructions instead of 56 for the fdlibm-kernel pair.
+__device__ __forceinline__ double sphere_term(double theta, double phi, bool odd) {
+  const m::IltTrigK K = m::ilt_trig_k();
+  double num, den;
+  m::tan_parts_short(K, phi / 2.0 + kPi / 4.0, &num, &den);
+  const double c = m::cos_plus_mpio2(K, theta, odd ? 0.5 : 0.0, odd ? 1.0 : 0.0);
+  const double trig = odd ? -c : c;
+  return (num * trig) * m::rcp_refined(den);
+}
+
+// GENERAL_T: sphere coordinates of the per-sample query points enter layer 1 through W1s.
+// FOUT != nullptr-mode (WRITE_F): instead of the Fourier sum, F_k = |F| e^{i theta} of every Laplace term is
+// written to (N, d, S) arrays for the de Hoog kernel (nonlinear in F, cannot be an MFMA).
+struct FOut {
+  double* fre;
+  double* fim;
+  const int* slot;  // slot index (8 per layer-3 tile) -> c*S + k, -1 = padding
+  int64_t row;      // sample row; < 0: do not store
+  int dS;
+  int angles;       // 1: store (theta, phi) instead of (Re F, Im F)
+};
+// sph_row (GENERAL_T only): when non-NULL, this lane's sample has EXPLICIT sphere inputs [theta_s | phi_s] (2S doubles)
+// -- LaplaceRepresentationFunc.forward on an arbitrary input row (w_nl.py:55-63) -- instead of the ones of s_k(tn).
+template <int HT, int NT3, bool GENERAL_T, bool WRITE_F = false>
+__device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn,
+                                       const FOut* fo = nullptr, const double* sph_row = nullptr) {
+  constexpr int KS = HT * 4;  // h / 4
+  v4d h1[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) h1[j] = load_bias_tile(n.b1, j, q);
+  if constexpr (GENERAL_T) {
+    // s_k = gamma + i pi k / T,  T = scale*t,  gamma = alpha - ln(tol)/(scale*T); theta_s = atan2(Im, Re),
+    // phi_s = asin((|s|^2-1)/(|s|^2+1)); input order [theta_s(0..S-1) | phi_s(0..S-1)]
+    const double Tt = n.scale * tn;
+    const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+    const int kss = (2 * n.S + 3) / 4;
+    gptr p = opaque(n.W1s);
+    for (int ks = 0; ks < kss; ++ks) {
+      const int i = 4 * ks + q;
+      double b = 0.0;
+      if (sph_row != nullptr) {
+        if (i < 2 * n.S) b = sph_row[i];
+      } else if (i < 2 * n.S) {
+        const int k = (i < n.S) ? i : i - n.S;
+        const double im = kPi * (double)k / Tt;
+        if (i < n.S) {
+          b = atan2(im, gamma);
+        } else {
+          const double a2 = gamma * gamma + im * im;
+          b = asin((a2 - 1.0) / (a2 + 1.0));
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < HT; ++m) h1[m] = mfma(p[m * 64 + lane], b, h1[m]);
+      p = opaque(p + HT * 64);
+    }
+  }
+  gemm_acc<HT, 2>(h1, n.W1p, lane, [&](int ks) { return ks == 0 ? p0 : p1; });
+  // Activations are applied as one batch of 32 independent tanh chains per layer.  (On gfx950 an FP64 MFMA
+  // holds the SIMD's VALU issue for its whole 64 cycles -- tools/ubench_f64.hip -- so interleaving the
+  // activation with the next layer's MFMAs buys nothing, while batching keeps the FP64 VALU latency hidden.)
+#pragma unroll
+  for (int j = 0; j < HT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      double ta, tb;
+      m::tanh_pair_d(h1[j][r], h1[j][r + 1], &ta, &tb);
+      h1[j][r] = ta;
+      h1[j][r + 1] = tb;
+    }
+
+  v4d h2[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) h2[j] = load_bias_tile(n.b2, j, q);
+  gemm_acc<HT, KS>(h2, n.W2p, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
+#pragma unroll
+  for (int j = 0; j < HT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      double ta, tb;
+      m::tanh_pair_d(h2[j][r], h2[j][r + 1], &ta, &tb);
+      h2[j][r] = ta;
+      h2[j][r + 1] = tb;
+    }
+
+  v4d o[NT3];
+#pragma unroll
+  for (int j = 0; j < NT3; ++j) o[j] = load_bias_tile(n.b3p, j, q);
+  gemm_acc<NT3, KS>(o, n.W3p, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
+
+  // sphere -> complex, keep the component the Fourier phase i^k selects, then sum over k by MFMA
+  v4d ax[1];
+  ax[0] = splat(0.0);
+  gptr cp = opaque(n.Cp);
+#pragma unroll
+  for (int j = 0; j < NT3; ++j) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int g = 2 * j + r;
+      // (not paired: a saturated phi must be EXACTLY pi/2 to reproduce the reference's clamped |F|)
+      const double theta = m::tanh_d(o[j][r]) * kPi;                               // w_nl.py:59
+      const double phi = m::tanh_d(o[j][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
+      // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
+      double num, den;
+      m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+      if constexpr (WRITE_F) {
+        const int idx = fo->slot[4 * g + q];
+        if (fo->row >= 0 && idx >= 0 && fo->angles) {
+          fo->fre[fo->row * fo->dS + idx] = theta;  // the module's own outputs (theta, phi), w_nl.py:59-63
+          fo->fim[fo->row * fo->dS + idx] = phi;
+        } else if (fo->row >= 0 && idx >= 0) {
+          double sn, cs;
+          m::sincos_bounded(theta, &sn, &cs);
+          const double rad = num * m::rcp_refined(den);
+          fo->fre[fo->row * fo->dS + idx] = rad * cs;
+          fo->fim[fo->row * fo->dS + idx] = rad * sn;
+        }
+      } else {
+        (void)num;
+        (void)den;
+        ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
+      }
+    }
+  }
+  return ax[0];
+}
+
+// ------------------------------------------------------------------ latency-split rollout of one 16-sample tile
+// nl_rollout_kernel gives every wavefront a whole 16-sample tile, which fills the chip only when K/16 >= 1024
+// wavefronts.  When the population is sharded over several GPUs (K/G = 2048 at 8 GPUs) most SIMDs would idle
+// while 40 strictly sequential horizon steps run at single-wave speed.  Here ONE workgroup (4 waves = the 4
+// SIMDs of a CU) owns the 16-sample tile and splits every layer's OUTPUT tiles over its waves; the full
+// activation vector is exchanged through LDS ([k-step][lane] images, conflict-free ds_read_b64/ds_write_b64),
+// three barriers per horizon step.  Per-step latency drops ~4x; total MFMA work is unchanged.
+//
+// Where the GRU latents of a step come from is a policy:
+//   PaDirect   the (K, T, 2) tensor an earlier launch wrote (nl_rollout_split_kernel)
+//   PaHandoff  (kernels_fused.hip) tiles published by encoder workgroups of the SAME launch, behind per-tile flags
+// Policy interface (all calls are made by all four waves, in this order per horizon step t):
+//   begin(t0, wv, lane, kc)      before the loop; leaves the latents of step t0 in cur0/cur1
+//   after_barrier1(t, ...)       between the first and second barrier of step t   (poll for step t+1)
+//   after_barrier2(t, ...)       after the second barrier of step t               (issue the loads of step t+1)
+//   advance()                    end of step t: the latents of step t+1 become cur0/cur1
+struct PaDirect {
+  const double* pa;
+  int T;
+  double cur0, cur1, nxt0, nxt1;
+  __device__ __forceinline__ void load(int t, int64_t kc, double* a0, double* a1) const {
+    const double* p = pa + (kc * T + t) * 2;
+    *a0 = p[0];
+    *a1 = p[1];
+  }
+  __device__ __forceinline__ void begin(int t0, int, int, int64_t kc) { load(t0, kc, &cur0, &cur1); }
+  __device__ __forceinline__ void after_barrier1(int, int, int, int) {}
+  __device__ __forceinline__ void after_barrier2(int t, int t_end, int64_t kc) {
+    if (t + 1 < t_end) load(t + 1, kc, &nxt0, &nxt1);
+  }
+  __device__ __forceinline__ void advance() {
+    cur0 = nxt0;
+    cur1 = nxt1;
+  }
+};
+
+template <int HT, int NT3, class PA>
+__device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t tile, PA& src, double* __restrict__ H1,
+                                                   double* __restrict__ H2, double* __restrict__ AX) {
+  constexpr int KS = HT * 4;           // k-steps over the hidden dimension
+  constexpr int TW = HT / 4;           // layer-1/2 output tiles per wave
+  constexpr int NTW = (NT3 + 3) / 4;   // layer-3 output tiles per wave (tile j = wave + 4 i)
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = tile * 16 + c;
+  const bool valid = k < a.K;
+  const int64_t kc = valid ? k : a.K - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
+  const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
+  const int ep = (int)(kc / a.Kep);  // episode of this lane's sample (0 for the single planner)
+  const int uoff = ep * a.T * a.nu;
+  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * d : a.xcarry + kc * d;
+  if (i0 < d) {
+    x0 = st[i0];
+    m0 = n.state_mean[i0];
+    s0 = n.state_std[i0];
+  }
+  if (i1 < d) {
+    x1 = st[i1];
+    m1 = n.state_mean[i1];
+    s1 = n.state_std[i1];
+  }
+  const double Tt = n.scale * a.tn;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double factor = exp(gamma * a.tn) / Tt;
+  // this wave's layer-3 tiles (clamped: a wave with fewer tiles recomputes the last one and drops it)
+  int j3[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) j3[i] = (wv + 4 * i < NT3) ? wv + 4 * i : NT3 - 1;
+
+  double cost = 0.0, pcost = 0.0;
+  if (!first_chunk) {
+    cost = a.ccarry[kc * 2];
+    pcost = a.ccarry[kc * 2 + 1];
+  }
+  src.begin(a.t_begin, wv, lane, kc);
+  for (int t = a.t_begin; t < a.t_end; ++t) {
+    const double pa0 = src.cur0, pa1 = src.cur1;
+    const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa0 : (i0 == d + 1 ? pa1 : 0.0));
+    const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa0 : (i1 == d + 1 ? pa1 : 0.0));
+    // ---- layer 1: output tiles TW*wv .. TW*wv+TW-1
+    {
+      v4d acc[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b1, TW * wv + i, q);
+      gptr p = opaque(n.W1p + (size_t)TW * wv * 64);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const double b = ks == 0 ? p0 : p1;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = mfma(p[(ks * HT + i) * 64 + lane], b, acc[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          double ta, tb;
+          m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+          H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+          H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+        }
+    }
+    __syncthreads();
+    src.after_barrier1(t, a.t_end, wv, lane);
+    // ---- layer 2
+    {
+      v4d acc[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b2, TW * wv + i, q);
+      gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
+      double a_cur[TW], a_nxt[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
+      double b_cur = H1[lane], b_nxt = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          p = opaque(p + HT * 64);
+#pragma unroll
+          for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
+          b_nxt = H1[(ks + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
+#pragma unroll
+        for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
+        b_cur = b_nxt;
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          double ta, tb;
+          m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+          H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+          H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+        }
+    }
+    __syncthreads();
+    src.after_barrier2(t, a.t_end, kc);
+    // ---- layer 3 (own tiles) + sphere->complex + partial ILT sum
+    v4d ax = splat(0.0);
+    {
+      v4d o[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile(n.b3p, j3[i], q);
+      gptr p = opaque(n.W3p);
+      double a_cur[NTW], a_nxt[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
+      double b_cur = H2[lane], b_nxt = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          p = opaque(p + NT3 * 64);
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
+          b_nxt = H2[(ks + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
+        b_cur = b_nxt;
+      }
+      gptr cp = opaque(n.Cp);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        if (wv + 4 * i < NT3) {  // wave-uniform
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int g = 2 * j3[i] + r;
+            const double theta = m::tanh_d(o[i][r]) * kPi;
+            const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
+            ax = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax);
+          }
+        }
+      }
+    }
+    AX[(wv * 2 + 0) * 64 + lane] = ax[0];
+    AX[(wv * 2 + 1) * 64 + lane] = ax[1];
+    __syncthreads();
+    // every wave forms the same full sums (fixed order) and keeps its own copy of the state
+    const double ax0 = ((AX[0 * 64 + lane] + AX[2 * 64 + lane]) + AX[4 * 64 + lane]) + AX[6 * 64 + lane];
+    const double ax1 = ((AX[1 * 64 + lane] + AX[3 * 64 + lane]) + AX[5 * 64 + lane]) + AX[7 * 64 + lane];
+    if (i0 < d) x0 = x0 + factor * ax0;
+    if (i1 < d) x1 = x1 + factor * ax1;
+    if (wv == 0) {
+      if (valid && a.states != nullptr) {
+        double* so = a.states + (k * a.T + t) * d;
+        if (i0 < d) so[i0] = x0;
+        if (i1 < d) so[i1] = x1;
+      }
+      double xs[NLC_MAX_D];
+#pragma unroll
+      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+      double u[NLC_MAX_NU] = {0.0, 0.0};
+      double pc = 0.0;
+      for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(kc * a.T + t) * a.nu + j];
+      for (int j = 0; j < a.nu; ++j) {
+        double acj = 0.0;
+        for (int i = 0; i < a.nu; ++i) {
+          double e = a.noise[(kc * a.T + t) * a.nu + i];
+          if (a.noise_abs_cost) e = fabs(e);
+          acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+        }
+        pc += a.U[uoff + t * a.nu + j] * acj;
+      }
+      cost += running_cost(a.env, xs, u, a.nu);
+      pcost += pc;
+    }
+    src.advance();
+  }
+  if (wv == 0 && valid) {
+    if (last_chunk) {
+      if (q == 0) a.cost_total[k] = cost + pcost;
+    } else {
+      if (i0 < d) a.xcarry[k * d + i0] = x0;
+      if (i1 < d) a.xcarry[k * d + i1] = x1;
+      if (q == 0) {
+        a.ccarry[k * 2] = cost;
+        a.ccarry[k * 2 + 1] = pcost;
+      }
+    }
+  }
+}
+
+}  // namespace nlc

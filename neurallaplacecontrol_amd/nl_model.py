@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from ._weights import WeightsKeyMixin
 from .laplace import compute_device, laplace_reconstruct
 
 
@@ -97,7 +98,7 @@ def _cme_terms(s_recon_terms):
     raise NotImplementedError("ilt_algorithm='cme' is not implemented on the HIP path (fourier, dehoog only)")
 
 
-class NeuralLaplaceModel(nn.Module):
+class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
     _dyn_id = _lib.DYN_NL  # rollout the fused planner selects for NLDynamics(model, dt)
 
     def __init__(
@@ -146,7 +147,6 @@ class NeuralLaplaceModel(nn.Module):
         self.register_buffer("action_std", torch.tensor(action_std))
         self.register_buffer("dt", torch.tensor(dt))
         self._ctx = None
-        self._key_ts = None
         self._uploaded_key = None
         self._rep_dev = None  # (key, device copy of laplace_rep_func) for the staged path
 
@@ -176,27 +176,8 @@ class NeuralLaplaceModel(nn.Module):
         return m
 
     # ------------------------------------------------------------------ HIP plumbing
-    def _weights_key(self):
-        """Changes whenever a parameter / buffer is written in place (``_version``), replaced or moved (``data_ptr``;
-        a dtype or device change always re-allocates).  Planners evaluate this once per command, so the tensor list
-        is cached; ``_apply`` (.to/.double/.cuda) and ``load_state_dict`` drop the cache."""
-        ts = self._key_ts
-        if ts is None:
-            ts = self._key_ts = [p for p in self.parameters()] + [b for b in self.buffers()]
-        return tuple([(t.data_ptr(), t._version) for t in ts]) + (
-            self.normalize,
-            self.normalize_time,
-            self.ilt_algorithm,
-            repr(self.ilt_options) if self.ilt_options is not None else None,
-        )
-
-    def _apply(self, fn, *args, **kwargs):
-        self._key_ts = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._key_ts = None
-        return super().load_state_dict(*args, **kwargs)
+    def _weights_key_extra(self):
+        return (self.normalize, self.normalize_time, self.ilt_algorithm, repr(self.ilt_options) if self.ilt_options is not None else None)
 
     def model_desc(self):
         d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)
@@ -270,6 +251,22 @@ class NeuralLaplaceModel(nn.Module):
             ctx.use_torch_stream()
             ctx.check(ctx.lib.nlc_gru_encode(ctx.h, _lib.ptr(win), N, B, _lib.ptr(out)))
         return out
+
+    def rep_func_hip(self, i):
+        """``self.laplace_rep_func(i)`` on the MFMA kernel (``nlc_rep_func``): rows ``[theta_s | phi_s | p]`` of length
+        2S + d + 2 -> ``(theta, phi)`` of shape (N, d, S) each, as ``LaplaceRepresentationFunc.forward`` (w_nl.py:55-63)."""
+        self._no_grad_only()
+        dev = compute_device(i, next(self.parameters()))
+        ctx = self.hip_ctx(dev)
+        S, d = self.s_recon_terms, self.output_dim
+        rows = i.detach().to(dev, torch.float64).reshape(-1, 2 * S + d + 2).contiguous()
+        N = rows.shape[0]
+        theta = torch.empty((N, d, S), dtype=torch.float64, device=dev)
+        phi = torch.empty((N, d, S), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            ctx.use_torch_stream()
+            ctx.check(ctx.lib.nlc_rep_func(ctx.h, _lib.ptr(rows), N, _lib.ptr(theta), _lib.ptr(phi)))
+        return theta, phi
 
     def _forward_train(self, in_batch_obs, in_batch_action, ts_pred):
         """Grad-mode forward (the reference trains through ``model(...)``, ``train_utils.py:388-407``): the op sequence of

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from ._weights import WeightsKeyMixin
 from .laplace import compute_device
 
 _BLOB_KEYS = [f"x_ode_func_in_x_and_u.linear_tanh_stack.{i}.{p}" for i in (0, 2, 4) for p in ("weight", "bias")]
@@ -45,7 +46,7 @@ class xOdeFuncInXAndU(nn.Module):  # noqa: N801  (reference class name, train_ut
         return self.linear_tanh_stack(torch.cat((x, self.u), 1))
 
 
-class NODE(nn.Module):
+class NODE(WeightsKeyMixin, nn.Module):
     _dyn_id = _lib.DYN_NODE  # rollout the fused planner selects for NLDynamics(model, dt)
     step_size = 0.05  # options={"step_size": 0.05} (train_utils.py:722)
 
@@ -88,7 +89,6 @@ class NODE(nn.Module):
         self.register_buffer("action_std", torch.tensor(action_std))
         self.register_buffer("dt", torch.tensor(dt))
         self._ctx = None
-        self._key_ts = None
         self._uploaded_key = None
 
     @classmethod
@@ -109,19 +109,8 @@ class NODE(nn.Module):
         return m
 
     # ------------------------------------------------------------------ HIP plumbing
-    def _weights_key(self):
-        ts = self._key_ts
-        if ts is None:
-            ts = self._key_ts = [p for p in self.parameters()] + [b for b in self.buffers()]
-        return tuple([(t.data_ptr(), t._version) for t in ts]) + (self.normalize, self.normalize_time, self.step_size)
-
-    def _apply(self, fn, *args, **kwargs):
-        self._key_ts = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._key_ts = None
-        return super().load_state_dict(*args, **kwargs)
+    def _weights_key_extra(self):
+        return (self.normalize, self.normalize_time, self.step_size)
 
     def model_desc(self):
         d = self.state_dim

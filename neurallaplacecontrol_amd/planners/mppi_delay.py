@@ -23,6 +23,7 @@ command), ``compute_device``, ``store_rollouts``.
 """
 
 import ctypes as C
+import os
 
 import torch
 from torch.distributions.multivariate_normal import MultivariateNormal
@@ -74,6 +75,7 @@ class MPPIDelay:
         process_group=None,
         compute_device=None,
         store_rollouts=True,
+        planner_options=None,
     ):
         self.d = torch.device(device)
         self.dtype = noise_sigma.dtype
@@ -181,6 +183,13 @@ class MPPIDelay:
         # every planner owns its ctx: U and the folded layer-1 bias live there, so two planners over one model
         # must not share one (the model's own ctx serves model.forward only)
         self.ctx = _lib.Ctx(self.cd.index)
+        # tuning knobs of include/nlc.h (nlc_set_option); the NLC_* environment variables are read ONCE, here
+        opts = {"rollout_variant": os.environ.get("NLC_ROLLOUT_VARIANT"), "fused_roll_cap": os.environ.get("NLC_FUSED_ROLL_CAP"),
+                "fused_max_samples": os.environ.get("NLC_FUSED_MAX_SAMPLES")}
+        opts.update(planner_options or {})
+        for name, value in opts.items():
+            if value is not None:
+                self.ctx.set_option(name, float(value))
         self._model_key = None
         self._B = None
         self._buf = None

@@ -18,13 +18,14 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from ._weights import WeightsKeyMixin
 from .laplace import compute_device
 
 _BLOB_KEYS = ["gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0", "linear_out.weight",
               "linear_out.bias"]
 
 
-class DeltaTRNN(nn.Module):
+class DeltaTRNN(WeightsKeyMixin, nn.Module):
     _dyn_id = _lib.DYN_DTRNN  # rollout the fused planner selects for NLDynamics(model, dt)
 
     def __init__(
@@ -56,7 +57,6 @@ class DeltaTRNN(nn.Module):
         self.register_buffer("action_std", torch.tensor(action_std))
         self.register_buffer("dt", torch.tensor(dt))
         self._ctx = None
-        self._key_ts = None
         self._uploaded_key = None
 
     @classmethod
@@ -77,19 +77,8 @@ class DeltaTRNN(nn.Module):
         return m
 
     # ------------------------------------------------------------------ HIP plumbing
-    def _weights_key(self):
-        ts = self._key_ts
-        if ts is None:
-            ts = self._key_ts = [p for p in self.parameters()] + [b for b in self.buffers()]
-        return tuple([(t.data_ptr(), t._version) for t in ts]) + (self.normalize, self.normalize_time)
-
-    def _apply(self, fn, *args, **kwargs):
-        self._key_ts = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._key_ts = None
-        return super().load_state_dict(*args, **kwargs)
+    def _weights_key_extra(self):
+        return (self.normalize, self.normalize_time)
 
     def model_desc(self):
         """Resolve the reference's branch structure (train_utils.py:618-626): the raw-input ``else`` belongs to
@@ -209,7 +198,6 @@ class RNN(DeltaTRNN):
         self.register_buffer("action_mean", torch.tensor(action_mean))
         self.register_buffer("action_std", torch.tensor(action_std))
         self._ctx = None
-        self._key_ts = None
         self._uploaded_key = None
 
     @classmethod

@@ -266,6 +266,26 @@ def test_gru_encoder_vs_reference_golden(nlc, env):
 
 
 @pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_repfunc_kernel_vs_reference_golden(nlc, env):
+    """G2, row a8 pinned directly on the GPU: the MFMA representation-function kernel (``nl_repfunc_kernel`` behind
+    ``nlc_rep_func``) on the fixture's random input rows vs the outputs of the REAL reference module
+    ``LaplaceRepresentationFunc.forward`` (w_nl.py:55-63): theta = pi tanh(.), phi = (pi/2) tanh(.) per (dim, term)."""
+    g = np.load(f"{GOLD}/g2_stages_{env}.npz")
+    model = build_model(nlc, load_sd(g))
+    rep_in = T64(g["rep_in"])
+    with torch.no_grad():
+        theta, phi = model.rep_func_hip(rep_in.cuda())
+    assert theta.shape == g["rep_theta"].shape and phi.shape == g["rep_phi"].shape
+    np.testing.assert_allclose(theta.cpu().numpy(), g["rep_theta"], **TOL)
+    np.testing.assert_allclose(phi.cpu().numpy(), g["rep_phi"], **TOL)
+    # ragged N (not a multiple of the 16-row MFMA tile) and a single row
+    with torch.no_grad():
+        th1, ph1 = model.rep_func_hip(rep_in[:1].cuda())
+    np.testing.assert_allclose(th1.cpu().numpy(), g["rep_theta"][:1], **TOL)
+    np.testing.assert_allclose(ph1.cpu().numpy(), g["rep_phi"][:1], **TOL)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
 def test_model_forward_vs_golden(nlc, env):
     """G3: fused HIP NeuralLaplaceModel.forward vs the reference model (ILT body = build's restatement)."""
     g = np.load(f"{GOLD}/g3_nl_{env}.npz")
@@ -606,7 +626,9 @@ def test_full_size_cfg2_properties(nlc):
 
 @pytest.mark.parametrize("env,K,T", [("oderl-cartpole", 1024, 20), ("oderl-acrobot", 4096, 12), ("oderl-pendulum", 16400, 6)])
 def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
-    """Wave-per-tile and latency-split (4 waves per 16-sample tile, LDS exchange) rollout kernels: same numbers."""
+    """Wave-per-tile (1), latency-split (2: 4 waves per 16-sample tile, LDS exchange) and fused one-launch (3: GRU encode
+    and split rollout as roles of one persistent grid, latents handed over inside the launch) rollout bodies: same
+    numbers; 2 and 3 share every arithmetic instruction, so they must agree bit for bit."""
     from oracle import nl_model as onl
 
     st = onl.ENV_STATS[env]
@@ -618,7 +640,7 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
     U0 = torch.randn(T, nu, dtype=torch.float64) * 0.2
     state, ab = nlc.initial_state(env), torch.randn(4, nu, dtype=torch.float64)
     out = {}
-    for variant in ("1", "2"):
+    for variant in ("1", "2", "3"):
         monkeypatch.setenv("NLC_ROLLOUT_VARIANT", variant)
         mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
                              lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
@@ -627,6 +649,42 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
         out[variant] = (act.clone(), mppi.states.clone(), mppi.cost_total.clone())
     for a, b in zip(out["1"], out["2"]):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-11, atol=1e-11)
+    for a, b in zip(out["2"], out["3"]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("K,cap", [(2048, 0), (2048, 40), (1000, 0), (4096, 0)])
+def test_fused_plan_handoff_repeated_commands(nlc, K, cap):
+    """The fused body hands every 16-sample tile's GRU latents from an encoder wavefront to a rollout workgroup INSIDE
+    the launch (write-through stores + flag, sc1 loads behind a barrier).  A stale or early read would show up as a
+    difference to the two-launch path: 25 consecutive commands (the latent buffer is rewritten in place every command,
+    so a stale line of the previous command is a wrong value), all states / costs / actions bit-identical.  cap = 40
+    starts only 40 rollout workgroups right away: the other tiles drain after the encoders, beside busy CUs."""
+    from oracle import nl_model as onl
+
+    env, T = "oderl-cartpole", 40
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    planners = {}
+    for variant in (2, 3):
+        opts = {"rollout_variant": variant}
+        if variant == 3 and cap:
+            opts["fused_roll_cap"] = cap
+        planners[variant] = nlc.MPPIDelay(
+            nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+            u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=3, planner_options=opts,
+        )
+    planners[3].U = planners[2].U
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    for step in range(25):
+        acts = {v: p.command(state, ab) for v, p in planners.items()}
+        assert torch.equal(acts[2], acts[3]), step
+        assert torch.equal(planners[2].states, planners[3].states), step
+        assert torch.equal(planners[2].cost_total, planners[3].cost_total), step
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = acts[2].cpu()
 
 
 def _subset_check(nlc, env, K, T, B, n_check=64, seed=0):
@@ -751,36 +809,6 @@ def test_collector_variant_encode_obs_time_with_oracle_dynamics(nlc):
         m.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
         acts.append(m.command(st, buf))
     assert torch.equal(acts[0], acts[1])
-
-
-def test_horizon_chunked_two_stream_rollout_agrees(nlc, monkeypatch):
-    """NLC_HORIZON_CHUNKS (GRU encode on the side stream overlapping the rollout, state carried between launches)
-    gives the same numbers as the single-launch path."""
-    from oracle import nl_model as onl
-
-    env, K, T = "oderl-acrobot", 1040, 13  # ragged K, T not divisible by the chunk count
-    st = onl.ENV_STATS[env]
-    d, nu, A = st["d"], st["nu"], st["act_high"]
-    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
-    model = build_model(nlc, sd)
-    torch.manual_seed(8)
-    raw = torch.randn(K, T, nu, dtype=torch.float64)
-    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.2
-    state, ab = nlc.initial_state(env), torch.randn(4, nu, dtype=torch.float64)
-    out = {}
-    for chunks in ("1", "4"):
-        monkeypatch.setenv("NLC_HORIZON_CHUNKS", chunks)
-        for variant in ("1", "2"):
-            monkeypatch.setenv("NLC_ROLLOUT_VARIANT", variant)
-            mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
-                                 lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
-            mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
-            act = mppi.command(state, ab)
-            out[(chunks, variant)] = (act.clone(), mppi.states.clone(), mppi.cost_total.clone())
-    ref = out[("1", "1")]
-    for key, val in out.items():
-        for a, b in zip(ref, val):
-            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-11, atol=1e-11, err_msg=str(key))
 
 
 def test_dehoog_model_forward_multi_time_uses_torch_repfunc(nlc):

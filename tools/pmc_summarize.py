@@ -1,6 +1,9 @@
 """Reduce rocprofv3 --pmc counter_collection.csv files to per-kernel means (JSON on stdout).
 
-    python tools/pmc_summarize.py gpurun_out/pmc_h_FETCH_SIZE gpurun_out/pmc_h_WRITE_SIZE gpurun_out/pmc_h_mfma
+    python tools/pmc_summarize.py [--commit HASH] [--device NAME] gpurun_out/pmc_h_FETCH_SIZE gpurun_out/pmc_h_WRITE_SIZE ...
+
+The "_meta" entry records where the numbers come from (commit, device, date) and, per key, the rocprof kernel names that
+were folded into it: bench.py refuses a summary whose kernel names are not the library's (a stale file).
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB; on gfx950 FETCH_SIZE counts 32 B per 64 B request and is
 doubled here (calibrated with tools/pmc_calib.hip, profiles/r1_pmc_calib_*.csv; MI355X_MICROARCH.md, HBM section).
@@ -11,8 +14,8 @@ import glob
 import json
 import sys
 
-KEYS = ("gru_encode", "nl_rollout", "ilt_fourier_bwd", "ilt_fourier", "ilt_dehoog", "perturb", "weight_partial",
-        "oracle_rollout", "rnn_encode", "rnn_rollout", "merge")
+KEYS = ("gru_encode", "nl_plan_fused", "nl_rollout", "nl_repfunc", "ilt_fourier_bwd", "ilt_fourier", "ilt_dehoog", "perturb",
+        "weight_partial", "oracle_rollout", "rnn_encode", "rnn_rollout", "merge", "step_tail")
 
 
 def short(name):
@@ -23,13 +26,21 @@ def short(name):
 
 
 def main():
+    import datetime
+
+    argv, meta = sys.argv[1:], {"date": datetime.date.today().isoformat()}
+    while argv and argv[0].startswith("--"):
+        meta[argv[0][2:]] = argv[1]
+        argv = argv[2:]
+    names = collections.defaultdict(set)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in sys.argv[1:]:
+    for d in argv:
         for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
             per_dispatch = collections.defaultdict(lambda: collections.defaultdict(float))
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if k:
+                    names[k].add(r["Kernel_Name"].split("(")[0][:120])
                     per_dispatch[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
             for (k, _), cs in per_dispatch.items():
                 for c, v in cs.items():
@@ -47,6 +58,8 @@ def main():
             if o.get("SQ_INSTS_VALU_MFMA_F64"):
                 o["cycles_per_mfma"] = o["SQ_VALU_MFMA_BUSY_CYCLES"] / o["SQ_INSTS_VALU_MFMA_F64"]
         out[k] = o
+    meta["kernel_names"] = {k: sorted(v) for k, v in names.items()}
+    out["_meta"] = meta
     json.dump(out, sys.stdout, indent=1)
     print()
 
