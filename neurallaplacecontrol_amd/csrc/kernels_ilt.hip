@@ -479,21 +479,35 @@ __device__ __forceinline__ cplx csqrt_(cplx z) {
 // showed the real cause -- the compiler had deferred the B recurrence to the end of the kernel and spilled every
 // d_n z to scratch, 1 GB of HBM writes and 3.5x the algorithmic traffic per launch (profiles/r1g_pmc_dehoog.json
 // vs r1h_pmc_kernels.json); the per-diagonal fence below now pins both recurrences.
-template <int M, int CH, int W, bool FDIRECT>
+// FMODE 0: (theta, phi) rows, sphere -> complex conversion here; 1: F (re, im) rows (N, d, S); both staged through LDS.
+// FMODE 2 (planner path): F is SLOT-major (8*nt3, N) as the representation kernel's MFMA epilogue stores it; a wavefront
+// owns 64 consecutive samples of ONE dim, so term k of its rows is one full 512-B line -- no LDS, no barrier, and the
+// kernel reads exactly the bytes it needs (row-major rows of 33 doubles straddle the 17-term chunks: 1.8x the traffic).
+template <int M, int CH, int W, int FMODE>
 __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
   constexpr int S = 2 * M + 1;
   constexpr int CP = CH | 1;
   constexpr int ROWS = 64;
-  __shared__ double fr[ROWS * CP];
-  __shared__ double fi[ROWS * CP];
+  constexpr bool FDIRECT = FMODE == 1;
+  constexpr bool SLOT = FMODE == 2;
+  __shared__ double fr[SLOT ? 1 : ROWS * CP];
+  __shared__ double fi[SLOT ? 1 : ROWS * CP];
   const int lane = threadIdx.x;
   const int64_t rows_total = a.N * a.d;
-  const int64_t nblk = (rows_total + ROWS - 1) / ROWS;
+  const int64_t nsb = (a.N + ROWS - 1) / ROWS;  // SLOT: sample blocks
+  const int64_t nblk = SLOT ? nsb * a.d : (rows_total + ROWS - 1) / ROWS;
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t row0 = blk * ROWS;
-    const int rows_here = (int)((rows_total - row0 < ROWS) ? (rows_total - row0) : ROWS);
+    // SLOT: block = (sample block, dim); otherwise 64 consecutive (point, dim) rows
+    const int cdim = SLOT ? (int)(blk % a.d) : 0;
+    const int64_t n0 = SLOT ? (blk / a.d) * ROWS : 0;
+    const int64_t row0 = SLOT ? 0 : blk * ROWS;
+    const int rows_here = SLOT ? (int)((a.N - n0 < ROWS) ? (a.N - n0) : ROWS)
+                               : (int)((rows_total - row0 < ROWS) ? (rows_total - row0) : ROWS);
     const bool valid = lane < rows_here;
-    const int64_t row = row0 + (valid ? lane : 0);
+    const int64_t nsmp = n0 + (valid ? lane : 0);                     // SLOT: this lane's sample
+    const int64_t row = SLOT ? nsmp * a.d + cdim : row0 + (valid ? lane : 0);
+    const int* ei = SLOT ? a.eidx + cdim * S : nullptr;               // wave-uniform slot of every term
+    cplx abuf[SLOT ? CH : 1];
     const double t = (a.t_stride ? a.t[row / a.d] : a.t[0]) / a.t_div;
     const double Tt = a.scale * t;
     const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
@@ -505,9 +519,18 @@ __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
     // A/B continued-fraction recurrence, fed with d_1, d_2, ... as the diagonals produce them
     cplx A_prev = {0.0, 0.0}, A_cur = {0.0, 0.0}, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
     cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int n = 0; n <= 2 * M; ++n) {
-      if (n % CH == 0) {
+      if (SLOT && n % CH == 0) {
+        // terms [n, n + nt) of this lane's row: one coalesced line per term and array
+        const int nt = (S - n < CH) ? (S - n) : CH;
+#pragma clang loop unroll(full)
+        for (int k = 0; k < CH; ++k)
+          if (k < nt) {
+            const int64_t at = (int64_t)ei[n + k] * a.N + nsmp;
+            abuf[k] = {a.fre[at], a.fim[at]};
+          }
+      } else if (n % CH == 0) {
         // stage terms [n, n + nt) of the block's rows: coalesced over (row, term) pairs
         const int nt = (S - n < CH) ? (S - n) : CH;
         if (n != 0) __syncthreads();
@@ -532,7 +555,12 @@ __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
         }
         __syncthreads();
       }
-      const cplx an = {fr[lane * CP + n % CH], fi[lane * CP + n % CH]};
+      cplx an;
+      if constexpr (SLOT) {
+        an = abuf[n % CH];
+      } else {
+        an = {fr[lane * CP + n % CH], fi[lane * CP + n % CH]};
+      }
       if (n == 0) {
         d0 = {0.5 * an.re, 0.5 * an.im};  // a_0 enters halved
         a_prev = d0;
@@ -584,21 +612,25 @@ __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
     const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
     const cplx res = cdiv(An, Bn);
     if (valid) a.x[row] = exp(gamma * t) / Tt * res.re;
-    __syncthreads();
+    if (!SLOT) __syncthreads();
   }
 }
 
 hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s) {
   const int64_t rows_total = a.N * a.d;
   if (rows_total <= 0) return hipSuccess;
-  const int64_t nblk = (rows_total + 63) / 64;
+  const bool slot = a.eidx != nullptr;
+  if (slot && a.fre == nullptr) return hipErrorInvalidValue;
+  const int64_t nblk = slot ? (a.N + 63) / 64 * a.d : (rows_total + 63) / 64;
   const unsigned grid = (unsigned)(nblk < 16384 ? nblk : 16384);
 #define NLC_DH(...)                                                                                   \
   do {                                                                                                \
-    if (a.fre != nullptr)                                                                             \
-      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, true>), dim3(grid), dim3(64), 0, s, a);      \
+    if (slot)                                                                                         \
+      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, 2>), dim3(grid), dim3(64), 0, s, a);         \
+    else if (a.fre != nullptr)                                                                        \
+      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, 1>), dim3(grid), dim3(64), 0, s, a);         \
     else                                                                                              \
-      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, false>), dim3(grid), dim3(64), 0, s, a);     \
+      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, 0>), dim3(grid), dim3(64), 0, s, a);         \
   } while (0)
   switch (a.S) {
     case 33:

@@ -163,11 +163,50 @@ __global__ __launch_bounds__(256) void nl_repfunc_kernel(const RepFuncArgs a) {
   const int i0 = q, i1 = 4 + q;
   const double* ob = a.obs + (a.obs_per_sample ? kc : kc / a.Kep) * a.obs_stride;
   const double* pa = a.pa + kc * a.pa_stride;
-  const double p0 = (i0 < d) ? (ob[i0] - n.state_mean[i0]) / n.state_std[i0]
+  double x0 = (i0 < d) ? ob[i0] : 0.0, x1 = (i1 < d) ? ob[i1] : 0.0;
+  if constexpr (!GENERAL_T) {
+    if (a.tail_prev) {
+      // tail of the previous horizon step (step_tail_kernel's arithmetic, in the MFMA lane layout: lane group q owns
+      // state dims q and 4+q of sample c): x <- x + dx (mppi_with_model.py:120-121), store, running cost
+      const StepTailArgs& s = a.tail;
+      const int64_t e = kc / s.Kep;
+      const double* src = s.first ? s.state0 + (s.state_per_sample ? kc : e) * d : s.x + kc * d;
+      if (i0 < d) x0 = src[i0] + s.dx[kc * d + i0];
+      if (i1 < d) x1 = src[i1] + s.dx[kc * d + i1];
+      double xs[NLC_MAX_D];
+#pragma unroll
+      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+      if (valid) {
+        if (i0 < d) s.x[k * d + i0] = x0;
+        if (i1 < d) s.x[k * d + i1] = x1;
+        if (s.states != nullptr) {
+          if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
+          if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
+        }
+      }
+      if (q == 0 && valid) {
+        double u[NLC_MAX_NU] = {0.0, 0.0};
+        for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
+        double pc = 0.0;
+        for (int j = 0; j < s.nu; ++j) {
+          double acj = 0.0;
+          for (int ii = 0; ii < s.nu; ++ii) {
+            double ev = s.noise[(k * s.T + s.t) * s.nu + ii];
+            if (s.noise_abs_cost) ev = fabs(ev);
+            acj += (s.lambda_ * ev) * s.sigma_inv[ii * s.nu + j];
+          }
+          pc += s.U[(e * s.T + s.t) * s.nu + j] * acj;
+        }
+        s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
+        s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
+      }
+    }
+  }
+  const double p0 = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0]
                              : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
-  const double p1 = (i1 < d) ? (ob[i1] - n.state_mean[i1]) / n.state_std[i1]
+  const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
                              : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
-  const FOut fo{a.fre, a.fim, a.slot, valid ? k : -1, d * n.S, a.write_angles};
+  const FOut fo{a.fre, a.fim, a.slot, valid ? k : -1, d * n.S, a.write_angles, a.slot_major ? a.N : (int64_t)0};
   if constexpr (GENERAL_T) {
     const double* sph_row = a.sph != nullptr ? a.sph + kc * a.sph_stride : nullptr;
     const double tn = a.sph != nullptr ? 1.0 : a.ts[kc] / n.time_div;

@@ -61,6 +61,7 @@ struct nlc_ctx {
   NlNetArgs net{}; // general-t variant (b1 = raw bias)
   std::vector<double> W1s_host, b1_host;  // for folding the constant sphere inputs at configure time
   int* slot_dev = nullptr;                // (8*nt3) layer-3 slot -> c*S + k (de Hoog path)
+  int* eidx_dev = nullptr;                // (d*S) inverse: term k of dim c -> slot (slot-major F of the planner path)
 
   // Delta-t RNN baseline model
   bool has_rnn = false;
@@ -273,6 +274,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   if (c->rnn_base) hipFree(c->rnn_base);
   if (c->node_base) hipFree(c->node_base);
   if (c->slot_dev) hipFree(c->slot_dev);
+  if (c->eidx_dev) hipFree(c->eidx_dev);
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
   if (c->b1fold) hipFree(c->b1fold);
@@ -486,6 +488,13 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
     c->slot_dev = nullptr;
     NLC_HIP(c, hipMalloc((void**)&c->slot_dev, slot.size() * sizeof(int)));
     NLC_HIP(c, hipMemcpy(c->slot_dev, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> eidx((size_t)dd * S, 0);
+    for (size_t i = 0; i < slot.size(); ++i)
+      if (slot[i] >= 0) eidx[slot[i]] = (int)i;
+    if (c->eidx_dev) hipFree(c->eidx_dev);
+    c->eidx_dev = nullptr;
+    NLC_HIP(c, hipMalloc((void**)&c->eidx_dev, eidx.size() * sizeof(int)));
+    NLC_HIP(c, hipMemcpy(c->eidx_dev, eidx.data(), eidx.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   NLC_HIP(c, hipStreamSynchronize(c->stream));
   if (c->arena.base) hipFree(c->arena.base);
@@ -1055,8 +1064,8 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.xcarry = take(d.dynamics == NLC_DYN_NL ? KE * d.d : 0);
   w.ccarry = take(d.dynamics == NLC_DYN_NL ? KE * 2 : 0);
   const bool dh = d.dynamics == NLC_DYN_NL && c->md.ilt.algo == NLC_ILT_DEHOOG;
-  w.fre = take(dh ? KE * d.d * c->S : 0);
-  w.fim = take(dh ? KE * d.d * c->S : 0);
+  w.fre = take(dh ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
+  w.fim = take(dh ? KE * 8 * (size_t)c->net.nt3 : 0);
   w.dx = take(dh ? KE * d.d : 0);
   w.tconst = take(dh ? 8 : 0);
   w.rq = take(d.dynamics == NLC_DYN_DTRNN ? KE * d.T * d.d : 0);  // hidden part of linear_out, (T, K, d)
@@ -1293,8 +1302,11 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       rf.slot = c->slot_dev;
       rf.fre = ws + w.fre;
       rf.fim = ws + w.fim;
+      // F travels slot-major between the two kernels of a step: four 128-B runs per store instruction of the MFMA
+      // epilogue, one full line per de Hoog load (kernels_ilt.hip, FMODE 2)
+      rf.slot_major = 1;
       IltArgs ia{nullptr, nullptr, tconst, ws + w.dx, KE, d.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol),
-                 c->md.ilt.scale, rf.fre, rf.fim, 1.0, 0, 0, 0, 0};
+                 c->md.ilt.scale, rf.fre, rf.fim, 1.0, 0, 0, 0, 0, c->eidx_dev};
       StepTailArgs st{};
       st.K = KE;
       st.Kep = d.K;
@@ -1316,21 +1328,30 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       st.noise_abs_cost = d.noise_abs_cost;
       st.states = buf->states;
       st.cost_total = buf->cost_total;
+      // two launches per horizon step: [tail of step t-1 +] representation function -> F, then de Hoog -> dx; the tail
+      // of the LAST step is a launch of its own
       for (int t = 0; t < d.T; ++t) {
-        rf.obs = (t == 0) ? state_dev : r.xcarry;
+        rf.obs = state_dev;
         rf.obs_per_sample = (t == 0) ? state_per_sample : 1;
         rf.pa = pa + (size_t)t * 2;
+        rf.tail_prev = t > 0;
+        if (t > 0) {
+          rf.tail = st;
+          rf.tail.t = t - 1;
+          rf.tail.first = t - 1 == 0;
+          rf.tail.last = 0;
+        }
         {
           ProfScope ps(c, "nl_repfunc_kernel");
           NLC_HIP(c, launch_nl_repfunc(rf, c->stream));
         }
-        {
-          ProfScope ps(c, "ilt_dehoog_kernel");
-          NLC_HIP(c, launch_ilt_dehoog(ia, c->stream));
-        }
-        st.t = t;
-        st.first = t == 0;
-        st.last = t == d.T - 1;
+        ProfScope ps(c, "ilt_dehoog_kernel");
+        NLC_HIP(c, launch_ilt_dehoog(ia, c->stream));
+      }
+      st.t = d.T - 1;
+      st.first = d.T == 1;
+      st.last = 1;
+      {
         ProfScope ps(c, "step_tail_kernel");
         NLC_HIP(c, launch_step_tail(st, c->stream));
       }

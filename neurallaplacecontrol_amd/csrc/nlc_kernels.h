@@ -24,6 +24,10 @@ struct IltArgs {
   int t_stride;  // de Hoog: 1 = one t per point, 0 = t[0] for all points
   int rpp, iters;  // rows per pass / passes per block tile (set by the launcher)
   int dbg;         // 0 normal; timing experiments only: 1 memory-only, 2 arithmetic-only
+  // de Hoog, planner path: when non-NULL, (fre, fim) are SLOT-major (8*nt3, N) arrays -- element e of every sample
+  // contiguous, as the representation kernel's MFMA epilogue stores them -- and eidx[c*S + k] names the slot of term k
+  // of dim c; one wavefront then owns 64 consecutive samples of ONE dim and every load is a full 512-B line
+  const int* eidx;
 };
 hipError_t launch_ilt_fourier(const IltArgs& a, hipStream_t s);
 // backward of the Fourier ILT with respect to theta / phi (training through laplace_reconstruct)
@@ -223,6 +227,26 @@ struct ForwardArgs {
 };
 hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s);
 
+// x <- x + dx, running cost, state store: the per-step tail of the staged (de Hoog) planner path
+struct StepTailArgs {
+  int64_t K, Kep;
+  int T, t, nu, d, env, first, last;
+  int state_per_sample;
+  const double* state0;  // read when first
+  double* x;             // (K, d) carried state
+  const double* dx;      // (K, d)
+  double* ccarry;        // (K, 2) running cost / perturbation cost
+  const double* perturbed;
+  const double* noise;
+  const double* U;
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale;
+  int noise_abs_cost;
+  double* states;      // (K, T, d) or NULL
+  double* cost_total;  // (K), written when last
+};
+hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s);
+
 // representation function only: F_k (re, im) of every Laplace term -> (N, d, S) arrays (de Hoog path)
 struct RepFuncArgs {
   NlNetArgs net;
@@ -244,28 +268,14 @@ struct RepFuncArgs {
   const double* sph;
   int64_t sph_stride;
   int write_angles;
+  int slot_major;     // 1: fre / fim are (8*nt3, N) slot-major (planner path; see IltArgs::eidx)
+  // planner path, horizon step t > 0: the tail of step t-1 runs as this launch's prologue -- x <- xcarry + dx, store,
+  // running + perturbation cost into ccarry (StepTailArgs semantics) -- and the new x is the observation
+  int tail_prev;      // 0: no prologue (obs is read as given)
+  StepTailArgs tail;  // tail.t = the PREVIOUS step
 };
 hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s);
 
-// x <- x + dx, running cost, state store: the per-step tail of the staged (de Hoog) planner path
-struct StepTailArgs {
-  int64_t K, Kep;
-  int T, t, nu, d, env, first, last;
-  int state_per_sample;
-  const double* state0;  // read when first
-  double* x;             // (K, d) carried state
-  const double* dx;      // (K, d)
-  double* ccarry;        // (K, 2) running cost / perturbation cost
-  const double* perturbed;
-  const double* noise;
-  const double* U;
-  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
-  double lambda_, u_scale;
-  int noise_abs_cost;
-  double* states;      // (K, T, d) or NULL
-  double* cost_total;  // (K), written when last
-};
-hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ oracle-dynamics rollout (§8f-1)
 struct OracleRolloutArgs {

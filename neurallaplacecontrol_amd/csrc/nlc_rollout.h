@@ -33,6 +33,8 @@ struct FOut {
   int64_t row;      // sample row; < 0: do not store
   int dS;
   int angles;       // 1: store (theta, phi) instead of (Re F, Im F)
+  int64_t n_rows;   // > 0: slot-major (8*nt3, n_rows) arrays -- slot 4g+q of sample `row` at (4g+q)*n_rows + row, so one
+                    // store instruction writes four 128-B runs (16 consecutive samples per lane group q)
 };
 // sph_row (GENERAL_T only): when non-NULL, this lane's sample has EXPLICIT sphere inputs [theta_s | phi_s] (2S doubles)
 // -- LaplaceRepresentationFunc.forward on an arbitrary input row (w_nl.py:55-63) -- instead of the ones of s_k(tn).
@@ -127,8 +129,9 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
           double sn, cs;
           m::sincos_bounded(theta, &sn, &cs);
           const double rad = num * m::rcp_refined(den);
-          fo->fre[fo->row * fo->dS + idx] = rad * cs;
-          fo->fim[fo->row * fo->dS + idx] = rad * sn;
+          const int64_t at = fo->n_rows > 0 ? (int64_t)(4 * g + q) * fo->n_rows + fo->row : fo->row * fo->dS + idx;
+          fo->fre[at] = rad * cs;
+          fo->fim[at] = rad * sn;
         }
       } else {
         (void)num;

@@ -49,6 +49,34 @@ def tame_(sd, d, S, shift=PHI_BIAS_SHIFT):
     return sd
 
 
+def tame_dehoog_(sd, d, S, t_norm=0.125, alpha=1e-10, tol=1e-9, scale=2.0, w3_scale=0.02):
+    """"Trained-like" weights for a DE HOOG model.  The quotient-difference table acts on the RATIOS of consecutive
+    Laplace terms, so on the output of a random network (terms unrelated to each other) it hits near-poles: |dx| ~ 1e3
+    and a 1e-10 state perturbation grows to O(100) by T = 40 even with the phi shift of tame_() -- no two float64
+    implementations can agree there.  A trained model's F(s_k) IS (close to) a Laplace transform sampled on the
+    contour, smooth in k.  This puts the last layer there: biases = the sphere coordinates of F_c(s) = a_c / (s + b_c)
+    on the model's own contour s_k = gamma + i pi k / T (planning time t_norm), weights scaled by w3_scale so the
+    state / action dependence is a perturbation of that transform.  x_c(t) = a_c e^{-b_c t}: |dx| ~ 0.02 per step."""
+    import math
+
+    T = scale * t_norm
+    gamma = alpha - math.log(tol) / (scale * T)
+    k = torch.arange(S, dtype=torch.float64)
+    s_k = torch.complex(torch.full((S,), gamma, dtype=torch.float64), math.pi * k / T)
+    W = sd["laplace_rep_func.linear_tanh_stack.4.weight"]
+    b = sd["laplace_rep_func.linear_tanh_stack.4.bias"]
+    W *= w3_scale
+    for c in range(d):
+        a_c, b_c = 0.03 * (c + 1) * (-1.0) ** c, 1.0 + 0.5 * c
+        F = a_c / (s_k + b_c)
+        theta = torch.atan2(F.imag, F.real)
+        r2 = F.real**2 + F.imag**2
+        phi = torch.asin((r2 - 1.0) / (r2 + 1.0))
+        b[c * S : (c + 1) * S] = torch.atanh(torch.clamp(theta / math.pi, -1 + 1e-12, 1 - 1e-12))
+        b[(d + c) * S : (d + c + 1) * S] = torch.atanh(torch.clamp(phi / (math.pi / 2), -1 + 1e-12, 1 - 1e-12))
+    return sd
+
+
 def make_synthetic_state_dict(
     seed=0, d=5, nu=1, h=128, S=17, state_std=None, action_std=None, dt=0.05, encode_obs_time=False, tame=False
 ):
@@ -85,7 +113,9 @@ def make_synthetic_state_dict(
     # w_nl.py:115 registers torch.tensor(dt) = FLOAT32; model.double() (mppi_with_model.py:101)
     # then widens it, so the time normaliser is float32(0.05) = 0.05000000074505806.
     sd["dt"] = torch.tensor(dt, dtype=torch.float32).to(torch.float64)
-    if tame:
+    if tame == "dehoog":
+        tame_dehoog_(sd, d, S)
+    elif tame:
         tame_(sd, d, S)
     return sd
 

@@ -610,7 +610,7 @@ def test_full_size_cfg2_properties(nlc):
     U_shift = torch.roll(U_before, -1, 0)
     U_shift[-1] = 0
     pc = torch.sum(U_shift * (eps[idx] @ torch.inverse(sig)), dim=(1, 2))
-    np.testing.assert_allclose(mppi.cost_total.cpu()[idx].numpy(), (cost_ref + pc).numpy(), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(mppi.cost_total.cpu()[idx].numpy(), (cost_ref + pc).numpy(), rtol=tol, atol=tol)
     # (2) properties over the whole population
     assert torch.all(V.abs() <= 1.0 + 1e-15)  # bounded to [-A, A]/A
     np.testing.assert_allclose((U_shift + eps).clamp(-1, 1).numpy(), V.numpy(), rtol=0, atol=1e-15)
@@ -687,7 +687,7 @@ def test_fused_plan_handoff_repeated_commands(nlc, K, cap):
         ab[-1] = acts[2].cpu()
 
 
-def _subset_check(nlc, env, K, T, B, n_check=64, seed=0):
+def _subset_check(nlc, env, K, T, B, n_check=64, seed=0, S=17, algo="fourier", tol=1e-7, weights_seed=0, tame=True):
     """Shared body of the full-size configs: command() on the GPU, a strided sample subset through the oracle."""
     from oracle import envs as oenvs
     from oracle import mppi as omppi
@@ -695,8 +695,8 @@ def _subset_check(nlc, env, K, T, B, n_check=64, seed=0):
 
     st = onl.ENV_STATS[env]
     d, nu, A = st["d"], st["nu"], st["act_high"]
-    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
-    model = build_model(nlc, sd)
+    sd = onl.make_synthetic_state_dict(weights_seed, d, nu, 128, S, st["state_std"], [A / 2], tame=tame)
+    model = build_model(nlc, sd, S=S, algo=algo)
     sig = nlc.noise_sigma(nu)
     torch.manual_seed(seed)
     mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cuda", lambda_=1.0,
@@ -708,12 +708,13 @@ def _subset_check(nlc, env, K, T, B, n_check=64, seed=0):
     V, eps = mppi.perturbed_action.cpu(), mppi.noise.cpu()
     idx = torch.arange(0, K, K // n_check)
     ts = torch.full((len(idx), 1), 0.05, dtype=torch.float64)
-    cost_ref, states_ref, _ = omppi.rollout(state, ab, V[idx], A, onl.nl_dynamics(sd, ts, S=17), oenvs.RUNNING_COST[env], d)
-    np.testing.assert_allclose(mppi.states.cpu()[idx].numpy(), states_ref.numpy(), rtol=1e-7, atol=1e-7)
+    cost_ref, states_ref, _ = omppi.rollout(state, ab, V[idx], A, onl.nl_dynamics(sd, ts, S=S, ilt_algorithm=algo),
+                                            oenvs.RUNNING_COST[env], d)
+    np.testing.assert_allclose(mppi.states.cpu()[idx].numpy(), states_ref.numpy(), rtol=tol, atol=tol)
     U_shift = torch.roll(U_before, -1, 0)
     U_shift[-1] = 0
     pc = torch.sum(U_shift * (eps[idx] @ torch.inverse(sig)), dim=(1, 2))
-    np.testing.assert_allclose(mppi.cost_total.cpu()[idx].numpy(), (cost_ref + pc).numpy(), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(mppi.cost_total.cpu()[idx].numpy(), (cost_ref + pc).numpy(), rtol=tol, atol=tol)
     cost, omega = mppi.cost_total.cpu(), mppi.omega.cpu()
     w = torch.exp(-(cost - cost.min()))
     np.testing.assert_allclose(omega.numpy(), (w / w.sum()).numpy(), rtol=1e-10, atol=1e-16)
@@ -735,6 +736,17 @@ def test_cfg3_pendulum_shard_32768x40_window5(nlc):
 def test_cfg4_acrobot_shard_32768x60(nlc):
     """BASELINE configs[3] per-GPU shard: acrobot (nx=6, nu=2), 262144/8 samples, H=60."""
     _subset_check(nlc, "oderl-acrobot", 32768, 60, 4)
+
+
+def test_full_size_cfg5_dehoog(nlc):
+    """BASELINE configs[4] at its own size: cartpole, de Hoog ILT with 33 terms, K = 16384, T = 40, on the staged
+    all-HIP path.  64 strided samples through the oracle (mpmath's de Hoog recurrences with IEEE divisions; the kernel
+    divides by a refined reciprocal inside the QD table): states after 40 sequential steps and costs must meet the
+    north-star bar of 1e-5; softmax weights, U and the action are checked over the whole population.
+    Weights: the "trained-like" de Hoog model of oracle.nl_model.tame_dehoog_ (F(s_k) a perturbed Laplace transform;
+    with the Fourier models' phi-shifted random weights the QD table hits near-poles and a 1e-10 perturbation of the
+    state grows to O(100) by T = 40 in the ORACLE itself -- nothing to compare)."""
+    _subset_check(nlc, "oderl-cartpole", 16384, 40, 4, S=33, algo="dehoog", tol=1e-5, tame="dehoog")
 
 
 def test_cfg5_dehoog_planner_staged_hip_path(nlc):
