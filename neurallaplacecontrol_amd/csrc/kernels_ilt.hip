@@ -15,6 +15,10 @@
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
+#ifndef NLC_ILT_EXPERIMENTS
+#define NLC_ILT_EXPERIMENTS 0
+#endif
+
 namespace nlc {
 
 // ------------------------------------------------------------------ rep-func inputs
@@ -62,7 +66,8 @@ hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s) {
 // coalesced loads (lane i <-> flat element i), parks the per-element contribution in LDS and lets one
 // thread per row add its S terms (row stride padded odd: conflict-free ds_read_b64).
 
-// DBG: 0 = product; 1 / 2 = timing experiments (memory only / arithmetic only), env NLC_ILT_DBG
+// DBG: 0 = product; 1 / 2 = timing experiments (memory only / arithmetic only), instantiated by the tools build only
+// (-DNLC_ILT_EXPERIMENTS=1)
 // ITERS > 0: passes per tile known at compile time -> the pass loop is fully unrolled (straight-line code is
 // what lets the compiler keep counted s_waitcnt vmcnt(N) instead of draining the pipeline); 0: runtime loop.
 //
@@ -313,19 +318,25 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   if (a.iters < 8) return hipErrorInvalidValue;
   const int rows = a.rpp * a.iters;
   const int64_t nblk = (rows_total + rows - 1) / rows;
-  // persistent grid: 1024-4096 blocks measure the same within run-to-run noise (NLC_ILT_GRID: experiments)
-  static const int64_t cap = [] {  // read once: no getenv on the launch path
+  // persistent grid: 1024-4096 blocks measured the same within run-to-run noise (round 1)
+  int64_t cap = 2048;
+  a.dbg = 0;
+#if NLC_ILT_EXPERIMENTS
+  // tools build only (make EXTRA_kernels_ilt=-DNLC_ILT_EXPERIMENTS=1): grid size and the two timing variants of the
+  // kernel (1 memory-only, 2 arithmetic-only) from the environment, read once
+  static const int64_t cap_env = [] {
     const char* ev = std::getenv("NLC_ILT_GRID");
     return (ev && std::atoll(ev) > 0) ? (int64_t)std::atoll(ev) : (int64_t)2048;
   }();
-  const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
-  const size_t shmem = (size_t)rows * SP * sizeof(double);
-  a.dbg = 0;
-  static const int dbg_env = [] {  // 1 memory-only, 2 arithmetic-only (timing experiments); read once
+  static const int dbg_env = [] {
     const char* ev = std::getenv("NLC_ILT_DBG");
     return ev ? std::atoi(ev) : 0;
   }();
+  cap = cap_env;
   a.dbg = dbg_env;
+#endif
+  const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
+  const size_t shmem = (size_t)rows * SP * sizeof(double);
 #define NLC_ILT_LAUNCH(D)                                                                              \
   switch (a.iters) {                                                                                   \
     case 8: hipLaunchKernelGGL((ilt_fourier_kernel<D, 8>), dim3(grid), dim3(256), shmem, s, a); break;   \
@@ -334,11 +345,14 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
     case 32: hipLaunchKernelGGL((ilt_fourier_kernel<D, 32>), dim3(grid), dim3(256), shmem, s, a); break; \
     default: hipLaunchKernelGGL((ilt_fourier_kernel<D, 0>), dim3(grid), dim3(256), shmem, s, a); break;  \
   }
+#if NLC_ILT_EXPERIMENTS
   if (a.dbg == 1) {
     NLC_ILT_LAUNCH(1)
   } else if (a.dbg == 2) {
     NLC_ILT_LAUNCH(2)
-  } else {
+  } else
+#endif
+  {
     NLC_ILT_LAUNCH(0)
   }
 #undef NLC_ILT_LAUNCH

@@ -1,5 +1,6 @@
 // Host build of neurallaplacecontrol_amd/csrc/nlc_math.h for tests/test_math_host.py (g++, no GPU).
 #include "../../neurallaplacecontrol_amd/csrc/nlc_math.h"
+#include "../../tools/nlc_math_table.h"  // the measured-and-dropped table-driven alternative (not in the product)
 extern "C" {
 void nlc_t_tanh(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::tanh_d(x[i]); }
 void nlc_t_sigmoid(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = nlc::m::sigmoid_d(x[i]); }
