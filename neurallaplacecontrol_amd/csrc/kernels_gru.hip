@@ -17,8 +17,10 @@
 
 namespace nlc {
 
+// (G = 128, hidden_units = 256: the two layers' images are 128 KB of LDS for the four waves -- one workgroup per CU, one
+// wave per SIMD, as for the baselines' rnn_encode_kernel<128>)
 template <int G>
-__global__ __launch_bounds__(256, 2) void gru_encode_kernel(const GruArgs a) {
+__global__ __launch_bounds__(256, G <= 64 ? 2 : 1) void gru_encode_kernel(const GruArgs a) {
   constexpr int KS = G / 4;    // k-steps over the hidden dimension
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, c = lane & 15;
@@ -49,6 +51,8 @@ hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s) {
     hipLaunchKernelGGL((gru_encode_kernel<64>), dim3(grid), dim3(256), 0, s, a);
   } else if (g == 32) {
     hipLaunchKernelGGL((gru_encode_kernel<32>), dim3(grid), dim3(256), 0, s, a);
+  } else if (g == 128) {
+    hipLaunchKernelGGL((gru_encode_kernel<128>), dim3(grid), dim3(256), 0, s, a);
   } else {
     return hipErrorInvalidValue;
   }

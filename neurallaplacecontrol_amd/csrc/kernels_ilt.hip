@@ -446,221 +446,4 @@ hipError_t launch_ilt_fourier_bwd(const IltBwdArgs& a_in, hipStream_t s) {
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ de Hoog, Knight & Stokes
-struct cplx {
-  double re, im;
-};
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
-}
-// a / b = a conj(b) / |b|^2 with ONE refined reciprocal (v_rcp_f64 + one cubic refinement step, <= 1 ulp) instead of two IEEE
-// divisions (v_div_scale / v_div_fmas / v_div_fixup sequences with their VCC hazards): the QD table needs ~M^2 of
-// these per row, and they were 55 % of the kernel's issue slots.
-__device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
-  const double inv = m::rcp_refined(b.re * b.re + b.im * b.im);
-  return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
-}
-__device__ __forceinline__ cplx csqrt_(cplx z) {
-  // principal branch
-  const double mag = hypot(z.re, z.im);
-  double re = sqrt(0.5 * (mag + fabs(z.re)));
-  double im = (re == 0.0) ? 0.0 : 0.5 * z.im / re;
-  if (z.re < 0.0) {
-    const double t = re;
-    re = fabs(im);
-    im = copysign(t, z.im);
-  }
-  return {re, im};
-}
-
-// One thread per (point, dim) row; a block is one wavefront = 64 rows.
-//
-// The QD table is built anti-diagonal by anti-diagonal ("progressive" form): Laplace term a_n extends every column
-// by one entry, and the new diagonal is computed in place over the previous one -- D[c-1] holds the entry of column c
-// (c = 1: q_1, 2: e_1, 3: q_2, ...) on the current diagonal -- with the same rhombus rules as mpmath's column-wise
-// sweep (calculus/inverselaplace.py:476-531), so every entry is the same arithmetic on the same operands:
-//     e_r^(i)     = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)            (even column)
-//     q_(r+1)^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)                  (odd column)
-// The last entry of diagonal n is the continued-fraction coefficient d_n = -(entry at i = 0), consumed at once by the
-// A/B recurrence.  Storage is ONE diagonal (2M complex = 128 VGPRs at M = 16) instead of the two full columns of the
-// column-wise form (354 VGPRs, one wave per SIMD), and the F_k rows are staged through LDS in chunks of CH terms, so
-// two waves per SIMD share the VALU (a single wave issues FP64 VALU at half rate: tools/ubench_valu64.hip).
-// Measured (N = 655 360 points, d = 5): S = 33 2.50 -> 1.39 ms, S = 17 0.70 -> 0.48 ms; 9.6 k VALU instructions per
-// 64 rows at S = 33 (7.3 k QD + 2.3 k sphere->complex conversion): the kernel is bound by its FP64 instruction
-// count.  An intermediate version (1.65 ms) looked latency-bound at 66 % VALU utilisation; the PMC traffic counters
-// showed the real cause -- the compiler had deferred the B recurrence to the end of the kernel and spilled every
-// d_n z to scratch, 1 GB of HBM writes and 3.5x the algorithmic traffic per launch (profiles/r1g_pmc_dehoog.json
-// vs r1h_pmc_kernels.json); the per-diagonal fence below now pins both recurrences.
-// FMODE 0: (theta, phi) rows, sphere -> complex conversion here; 1: F (re, im) rows (N, d, S); both staged through LDS.
-// FMODE 2 (planner path): F is SLOT-major (8*nt3, N) as the representation kernel's MFMA epilogue stores it; a wavefront
-// owns 64 consecutive samples of ONE dim, so term k of its rows is one full 512-B line -- no LDS, no barrier, and the
-// kernel reads exactly the bytes it needs (row-major rows of 33 doubles straddle the 17-term chunks: 1.8x the traffic).
-template <int M, int CH, int W, int FMODE>
-__global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
-  constexpr int S = 2 * M + 1;
-  constexpr int CP = CH | 1;
-  constexpr int ROWS = 64;
-  constexpr bool FDIRECT = FMODE == 1;
-  constexpr bool SLOT = FMODE == 2;
-  __shared__ double fr[SLOT ? 1 : ROWS * CP];
-  __shared__ double fi[SLOT ? 1 : ROWS * CP];
-  const int lane = threadIdx.x;
-  const int64_t rows_total = a.N * a.d;
-  const int64_t nsb = (a.N + ROWS - 1) / ROWS;  // SLOT: sample blocks
-  const int64_t nblk = SLOT ? nsb * a.d : (rows_total + ROWS - 1) / ROWS;
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    // SLOT: block = (sample block, dim); otherwise 64 consecutive (point, dim) rows
-    const int cdim = SLOT ? (int)(blk % a.d) : 0;
-    const int64_t n0 = SLOT ? (blk / a.d) * ROWS : 0;
-    const int64_t row0 = SLOT ? 0 : blk * ROWS;
-    const int rows_here = SLOT ? (int)((a.N - n0 < ROWS) ? (a.N - n0) : ROWS)
-                               : (int)((rows_total - row0 < ROWS) ? (rows_total - row0) : ROWS);
-    const bool valid = lane < rows_here;
-    const int64_t nsmp = n0 + (valid ? lane : 0);                     // SLOT: this lane's sample
-    const int64_t row = SLOT ? nsmp * a.d + cdim : row0 + (valid ? lane : 0);
-    const int* ei = SLOT ? a.eidx + cdim * S : nullptr;               // wave-uniform slot of every term
-    cplx abuf[SLOT ? CH : 1];
-    const double t = (a.t_stride ? a.t[row / a.d] : a.t[0]) / a.t_div;
-    const double Tt = a.scale * t;
-    const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
-    const double ang = kPi * (t / Tt);
-    const cplx z = {cos(ang), sin(ang)};
-
-    cplx D[2 * M];
-    cplx a_prev = {0.0, 0.0}, d0 = {0.0, 0.0};
-    // A/B continued-fraction recurrence, fed with d_1, d_2, ... as the diagonals produce them
-    cplx A_prev = {0.0, 0.0}, A_cur = {0.0, 0.0}, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
-    cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
-#pragma clang loop unroll(full)
-    for (int n = 0; n <= 2 * M; ++n) {
-      if (SLOT && n % CH == 0) {
-        // terms [n, n + nt) of this lane's row: one coalesced line per term and array
-        const int nt = (S - n < CH) ? (S - n) : CH;
-#pragma clang loop unroll(full)
-        for (int k = 0; k < CH; ++k)
-          if (k < nt) {
-            const int64_t at = (int64_t)ei[n + k] * a.N + nsmp;
-            abuf[k] = {a.fre[at], a.fim[at]};
-          }
-      } else if (n % CH == 0) {
-        // stage terms [n, n + nt) of the block's rows: coalesced over (row, term) pairs
-        const int nt = (S - n < CH) ? (S - n) : CH;
-        if (n != 0) __syncthreads();
-#pragma nounroll
-        for (int e = lane; e < ROWS * nt; e += ROWS) {
-          const int r = e / nt, k = e - r * nt;
-          if (r < rows_here) {
-            const int64_t gi = (row0 + r) * S + n + k;
-            if constexpr (FDIRECT) {  // F_k supplied directly (staged planner / model path)
-              fr[r * CP + k] = a.fre[gi];
-              fi[r * CP + k] = a.fim[gi];
-            } else {
-              const double theta = a.theta[gi];
-              const double phi = a.phi[gi];
-              const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
-              double sn, cs;
-              m::sincos_bounded(theta, &sn, &cs);
-              fr[r * CP + k] = rad * cs;
-              fi[r * CP + k] = rad * sn;
-            }
-          }
-        }
-        __syncthreads();
-      }
-      cplx an;
-      if constexpr (SLOT) {
-        an = abuf[n % CH];
-      } else {
-        an = {fr[lane * CP + n % CH], fi[lane * CP + n % CH]};
-      }
-      if (n == 0) {
-        d0 = {0.5 * an.re, 0.5 * an.im};  // a_0 enters halved
-        a_prev = d0;
-        A_cur = d0;
-        continue;
-      }
-      cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
-      a_prev = an;
-      cplx old1 = D[0];              // previous diagonal, column c-1
-      cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
-      D[0] = newv;
-#pragma unroll
-      for (int c = 2; c <= n; ++c) {
-        const cplx oldc = D[c - 1];
-        const cplx val = (c & 1) ? cdiv(cmul(old2, newv), old1) : cadd(csub(newv, old1), old2);
-        D[c - 1] = val;
-        old2 = old1;
-        old1 = oldc;
-        newv = val;
-      }
-      // d_n = -(entry at i = 0); d_2M only enters the remainder
-      d_last = d_cur;
-      d_cur = {-newv.re, -newv.im};
-      if (n != 2 * M) {
-        const cplx dz = cmul(d_cur, z);
-        const cplx An = cadd(A_cur, cmul(dz, A_prev));
-        const cplx Bn = cadd(B_cur, cmul(dz, B_prev));
-        A_prev = A_cur;
-        A_cur = An;
-        B_prev = B_cur;
-        B_cur = Bn;
-      }
-      // keep the diagonals apart: hoisting the next terms' LDS reads / interleaving diagonals only costs registers
-      // (the asm ties this diagonal's results -- including BOTH continued-fraction recurrences, which the compiler
-      // otherwise defers to the end of the kernel, spilling every d_n z to scratch: 1 GB of HBM writes per launch --
-      // to a memory barrier, so the arithmetic cannot sink below the following reads either)
-      asm volatile(""
-                   : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
-    const cplx diff = csub(d_last, d_cur);
-    const cplx one = {1.0, 0.0};
-    cplx brem = cadd(one, cmul(diff, z));
-    brem = {0.5 * brem.re, 0.5 * brem.im};
-    const cplx inner = cadd(one, cdiv(cmul(d_cur, z), brem));
-    const cplx rem = cmul(brem, csub(csqrt_(inner), one));
-    const cplx An = cadd(A_cur, cmul(rem, A_prev));
-    const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
-    const cplx res = cdiv(An, Bn);
-    if (valid) a.x[row] = exp(gamma * t) / Tt * res.re;
-    if (!SLOT) __syncthreads();
-  }
-}
-
-hipError_t launch_ilt_dehoog(const IltArgs& a, hipStream_t s) {
-  const int64_t rows_total = a.N * a.d;
-  if (rows_total <= 0) return hipSuccess;
-  const bool slot = a.eidx != nullptr;
-  if (slot && a.fre == nullptr) return hipErrorInvalidValue;
-  const int64_t nblk = slot ? (a.N + 63) / 64 * a.d : (rows_total + 63) / 64;
-  const unsigned grid = (unsigned)(nblk < 16384 ? nblk : 16384);
-#define NLC_DH(...)                                                                                   \
-  do {                                                                                                \
-    if (slot)                                                                                         \
-      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, 2>), dim3(grid), dim3(64), 0, s, a);         \
-    else if (a.fre != nullptr)                                                                        \
-      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, 1>), dim3(grid), dim3(64), 0, s, a);         \
-    else                                                                                              \
-      hipLaunchKernelGGL((ilt_dehoog_kernel<__VA_ARGS__, 0>), dim3(grid), dim3(64), 0, s, a);         \
-  } while (0)
-  switch (a.S) {
-    case 33:
-      NLC_DH(16, 17, 2);  // 212-249 VGPRs, two 17-term chunks of 17 KB LDS: 8 waves per CU
-      break;
-    case 17:
-      NLC_DH(8, 9, 3);  // 143-148 VGPRs, two 9-term chunks of 9 KB LDS: 12 waves per CU
-      break;
-    case 9:
-      NLC_DH(4, 9, 3);
-      break;
-    default:
-      return hipErrorInvalidValue;
-  }
-#undef NLC_DH
-  return hipGetLastError();
-}
-
 }  // namespace nlc

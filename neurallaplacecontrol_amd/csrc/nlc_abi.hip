@@ -370,8 +370,8 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
     ProfScope ps(c, "ilt_fourier_kernel");
     NLC_HIP(c, launch_ilt_fourier(a, c->stream));
   } else {
-    if (d->terms != 33 && d->terms != 17 && d->terms != 9)
-      return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
+    if (d->terms < 3 || d->terms > 33 || d->terms % 2 == 0)
+      return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be odd, 3 .. 33 (2M+1 terms)");
     ProfScope ps(c, "ilt_dehoog_kernel");
     NLC_HIP(c, launch_ilt_dehoog(a, c->stream));
   }
@@ -405,7 +405,8 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   NLC_GUARD_BEGIN
   if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
   if (int r = check_ilt(c, &d->ilt)) return r;
-  if (d->h != 128) return fail(c, NLC_ERR_UNSUPPORTED, "hidden_units must be 128 (GRU hidden 64)");
+  if (d->h != 64 && d->h != 128 && d->h != 256)
+    return fail(c, NLC_ERR_UNSUPPORTED, "hidden_units must be 64, 128 or 256 (the kernels are instantiated for these widths)");
   if (d->d < 1 || d->d > 6) return fail(c, NLC_ERR_UNSUPPORTED, "state_dim must be in 1..6");
   if (d->nin < 1 || d->nin > NLC_MAX_NIN) return fail(c, NLC_ERR_UNSUPPORTED, "GRU input dim must be in 1..3");
   if (d->ilt.scale != 2.0) return fail(c, NLC_ERR_UNSUPPORTED, "fused model path needs ILT scale == 2");
@@ -587,8 +588,8 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
   if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
-  if (c->md.ilt.algo == NLC_ILT_DEHOOG && c->S != 33 && c->S != 17 && c->S != 9)
-    return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
+  if (c->md.ilt.algo == NLC_ILT_DEHOOG && (c->S < 3 || c->S > 33 || c->S % 2 == 0))
+    return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be odd, 3 .. 33 (2M+1 terms)");
   if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
   if (N == 0) return NLC_OK;
   if (!obs || !window || !ts || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
@@ -975,8 +976,8 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     // nin == nu + 1: an encode_obs_time model; the rollout appends the harness's constant time channel
     if (c->md.d != d->d || (c->md.nin != d->nu && c->md.nin != d->nu + 1))
       return fail(c, NLC_ERR_BAD_SHAPE, "model state/action dims differ from the planner's");
-    if (c->md.ilt.algo == NLC_ILT_DEHOOG && c->S != 33 && c->S != 17 && c->S != 9)
-      return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be 9, 17 or 33");
+    if (c->md.ilt.algo == NLC_ILT_DEHOOG && (c->S < 3 || c->S > 33 || c->S % 2 == 0))
+      return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be odd, 3 .. 33 (2M+1 terms)");
   } else if (d->dynamics == NLC_DYN_ORACLE) {
     if (d->delay < 0 || d->delay > d->B - 1)
       return fail(c, NLC_ERR_BAD_ARG, "oracle dynamics: delay must be in [0, action_buffer_size-1]");
@@ -1359,7 +1360,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     }
     // rollout_variant (nlc_set_option): 0 auto, 1 wave-per-tile, 2 latency-split, 3 fused one-launch body
     int variant = c->opt_rollout_variant;
-    const bool fused_ok = c->g == 64 && c->net.nt3 <= 21 && KE * d.T * 16 < (int64_t)1 << 31;
+    const bool fused_ok = c->md.h == 128 && c->g == 64 && c->net.nt3 <= 21 && KE * d.T * 16 < (int64_t)1 << 31;
     if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
     if (variant == 0 && fused_ok && KE <= c->opt_fused_max_samples) variant = 3;
     if (variant == 3) {

@@ -1,0 +1,207 @@
+// Kernel templates of the representation MLP + ILT + rollout (dataflow: top of kernels_nl.hip) and the launcher bodies
+// for ONE hidden width h = 16 HT.  Each width is its own translation unit (kernels_nl.hip: h = 128, the harness's
+// hidden_units; kernels_nl_h64.hip: the class default w_nl.py:72; kernels_nl_h256.hip: config.py's alternative) so
+// the three sets of instantiations compile in parallel.
+#pragma once
+#include "nlc_device.h"
+#include "nlc_envcost.h"
+#include "nlc_kernels.h"
+#include "nlc_rollout.h"
+
+namespace nlc {
+
+// ------------------------------------------------------------------ T-step rollout (planner)
+template <int HT, int NT3>
+__global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool valid = k < a.K;
+  const int64_t kc = valid ? k : a.K - 1;
+  const int d = n.d;
+
+  // lane (q) owns latent indices i0 = q and i1 = 4 + q: state dims, then the two GRU latents
+  const int i0 = q, i1 = 4 + q;
+  double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, s0 = 1.0, s1 = 1.0;
+  const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
+  const int ep = (int)(kc / a.Kep);  // episode of this lane's sample (0 for the single planner)
+  const int uoff = ep * a.T * a.nu;
+  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * d : a.xcarry + kc * d;
+  if (i0 < d) {
+    x0 = st[i0];
+    m0 = n.state_mean[i0];
+    s0 = n.state_std[i0];
+  }
+  if (i1 < d) {
+    x1 = st[i1];
+    m1 = n.state_mean[i1];
+    s1 = n.state_std[i1];
+  }
+  // ILT prefactor e^{gamma t}/T: constant over the rollout (ts_pred is constant)
+  const double Tt = n.scale * a.tn;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double factor = exp(gamma * a.tn) / Tt;
+
+  double cost = 0.0, pcost = 0.0;
+  if (!first_chunk) {
+    cost = a.ccarry[kc * 2];
+    pcost = a.ccarry[kc * 2 + 1];
+  }
+  for (int t = a.t_begin; t < a.t_end; ++t) {
+    const double* pa = a.pa + (kc * a.T + t) * 2;
+    const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+    const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+    const v4d ax = nl_eval<HT, NT3, false>(n, lane, q, p0, p1, a.tn);
+    // state + model(state, window, ts_pred)   (mppi_with_model.py:120-121)
+    if (i0 < d) x0 = x0 + factor * ax[0];
+    if (i1 < d) x1 = x1 + factor * ax[1];
+    if (valid && a.states != nullptr) {
+      double* so = a.states + (k * a.T + t) * d;
+      if (i0 < d) so[i0] = x0;
+      if (i1 < d) so[i1] = x1;
+    }
+    // gather the sample's full state into every lane of its column
+    double xs[NLC_MAX_D];
+#pragma unroll
+    for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+    double u[NLC_MAX_NU] = {0.0, 0.0};
+    double pc = 0.0;
+    for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(kc * a.T + t) * a.nu + j];
+    // perturbation cost sum_j U[t,j] * (lambda * eps @ Sigma^-1)[j]   (mppi_delay.py:335,343)
+    for (int j = 0; j < a.nu; ++j) {
+      double acj = 0.0;
+      for (int i = 0; i < a.nu; ++i) {
+        double e = a.noise[(kc * a.T + t) * a.nu + i];
+        if (a.noise_abs_cost) e = fabs(e);
+        acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+      }
+      pc += a.U[uoff + t * a.nu + j] * acj;
+    }
+    cost += running_cost(a.env, xs, u, a.nu);
+    pcost += pc;
+  }
+  if (valid) {
+    if (last_chunk) {
+      if (q == 0) a.cost_total[k] = cost + pcost;
+    } else {
+      if (i0 < d) a.xcarry[k * d + i0] = x0;
+      if (i1 < d) a.xcarry[k * d + i1] = x1;
+      if (q == 0) {
+        a.ccarry[k * 2] = cost;
+        a.ccarry[k * 2 + 1] = pcost;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ latency-split rollout (small K per GPU)
+// one workgroup per 16-sample tile: rollout_split_tile (nlc_rollout.h), GRU latents from the (K, T, 2) tensor
+template <int HT, int NT3>
+__global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs a) {
+  constexpr int KS = HT * 4;
+  __shared__ double H1[KS * 64], H2[KS * 64], AX[4 * 2 * 64];
+  PaDirect src{a.pa, a.T, 0.0, 0.0, 0.0, 0.0};
+  rollout_split_tile<HT, NT3>(a, (int64_t)blockIdx.x, src, H1, H2, AX);
+}
+
+// ------------------------------------------------------------------ single model forward, per-sample t
+template <int HT, int NT3>
+__global__ __launch_bounds__(256) void nl_forward_kernel(const ForwardArgs a) {
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool valid = k < a.N;
+  const int64_t kc = valid ? k : a.N - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  const double* ob = a.obs + kc * d;
+  const double* pa = a.pa + kc * 2;
+  const double p0 = (i0 < d) ? (ob[i0] - n.state_mean[i0]) / n.state_std[i0]
+                             : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+  const double p1 = (i1 < d) ? (ob[i1] - n.state_mean[i1]) / n.state_std[i1]
+                             : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+  const double tn = a.ts[kc] / n.time_div;  // w_nl.py:122
+  const v4d ax = nl_eval<HT, NT3, true>(n, lane, q, p0, p1, tn);
+  const double Tt = n.scale * tn;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double factor = exp(gamma * tn) / Tt;
+  if (valid) {
+    if (i0 < d) a.out[k * d + i0] = factor * ax[0];
+    if (i1 < d) a.out[k * d + i1] = factor * ax[1];
+  }
+}
+
+// ------------------------------------------------------------------ representation function only (de Hoog path)
+// One model evaluation per sample, output = F_k (re, im) of all d*S Laplace terms.  Used (a) per horizon step by
+// the de Hoog planner path (folded constant-t bias) and (b) by NeuralLaplaceModel.forward with per-row t.
+template <int HT, int NT3, bool GENERAL_T>
+__global__ __launch_bounds__(256) void nl_repfunc_kernel(const RepFuncArgs a) {
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool valid = k < a.N;
+  const int64_t kc = valid ? k : a.N - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  const double* ob = a.obs + (a.obs_per_sample ? kc : kc / a.Kep) * a.obs_stride;
+  const double* pa = a.pa + kc * a.pa_stride;
+  double x0 = (i0 < d) ? ob[i0] : 0.0, x1 = (i1 < d) ? ob[i1] : 0.0;
+  if constexpr (!GENERAL_T) {
+    if (a.tail_prev) {
+      // tail of the previous horizon step (step_tail_kernel's arithmetic, in the MFMA lane layout: lane group q owns
+      // state dims q and 4+q of sample c): x <- x + dx (mppi_with_model.py:120-121), store, running cost
+      const StepTailArgs& s = a.tail;
+      const int64_t e = kc / s.Kep;
+      const double* src = s.first ? s.state0 + (s.state_per_sample ? kc : e) * d : s.x + kc * d;
+      if (i0 < d) x0 = src[i0] + s.dx[kc * d + i0];
+      if (i1 < d) x1 = src[i1] + s.dx[kc * d + i1];
+      double xs[NLC_MAX_D];
+#pragma unroll
+      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+      if (valid) {
+        if (i0 < d) s.x[k * d + i0] = x0;
+        if (i1 < d) s.x[k * d + i1] = x1;
+        if (s.states != nullptr) {
+          if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
+          if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
+        }
+      }
+      if (q == 0 && valid) {
+        double u[NLC_MAX_NU] = {0.0, 0.0};
+        for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
+        double pc = 0.0;
+        for (int j = 0; j < s.nu; ++j) {
+          double acj = 0.0;
+          for (int ii = 0; ii < s.nu; ++ii) {
+            double ev = s.noise[(k * s.T + s.t) * s.nu + ii];
+            if (s.noise_abs_cost) ev = fabs(ev);
+            acj += (s.lambda_ * ev) * s.sigma_inv[ii * s.nu + j];
+          }
+          pc += s.U[(e * s.T + s.t) * s.nu + j] * acj;
+        }
+        s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
+        s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
+      }
+    }
+  }
+  const double p0 = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0]
+                             : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+  const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
+                             : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+  const FOut fo{a.fre, a.fim, a.slot, valid ? k : -1, d * n.S, a.write_angles, a.slot_major ? a.N : (int64_t)0};
+  if constexpr (GENERAL_T) {
+    const double* sph_row = a.sph != nullptr ? a.sph + kc * a.sph_stride : nullptr;
+    const double tn = a.sph != nullptr ? 1.0 : a.ts[kc] / n.time_div;
+    nl_eval<HT, NT3, true, true>(n, lane, q, p0, p1, tn, &fo, sph_row);
+  } else {
+    nl_eval<HT, NT3, false, true>(n, lane, q, p0, p1, a.tn, &fo);
+  }
+}
+
+// instantiated layer-3 tile counts; other (d,S) round up to the next one (zero-padded tiles)
+#define NLC_FOR_NT3(X) X(7) X(9) X(11) X(13) X(17) X(21) X(25)
+
+}  // namespace nlc
