@@ -279,7 +279,7 @@ int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
  * the device.  With action_host == NULL nothing is copied back and the call does not synchronise. */
 int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
                     double* action_host);
-/* Multi-GPU note: the library owns NO communicator.  SURVEY 8b sketched an nlc_comm_init(); it was dropped on purpose:
+/* Multi-GPU note: the library owns NO communicator.  SURVEY 8b sketched a communicator-initialisation entry point; it was dropped on purpose:
  * the one exchange of a K-sharded command is the all-gather of buf->partials ((2+T*nu) doubles per rank and episode)
  * between nlc_mppi_rollout and nlc_mppi_finish, and the caller brings it -- torch.distributed over RCCL in the Python
  * mirror (sharding.py), rcclAllGather / MPI_Allgather on `gathered_dev` for a C caller -- so the library never competes
