@@ -44,6 +44,10 @@ extern "C" {
 /* ILT algorithms (torchlaplace `ilt_algorithm`, call site w_nl.py:141) */
 #define NLC_ILT_FOURIER 0
 #define NLC_ILT_DEHOOG 1
+/* the closed-form LINEAR algorithms torchlaplace also offers (reference knob config.py:36 nl_ilt_algorithm): stand-alone
+ * reconstruction only (nlc_ilt_rep_inputs / nlc_ilt_reconstruct; models with these algorithms plan on the generic path) */
+#define NLC_ILT_FIXED_TALBOT 2 /* "fixed_tablot": Abate & Valko, M = terms nodes, r = 2M/5 (mpmath FixedTalbot) */
+#define NLC_ILT_STEHFEST 3     /* "stehfest": Gaver-Stehfest, terms even (mpmath Stehfest) */
 
 /* env running costs (mppi_with_model.py:145-171 -> ctcartpole.py:289-346, ctpendulum.py:139-155,
  * ctacrobot.py:233-255) and oracle dynamics (oracle.py:11-224) */
@@ -88,8 +92,8 @@ int nlc_device_info(nlc_ctx* ctx, char* name, int name_len, int* num_cus, int* c
  *      [theta_s | phi_s | p] input order are the recalled defaults, exposed here as parameters. ---- */
 typedef struct {
   int32_t algo;  /* NLC_ILT_* */
-  int32_t terms; /* S = ilt_reconstruction_terms (de Hoog: odd, 2M+1) */
-  double alpha;  /* fourier 1e-3, dehoog 1e-10 */
+  int32_t terms; /* S = ilt_reconstruction_terms (de Hoog: odd, 2M+1 <= 33; Stehfest: even <= 20) */
+  double alpha;  /* fourier 1e-3, dehoog 1e-10 (unused by the linear algorithms, as are tol and scale) */
   double tol;    /* 10*alpha */
   double scale;  /* 2.0 */
 } nlc_ilt_desc;

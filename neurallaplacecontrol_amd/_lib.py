@@ -15,7 +15,7 @@ NLC_MAX_NU = 2
 NLC_MAX_NIN = 3
 NLC_MAX_D = 8
 
-ILT_ALGOS = {"fourier": 0, "dehoog": 1}
+ILT_ALGOS = {"fourier": 0, "dehoog": 1, "fixed_tablot": 2, "stehfest": 3}
 ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
 DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN, DYN_NODE = 0, 1, 2, 3, 4
 
@@ -320,11 +320,18 @@ def ptr(t):
 
 def ilt_desc(algo, terms, options=None):
     """Resolve the torchlaplace defaults recalled in SURVEY §A.3 (parity unpinned vs upstream)."""
+    if algo == "cme":
+        raise NotImplementedError(
+            "ilt_algorithm='cme': the method's node / weight parameter sets (one per order; the reference only carries "
+            "the LIST of orders, config.py:278-418) ship inside torchlaplace, which is absent here -- they are the result "
+            "of a numerical optimisation and cannot be restated offline.  fourier, dehoog, fixed_tablot and stehfest run."
+        )
     if algo not in ILT_ALGOS:
         raise NotImplementedError(
-            f"ilt_algorithm={algo!r}: only 'fourier' and 'dehoog' are implemented on the HIP path"
+            f"ilt_algorithm={algo!r}: fourier, dehoog, fixed_tablot and stehfest are implemented on the HIP path"
         )
-    o = {"fourier": dict(alpha=1.0e-3, scale=2.0), "dehoog": dict(alpha=1.0e-10, scale=2.0)}[algo]
+    o = {"fourier": dict(alpha=1.0e-3, scale=2.0), "dehoog": dict(alpha=1.0e-10, scale=2.0),
+         "fixed_tablot": dict(alpha=1.0, scale=1.0), "stehfest": dict(alpha=1.0, scale=1.0)}[algo]
     if options:
         o.update(options)
     tol = o.get("tol")

@@ -37,9 +37,15 @@ __global__ __launch_bounds__(256) void rep_inputs_kernel(const RepInArgs a) {
     } else {
       const double t = a.t_batched ? a.t[row] : a.t[j];
       const double Tt = a.scale * t;
-      const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
       const int k = col < a.S ? col : col - a.S;
-      const double im = kPi * (double)k / Tt;
+      double gamma, im;
+      if (a.node_re != nullptr) {  // fixed Talbot / Stehfest nodes
+        gamma = a.node_re[k] / t;
+        im = a.node_im[k] / t;
+      } else {
+        gamma = a.alpha - a.log_tol / (a.scale * Tt);
+        im = kPi * (double)k / Tt;
+      }
       if (col < a.S) {
         v = atan2(im, gamma);
       } else {
@@ -57,6 +63,33 @@ hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s) {
   const int64_t want = (total + 255) / 256;
   const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
   hipLaunchKernelGGL(rep_inputs_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ linear closed-form algorithms (fixed Talbot, Stehfest)
+// One thread per (point, dim) row walks its S (theta, phi) pairs; a wavefront's 64 rows are 64 * S contiguous doubles,
+// so the lines it touches are shared by neighbouring threads' later iterations (L1 / L2 hits).  Not a tuned stream like
+// the Fourier kernel: these two algorithms exist for coverage of the reference's nl_ilt_algorithm knob.
+__global__ __launch_bounds__(256) void ilt_linear_kernel(const IltLinArgs a) {
+  const int64_t rows = a.N * a.d;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
+    const double* th = a.theta + row * a.S;
+    const double* ph = a.phi + row * a.S;
+    double acc = 0.0;
+    for (int k = 0; k < a.S; ++k) {
+      const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
+      double sn, cs;
+      m::sincos_bounded(th[k], &sn, &cs);
+      acc += a.wr[k] * (rad * cs) - a.wi[k] * (rad * sn);
+    }
+    a.x[row] = acc / a.t[row / a.d];
+  }
+}
+hipError_t launch_ilt_linear(const IltLinArgs& a, hipStream_t s) {
+  const int64_t rows = a.N * a.d;
+  if (rows <= 0) return hipSuccess;
+  const int64_t want = (rows + 255) / 256;
+  hipLaunchKernelGGL(ilt_linear_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -61,6 +61,8 @@ struct nlc_ctx {
   NlNetArgs net{}; // general-t variant (b1 = raw bias)
   std::vector<double> W1s_host, b1_host;  // for folding the constant sphere inputs at configure time
   int* slot_dev = nullptr;                // (8*nt3) layer-3 slot -> c*S + k (de Hoog path)
+  double* lin_tab = nullptr;              // nodes / weights of the linear ILT algorithms, cached per (algo, terms)
+  int lin_algo = -1, lin_S = 0;
   int* eidx_dev = nullptr;                // (d*S) inverse: term k of dim c -> slot (slot-major F of the planner path)
 
   // Delta-t RNN baseline model
@@ -275,6 +277,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   if (c->node_base) hipFree(c->node_base);
   if (c->slot_dev) hipFree(c->slot_dev);
   if (c->eidx_dev) hipFree(c->eidx_dev);
+  if (c->lin_tab) hipFree(c->lin_tab);
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
   if (c->b1fold) hipFree(c->b1fold);
@@ -335,8 +338,61 @@ static int check_ilt(nlc_ctx* c, const nlc_ilt_desc* d) {
   if (!d) return fail(c, NLC_ERR_BAD_ARG, "ilt desc is NULL");
   if (d->terms < 1 || d->terms > kMaxTerms) return fail(c, NLC_ERR_BAD_SHAPE, "ilt terms out of range [1,129]");
   if (!(d->tol > 0.0) || !(d->scale > 0.0)) return fail(c, NLC_ERR_BAD_ARG, "ilt tol/scale must be positive");
-  if (d->algo != NLC_ILT_FOURIER && d->algo != NLC_ILT_DEHOOG)
-    return fail(c, NLC_ERR_UNSUPPORTED, "ilt_algorithm: only 'fourier' and 'dehoog' are implemented");
+  if (d->algo != NLC_ILT_FOURIER && d->algo != NLC_ILT_DEHOOG && d->algo != NLC_ILT_FIXED_TALBOT &&
+      d->algo != NLC_ILT_STEHFEST)
+    return fail(c, NLC_ERR_UNSUPPORTED, "ilt_algorithm: fourier, dehoog, fixed_tablot and stehfest are implemented");
+  if (d->algo == NLC_ILT_STEHFEST && (d->terms % 2 != 0 || d->terms < 2 || d->terms > 20))
+    return fail(c, NLC_ERR_UNSUPPORTED, "stehfest: ilt_reconstruction_terms must be even, 2 .. 20 (Salzer weights in float64)");
+  if (d->algo == NLC_ILT_FIXED_TALBOT && d->terms < 2)
+    return fail(c, NLC_ERR_UNSUPPORTED, "fixed_tablot: ilt_reconstruction_terms must be >= 2");
+  return NLC_OK;
+}
+
+// nodes and weights of the linear algorithms (mpmath 1.3.0 calculus/inverselaplace.py: FixedTalbot.calc_laplace_parameter /
+// calc_time_domain_solution, Stehfest._coeff), uploaded once per (algorithm, terms): [node_re | node_im | w_re | w_im]
+static int linear_tables(nlc_ctx* c, const nlc_ilt_desc* d, const double** tab) {
+  const int S = d->terms;
+  if (c->lin_tab && c->lin_algo == d->algo && c->lin_S == S) {
+    *tab = c->lin_tab;
+    return NLC_OK;
+  }
+  std::vector<double> h((size_t)4 * S, 0.0);
+  double *nr = h.data(), *ni = nr + S, *wr = ni + S, *wi = wr + S;
+  if (d->algo == NLC_ILT_FIXED_TALBOT) {
+    const int M = S;
+    const double r = 2.0 * M / 5.0;
+    nr[0] = r;
+    wr[0] = 0.4 * std::exp(r) / 2.0;
+    for (int k = 1; k < M; ++k) {
+      const double th = k * M_PI / M, cot = 1.0 / std::tan(th);
+      nr[k] = r * th * cot;
+      ni[k] = r * th;
+      const double e = 0.4 * std::exp(nr[k]), cr = std::cos(ni[k]), ci = std::sin(ni[k]);
+      const double fi = th * (1.0 + cot * cot) - cot;  // factor 1 + i fi
+      wr[k] = e * (cr - ci * fi);
+      wi[k] = e * (ci + cr * fi);
+    }
+  } else {
+    const int M = S, M2 = S / 2;
+    auto fac = [](int n) {
+      long double f = 1.0L;
+      for (int i = 2; i <= n; ++i) f *= i;
+      return f;
+    };
+    for (int k = 1; k <= M; ++k) {
+      long double z = 0.0L;
+      for (int j = (k + 1) / 2; j <= (k < M2 ? k : M2); ++j)
+        z += std::pow((long double)j, M2) * fac(2 * j) / (fac(M2 - j) * fac(j) * fac(j - 1) * fac(k - j) * fac(2 * j - k));
+      nr[k - 1] = k * M_LN2;
+      wr[k - 1] = (double)(((k + M2) % 2 ? -1.0L : 1.0L) * z * (long double)M_LN2);
+    }
+  }
+  if (!c->lin_tab) NLC_HIP(c, hipMalloc((void**)&c->lin_tab, (size_t)4 * kMaxTerms * sizeof(double)));
+  NLC_HIP(c, hipStreamSynchronize(c->stream));  // a kernel of an earlier call may still read the old tables
+  NLC_HIP(c, hipMemcpy(c->lin_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->lin_algo = d->algo;
+  c->lin_S = S;
+  *tab = c->lin_tab;
   return NLC_OK;
 }
 
@@ -349,7 +405,13 @@ extern "C" int nlc_ilt_rep_inputs(nlc_ctx* c, const nlc_ilt_desc* d, const doubl
   if (B * Tt == 0) return NLC_OK;
   if (!p || !t || !out) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
-  RepInArgs a{p, t, out, B, Tt, P, d->terms, t_batched, d->alpha, std::log(d->tol), d->scale};
+  RepInArgs a{p, t, out, B, Tt, P, d->terms, t_batched, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr};
+  if (d->algo == NLC_ILT_FIXED_TALBOT || d->algo == NLC_ILT_STEHFEST) {
+    const double* tab = nullptr;
+    if (int r = linear_tables(c, d, &tab)) return r;
+    a.node_re = tab;
+    a.node_im = tab + d->terms;
+  }
   ProfScope ps(c, "rep_inputs_kernel");
   NLC_HIP(c, launch_rep_inputs(a, c->stream));
   return NLC_OK;
@@ -366,7 +428,13 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
   if (!theta || !phi || !t || !x) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
   IltArgs a{theta, phi, t, x, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr, 1.0, 1, 0, 0, 0};
-  if (d->algo == NLC_ILT_FOURIER) {
+  if (d->algo == NLC_ILT_FIXED_TALBOT || d->algo == NLC_ILT_STEHFEST) {
+    const double* tab = nullptr;
+    if (int r = linear_tables(c, d, &tab)) return r;
+    IltLinArgs la{theta, phi, t, x, N, dd, d->terms, tab + 2 * d->terms, tab + 3 * d->terms};
+    ProfScope ps(c, "ilt_linear_kernel");
+    NLC_HIP(c, launch_ilt_linear(la, c->stream));
+  } else if (d->algo == NLC_ILT_FOURIER) {
     ProfScope ps(c, "ilt_fourier_kernel");
     NLC_HIP(c, launch_ilt_fourier(a, c->stream));
   } else {
@@ -405,6 +473,8 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   NLC_GUARD_BEGIN
   if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
   if (int r = check_ilt(c, &d->ilt)) return r;
+  if (d->ilt.algo != NLC_ILT_FOURIER && d->ilt.algo != NLC_ILT_DEHOOG)
+    return fail(c, NLC_ERR_UNSUPPORTED, "fused model kernels: ilt_algorithm must be fourier or dehoog");
   if (d->h != 64 && d->h != 128 && d->h != 256)
     return fail(c, NLC_ERR_UNSUPPORTED, "hidden_units must be 64, 128 or 256 (the kernels are instantiated for these widths)");
   if (d->d < 1 || d->d > 6) return fail(c, NLC_ERR_UNSUPPORTED, "state_dim must be in 1..6");

@@ -53,8 +53,24 @@ struct RepInArgs {
   int64_t B, Tt;
   int P, S, t_batched;
   double alpha, log_tol, scale;
+  // linear algorithms: query points s_k = (node_re[k] + i node_im[k]) / t from device tables (NULL: Fourier / de Hoog)
+  const double* node_re;
+  const double* node_im;
 };
 hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s);
+
+// fixed Talbot / Stehfest: x[n,c] = (1/t_n) sum_k (wr_k Re F_k - wi_k Im F_k), query points s_k = (node_k) / t
+struct IltLinArgs {
+  const double* theta;  // (N, d, S)
+  const double* phi;
+  const double* t;      // (N)
+  double* x;            // (N, d)
+  int64_t N;
+  int d, S;
+  const double* wr;     // (S) device tables
+  const double* wi;
+};
+hipError_t launch_ilt_linear(const IltLinArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ GRU action encoder (a7)
 // Action source: either an explicit window tensor (N, B, nin), or the MPPI history

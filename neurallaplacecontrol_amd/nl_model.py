@@ -94,8 +94,23 @@ _BLOB_KEYS = [
 ]
 
 
+def cme_reconstruction_terms():
+    """Orders for which the CME (concentrated matrix-exponential) inversion method has published parameter sets -- the
+    values of the reference's ``config.CME_reconstruction_terms()`` (config.py:278-418), generated from their run
+    structure: 3..75, 101, 111..211 step 10, 216, 221, 231..391 step 10, 396, 401, 421..1001 step 20 (136 orders)."""
+    t, out = 3, [3]
+    for step, count in ((1, 72), (26, 1), (10, 11), (5, 2), (10, 17), (5, 2), (20, 30)):
+        for _ in range(count):
+            t += step
+            out.append(t)
+    return np.array(out)
+
+
 def _cme_terms(s_recon_terms):
-    raise NotImplementedError("ilt_algorithm='cme' is not implemented on the HIP path (fourier, dehoog only)")
+    """Term snapping of the reference constructor for ``ilt_algorithm == "cme"`` (w_nl.py:86-88), quirk included: the
+    entry two places BEFORE the first order >= s_recon_terms (17 -> 15, 33 -> 31)."""
+    terms = cme_reconstruction_terms()
+    return int(terms[np.argmin(terms < s_recon_terms) - 2])
 
 
 class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
@@ -183,7 +198,10 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
         d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)
         desc = _lib.ModelDesc()
         desc.d, desc.nin, desc.h = d, nin, self.hidden_units
-        desc.ilt = _lib.ilt_desc(self.ilt_algorithm, self.s_recon_terms, self.ilt_options)
+        # the fused kernels exist for fourier / dehoog; a model with another algorithm still uses this ctx for its GRU
+        # encoder (encode_actions), so its weights are packed under a Fourier descriptor of the same term count
+        fused_algo = self.ilt_algorithm in ("fourier", "dehoog")
+        desc.ilt = _lib.ilt_desc(self.ilt_algorithm if fused_algo else "fourier", self.s_recon_terms, self.ilt_options if fused_algo else None)
         f64 = lambda t: t.detach().to("cpu", torch.float64).reshape(-1)  # noqa: E731
         if self.normalize:
             sm, ss = f64(self.state_mean), f64(self.state_std)

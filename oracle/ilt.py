@@ -26,13 +26,64 @@ import torch
 ILT_DEFAULTS = {
     "fourier": dict(alpha=1.0e-3, scale=2.0),
     "dehoog": dict(alpha=1.0e-10, scale=2.0),
+    # the two other closed-form algorithms torchlaplace offers (reference knob config.py:36 nl_ilt_algorithm): no
+    # abscissa parameters; nodes and weights restated from mpmath 1.3.0 calculus/inverselaplace.py (FixedTalbot :18-187,
+    # Stehfest :192-352), parity unpinned vs upstream like the rest of stage a9
+    "fixed_tablot": dict(alpha=0.0, scale=1.0),
+    "stehfest": dict(alpha=0.0, scale=1.0),
 }
+LINEAR_ALGOS = ("fixed_tablot", "stehfest")
+
+
+def talbot_tables(S):
+    """Fixed Talbot (Abate & Valko 2004) with M = S nodes, r = 2M/5 (mpmath FixedTalbot.calc_laplace_parameter):
+    s_k = delta_k / t,  delta_0 = r,  delta_k = r theta_k (cot theta_k + i),  theta_k = k pi / M;
+    x(t) = (1/t) Re sum_k W_k F(s_k),  W_0 = (2/5) e^{r} / 2,
+    W_k = (2/5) e^{delta_k} (1 + i theta_k (1 + cot^2 theta_k) - i cot theta_k)   (calc_time_domain_solution).
+    Returns (delta_re, delta_im, W_re, W_im), each (S,) float64."""
+    M = S
+    r = 2.0 * M / 5.0
+    k = torch.arange(M, dtype=torch.float64)
+    theta = k * math.pi / M
+    cot = torch.zeros(M, dtype=torch.float64)
+    cot[1:] = 1.0 / torch.tan(theta[1:])
+    d_re = r * theta * cot
+    d_im = r * theta
+    d_re[0], d_im[0] = r, 0.0
+    delta = torch.complex(d_re, d_im)
+    fac = torch.complex(torch.ones(M, dtype=torch.float64), theta * (1.0 + cot * cot) - cot)
+    W = 0.4 * torch.exp(delta) * fac
+    W[0] = 0.4 * math.exp(r) / 2.0
+    return d_re, d_im, W.real.clone(), W.imag.clone()
+
+
+def stehfest_tables(S):
+    """Gaver-Stehfest with M = S (even) real nodes s_k = k ln2 / t, k = 1..M, and Salzer weights V_k
+    (mpmath Stehfest._coeff): x(t) = (ln2 / t) sum_k V_k Re F(s_k).  Returns (node_re, node_im, W_re, W_im)."""
+    if S % 2 or S < 2:
+        raise ValueError("stehfest needs an even number of terms")
+    M, M2 = S, S // 2
+    V = []
+    for k in range(1, M + 1):
+        z = 0
+        for j in range((k + 1) // 2, min(k, M2) + 1):
+            z += (j**M2 * math.factorial(2 * j)) / (
+                math.factorial(M2 - j) * math.factorial(j) * math.factorial(j - 1) * math.factorial(k - j) * math.factorial(2 * j - k)
+            )
+        V.append((-1) ** (k + M2) * z)
+    V = torch.tensor(V, dtype=torch.float64)
+    node = torch.arange(1, M + 1, dtype=torch.float64) * math.log(2.0)
+    return node, torch.zeros(M, dtype=torch.float64), math.log(2.0) * V, torch.zeros(M, dtype=torch.float64)
+
+
+def linear_tables(algo, S):
+    return talbot_tables(S) if algo == "fixed_tablot" else stehfest_tables(S)
 
 
 def ilt_options(algo, options=None):
     """Resolve (alpha, tol, scale) for an algorithm; tol defaults to 10*alpha."""
     if algo not in ILT_DEFAULTS:
-        raise ValueError(f"unsupported ilt_algorithm {algo!r} (oracle restates 'fourier' and 'dehoog')")
+        raise ValueError(f"unsupported ilt_algorithm {algo!r} (oracle restates fourier, dehoog, fixed_tablot, stehfest)")
     o = dict(ILT_DEFAULTS[algo])
     if options:
         o.update(options)
@@ -143,6 +194,10 @@ def ilt_from_sphere(theta, phi, t, algo="fourier", options=None):
     """theta, phi: (N, d, S) rep-func outputs; t: (N,) -> x (N, d)."""
     alpha, tol, scale = ilt_options(algo, options)
     t = t.to(torch.float64)
+    if algo in LINEAR_ALGOS:
+        _, _, wr, wi = linear_tables(algo, theta.shape[-1])
+        fr, fi = sphere_to_complex(theta, phi)
+        return (fr * wr - fi * wi).sum(-1) / t.view(-1, 1)
     T = scale * t
     gamma = alpha - math.log(tol) / (scale * T)
     fr, fi = sphere_to_complex(theta, phi)
@@ -160,7 +215,11 @@ def rep_func_inputs(p, t, S, algo="fourier", options=None):
     if t.dim() == 0:
         t = t.view(1)
     t2 = t.view(1, -1).expand(B, -1) if t.dim() == 1 else t
-    sr, si, _, _ = query_points(t2, S, alpha, tol, scale)
+    if algo in LINEAR_ALGOS:
+        nr, ni, _, _ = linear_tables(algo, S)
+        sr, si = nr / t2.unsqueeze(-1), ni / t2.unsqueeze(-1)
+    else:
+        sr, si, _, _ = query_points(t2, S, alpha, tol, scale)
     th_s, ph_s = complex_to_sphere(sr, si)
     Tt = t2.shape[1]
     inp = torch.cat((th_s, ph_s, p.view(B, 1, -1).expand(B, Tt, p.shape[1])), dim=-1)

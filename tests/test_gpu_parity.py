@@ -851,6 +851,73 @@ def test_state_dim_4_planner(nlc):
     np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-8, atol=1e-9)
 
 
+@pytest.mark.parametrize("algo,S", [("fixed_tablot", 17), ("fixed_tablot", 33), ("fixed_tablot", 8), ("stehfest", 16), ("stehfest", 12)])
+def test_ilt_linear_algorithms_vs_oracle(nlc, algo, S):
+    """fixed_tablot / stehfest (the other closed-form values of the reference's nl_ilt_algorithm knob, config.py:36):
+    HIP rep-func inputs (query points on the algorithm's own contour, sphere projection) and HIP reconstruction vs the
+    oracle's restatement of mpmath's FixedTalbot / Stehfest, and a full laplace_reconstruct through a torch rep func."""
+    from oracle import ilt as oilt
+
+    torch.manual_seed(S)
+    N, d, P = 333, 3, 5
+    t = torch.rand(N, dtype=torch.float64) * 2 + 0.05
+    p = torch.randn(N, P, dtype=torch.float64)
+    ref_in, _ = oilt.rep_func_inputs(p, t.view(N, 1), S, algo)
+    got_in, _ = nlc.laplace.rep_func_inputs(p.cuda(), t.view(N, 1).cuda(), S, algo)
+    np.testing.assert_allclose(got_in.cpu().numpy(), ref_in.numpy(), rtol=1e-12, atol=1e-12)
+    theta = (torch.rand(N, d, S, dtype=torch.float64) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S, dtype=torch.float64) * 2 - 1) * np.pi / 2 * 0.9
+    ref = oilt.ilt_from_sphere(theta, phi, t, algo)
+    got = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), algo).cpu()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-9, atol=1e-11 * scale)
+    lin = torch.nn.Linear(2 * S + P, 2 * d * S).double()
+
+    def rep(i):
+        o = lin(i.reshape(-1, i.shape[-1])).view(-1, 2 * d, S)
+        return torch.tanh(o[:, :d]) * np.pi, torch.tanh(o[:, d:]) * np.pi / 2
+
+    with torch.no_grad():
+        ref2 = oilt.laplace_reconstruct(rep, p, t.view(N, 1), recon_dim=d, ilt_algorithm=algo, ilt_reconstruction_terms=S)
+        lin = lin.cuda()
+        got2 = nlc.laplace_reconstruct(rep, p.cuda(), t.view(N, 1).cuda(), recon_dim=d, ilt_algorithm=algo,
+                                       ilt_reconstruction_terms=S).cpu()
+    scale2 = float(ref2.abs().max())
+    np.testing.assert_allclose(got2.numpy(), ref2.numpy(), rtol=1e-8, atol=1e-10 * scale2)
+
+
+def test_model_with_linear_ilt_and_cme_constructor(nlc):
+    """A NeuralLaplaceModel configured with fixed_tablot runs (HIP GRU -> torch rep func -> HIP ILT) and plans on the
+    generic path; with "cme" the constructor snaps the term count like the reference (w_nl.py:86-88) and the forward
+    says why the method cannot run here."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-pendulum"]
+    d, nu, S = st["d"], st["nu"], 17
+    sd = onl.make_synthetic_state_dict(3, d, nu, 128, S, st["state_std"], [1.0], tame=True)
+    model = build_model(nlc, sd, S=S, algo="fixed_tablot")
+    torch.manual_seed(2)
+    obs, win = torch.randn(21, d, dtype=torch.float64), torch.randn(21, 4, nu, dtype=torch.float64)
+    ts = torch.full((21, 1), 0.05, dtype=torch.float64)
+    ref = onl.nl_forward(sd, obs, win, ts, S=S, ilt_algorithm="fixed_tablot")
+    with torch.no_grad():
+        got = model(obs.cuda(), win.cuda(), ts.cuda()).cpu()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy(), ref.numpy().reshape(got.shape), rtol=1e-7, atol=1e-9 * scale)
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-pendulum"), d, nlc.noise_sigma(nu), 64, 3, "cpu",
+                         lambda_=1.0, u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), u_scale=2.0)
+    assert not mppi.fused_dynamics  # generic path: the model's forward is the dynamics callable
+    with torch.no_grad():
+        act = mppi.command(nlc.initial_state("oderl-pendulum"), torch.zeros(4, nu, dtype=torch.float64))
+    assert torch.isfinite(act).all()
+    cme = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=33, ilt_algorithm="cme", state_mean=np.zeros(d),
+                                 state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]))
+    assert cme.s_recon_terms == 31 and cme.laplace_rep_func.linear_tanh_stack[4].out_features == 2 * d * 31
+    with pytest.raises(NotImplementedError, match="cme"):
+        with torch.no_grad():
+            cme.double().cuda()(obs.cuda(), win.cuda(), ts.cuda())
+
+
 def test_error_paths_raise(nlc):
     from neurallaplacecontrol_amd import _lib
 

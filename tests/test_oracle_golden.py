@@ -382,3 +382,48 @@ def test_g11_node_oracle_matches_reference_classes(env, golden_dir):
     for k, v in sd.items():
         if k.startswith("x_ode_func") or k in ("dt", "state_std", "action_std"):
             np.testing.assert_allclose(mine[k].numpy(), v.numpy(), rtol=1e-15, atol=0, err_msg=k)
+
+
+def test_cme_term_table_and_snapping_vs_reference_golden(golden_dir):
+    """G12: the product's generated CME order table and its constructor term snapping (nl_model.cme_reconstruction_terms,
+    _cme_terms) against the reference's config.CME_reconstruction_terms() / w_nl.py:86-88 expression."""
+    from neurallaplacecontrol_amd import nl_model
+
+    g = np.load(os.path.join(golden_dir, "g12_cme_terms.npz"))
+    assert np.array_equal(nl_model.cme_reconstruction_terms(), g["terms"])
+    got = np.array([nl_model._cme_terms(int(s)) for s in g["requested"]])
+    assert np.array_equal(got, g["snapped"])
+
+
+@pytest.mark.parametrize("algo,S,tol", [("fixed_tablot", 17, 1e-9), ("fixed_tablot", 33, 5e-6), ("stehfest", 16, 1e-3), ("stehfest", 12, 1e-3)])
+def test_oracle_linear_ilt_algorithms_known_answers(algo, S, tol):
+    """Fixed Talbot / Stehfest (restated from mpmath FixedTalbot / Stehfest) on analytic Laplace pairs, and against
+    mpmath.invertlaplace itself run at a working precision that makes its own rounding negligible."""
+    import mpmath
+
+    from oracle import ilt as oilt
+
+    t = torch.tensor([0.125, 0.4, 1.1, 2.0], dtype=torch.float64)
+    nr, ni, _, _ = oilt.linear_tables(algo, S)
+    s = torch.complex(nr, ni).view(1, -1) / t.view(-1, 1)
+    pairs = [(lambda z: 1.0 / (z + 1.5), lambda tt: torch.exp(-1.5 * tt)),
+             (lambda z: 1.0 / z**2, lambda tt: tt),
+             (lambda z: (z + 0.3) / ((z + 0.3) ** 2 + 4.0), lambda tt: torch.exp(-0.3 * tt) * torch.cos(2.0 * tt))]
+    # (Stehfest: one well-scaled, non-oscillating transform -- its Salzer weights reach 1e8 and amplify the rounding of
+    # the sphere round trip of a small |F|)
+    for F, f in pairs[: 3 if algo == "fixed_tablot" else 1]:
+        Fs = F(s)
+        th, ph = oilt.complex_to_sphere(Fs.real, Fs.imag)
+        x = oilt.ilt_from_sphere(th.unsqueeze(1), ph.unsqueeze(1), t, algo).squeeze(1)
+        np.testing.assert_allclose(x.numpy(), f(t).numpy(), rtol=tol, atol=tol)
+    mpmath.mp.dps = 60
+    method = "talbot" if algo == "fixed_tablot" else "stehfest"
+    Fs = 1.0 / (s + 1.5)
+    th, ph = oilt.complex_to_sphere(Fs.real, Fs.imag)
+    x = oilt.ilt_from_sphere(th.unsqueeze(1), ph.unsqueeze(1), t, algo).squeeze(1)
+    for i, tt in enumerate(t.tolist()):
+        ilt = (mpmath.calculus.inverselaplace.FixedTalbot if algo == "fixed_tablot" else mpmath.calculus.inverselaplace.Stehfest)(mpmath.mp)
+        ilt.calc_laplace_parameter(tt, degree=S)
+        ref = ilt.calc_time_domain_solution([1 / (p + mpmath.mpf(1.5)) for p in ilt.p], tt, manual_prec=True)
+        mpmath.mp.dps = 60
+        assert abs(float(ref) - float(x[i])) <= tol * 10 * max(1.0, abs(float(ref))), (algo, S, tt, float(ref), float(x[i]))
