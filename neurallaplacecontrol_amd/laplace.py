@@ -117,11 +117,50 @@ class _IltFn(torch.autograd.Function):
         return g_theta, g_phi, None, None, None
 
 
+def _dehoog_autograd(theta, phi, t, desc):
+    """de Hoog reconstruction as differentiable PyTorch-ROCm tensor ops (complex128), used ONLY when theta / phi require
+    grad: the reference trains the representation function through whatever ilt_algorithm is configured
+    (train_utils.py:388-407 -> w_nl.py:137-144), and reverse mode through the O(M^2) quotient-difference table is the
+    training path, not the planning hot path (the no-grad forward is the HIP kernel ilt_dehoog_kernel).
+    Same recurrences as that kernel: mpmath 1.3.0 calculus/inverselaplace.py:476-531."""
+    import math
+
+    S = theta.shape[-1]
+    M = (S - 1) // 2
+    t = t.to(torch.float64).view(-1, 1)
+    T = desc.scale * t
+    gamma = desc.alpha - math.log(desc.tol) / (desc.scale * T)
+    r = torch.tan(phi / 2.0 + math.pi / 4.0)
+    fp = torch.complex(r * torch.cos(theta), r * torch.sin(theta))  # (N, d, S)
+    a = [fp[..., 0] / 2.0] + [fp[..., i] for i in range(1, S)]
+    q = [a[i + 1] / a[i] for i in range(2 * M)]       # column r = 1
+    e = [torch.zeros_like(a[0]) for _ in range(S)]    # column r = 0
+    d = [a[0], -q[0]]
+    for rr in range(1, M + 1):
+        mr = 2 * (M - rr) + 1
+        e = [q[i + 1] - q[i] + e[i + 1] for i in range(mr)]
+        d.append(-e[0])
+        if rr != M:
+            q = [q[i + 1] * e[i + 1] / e[i] for i in range(mr - 1)]
+            d.append(-q[0])
+    ang = math.pi * (t / T)
+    z = torch.complex(torch.cos(ang), torch.sin(ang))
+    A_prev, A_cur = torch.zeros_like(d[0]), d[0]
+    B_prev, B_cur = torch.ones_like(d[0]), torch.ones_like(d[0])
+    for i in range(1, 2 * M):
+        A_prev, A_cur = A_cur, A_cur + d[i] * A_prev * z
+        B_prev, B_cur = B_cur, B_cur + d[i] * B_prev * z
+    brem = (1.0 + (d[2 * M - 1] - d[2 * M]) * z) / 2.0
+    rem = brem * (torch.sqrt(1.0 + d[2 * M] * z / brem) - 1.0)
+    res = (A_cur + rem * A_prev) / (B_cur + rem * B_prev)
+    return torch.exp(gamma * t) / T * res.real
+
+
 def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=None):
     """theta, phi: (N, d, S) representation-function outputs, t: (N,) -> x (N, d).
 
-    Differentiable with respect to theta / phi for the Fourier algorithm (HIP backward kernel); with de Hoog the
-    inputs must not require grad."""
+    Differentiable with respect to theta / phi: Fourier through the HIP backward kernel, de Hoog through PyTorch-ROCm
+    tensor ops (training path only; the no-grad forward is the HIP kernel)."""
     dev = compute_device(theta, phi, t)
     needs_grad = torch.is_grad_enabled() and (
         (torch.is_tensor(theta) and theta.requires_grad) or (torch.is_tensor(phi) and phi.requires_grad)
@@ -135,8 +174,11 @@ def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=No
     desc = _lib.ilt_desc(ilt_algorithm, S, options)
     ctx = ctx or default_ctx(dev.index)
     if needs_grad:
+        if desc.algo == 1:
+            return _dehoog_autograd(theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc)
         if desc.algo != 0:
-            raise NotImplementedError("autograd through the HIP ILT is implemented for ilt_algorithm='fourier' only")
+            raise NotImplementedError("autograd through the ILT is implemented for ilt_algorithm 'fourier' (HIP backward "
+                                      "kernel) and 'dehoog' (PyTorch-ROCm tensor ops)")
         return _IltFn.apply(
             theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc, ctx
         )

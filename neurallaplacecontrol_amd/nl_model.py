@@ -290,8 +290,8 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
         """Grad-mode forward (the reference trains through ``model(...)``, ``train_utils.py:388-407``): the op sequence of
         ``w_nl.py:117-145`` with the GRU encoder and the representation MLP on PyTorch-ROCm (their backward is
         autograd's) and the line integral in HIP, forward AND backward (``nlc_ilt_reconstruct_backward``)."""
-        if self.ilt_algorithm != "fourier":
-            raise NotImplementedError("training through the HIP ILT is implemented for ilt_algorithm='fourier' only")
+        if self.ilt_algorithm not in ("fourier", "dehoog"):
+            raise NotImplementedError("training through the ILT is implemented for ilt_algorithm 'fourier' and 'dehoog'")
         dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
         if next(self.parameters()).device != dev:
             raise RuntimeError("training forward: move the model to the GPU first (model.to('cuda'))")

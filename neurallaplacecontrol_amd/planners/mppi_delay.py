@@ -117,8 +117,8 @@ class MPPIDelay:
         self.noise_dist = MultivariateNormal(self.noise_mu, covariance_matrix=self.noise_sigma)
         self.u_init = u_init.to(self.d)
 
-        if rollout_samples != 1 or rollout_var_cost != 0:
-            raise NotImplementedError("rollout_samples > 1 / rollout_var_cost are not implemented on the HIP planner")
+        if rollout_samples < 1:
+            raise ValueError("rollout_samples must be >= 1")
         self.M = rollout_samples
         self.rollout_var_cost = rollout_var_cost
         self.rollout_var_discount = rollout_var_discount
@@ -167,6 +167,17 @@ class MPPIDelay:
         self.cost_external = self.fused_dynamics and not self.fused
         if self.cost_external:
             self.store_rollouts = True  # the cost callables read the stored states
+        if self.M > 1:
+            # rollout_samples M > 1 (reference :291-292, 310).  The reference never replicates the state M times: its M
+            # cost rows are copies and ``c.var(dim=0)`` is the variance of the running cost OVER THE K SAMPLES, one number
+            # per horizon step -- every sample's cost gets the same rollout_var_cost * sum_t var_t * discount^t.  Softmax
+            # weights, U and the action do not see a constant shift; it is added to .cost_total after the command, from
+            # the stored rollout.
+            if process_group is not None:
+                raise NotImplementedError("rollout_samples > 1 with a K-sharded planner (the variance is over the whole population)")
+            if int(getattr(self, "E", 1)) > 1:
+                raise NotImplementedError("rollout_samples > 1 with BatchedMPPIDelay")
+            self.store_rollouts = True
         if isinstance(dynamics, OracleDynamics) and not self.fused_dynamics:
             raise NotImplementedError("OracleDynamics needs the default rollout options (no step-dependent dynamics)")
 
@@ -390,6 +401,8 @@ class MPPIDelay:
                 ctx.check(
                     lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act))
                 )
+            if self.M > 1 and self.rollout_var_cost != 0 and self.fused_dynamics:
+                self._add_rollout_var_cost()
         action = act.view(self.u_per_command, self.nu)
         if self.u_per_command == 1:
             action = action[0]
@@ -401,6 +414,15 @@ class MPPIDelay:
 
     def _running_cost(self, state, u):
         return self.running_cost(state, u)
+
+    def _add_rollout_var_cost(self):
+        """cost_total += rollout_var_cost * sum_t Var_k[c_t] * discount^t (reference :291-292, 310; see __init__)."""
+        A = self.u_scale * self._perturbed
+        var = torch.zeros((), dtype=torch.float64, device=self.cd)
+        for t in range(self.T):
+            c = self._running_cost(self._states[:, t], A[:, t])
+            var = var + c.var(dim=0) * (self.rollout_var_discount**t)
+        self._cost_total += var * self.rollout_var_cost
 
     def _external_cost(self):
         """cost_external: the fused rollout left the states (K, T, nx) and the perturbation cost (:343-344) on the
@@ -421,6 +443,7 @@ class MPPIDelay:
         window = ab.shape[0]
         time_buffer = ab[:, nu:].clone() if self.encode_obs_time else None
         cost = torch.zeros(K, dtype=torch.float64, device=dev)
+        cost_var = torch.zeros(K, dtype=torch.float64, device=dev)
         states, actions = [], []
         for t in range(T):
             win = hist[:, t : t + window, :]
@@ -432,13 +455,17 @@ class MPPIDelay:
                 win = torch.cat((win, time_buffer.view(1, -1, 1).repeat(K, 1, 1)), dim=2)
             x = self._dynamics(x, win, t)
             u = hist[:, t + window - 1, :]
-            cost = cost + self._running_cost(x, u)
+            c = self._running_cost(x, u)
+            cost = cost + c
+            if self.M > 1:
+                cost_var = cost_var + c.var(dim=0) * (self.rollout_var_discount**t)
             states.append(x)
             actions.append(u)
         actions = torch.stack(actions, dim=-2)
         states = torch.stack(states, dim=-2)
         if self.terminal_state_cost:
             cost = cost + self.terminal_state_cost(states, actions)
+        cost = cost + cost_var * self.rollout_var_cost  # reference :310
         # action perturbation cost (reference :329-344)
         Ud = self.U.to(dev)
         sig_inv = self.noise_sigma_inv.to(dev)

@@ -24,21 +24,30 @@ def perturb(U, noise, u_scale, u_min, u_max, sample_null_action=False):
     return V, V - U
 
 
-def rollout(state, action_buffer, V, u_scale, dynamics, running_cost, nx):
-    """:232-313 with M=1, encode_obs_time=False (the terminal cost is added by the caller)."""
+def rollout(state, action_buffer, V, u_scale, dynamics, running_cost, nx, rollout_samples=1, rollout_var_cost=0.0,
+            rollout_var_discount=0.95):
+    """:232-313, encode_obs_time=False (the terminal cost is added by the caller).
+    rollout_samples M > 1 (:291-292, 310): the reference does NOT replicate the state M times -- its cost_samples rows are
+    M copies of the same running cost, and ``c.var(dim=0)`` of the (K,) cost vector is the (unbiased) variance OVER THE K
+    SAMPLES, one number per horizon step: every sample's cost gets the same rollout_var_cost * sum_t var_t discount^t."""
     K, T, nu = V.shape
     B = action_buffer.shape[0]
     x = state if state.shape == (K, nx) else state.view(1, -1).repeat(K, 1)
     A = u_scale * V
     hist = torch.cat((action_buffer[1:].view(1, -1, nu).repeat(K, 1, 1), A), dim=1)
     cost = torch.zeros(K, dtype=V.dtype)
+    cost_var = torch.zeros(K, dtype=V.dtype)
     states, actions = [], []
     for t in range(T):
         x = dynamics(x, hist[:, t : t + B, :])
         u = hist[:, t + B - 1, :]
-        cost = cost + running_cost(x, u)
+        c = running_cost(x, u)
+        cost = cost + c
+        if rollout_samples > 1:
+            cost_var = cost_var + c.var(dim=0) * (rollout_var_discount**t)
         states.append(x)
         actions.append(u)
+    cost = cost + cost_var * rollout_var_cost
     return cost, torch.stack(states, dim=-2), torch.stack(actions, dim=-2)
 
 
@@ -60,6 +69,9 @@ def mppi_command(
     noise_abs_cost=False,
     u_per_command=1,
     terminal_state_cost=None,
+    rollout_samples=1,
+    rollout_var_cost=0.0,
+    rollout_var_discount=0.95,
 ):
     """One ``command()`` given the noise draw; returns a dict of every public output."""
     U = torch.roll(U, -1, dims=0)
@@ -69,7 +81,8 @@ def mppi_command(
         action_cost = lambda_ * torch.abs(eps) @ noise_sigma_inv
     else:
         action_cost = lambda_ * eps @ noise_sigma_inv
-    cost, states, actions = rollout(state, action_buffer, V, u_scale, dynamics, running_cost, nx)
+    cost, states, actions = rollout(state, action_buffer, V, u_scale, dynamics, running_cost, nx, rollout_samples,
+                                    rollout_var_cost, rollout_var_discount)
     if terminal_state_cost is not None:  # :306-308, called with the (K,T,nx) states and the scaled (K,T,nu) actions
         cost = cost + terminal_state_cost(states, actions)
     actions = actions / u_scale

@@ -29,6 +29,8 @@ Fixtures:
   g8_cost_variants.npz        cartpole, reference MPPIDelay with the harness running_cost's non-default branches
                               (state_constraint / change_goal / change_goal_flipped, mppi_with_model.py:146-162) evaluated
                               by the REAL env class, NL and oracle dynamics, plus a terminal_state_cost
+  g13_rollout_samples_<env>.npz  reference MPPIDelay(rollout_samples=3, rollout_var_cost=0.7, rollout_var_discount=0.9),
+                              oracle dynamics, two commands (mppi_delay.py:291-292, 310)
   g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
                               constant time channel B-1..0 (mppi_with_model.py:110-119) + reference MPPIDelay
 """
@@ -562,8 +564,47 @@ def make_g4():
     print("g4 done")
 
 
+def make_g13(MPPIDelay, envs, dyn):
+    """rollout_samples M > 1 with a rollout_var_cost (mppi_delay.py:291-292, 310): pendulum and acrobot, oracle dynamics,
+    two consecutive commands.  (The reference does NOT replicate the state M times, so the variance it adds is the
+    variance of the running cost OVER THE K SAMPLES -- one number per horizon step, the same for every sample.)"""
+    from functools import partial
+
+    K, T, B = 96, 7, 4
+    for env_name in ("oderl-pendulum", "oderl-acrobot"):
+        env = envs[env_name]()
+        nx, nu, A = oenvs.OBS_DIM[env_name], oenvs.ACT_DIM[env_name], oenvs.ACTION_HIGH[env_name]
+
+        def running_cost(state, action, env=env):
+            return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+        torch.manual_seed(1300)
+        dynamics = partial(dyn[env_name], ts=torch.full((K, 1), 0.05, dtype=torch.double), delay=1, friction=False)
+        mppi = MPPIDelay(dynamics, running_cost, nx, noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                         u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, rollout_samples=3, rollout_var_cost=0.7,
+                         rollout_var_discount=0.9)
+        state = oenvs.initial_state(env_name, seed=5)
+        action_buffer = (torch.rand(B, nu, dtype=torch.double) - 0.5) * A
+        out = {}
+        for step in range(2):
+            c = capture_command(mppi, state.numpy(), action_buffer)
+            for k, v in c.items():
+                out[f"s{step}_{k}"] = v
+            out[f"s{step}_state"] = np_(state)
+            out[f"s{step}_action_buffer"] = np_(action_buffer)
+            state = mppi.states[0, 0].clone()
+            action_buffer = torch.roll(action_buffer, -1, dims=0)
+            action_buffer[-1] = torch.as_tensor(c["action"])
+        np.savez_compressed(f"{HERE}/g13_rollout_samples_{env_name.split('-')[1]}.npz", K=K, T=T, B=B, delay=1, nx=nx, nu=nu,
+                            A=A, M=3, var_cost=0.7, var_discount=0.9, **out)
+        print("g13", env_name, "action", out["s1_action"])
+
+
 def main():
     MPPIDelay, w_nl, envs, dyn = load_reference_modules()
+    if os.environ.get("NLC_GOLDEN_ONLY") == "g13":
+        make_g13(MPPIDelay, envs, dyn)
+        return
     make_g1(MPPIDelay, envs, dyn)
     make_g2_g3(MPPIDelay, w_nl, envs)
     make_g4()
@@ -571,6 +612,7 @@ def main():
     make_g6(MPPIDelay, w_nl, envs)
     make_g8(MPPIDelay, w_nl, envs, dyn)
     make_g7(MPPIDelay, w_nl, envs, only=os.environ.get("NLC_G7_ONLY", "cfg1,cfg3,cfg4").split(","))
+    make_g13(MPPIDelay, envs, dyn)
 
 
 if __name__ == "__main__":

@@ -140,10 +140,10 @@ def test_laplace_reconstruct_trains_rep_func_through_hip_ilt(nlc):
     for a, b in zip((lin_d.weight.grad, lin_d.bias.grad, p_d.grad), ref_grads):
         sc = float(b.abs().max())
         np.testing.assert_allclose(a.cpu().numpy() / sc, b.numpy() / sc, rtol=1e-8, atol=1e-11)
-    with pytest.raises(NotImplementedError):
-        nlc.ilt_reconstruct(torch.zeros(2, 1, 17, dtype=torch.float64, device="cuda", requires_grad=True),
-                            torch.zeros(2, 1, 17, dtype=torch.float64, device="cuda"),
-                            torch.full((2,), 0.1, dtype=torch.float64, device="cuda"), "dehoog")
+    with pytest.raises(NotImplementedError):  # no reverse mode for the two linear algorithms
+        nlc.ilt_reconstruct(torch.zeros(2, 1, 16, dtype=torch.float64, device="cuda", requires_grad=True),
+                            torch.zeros(2, 1, 16, dtype=torch.float64, device="cuda"),
+                            torch.full((2,), 0.1, dtype=torch.float64, device="cuda"), "stehfest")
 
 
 def test_ilt_fourier_full_bench_size_vs_oracle(nlc):
@@ -918,6 +918,70 @@ def test_model_with_linear_ilt_and_cme_constructor(nlc):
             cme.double().cuda()(obs.cuda(), win.cuda(), ts.cuda())
 
 
+@pytest.mark.parametrize("env", ["pendulum", "acrobot"])
+def test_rollout_samples_vs_reference_golden(nlc, env):
+    """G13: rollout_samples = 3 with a rollout_var_cost (mppi_delay.py:291-292, 310) vs the REAL reference planner, on
+    the fused oracle-dynamics rollout and on the generic callable path."""
+    from oracle import envs as oenvs
+
+    g = np.load(f"{GOLD}/g13_rollout_samples_{env}.npz")
+    name = "oderl-" + env
+    d, nu, K, T, A, delay = int(g["nx"]), int(g["nu"]), int(g["K"]), int(g["T"]), float(g["A"]), int(g["delay"])
+    kw = dict(rollout_samples=int(g["M"]), rollout_var_cost=float(g["var_cost"]), rollout_var_discount=float(g["var_discount"]))
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64, device="cuda")
+
+    def make(U0, fused=True):
+        if fused:
+            dyn, cost = nlc.OracleDynamics(name, 0.05, delay), nlc.EnvCost(name)
+        else:
+            dyn = lambda s, w: oenvs.ORACLE_DYNAMICS[name](s, w, ts, delay)  # noqa: E731  (torch ops on the device)
+            cost = lambda s, u: nlc.EnvCost(name)(s, u)  # noqa: E731
+        p = nlc.MPPIDelay(dyn, cost, d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0, **kw)
+        assert p.fused == fused
+        return p
+
+    check_command_steps(nlc, g, make)
+    check_command_steps(nlc, g, lambda U0: make(U0, fused=False))
+
+
+def test_dehoog_autograd_path(nlc):
+    """Training through a de Hoog model (the reference trains through whatever ilt_algorithm is configured,
+    train_utils.py:388-407): with grad-requiring theta / phi ilt_reconstruct runs the de Hoog recurrences as PyTorch-ROCm
+    tensor ops.  Its forward must equal the HIP kernel's and the oracle's; its reverse-mode gradient must be consistent
+    with forward mode (<g, J v> = <J^T g, v>) -- finite differences cannot resolve the QD table's conditioning."""
+    import torch.autograd.forward_ad as fwAD
+
+    from oracle import ilt as oilt
+
+    torch.manual_seed(5)
+    N, d, S = 40, 3, 17
+    t = torch.rand(N, dtype=torch.float64) * 2 + 0.05
+    alpha, tol, scale = oilt.ilt_options("dehoog")
+    sr, si, _, _ = oilt.query_points(t, S, alpha, tol, scale)
+    s = torch.complex(sr, si).unsqueeze(1)
+    a = torch.rand(N, d, 1, dtype=torch.float64) + 0.5
+    F = 1.0 / (s + a)
+    theta, phi = oilt.complex_to_sphere(F.real, F.imag)
+    ref = oilt.ilt_from_sphere(theta, phi, t, "dehoog")
+    hip = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), "dehoog")
+    th, ph = theta.cuda().requires_grad_(), phi.cuda().requires_grad_()
+    x = nlc.ilt_reconstruct(th, ph, t.cuda(), "dehoog")
+    assert x.requires_grad
+    np.testing.assert_allclose(x.detach().cpu().numpy(), ref.numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), hip.cpu().numpy(), rtol=1e-7, atol=1e-9)
+    g = torch.randn_like(x)
+    gth, gph = torch.autograd.grad(x, (th, ph), g)
+    assert torch.isfinite(gth).all() and torch.isfinite(gph).all()
+    vth, vph = torch.randn_like(gth), torch.randn_like(gph)
+    with fwAD.dual_level():
+        xd = nlc.laplace._dehoog_autograd(fwAD.make_dual(theta.cuda(), vth), fwAD.make_dual(phi.cuda(), vph), t.cuda(),
+                                          nlc._lib.ilt_desc("dehoog", S))
+        jv = fwAD.unpack_dual(xd).tangent
+    lhs, rhs = float((g * jv).sum()), float((gth * vth).sum() + (gph * vph).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)  # (the two modes round the QD table differently)
+
+
 def test_error_paths_raise(nlc):
     from neurallaplacecontrol_amd import _lib
 
@@ -931,9 +995,6 @@ def test_error_paths_raise(nlc):
     with pytest.raises(ValueError):
         nlc.ilt_reconstruct(torch.zeros(2, 1, 17).double().cuda(), torch.zeros(2, 2, 17).double().cuda(),
                             torch.ones(2).double().cuda())
-    with pytest.raises(NotImplementedError):
-        nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum"), nlc.EnvCost("oderl-pendulum"), 3, nlc.noise_sigma(1), 8, 4,
-                      rollout_samples=3)
     with pytest.raises(_lib.NlcError):  # nx does not match the env
         m = nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum"), nlc.EnvCost("oderl-pendulum"), 5, nlc.noise_sigma(1), 8, 4)
         m.command(torch.zeros(5).double(), torch.zeros(4, 1).double())

@@ -427,3 +427,26 @@ def test_oracle_linear_ilt_algorithms_known_answers(algo, S, tol):
         ref = ilt.calc_time_domain_solution([1 / (p + mpmath.mpf(1.5)) for p in ilt.p], tt, manual_prec=True)
         mpmath.mp.dps = 60
         assert abs(float(ref) - float(x[i])) <= tol * 10 * max(1.0, abs(float(ref))), (algo, S, tt, float(ref), float(x[i]))
+
+
+@pytest.mark.parametrize("env", ["pendulum", "acrobot"])
+def test_g13_rollout_samples_vs_reference(env, golden_dir):
+    """G13: oracle MPPI with rollout_samples = 3 and a rollout_var_cost vs the REAL reference planner (mppi_delay.py:291-292,
+    310): the variance term is one constant per command, so costs shift and weights / U / action do not."""
+    g = np.load(f"{golden_dir}/g13_rollout_samples_{env}.npz")
+    name = "oderl-" + env
+    nx, nu, A, delay = int(g["nx"]), int(g["nu"]), float(g["A"]), int(g["delay"])
+    K = int(g["K"])
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    dyn = lambda s, w: oenvs.ORACLE_DYNAMICS[name](s, w, ts, delay)  # noqa: E731
+    for step in range(2):
+        pre = f"s{step}_"
+        out = omppi.mppi_command(
+            T(g[pre + "U_before"]), T(g[pre + "state"]), T(g[pre + "action_buffer"]), T(g[pre + "noise_raw"]), dyn,
+            oenvs.RUNNING_COST[name], nx, sigma_inv(nu), 1.0, A, torch.tensor(-A), torch.tensor(A),
+            rollout_samples=int(g["M"]), rollout_var_cost=float(g["var_cost"]), rollout_var_discount=float(g["var_discount"]),
+        )
+        np.testing.assert_allclose(out["cost_total"].numpy(), g[pre + "cost_total"], **TOL)
+        np.testing.assert_allclose(out["omega"].numpy(), g[pre + "omega"], **TOL)
+        np.testing.assert_allclose(out["U"].numpy(), g[pre + "U_after"], **TOL)
+        np.testing.assert_allclose(out["action"].numpy(), g[pre + "action"], **TOL)
