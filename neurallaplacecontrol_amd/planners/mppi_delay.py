@@ -30,7 +30,7 @@ from torch.distributions.multivariate_normal import MultivariateNormal
 
 from .. import _lib
 from ..envs import EnvCost, NLDynamics, OracleDynamics
-from ..sharding import gather_partials, shard_range, slice_noise
+from ..sharding import check_same_on_all_ranks, gather_partials, replicate_from_rank0, shard_range, slice_noise
 
 
 def _per_dim(v, nu, name):
@@ -210,6 +210,9 @@ class MPPIDelay:
         self._noise = self._perturbed = self._states = self._actions = None
         self._cost_total = self._cost_nz = self._omega = None
 
+        if self.pg is not None and self.G > 1:
+            check_same_on_all_ranks((self.K, self.T, self.nu, self.seed, int(self.noise_rng == "philox")), self.pg,
+                                    "num_samples / horizon / nu / seed / noise_rng", self.cd)
         # T x nu control sequence; defaults to a noise draw (consumes the RNG like the reference :161-164)
         self.U = U_init if U_init is not None else self.noise_dist.sample(self._lead(self.T))
 
@@ -315,6 +318,9 @@ class MPPIDelay:
     @U.setter
     def U(self, value):
         value = torch.as_tensor(value).detach().to(dtype=torch.float64).reshape(self._lead(self.T, self.nu)).clone()
+        if self.pg is not None and self.G > 1:
+            # every rank applies the same update to its OWN copy of U: start them from rank 0's value
+            value = replicate_from_rank0(value, self.pg, self.cd)
         if self._buf is None:
             self._pending_U = value
         else:

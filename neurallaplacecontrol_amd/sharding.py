@@ -37,3 +37,33 @@ def slice_noise(raw, k_offset, k_local):
     """Every rank draws the SAME (K, T, nu) tensor from the same seed and keeps its slice, so the sharded
     run consumes the torch generator exactly like the single-GPU / reference run."""
     return raw[k_offset : k_offset + k_local]
+
+
+def replicate_from_rank0(t, group, compute_device=None):
+    """Every rank of a K-sharded planner must hold the SAME control sequence U (merge_kernel applies the same update to
+    each rank's own copy): U is drawn by the host RNG in the constructor / reset(), so instead of trusting identical
+    seeds the value of rank 0 is broadcast.  Returns a tensor like `t` (host float64)."""
+    import torch.distributed as dist
+
+    out = t.detach().to("cpu", torch.float64).contiguous().clone()
+    if dist.get_backend(group) == "gloo" or compute_device is None:
+        dist.broadcast(out, src=dist.get_global_rank(group, 0), group=group)
+        return out
+    dev = out.to(compute_device)  # RCCL moves device memory
+    dist.broadcast(dev, src=dist.get_global_rank(group, 0), group=group)
+    return dev.cpu()
+
+
+def check_same_on_all_ranks(values, group, what, compute_device=None):
+    """Raise if a small tuple of numbers (seeds, sizes) differs between the ranks of `group`."""
+    import torch.distributed as dist
+
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    G = dist.get_world_size(group)
+    if dist.get_backend(group) != "gloo" and compute_device is not None:
+        mine = mine.to(compute_device)
+    allv = torch.empty(G * mine.numel(), dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(allv, mine, group=group)
+    allv = allv.view(G, -1).cpu()
+    if not bool((allv == allv[0]).all()):
+        raise ValueError(f"K-sharded planner: {what} differ between ranks: {allv.tolist()}")

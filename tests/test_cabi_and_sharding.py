@@ -112,13 +112,25 @@ def test_bench_weights_equal_oracle_synthetic_weights():
 WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from neurallaplacecontrol_amd.sharding import shard_range, gather_partials, slice_noise, partial_width
+from neurallaplacecontrol_amd.sharding import (shard_range, gather_partials, slice_noise, partial_width,
+                                               replicate_from_rank0, check_same_on_all_ranks)
 from oracle import envs as oenvs, mppi as omppi
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 env, K, T, A, nu, nx = "oderl-pendulum", 64, 6, 2.0, 1, 3
+# ranks that drew DIFFERENT control sequences (badly seeded hosts) are brought to rank 0's; mismatching seeds raise
+torch.manual_seed(1000 + rank)
+U_own = torch.randn(T, nu, dtype=torch.float64) * 0.3
+U = replicate_from_rank0(U_own, dist.group.WORLD)
+assert (rank == 0) == bool(torch.equal(U, U_own))
+check_same_on_all_ranks((K, T, 7), dist.group.WORLD, "sizes / seed")
+try:
+    check_same_on_all_ranks((K, T, 7 + rank), dist.group.WORLD, "sizes / seed")
+    raise SystemExit("seed mismatch not detected")
+except ValueError:
+    pass
 torch.manual_seed(123)                     # same seed on every rank -> same global draw
-U = torch.randn(T, nu, dtype=torch.float64) * 0.3
+torch.randn(T, nu, dtype=torch.float64)    # (keeps the draw order of the unsharded reference run below: U, then the noise)
 raw = torch.randn(K, T, nu, dtype=torch.float64)
 state, ab = oenvs.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
 sig_inv = torch.ones(1, 1, dtype=torch.float64)
@@ -156,8 +168,10 @@ def test_two_rank_gloo_sharded_command(tmp_path):
     assert torch.equal(r0["U"], r1["U"]), "ranks disagree after the merge"
     # unsharded reference
     envn, K, T, A, nu, nx = "oderl-pendulum", 64, 6, 2.0, 1, 3
-    torch.manual_seed(123)
+    torch.manual_seed(1000)  # the workers end up with RANK 0's control sequence (replicate_from_rank0)
     U = torch.randn(T, nu, dtype=torch.float64) * 0.3
+    torch.manual_seed(123)
+    torch.randn(T, nu, dtype=torch.float64)
     raw = torch.randn(K, T, nu, dtype=torch.float64)
     ts = torch.full((K, 1), 0.05, dtype=torch.float64)
     full = omppi.mppi_command(U.clone(), oenvs.initial_state(envn), torch.zeros(4, nu, dtype=torch.float64), raw,
