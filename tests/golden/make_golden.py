@@ -29,6 +29,8 @@ Fixtures:
   g8_cost_variants.npz        cartpole, reference MPPIDelay with the harness running_cost's non-default branches
                               (state_constraint / change_goal / change_goal_flipped, mppi_with_model.py:146-162) evaluated
                               by the REAL env class, NL and oracle dynamics, plus a terminal_state_cost
+  g14_width_h<h>_<env>.npz    other hidden widths with the real reference classes: hidden_units 64 (class default, 33 terms)
+                              and 256: GRU encoder, representation module, forward, two MPPIDelay commands
   g13_rollout_samples_<env>.npz  reference MPPIDelay(rollout_samples=3, rollout_var_cost=0.7, rollout_var_discount=0.9),
                               oracle dynamics, two commands (mppi_delay.py:291-292, 310)
   g5_nl_obs_time_<env>.npz    encode_obs_time NL model (GRU input nu+1) behind the harness closure that appends the
@@ -564,6 +566,61 @@ def make_g4():
     print("g4 done")
 
 
+def make_g14(MPPIDelay, w_nl, envs):
+    """Other hidden widths with the REAL reference classes: hidden_units = 64 with the class defaults' 33 terms
+    (w_nl.py:72-73) on pendulum, hidden_units = 256 / 17 terms on acrobot: GRU encoder (real nn.GRU, hidden 32 / 128),
+    representation module, model.forward and two commands of the real MPPIDelay behind the harness closure (only
+    laplace_reconstruct is the build's restatement, as in G3)."""
+    for env_name, h, S in (("oderl-pendulum", 64, 33), ("oderl-acrobot", 256, 17)):
+        st = onl.ENV_STATS[env_name]
+        d, nu, A = st["d"], st["nu"], st["act_high"]
+        model = build_ref_model(w_nl, env_name, seed=14, S=S, h=h)
+        mine = onl.make_synthetic_state_dict(14, d, nu, h, S, state_std=st["state_std"], action_std=[A / 2.0])
+        for k, v in model.state_dict().items():
+            assert np.array_equal(np_(v), np_(mine[k])), f"synthetic weights differ from reference ctor: {k}"
+        torch.manual_seed(15)
+        N, B, K, T = 40, 4, 64, 8
+        out = {}
+        with torch.no_grad():
+            win = torch.randn(N, B, nu, dtype=torch.double)
+            rep_in = torch.randn(N, 2 * S + d + 2, dtype=torch.double)
+            theta, phi = model.laplace_rep_func(rep_in)
+            out.update(gru_in=np_(win), gru_out=np_(model.action_encoder(win)), rep_in=np_(rep_in), rep_theta=np_(theta),
+                       rep_phi=np_(phi))
+            model.laplace_rep_func.linear_tanh_stack[4].bias[d * S :] += onl.PHI_BIAS_SHIFT
+            sd = {k: np_(v) for k, v in model.state_dict().items()}
+            obs = torch.randn(N, d, dtype=torch.double) * torch.tensor(st["state_std"])
+            window = (torch.rand(N, B, nu, dtype=torch.double) * 2 - 1) * A
+            ts = torch.full((N, 1), 0.05, dtype=torch.double)
+            out.update(fwd_obs=np_(obs), fwd_window=np_(window), fwd_ts=np_(ts), fwd_out=np_(model(obs, window, ts)))
+            ts_pred = torch.full((K, 1), 0.05, dtype=torch.double)
+            env = envs[env_name]()
+
+            def dynamics(state, perturbed_action):
+                return state + model(state, perturbed_action, ts_pred)
+
+            def running_cost(state, action, env=env):
+                return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))
+
+            torch.manual_seed(16)
+            mppi = MPPIDelay(dynamics, running_cost, d, noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+            state = oenvs.initial_state(env_name, seed=4)
+            action_buffer = torch.zeros(B, nu, dtype=torch.double)
+            for step in range(2):
+                c = capture_command(mppi, state.numpy(), action_buffer)
+                for k, v in c.items():
+                    out[f"s{step}_{k}"] = v
+                out[f"s{step}_state"] = np_(state)
+                out[f"s{step}_action_buffer"] = np_(action_buffer)
+                state = mppi.states[0, 0].clone()
+                action_buffer = torch.roll(action_buffer, -1, dims=0)
+                action_buffer[-1] = torch.as_tensor(c["action"])
+        np.savez_compressed(f"{HERE}/g14_width_h{h}_{env_name.split('-')[1]}.npz", d=d, nu=nu, S=S, h=h, K=K, T=T, B=B, A=A,
+                            **out, **{f"w::{k}": v for k, v in sd.items()})
+        print("g14", env_name, h, "action", out["s1_action"])
+
+
 def make_g13(MPPIDelay, envs, dyn):
     """rollout_samples M > 1 with a rollout_var_cost (mppi_delay.py:291-292, 310): pendulum and acrobot, oracle dynamics,
     two consecutive commands.  (The reference does NOT replicate the state M times, so the variance it adds is the
@@ -605,6 +662,9 @@ def main():
     if os.environ.get("NLC_GOLDEN_ONLY") == "g13":
         make_g13(MPPIDelay, envs, dyn)
         return
+    if os.environ.get("NLC_GOLDEN_ONLY") == "g14":
+        make_g14(MPPIDelay, w_nl, envs)
+        return
     make_g1(MPPIDelay, envs, dyn)
     make_g2_g3(MPPIDelay, w_nl, envs)
     make_g4()
@@ -613,6 +673,7 @@ def main():
     make_g8(MPPIDelay, w_nl, envs, dyn)
     make_g7(MPPIDelay, w_nl, envs, only=os.environ.get("NLC_G7_ONLY", "cfg1,cfg3,cfg4").split(","))
     make_g13(MPPIDelay, envs, dyn)
+    make_g14(MPPIDelay, w_nl, envs)
 
 
 if __name__ == "__main__":

@@ -819,6 +819,36 @@ def test_other_hidden_widths_forward_and_planner(nlc, h, S, algo):
         np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("name", ["h64_pendulum", "h256_acrobot"])
+def test_other_hidden_widths_vs_reference_golden(nlc, name):
+    """G14: hidden_units 64 (class default with its 33 terms) and 256 against the REAL reference classes: HIP GRU encoder
+    (g = 32 / 128) vs nn.GRU, the representation kernel vs the module, model.forward, and two commands of the reference
+    planner on every rollout body of the width."""
+    g = np.load(f"{GOLD}/g14_width_{name}.npz")
+    sd = load_sd(g)
+    env = "oderl-" + name.split("_")[1]
+    d, nu, S, K, T, A = int(g["d"]), int(g["nu"]), int(g["S"]), int(g["K"]), int(g["T"]), float(g["A"])
+    raw = {k: v.clone() for k, v in sd.items()}
+    raw["laplace_rep_func.linear_tanh_stack.4.bias"][d * S :] += 3.0  # stage fixtures predate the phi-bias shift (-3)
+    m_raw = build_model(nlc, raw, S=S)
+    with torch.no_grad():
+        win = T64(g["gru_in"]) * raw["action_std"] + raw["action_mean"]
+        np.testing.assert_allclose(m_raw.encode_actions(win.cuda()).cpu().numpy(), g["gru_out"], **TOL)
+        th, ph = m_raw.rep_func_hip(T64(g["rep_in"]).cuda())
+        np.testing.assert_allclose(th.cpu().numpy(), g["rep_theta"], **TOL)
+        np.testing.assert_allclose(ph.cpu().numpy(), g["rep_phi"], **TOL)
+        model = build_model(nlc, sd, S=S)
+        got = model(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda()).cpu()
+        np.testing.assert_allclose(got.numpy(), g["fwd_out"], **TOL)
+        for variant in (1, 2):
+            def make(U0, variant=variant):
+                return nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), num_samples=K,
+                                     horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
+                                     u_scale=A, U_init=U0, planner_options={"rollout_variant": variant})
+
+            check_command_steps(nlc, g, make)
+
+
 def test_state_dim_4_planner(nlc):
     """SURVEY 8d's literal "state_dim = 4" variant: a 4-dim observation (no trig embedding), nu = 1, NL dynamics in the
     fused rollout, the running cost a caller's closure (no reference env has d = 4): K = 2048, T = 40."""

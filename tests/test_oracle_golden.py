@@ -450,3 +450,25 @@ def test_g13_rollout_samples_vs_reference(env, golden_dir):
         np.testing.assert_allclose(out["omega"].numpy(), g[pre + "omega"], **TOL)
         np.testing.assert_allclose(out["U"].numpy(), g[pre + "U_after"], **TOL)
         np.testing.assert_allclose(out["action"].numpy(), g[pre + "action"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["h64_pendulum", "h256_acrobot"])
+def test_g14_other_hidden_widths_vs_reference(name, golden_dir):
+    """G14: the oracle at hidden_units 64 (class default, 33 terms) and 256 against the REAL reference classes: nn.GRU of
+    hidden 32 / 128, representation module, model.forward, two commands of the reference planner."""
+    g = np.load(f"{golden_dir}/g14_width_{name}.npz")
+    sd = load_sd(g)
+    env = "oderl-" + name.split("_")[1]
+    d, nu, S, K, A, h = int(g["d"]), int(g["nu"]), int(g["S"]), int(g["K"]), float(g["A"]), int(g["h"])
+    assert sd["laplace_rep_func.linear_tanh_stack.0.weight"].shape[0] == h
+    # the stage fixtures were taken BEFORE the phi-bias shift of the stored (tamed) weights
+    raw = {k: v.clone() for k, v in sd.items()}
+    raw["laplace_rep_func.linear_tanh_stack.4.bias"][d * S :] -= onl.PHI_BIAS_SHIFT
+    np.testing.assert_allclose(onl.gru_encoder(raw, T(g["gru_in"])).numpy(), g["gru_out"], **TOL)
+    th, ph = onl.rep_func(raw, T(g["rep_in"]), d, S)
+    np.testing.assert_allclose(th.numpy(), g["rep_theta"], **TOL)
+    np.testing.assert_allclose(ph.numpy(), g["rep_phi"], **TOL)
+    out = onl.nl_forward(sd, T(g["fwd_obs"]), T(g["fwd_window"]), T(g["fwd_ts"]), S=S)
+    np.testing.assert_allclose(out.numpy(), g["fwd_out"], **TOL)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    run_steps(g, onl.nl_dynamics(sd, ts, S=S), oenvs.RUNNING_COST[env], d, nu, A)
