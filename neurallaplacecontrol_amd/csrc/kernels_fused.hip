@@ -10,11 +10,12 @@
 // Grid: 2 workgroups of 256 threads per CU, all co-resident (the host sizes the grid from the device's CU count and
 // this kernel's occupancy).  Roles are taken at run time and do NOT depend on dispatch order or placement for
 // correctness (only for speed):
-//   * census: the first workgroup to arrive on a CU (s_getreg HW_ID / XCC_ID -> per-CU counter) may take a rollout tile
-//     from the rollout ticket, so rollout workgroups sit on distinct CUs, at most roll_cap of them start right away;
+//   * census: the first workgroup to arrive on a CU (s_getreg HW_ID / XCC_ID -> per-CU counter) may take one of the first
+//     roll_cap rollout tiles (census ticket + the tile's owner word), so rollout workgroups sit on distinct CUs;
 //   * everybody else takes encoder tiles from the encoder ticket, in horizon-major order (all tiles of step t before
 //     step t+1), one tile per wavefront, and publishes each tile's latents;
-//   * when the encoder ticket runs dry the workgroup drains what is left of the rollout ticket.
+//   * when the encoder ticket runs dry the workgroup drains the rollout tiles that have no owner yet (drain ticket +
+//     owner word).
 // An encoder never waits for anything, so the grid drains even if a rollout workgroup had to give up (bounded spins).
 //
 // Hand-off of a tile's latents (256 B, (T, K, 2) horizon-major so a tile is two whole 128-B lines), following
@@ -95,7 +96,7 @@ struct PaHandoff {
   }
   __device__ __forceinline__ void begin(int t0, int wv, int lane, int64_t kc) {
     if (wv == kPollWave) {
-      wait(t0, T, lane);
+      if (t0 >= ready_upto) wait(t0, T, lane);
       stamp_max(sync + kFusedTimeRollBeginFirst, true);
       stamp_max(sync + kFusedTimeRollBeginLast, false);
     }
@@ -169,30 +170,40 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem) {
   }
 }
 
-// Encoder role: this wavefront draws encoder tiles (ticket order = horizon-major) until the ticket is spent.
+// One encoder tile: horizon step t of samples 16 j .. 16 j + 15, by one wavefront; the latents leave the wave as
+// write-through stores and are complete when this returns.
+template <int G>
+__device__ __forceinline__ void fused_encode_tile(const FusedArgs& a, int lane, int t, int j, double* H0, double* H1) {
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = (int64_t)j * 16 + c;
+  const bool valid = k < a.r.K;
+  const int64_t kk = valid ? k : a.r.K - 1;
+  const double o = gru_encode_tile<G>(a.g, lane, 0, kk, t, H0, H1);
+  if (valid && q < 2) {
+    unsigned long long* dst = (unsigned long long*)(a.r.pa + ((int64_t)t * a.r.K + k) * 2 + q);
+    __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, o), NLC_RLX_AGENT);  // global_store_dwordx2 sc1
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left this wave
+}
+
+// Encoder role: this wavefront draws encoder tiles (ticket order = horizon-major: all tiles of step t before step t+1)
+// until the ticket is spent.
 template <int G>
 __device__ __forceinline__ void fused_encode(double* smem) {
   constexpr int KSG = G / 4;
   const FusedArgs& a = *(const FusedArgs*)role_args();
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, c = lane & 15;
   unsigned* sync = a.ctl.sync;
   double* H0 = smem + (size_t)wv * 2 * KSG * 64;
   double* H1 = H0 + KSG * 64;
   for (;;) {
     const unsigned i = wave_ticket(sync + kFusedEncTicket, lane);
     if (i >= (unsigned)a.ctl.n_enc) break;
-    const int t = (int)(i / (unsigned)a.ctl.ntk), j = (int)(i - (unsigned)t * (unsigned)a.ctl.ntk);
-    const int64_t k = (int64_t)j * 16 + c;
-    const bool valid = k < a.r.K;
-    const int64_t kk = valid ? k : a.r.K - 1;
-    const double o = gru_encode_tile<G>(a.g, lane, 0, kk, t, H0, H1);
-    if (valid && q < 2) {
-      unsigned long long* dst = (unsigned long long*)(a.r.pa + ((int64_t)t * a.r.K + k) * 2 + q);
-      __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, o), NLC_RLX_AGENT);  // global_store_dwordx2 sc1
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left this wave
+    const unsigned tr = i / (unsigned)a.ctl.ntk;
+    const int t = (int)tr;
+    const int j = (int)(i - tr * (unsigned)a.ctl.ntk);
+    fused_encode_tile<G>(a, lane, t, j, H0, H1);
     wave_add_one(sync + kFusedFlags + i, lane);
     if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEncDone, lane);
     stamp_max(sync + kFusedTimeEncLast, false);
@@ -224,38 +235,49 @@ __global__ __launch_bounds__(256, 2) void nl_plan_fused_kernel(const FusedArgs a
     stamp_max(sync + kFusedTimeEntry, true);
     const unsigned nth = wave_ticket(sync + kFusedCuOcc + cu, lane);
     if (nth == 0) {  // wave-uniform
-      const unsigned tk = wave_ticket(sync + kFusedRollTicket, lane);
+      const unsigned tk = wave_ticket(sync + kFusedCensusTicket, lane);
       if (tk < (unsigned)a.roll_cap && tk < (unsigned)a.ntk) {
-        tile = (int)tk;
-      } else {
-        // a ticket beyond roll_cap is handed back so the drain phase below still sees every tile
-        __hip_atomic_fetch_add(sync + kFusedRollTicket, lane == 0 ? (unsigned)-1 : 0u, NLC_RLX_AGENT);
+        // ownership of a rollout tile is exclusive: the first add on its owner word (a drain workgroup may get there
+        // first when the encoder ticket is dry from the start, tiny K T)
+        if (wave_ticket(sync + kFusedFlags + (int64_t)av.r.T * a.ntk + tk, lane) == 0) tile = (int)tk;
       }
     }
     *s_tile = tile;  // every lane of wave 0 stores the same word
   }
   __syncthreads();
-  int tile = *s_tile;
+  int tile = __builtin_amdgcn_readfirstlane(*s_tile);
   __syncthreads();
 
+  // (Schedules that were measured and lost, profiles/r2_fused_small_shard.md: the chain's workgroup first encoding its
+  // own tile's first steps; chains that start only after a share of the encoder tiles is done; the CU's other workgroup
+  // sleeping while a chain runs.  One encoder tile is 158 us of a wave, a fifth of the launch: too coarse to place.)
   if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);
 
   // ---- encoder role: one tile (horizon step t, samples 16 j .. 16 j + 15) per wavefront and ticket
   __syncthreads();  // (a rollout may just have finished in this LDS)
   fused_encode<G>(smem);
 
-  // ---- drain: rollout tiles nobody has taken yet (K/16 > roll_cap, or fewer CUs than the host assumed)
+  // ---- drain: rollout tiles that have no owner yet (K/16 > roll_cap, or fewer CUs than the host assumed)
+  const int first_drain = a.roll_cap < a.ntk ? a.roll_cap : a.ntk;
   for (;;) {
     __syncthreads();
     if (wv == 0) {
+      // drain ticket k names tile (roll_cap + k) mod ntk: the tiles the census never offered first, then the offered
+      // ones (normally all owned by then: one add each to find out)
+      int drawn = -2;  // -2: ticket spent, stop
       const unsigned tk = wave_ticket(sync + kFusedRollTicket, lane);
-      *s_tile = tk < (unsigned)a.ntk ? (int)tk : -1;
+      if (tk < (unsigned)a.ntk) {
+        int cand = first_drain + (int)tk;
+        cand = cand >= a.ntk ? cand - a.ntk : cand;
+        drawn = wave_ticket(sync + kFusedFlags + (int64_t)av.r.T * a.ntk + cand, lane) == 0 ? cand : -1;  // -1: owned, draw again
+      }
+      *s_tile = drawn;
     }
     __syncthreads();
-    tile = *s_tile;
+    tile = __builtin_amdgcn_readfirstlane(*s_tile);
     __syncthreads();
-    if (tile < 0) break;
-    fused_rollout<HT, NT3>(tile, smem);
+    if (tile == -2) break;
+    if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);
   }
   if (NLC_FUSED_TRACE && wv == 0) wave_add_one(sync + kFusedStatExited, lane);
 }

@@ -206,7 +206,7 @@ hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s, int force_vari
 
 // One-launch planner body for small populations (kernels_fused.hip): GRU encode + split rollout as roles of one grid.
 // `sync` is a block of unsigned words the command's perturb kernel zeroes:
-constexpr int kFusedEncTicket = 0, kFusedRollTicket = 1, kFusedTimeout = 2;
+constexpr int kFusedEncTicket = 0, kFusedRollTicket = 1, kFusedTimeout = 2, kFusedCensusTicket = 3;
 // progress counters (diagnostics; one relaxed atomic add each): workgroups entered / rollout tiles started / finished /
 // encoder tiles published / workgroups exited
 constexpr int kFusedStatEntered = 4, kFusedStatRollStart = 5, kFusedStatRollDone = 6, kFusedStatEncDone = 7, kFusedStatExited = 8;
@@ -216,8 +216,9 @@ constexpr int kFusedStatEntered = 4, kFusedStatRollStart = 5, kFusedStatRollDone
 constexpr int kFusedTimeEntry = 9, kFusedTimeRollBeginFirst = 10, kFusedTimeRollBeginLast = 11, kFusedTimeRollEndFirst = 12,
               kFusedTimeRollEndLast = 13, kFusedTimeEncLast = 14;
 constexpr int kFusedCuOcc = 16;              // 2048 per-CU arrival counters (XCC_ID << 8 | SE/SH/CU id)
-constexpr int kFusedFlags = 16 + 2048;       // (T, ntk) one word per encoder tile
-inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)T * (size_t)((K + 15) / 16); }
+constexpr int kFusedFlags = 16 + 2048;       // (T, ntk) one word per encoder tile, then one (ntk) row of rollout-tile owner
+                                             // tickets (the first add owns the tile)
+inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)(T + 1) * (size_t)((K + 15) / 16); }
 struct FusedCtl {   // role assignment; passed to the kernel by value
   unsigned* sync;
   unsigned* timeout_host;  // pinned host word: non-zero = a rollout workgroup gave up waiting (command lost)

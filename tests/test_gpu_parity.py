@@ -654,13 +654,15 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("K,cap", [(2048, 0), (2048, 40), (1000, 0), (4096, 0)])
+@pytest.mark.parametrize("K,cap", [(2048, 0), (2048, 40), (1000, 0), (4096, 0), (600, 7), (16, 0), (2048, 200)])
 def test_fused_plan_handoff_repeated_commands(nlc, K, cap):
     """The fused body hands every 16-sample tile's GRU latents from an encoder wavefront to a rollout workgroup INSIDE
     the launch (write-through stores + flag, sc1 loads behind a barrier).  A stale or early read would show up as a
     difference to the two-launch path: 25 consecutive commands (the latent buffer is rewritten in place every command,
     so a stale line of the previous command is a wrong value), all states / costs / actions bit-identical.  cap = 40
-    starts only 40 rollout workgroups right away: the other tiles drain after the encoders, beside busy CUs."""
+    starts only 40 rollout workgroups at the census: the other tiles drain after the encoders, beside busy CUs.
+    K = 600 / 16: the encoder ticket is dry almost at once, so census and drain workgroups race for the rollout tiles
+    (exclusive owner words); cap = 200: more census rollouts than half the CUs."""
     from oracle import nl_model as onl
 
     env, T = "oderl-cartpole", 40

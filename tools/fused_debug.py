@@ -26,7 +26,7 @@ ab = torch.zeros(4, nu, dtype=torch.float64)
 
 def dump(tag):
     ntk = (K + 15) // 16
-    words = 16 + 2048 + T * ntk
+    words = 16 + 2048 + (T + 1) * ntk
     nd = ((words + 1) // 2 + 63) // 64 * 64
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):

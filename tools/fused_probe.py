@@ -34,6 +34,6 @@ for K in Ks:
         for _ in range(20): ab = step(ab)
         torch.cuda.synchronize(); p.ctx.profile(False)
         prof = {k: round(v["total_ms"] / v["launches"], 4) for k, v in p.ctx.profile_read().items()}
-        rec = dict(K=K, variant=variant, roll_cap=cap,  ms_per_command=round(ms, 4), kernels_ms=prof)
+        rec = dict(K=K, variant=variant, roll_cap=cap, ms_per_command=round(ms, 4), kernels_ms=prof)
         print(json.dumps(rec), flush=True)
         out.append(rec)
