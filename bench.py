@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--collective", choices=("torch", "native"), default="torch",
+                    help="N > 1: the per-command all-gather through torch.distributed (default) or inside nlc_mppi_finish on "
+                         "the library's own RCCL communicator (include/nlc.h, nlc_comm_init)")
     ap.add_argument("--samples", type=int, default=K_SAMPLES,
                     help="override K (experiments only; the headline metric is quoted at the default 16384)")
     args = ap.parse_args()
@@ -272,6 +275,7 @@ def main():
         nlc.NLDynamics(model, 0.05), nlc.EnvCost(ENV), d, nlc.noise_sigma(nu), num_samples=K_total, horizon=HORIZON,
         device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A_HIGH), u_max=torch.tensor(A_HIGH), u_scale=A_HIGH,
         noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(HORIZON, nu, dtype=torch.float64),
+        planner_options={"native_collective": int(args.collective == "native")},
     )
     state = nlc.initial_state(ENV, torch.Generator().manual_seed(0))
     abuf = torch.zeros(ABUF, nu, dtype=torch.float64)
@@ -435,7 +439,10 @@ def main():
         dtype="f64",
         data="synthetic",
         config=dict(workload=workload, samples_per_gpu=k_local, noise="device Philox4x32-10", device=info["name"],
-                    commit=git_commit()),
+                    commit=git_commit(),
+                    collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
+                                                        if args.collective == "native" else
+                                                        "rccl all-gather via torch.distributed between the two phases")),
         roofline=roofline,
         roofline_ilt=ilt,
         cpu_baseline=cpu,

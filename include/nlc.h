@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 5
+#define NLC_ABI_VERSION 6
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -36,6 +36,7 @@ extern "C" {
 #define NLC_ERR_HIP (-3)
 #define NLC_ERR_UNSUPPORTED (-4)
 #define NLC_ERR_STATE (-5)
+#define NLC_ERR_COMM (-6) /* RCCL reported an error (message in nlc_last_error) */
 
 #define NLC_MAX_NU 2   /* action dims (cartpole/pendulum 1, acrobot 2) */
 #define NLC_MAX_NIN 3  /* GRU input dims = nu + encode_obs_time */
@@ -277,17 +278,28 @@ int nlc_mppi_rollout(nlc_ctx* ctx, const double* state_host, int state_per_sampl
  * caller has completed buf->cost_total (rollout cost + perturbation cost, :339-344) this computes the softmax
  * partials. */
 int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
-/* Phase 2: merge G shard partials (gathered_dev: (G, E, 2+T*nu); pass buf->partials and G=1 on one GPU),
+/* Phase 2: merge G shard partials (gathered_dev: (G, E, 2+T*nu); pass buf->partials and G=1 on one GPU; NULL: gather
+ * them with the ctx's own communicator, see the multi-GPU note below),
  * omega, U[t] += sum_k omega_k noise[k,t] (:210-216) and return action = U[:u_per_command]*u_scale
  * (:217-224) into action_host (E*u_per_command*nu) -- synchronises the stream -- and/or into buf->action on
  * the device.  With action_host == NULL nothing is copied back and the call does not synchronise. */
 int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
                     double* action_host);
-/* Multi-GPU note: the library owns NO communicator.  SURVEY 8b sketched a communicator-initialisation entry point; it was dropped on purpose:
- * the one exchange of a K-sharded command is the all-gather of buf->partials ((2+T*nu) doubles per rank and episode)
- * between nlc_mppi_rollout and nlc_mppi_finish, and the caller brings it -- torch.distributed over RCCL in the Python
- * mirror (sharding.py), rcclAllGather / MPI_Allgather on `gathered_dev` for a C caller -- so the library never competes
- * with the host framework for the collective stream, ranks or device selection. */
+/* Multi-GPU: the one exchange of a K-sharded command is the all-gather of buf->partials ((2+T*nu) doubles per rank and
+ * episode) between nlc_mppi_rollout and nlc_mppi_finish (reference reduction :210-216).  Two ways:
+ *   (1) the caller brings the collective and passes `gathered_dev`: torch.distributed over RCCL in the Python mirror
+ *       (sharding.py, the default there), MPI_Allgather / its own RCCL communicator for a C caller -- the library does not
+ *       compete with the host framework for the collective stream, ranks or device selection;
+ *   (2) the library's own communicator (SURVEY 8b's sketch): rank 0 draws an id with nlc_comm_unique_id and ships the
+ *       NLC_COMM_ID_BYTES bytes to every rank by any means, every rank calls nlc_comm_init on its ctx (its device), and
+ *       nlc_mppi_finish with gathered_dev == NULL then runs ONE ncclAllGather on the command's own stream before the
+ *       merge -- no host hop between the rollout and the action.  RCCL is bound at run time (dlopen of librccl.so.1; the
+ *       copy already in the process is used if there is one); without it these return NLC_ERR_UNSUPPORTED.
+ * nlc_comm_unique_id has no ctx: its error text is returned by nlc_last_error(NULL). */
+#define NLC_COMM_ID_BYTES 128
+int nlc_comm_unique_id(void* id_out);
+int nlc_comm_init(nlc_ctx* ctx, int rank, int world, const void* id);
+int nlc_comm_destroy(nlc_ctx* ctx);
 
 /* ---- env side of the evaluation loop: the reference steps ONE env per process on the host,
  * step_env (mppi_with_model.py:193-216) = get_action (delay buffer, :25-28) + env.integrate_system(2, g, s0)

@@ -19,7 +19,8 @@ ILT_ALGOS = {"fourier": 0, "dehoog": 1, "fixed_tablot": 2, "stehfest": 3}
 ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
 DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN, DYN_NODE = 0, 1, 2, 3, 4
 
-ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE"}
+ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE", -6: "COMM"}
+COMM_ID_BYTES = 128
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnlc_hip.so")
 # tools/ only (A/B builds of one kernel on one box, tools/ab_cmd.sh): another build of the SAME library
@@ -57,6 +58,9 @@ SYMBOLS = [
     "nlc_mppi_rollout",
     "nlc_mppi_weights",
     "nlc_mppi_finish",
+    "nlc_comm_unique_id",
+    "nlc_comm_init",
+    "nlc_comm_destroy",
     "nlc_env_step",
     "nlc_env_obs",
     "nlc_profile_enable",
@@ -216,6 +220,9 @@ def load_library():
         lib.nlc_mppi_rollout.argtypes = [vp, vp, i32, vp, P(MppiBuffers), i32, C.c_uint64, C.c_uint64]
         lib.nlc_mppi_weights.argtypes = [vp, P(MppiBuffers)]
         lib.nlc_mppi_finish.argtypes = [vp, vp, i32, i32, P(MppiBuffers), vp]
+        lib.nlc_comm_unique_id.argtypes = [vp]
+        lib.nlc_comm_init.argtypes = [vp, i32, i32, vp]
+        lib.nlc_comm_destroy.argtypes = [vp]
         lib.nlc_profile_enable.argtypes = [vp, i32]
         lib.nlc_profile_reset.argtypes = [vp]
         lib.nlc_profile_count.argtypes = [vp]
@@ -258,6 +265,20 @@ class Ctx:
     def set_option(self, name, value):
         """Planner tuning knob of ``include/nlc.h`` (``nlc_set_option``)."""
         self.check(self.lib.nlc_set_option(self.h, name.encode(), float(value)))
+
+    def comm_unique_id(self):
+        """Rank 0: the NLC_COMM_ID_BYTES bytes every rank passes to ``comm_init`` (``nlc_comm_unique_id``)."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.lib.nlc_comm_unique_id(buf)
+        if rc != 0:
+            raise NlcError(rc, (self.lib.nlc_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        """The library's own RCCL communicator over the ranks of a K-sharded planner (``nlc_comm_init``)."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        self.check(self.lib.nlc_comm_init(self.h, int(rank), int(world), C.c_char_p(bytes(unique_id))))
 
     def device_info(self):
         name = C.create_string_buffer(128)

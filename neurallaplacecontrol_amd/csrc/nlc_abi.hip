@@ -1,5 +1,6 @@
 // Host side of libnlc_hip.so: context, weight repacking into MFMA fragment order, launch sequencing.
 // See include/nlc.h for the contract of every entry point and the reference interface it replaces.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -103,6 +104,11 @@ struct nlc_ctx {
   int64_t opt_fused_max_samples = 2048; // auto: populations up to this size take the fused body (measured: 4096 is slower)
   int fused_blocks_per_cu = -1;         // occupancy of the fused kernel (queried once)
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): reported by the next call
+  // optional native collective (nlc_comm_init): an RCCL communicator over the ranks of a K-sharded planner
+  void* comm = nullptr;
+  int comm_world = 0, comm_rank = 0;
+  double* comm_gather = nullptr;  // (world, E, 2+T*nu) receive buffer of the per-command all-gather
+  size_t comm_gather_n = 0;
 };
 
 namespace {
@@ -267,10 +273,103 @@ extern "C" int nlc_create(int device, nlc_ctx** out) {
   }
 }
 
+// ---- RCCL, bound at run time: the library links against HIP only, and a process that already holds an RCCL (the one
+// PyTorch-ROCm ships, same soname) must not get a second copy.
+namespace {
+struct Rccl {
+  typedef struct { char internal[NLC_COMM_ID_BYTES]; } UniqueId;  // = ncclUniqueId (rccl.h: 128 opaque bytes)
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;  // the id is passed BY VALUE (rccl.h)
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string why;
+  bool ok = false;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return &r;
+  tried = true;
+  void* h = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // already in the process (torch.distributed's)?
+    if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+    return &r;
+  }
+  r.GetUniqueId = (int (*)(Rccl::UniqueId*))dlsym(h, "ncclGetUniqueId");
+  r.CommInitRank = (int (*)(void**, int, Rccl::UniqueId, int))dlsym(h, "ncclCommInitRank");
+  r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+  r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+  if (!r.ok) r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+  return &r;
+}
+constexpr int kNcclFloat64 = 8;  // rccl.h: ncclFloat64 = ncclDouble = 8
+}  // namespace
+
+extern "C" int nlc_comm_unique_id(void* id_out) {
+  if (!id_out) return NLC_ERR_BAD_ARG;
+  Rccl* r = rccl();
+  if (!r->ok) {
+    g_create_error = r->why;
+    return NLC_ERR_UNSUPPORTED;
+  }
+  Rccl::UniqueId id;
+  const int rc = r->GetUniqueId(&id);
+  if (rc != 0) {
+    g_create_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(rc);
+    return NLC_ERR_COMM;
+  }
+  std::memcpy(id_out, id.internal, NLC_COMM_ID_BYTES);
+  return NLC_OK;
+}
+
+extern "C" int nlc_comm_destroy(nlc_ctx* c) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  hipSetDevice(c->device);
+  if (c->comm) {
+    hipStreamSynchronize(c->stream);
+    rccl()->CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  if (c->comm_gather) hipFree(c->comm_gather);
+  c->comm_gather = nullptr;
+  c->comm_gather_n = 0;
+  c->comm_world = 0;
+  return NLC_OK;
+}
+
+extern "C" int nlc_comm_init(nlc_ctx* c, int rank, int world, const void* id) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, NLC_ERR_BAD_ARG, "nlc_comm_init: bad rank / world / id");
+  Rccl* r = rccl();
+  if (!r->ok) return fail(c, NLC_ERR_UNSUPPORTED, r->why);
+  nlc_comm_destroy(c);
+  NLC_HIP(c, hipSetDevice(c->device));
+  Rccl::UniqueId uid;
+  std::memcpy(uid.internal, id, NLC_COMM_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = r->CommInitRank(&comm, world, uid, rank);
+  if (rc != 0) return fail(c, NLC_ERR_COMM, std::string("ncclCommInitRank: ") + r->GetErrorString(rc));
+  c->comm = comm;
+  c->comm_world = world;
+  c->comm_rank = rank;
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
 extern "C" void nlc_destroy(nlc_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  nlc_comm_destroy(c);
   prof_flush(c);
   if (c->arena.base) hipFree(c->arena.base);
   if (c->rnn_base) hipFree(c->rnn_base);
@@ -1585,11 +1684,29 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
   if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
-  if (!gathered || !buf || !buf->cost_nz) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
+  if (!buf || !buf->cost_nz) return fail(c, NLC_ERR_BAD_ARG, "NULL argument");
   if (!action_host && !buf->action) return fail(c, NLC_ERR_BAD_ARG, "neither action_host nor buf->action given");
   if (G < 1 || rank < 0 || rank >= G) return fail(c, NLC_ERR_BAD_ARG, "bad G / rank");
   const nlc_mppi_desc& d = c->pd;
   NLC_HIP(c, hipSetDevice(c->device));
+  if (!gathered) {
+    // the library's own collective: one all-gather of this rank's partials on the command's stream
+    if (!c->comm) return fail(c, NLC_ERR_BAD_ARG, "gathered_dev is NULL and no communicator (nlc_comm_init)");
+    if (G != c->comm_world || rank != c->comm_rank)
+      return fail(c, NLC_ERR_BAD_ARG, "G / rank differ from the communicator's");
+    if (!buf->partials) return fail(c, NLC_ERR_BAD_ARG, "NULL buf->partials");
+    const size_t per_rank = (size_t)d.E * (size_t)(2 + d.T * d.nu);
+    if (c->comm_gather_n < per_rank * (size_t)G) {
+      if (c->comm_gather) NLC_HIP(c, hipFree(c->comm_gather));
+      c->comm_gather = nullptr;
+      NLC_HIP(c, hipMalloc((void**)&c->comm_gather, per_rank * (size_t)G * sizeof(double)));
+      c->comm_gather_n = per_rank * (size_t)G;
+    }
+    ProfScope ps(c, "rccl_all_gather");
+    const int rc = rccl()->AllGather(buf->partials, c->comm_gather, per_rank, kNcclFloat64, c->comm, c->stream);
+    if (rc != 0) return fail(c, NLC_ERR_COMM, std::string("ncclAllGather: ") + rccl()->GetErrorString(rc));
+    gathered = c->comm_gather;
+  }
   MergeArgs m{};
   m.Kep = d.K;
   m.E = d.E;

@@ -30,7 +30,8 @@ from torch.distributions.multivariate_normal import MultivariateNormal
 
 from .. import _lib
 from ..envs import EnvCost, NLDynamics, OracleDynamics
-from ..sharding import check_same_on_all_ranks, gather_partials, replicate_from_rank0, shard_range, slice_noise
+from ..sharding import (check_same_on_all_ranks, gather_partials, replicate_from_rank0, shard_range, share_bytes_from_rank0,
+                        slice_noise)
 
 
 def _per_dim(v, nu, name):
@@ -196,11 +197,20 @@ class MPPIDelay:
         self.ctx = _lib.Ctx(self.cd.index)
         # tuning knobs of include/nlc.h (nlc_set_option); the NLC_* environment variables are read ONCE, here
         opts = {"rollout_variant": os.environ.get("NLC_ROLLOUT_VARIANT"), "fused_roll_cap": os.environ.get("NLC_FUSED_ROLL_CAP"),
-                "fused_max_samples": os.environ.get("NLC_FUSED_MAX_SAMPLES")}
+                "fused_max_samples": os.environ.get("NLC_FUSED_MAX_SAMPLES"),
+                "native_collective": os.environ.get("NLC_NATIVE_COLLECTIVE")}
         opts.update(planner_options or {})
+        # "native_collective": the per-command all-gather runs inside nlc_mppi_finish on the library's own RCCL
+        # communicator (include/nlc.h, nlc_comm_init) instead of torch.distributed between the two phases
+        self.native_collective = bool(float(opts.pop("native_collective") or 0)) and self.pg is not None
         for name, value in opts.items():
             if value is not None:
                 self.ctx.set_option(name, float(value))
+        if self.native_collective:
+            uid = share_bytes_from_rank0(self.ctx.comm_unique_id() if self.rank == 0 else None, _lib.COMM_ID_BYTES, self.pg,
+                                         self.cd)
+            with torch.cuda.device(self.cd):
+                self.ctx.comm_init(self.rank, self.G, uid)
         self._model_key = None
         self._B = None
         self._buf = None
@@ -393,7 +403,9 @@ class MPPIDelay:
                 self._external_rollout(st, per_sample, ab)
                 ctx.check(lib.nlc_mppi_weights(ctx.h, C.byref(self._buf)))
             self._commands += 1
-            if self.pg is not None:  # also for a 1-rank group: the collective path is the same code
+            if self.native_collective:
+                gathered = None  # nlc_mppi_finish gathers on the command's stream (its own communicator)
+            elif self.pg is not None:  # also for a 1-rank group: the collective path is the same code
                 gathered = gather_partials(self._partials, self._gathered, self.pg)
             else:
                 gathered = self._partials

@@ -67,3 +67,17 @@ def check_same_on_all_ranks(values, group, what, compute_device=None):
     allv = allv.view(G, -1).cpu()
     if not bool((allv == allv[0]).all()):
         raise ValueError(f"K-sharded planner: {what} differ between ranks: {allv.tolist()}")
+
+
+def share_bytes_from_rank0(payload, nbytes, group, compute_device=None):
+    """Rank 0's `payload` (bytes of length nbytes; ignored elsewhere) on every rank of `group` -- the unique id of the
+    library's own communicator (include/nlc.h, nlc_comm_init) travels through the group the caller already has."""
+    import torch.distributed as dist
+
+    t = torch.zeros(nbytes, dtype=torch.uint8)
+    if dist.get_rank(group) == 0:
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    if dist.get_backend(group) != "gloo" and compute_device is not None:
+        t = t.to(compute_device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
+    return bytes(t.cpu().tolist())

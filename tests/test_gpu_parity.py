@@ -1359,6 +1359,74 @@ dist.destroy_process_group()
 """
 
 
+_NATIVE_COLLECTIVE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import neurallaplacecontrol_amd as n
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))   # RCCL, one rank (one GPU on this box)
+sd = torch.load(os.path.join(sys.argv[2], "sd.pt"))
+d, nu, A, K, T = 5, 1, 3.0, 2048, 12
+import numpy as np
+model = n.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", state_mean=np.zeros(d),
+                             state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]),
+                             normalize=True, normalize_time=True).double()
+model.load_state_dict(sd)
+model = model.cuda()
+def planner(pg, native):
+    return n.MPPIDelay(n.NLDynamics(model, 0.05), n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+                       u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                       noise_rng="philox", seed=5, process_group=pg, planner_options={"native_collective": native})
+ps = [planner(None, 0), planner(dist.group.WORLD, 0), planner(dist.group.WORLD, 1)]
+assert ps[2].native_collective and not ps[1].native_collective and not ps[0].native_collective
+state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
+with torch.no_grad():
+    for step in range(4):
+        acts = [p.command(state, ab) for p in ps]
+        assert torch.equal(acts[0], acts[1]) and torch.equal(acts[0], acts[2]), (step, acts)
+        assert torch.equal(ps[0].U, ps[2].U) and torch.equal(ps[0].omega, ps[2].omega)
+        ab = torch.roll(ab, -1, 0); ab[-1] = acts[0].cpu()
+    ps[2].ctx.profile(True)
+    ps[2].command(state, ab); torch.cuda.synchronize()
+    ps[2].ctx.profile(False)
+    assert "rccl_all_gather" in ps[2].ctx.profile_read()
+# a second communicator on a fresh ctx, and the error paths of the C ABI
+import ctypes as C
+c = n._lib.Ctx(0)
+try:
+    c.check(c.lib.nlc_comm_init(c.h, 3, 2, C.c_char_p(b"x" * 128)))
+    raise SystemExit("bad rank accepted")
+except n._lib.NlcError as e:
+    assert e.code == -1
+c.comm_init(0, 1, c.comm_unique_id())
+c.check(c.lib.nlc_comm_destroy(c.h))
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], "ok"), "w").write("ok")
+"""
+
+
+def test_native_collective_one_rank_rccl(nlc, tmp_path):
+    """include/nlc.h's own communicator (nlc_comm_unique_id / nlc_comm_init; nlc_mppi_finish with gathered_dev == NULL
+    runs ncclAllGather on the command's stream): a one-rank RCCL group on this box's one GPU.  The planner with the
+    native collective, the one with torch.distributed's and the one without a group return bit-identical actions, U and
+    omega over consecutive commands."""
+    import subprocess
+    import sys
+
+    from oracle import nl_model as onl
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    st = onl.ENV_STATS["oderl-cartpole"]
+    torch.save(onl.make_synthetic_state_dict(8, 5, 1, 128, 17, st["state_std"], [1.5], tame=True), tmp_path / "sd.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_NATIVE_COLLECTIVE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+         "--master-port", "29547", str(script), repo, str(tmp_path)], env=env, timeout=600)
+    assert (tmp_path / "ok").read_text() == "ok"
+
+
 def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
     """`MPPIDelay(process_group=...)` through torch.distributed.run with world_size 2 (both ranks on this one GPU,
     gloo collective): every rank returns the same action, and it equals the unsharded planner's (Philox counters are
