@@ -821,6 +821,56 @@ def test_other_hidden_widths_forward_and_planner(nlc, h, S, algo):
         np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-7, atol=1e-8)
 
 
+def _random_shape_cases(n=14, seed=2024):
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        env = ["oderl-cartpole", "oderl-pendulum", "oderl-acrobot"][rng.randint(3)]
+        h = [64, 128, 256][rng.randint(3)]
+        algo = ["fourier", "fourier", "dehoog", "fixed_tablot", "stehfest"][rng.randint(5)]
+        if algo == "fourier":
+            S = int(rng.randint(3, 34))
+        elif algo == "stehfest":
+            S = int(2 * rng.randint(2, 8))
+        else:
+            S = int(2 * rng.randint(1, 17) + 1)
+        cases.append((i, env, h, algo, S, int(rng.randint(1, 7)), int(rng.randint(1, 11)), int(rng.randint(1, 400))))
+    return cases
+
+
+@pytest.mark.parametrize("i,env,h,algo,S,B,T,K", _random_shape_cases())
+def test_random_shape_sweep_planner_vs_oracle(nlc, i, env, h, algo, S, B, T, K):
+    """Seeded random shapes (env, hidden width, ILT algorithm and term count, window length B, horizon T, population K --
+    ragged against every tile size): one planning step on the auto-selected rollout body against the oracle."""
+    from oracle import envs as oenvs
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(100 + i, d, nu, h, S, st["state_std"], [A / 2], tame="dehoog" if algo == "dehoog" else True)
+    model = build_model(nlc, sd, S=S, algo=algo)
+    torch.manual_seed(500 + i)
+    sig = nlc.noise_sigma(nu)
+    raw = torch.randn(K, T, nu, dtype=torch.float64) @ torch.linalg.cholesky(sig).T
+    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.2
+    state, ab = nlc.initial_state(env), torch.randn(B, nu, dtype=torch.float64) * 0.3
+    tsk = torch.full((K, 1), 0.05, dtype=torch.float64)
+    ref = omppi.mppi_command(U0.clone(), state, ab, raw.clone(), onl.nl_dynamics(sd, tsk, S=S, ilt_algorithm=algo),
+                             oenvs.RUNNING_COST[env], d, torch.inverse(sig), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cpu", lambda_=1.0,
+                         u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+    mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+    with torch.no_grad():
+        act = mppi.command(state, ab)
+    # (fixed Talbot: its weights alternate at ~e^{0.4 S}, so last-bit differences of F_k come back amplified -- 8e-6
+    # relative at 27 terms after 8 untamed steps; the north-star bar is 1e-5)
+    tol = {"fourier": dict(rtol=1e-7, atol=1e-8), "fixed_tablot": dict(rtol=2e-5, atol=1e-6)}.get(algo, dict(rtol=1e-6, atol=1e-7))
+    np.testing.assert_allclose(mppi.states.numpy(), ref["states"].numpy(), **tol)
+    np.testing.assert_allclose(mppi.cost_total.numpy(), ref["cost_total"].numpy(), **tol)
+    np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), **tol)
+
+
 @pytest.mark.parametrize("name", ["h64_pendulum", "h256_acrobot"])
 def test_other_hidden_widths_vs_reference_golden(nlc, name):
     """G14: hidden_units 64 (class default with its 33 terms) and 256 against the REAL reference classes: HIP GRU encoder
