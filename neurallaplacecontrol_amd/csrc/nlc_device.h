@@ -29,12 +29,6 @@ __device__ __forceinline__ v4d splat(double x) { return v4d{x, x, x, x}; }
 // "base + constant" fragment addresses of an unrolled GEMM out of the enclosing loop and spills them.
 typedef const __attribute__((address_space(1))) double* gptr;  // global (HBM) address space
 __device__ __forceinline__ gptr opaque(gptr p) {
-#ifdef NLC_OPAQUE_UNIFORMIZE
-  // kernels_fused.hip reads its argument blocks from global memory: a wave-uniform pointer may arrive in a VGPR there
-  const uint64_t v = (uint64_t)p;
-  p = (gptr)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-#endif
   asm volatile("" : "+s"(p));
   return p;
 }

@@ -1,4 +1,5 @@
-/* Plain-C client of include/nlc.h: MPPI commands with oracle cartpole dynamics, one env step, and the Fourier line
+/* Plain-C client of include/nlc.h: MPPI commands with oracle cartpole dynamics (the third through the library's own RCCL
+ * communicator), one env step, and the Fourier line
  * integral with its backward; device buffers from the HIP runtime's C API, no Python and no torch.  Prints the action, the first cost and beta/eta so the GPU test can
  * compare them with the Python mirror driving the same library (device Philox noise, same seed and counter).
  *   gcc -std=c99 cabi_client.c -I include -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L<libdir> -lnlc_hip
@@ -54,9 +55,25 @@ int main(void) {
   if (ws < 0 || hipMalloc(&buf.workspace, (size_t)ws) != hipSuccess) return 4;
   double U[10] = {0}, state[5] = {0.01, 0.0, -1.0, 0.02, 0.0}, abuf[4] = {0.5, -0.25, 0.0, 1.0}, action[1] = {0};
   CHECK(nlc_mppi_set_U(ctx, U));
-  for (int cmd = 0; cmd < 2; ++cmd) {
+  /* tuning knobs: a known name is accepted, an unknown one is NLC_ERR_BAD_ARG */
+  CHECK(nlc_set_option(ctx, "rollout_variant", 0.0));
+  if (nlc_set_option(ctx, "no_such_option", 1.0) != NLC_ERR_BAD_ARG) return 6;
+  for (int cmd = 0; cmd < 3; ++cmd) {
     CHECK(nlc_mppi_rollout(ctx, state, 0, abuf, &buf, /*rng=*/1, /*seed=*/17, /*counter=*/(uint64_t)cmd));
-    CHECK(nlc_mppi_finish(ctx, buf.partials, 1, 0, &buf, action));
+    if (cmd < 2) {
+      CHECK(nlc_mppi_finish(ctx, buf.partials, 1, 0, &buf, action));
+    } else {
+      /* third command: the library's own RCCL communicator (one rank here) gathers inside nlc_mppi_finish */
+      unsigned char uid[NLC_COMM_ID_BYTES];
+      if (nlc_comm_unique_id(uid) != NLC_OK) {
+        fprintf(stderr, "nlc_comm_unique_id: %s\n", nlc_last_error(NULL));
+        return 7;
+      }
+      CHECK(nlc_comm_init(ctx, 0, 1, uid));
+      if (nlc_mppi_finish(ctx, NULL, 2, 0, &buf, action) != NLC_ERR_BAD_ARG) return 8; /* G != communicator's world */
+      CHECK(nlc_mppi_finish(ctx, NULL, 1, 0, &buf, action));
+      CHECK(nlc_comm_destroy(ctx));
+    }
     double part[2], c0;
     if (hipMemcpy(part, buf.partials, sizeof(part), hipMemcpyDeviceToHost) != hipSuccess) return 5;
     if (hipMemcpy(&c0, buf.cost_total, sizeof(c0), hipMemcpyDeviceToHost) != hipSuccess) return 5;

@@ -1830,7 +1830,7 @@ def test_cost_callables_path_equals_fused_envcost(nlc):
 
 def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
     """include/nlc.h is a real C boundary: tests/helpers/cabi_client.c (C99, gcc, HIP runtime C API for the device
-    buffers, no Python, no torch) runs two planner commands; the Python mirror driving the same library with the same
+    buffers, no Python, no torch) runs three planner commands; the Python mirror driving the same library with the same
     seed / command counters gives bit-identical numbers."""
     import subprocess
 
@@ -1841,29 +1841,38 @@ def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
         ["gcc", "-std=c99", os.path.join(repo, "tests", "helpers", "cabi_client.c"), "-I", os.path.join(repo, "include"),
          "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L" + libdir, "-lnlc_hip", "-L/opt/rocm/lib", "-lamdhip64",
          "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
-    lines = subprocess.check_output([exe], timeout=300).decode().strip().splitlines()
-    c_cmds = [[float(x) for x in ln.split()] for ln in lines[:2]]
-    c_U = [float(x) for x in lines[2].split()]
+    out = subprocess.check_output([exe], timeout=300, env=dict(os.environ, NCCL_DEBUG="WARN")).decode()
+
+    def numeric(ln):  # (RCCL may still print a banner to stdout at communicator creation)
+        try:
+            [float(x) for x in ln.split()]
+            return bool(ln.split())
+        except ValueError:
+            return False
+
+    lines = [ln for ln in out.strip().splitlines() if numeric(ln)]
+    c_cmds = [[float(x) for x in ln.split()] for ln in lines[:3]]
+    c_U = [float(x) for x in lines[3].split()]
     K, T, A = 512, 10, 3.0
     p = nlc.MPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 2), nlc.EnvCost("oderl-cartpole"), 5, torch.tensor(1.0).double(),
                       K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
                       U_init=torch.zeros(T, 1, dtype=torch.float64), noise_rng="philox", seed=17)
     state = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64)
     ab = torch.tensor([[0.5], [-0.25], [0.0], [1.0]], dtype=torch.float64)
-    for cmd in range(2):
+    for cmd in range(3):  # (the client's third command gathers with the library's own one-rank RCCL communicator)
         act = p.command(state, ab)
         part = p._partials.cpu()
         assert [float(act[0]), float(p.cost_total[0]), float(part[0]), float(part[1])] == c_cmds[cmd]
     assert p.U.reshape(-1).tolist() == c_U
     # env step through the C client == through BatchedEnv
-    c_env = [float(x) for x in lines[3].split()]
+    c_env = [float(x) for x in lines[4].split()]
     e = nlc.BatchedEnv("oderl-cartpole", 2, dt=0.05, action_delay=1, action_buffer_size=3)
     e.set_state_(torch.tensor([[0.1, -0.2, 3.0, 0.5], [-0.3, 0.4, 2.5, -1.0]], dtype=torch.float64))
     e.action_buffer.copy_(torch.tensor([0.5, 1.0, -2.0, 0.25, -0.5, 1.5], dtype=torch.float64).view(2, 3, 1))
     obs, rew = e.step(torch.tensor([[2.0], [-1.0]], dtype=torch.float64))
     assert obs.cpu().reshape(-1).tolist() + rew.cpu().tolist() == c_env
     # ILT forward / backward through the C client == through the Python mirror's autograd
-    c_ilt = [float(x) for x in lines[4].split()]
+    c_ilt = [float(x) for x in lines[5].split()]
     N, D, S = 3, 2, 17
     i = torch.arange(N * D * S, dtype=torch.float64)
     th = (3.0 * ((i * 37) % 101) / 101.0 - 1.5).view(N, D, S).cuda().requires_grad_()
