@@ -107,6 +107,9 @@ struct PaHandoff {
     if (wv == kPollWave && t + 1 < t_end && t + 1 >= ready_upto) wait(t + 1, t_end, lane);
   }
   __device__ __forceinline__ void after_barrier2(int t, int t_end, int64_t kc) {
+    if (NLC_FUSED_TRACE)  // trace build: when this chain entered the last third of step t
+      __hip_atomic_store(sync + kFusedFlags + (int64_t)(T + 1 + t) * ntk + tile, (unsigned)__builtin_amdgcn_s_memrealtime() | 1u,
+                         NLC_RLX_AGENT);
     if (t + 1 < t_end) load(t + 1, kc, &nxt0, &nxt1);
   }
   __device__ __forceinline__ void advance() {
@@ -187,9 +190,11 @@ __device__ __forceinline__ void fused_encode_tile(const FusedArgs& a, int lane, 
 }
 
 // Encoder role: this wavefront draws encoder tiles (ticket order = horizon-major: all tiles of step t before step t+1)
-// until the ticket is spent.
+// until the ticket is spent, or until it has encoded max_tiles of them (a chain's workgroup before it starts walking).
+// yield_cu >= 0 (the OTHER workgroup of a chain's CU): after yield_after tiles it stops drawing while that chain is
+// still running (see the kernel for why).  Never sleeps while it holds a tile: a chain elsewhere may be waiting for it.
 template <int G>
-__device__ __forceinline__ void fused_encode(double* smem) {
+__device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yield_cu, int yield_after) {
   constexpr int KSG = G / 4;
   const FusedArgs& a = *(const FusedArgs*)role_args();
   const int lane = threadIdx.x & 63;
@@ -197,14 +202,27 @@ __device__ __forceinline__ void fused_encode(double* smem) {
   unsigned* sync = a.ctl.sync;
   double* H0 = smem + (size_t)wv * 2 * KSG * 64;
   double* H1 = H0 + KSG * 64;
-  for (;;) {
+  for (int done = 0; done < max_tiles; ++done) {
+    if (yield_cu >= 0 && done >= yield_after) {
+      // bounded (~50 ms): nothing depends on this wait for correctness
+      for (unsigned spins = 0; spins < (1u << 14); ++spins) {
+        const unsigned st = __hip_atomic_load(sync + kFusedCuState + yield_cu, NLC_RLX_AGENT);
+        if (__builtin_amdgcn_readfirstlane(st) != 1u) break;
+        __builtin_amdgcn_s_sleep(127);
+      }
+    }
     const unsigned i = wave_ticket(sync + kFusedEncTicket, lane);
     if (i >= (unsigned)a.ctl.n_enc) break;
     const unsigned tr = i / (unsigned)a.ctl.ntk;
     const int t = (int)tr;
     const int j = (int)(i - tr * (unsigned)a.ctl.ntk);
     fused_encode_tile<G>(a, lane, t, j, H0, H1);
-    wave_add_one(sync + kFusedFlags + i, lane);
+    if (NLC_FUSED_TRACE) {
+      // trace build: the flag word carries the tile's completion time (any non-zero value publishes the tile)
+      __hip_atomic_fetch_or(sync + kFusedFlags + i, (unsigned)__builtin_amdgcn_s_memrealtime() | 1u, NLC_RLX_AGENT);
+    } else {
+      wave_add_one(sync + kFusedFlags + i, lane);
+    }
     if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEncDone, lane);
     stamp_max(sync + kFusedTimeEncLast, false);
     __builtin_amdgcn_wave_barrier();
@@ -226,10 +244,10 @@ __global__ __launch_bounds__(256, 2) void nl_plan_fused_kernel(const FusedArgs a
   // ---- census (wave 0, wave-uniform control flow: see wave_ticket): the FIRST workgroup to arrive on a CU may take a
   // rollout tile, so rollout workgroups sit on distinct CUs (two on one CU walk their chains at 19 us per horizon step
   // instead of 10.7: measured, profiles/r2_fused_small_shard.md)
+  const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID [3:0]
+  const unsigned cu = ((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu);
   if (wv == 0) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID [3:0]
-    const unsigned cu = ((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu);
     int tile = -1;
     if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEntered, lane);
     stamp_max(sync + kFusedTimeEntry, true);
@@ -241,21 +259,36 @@ __global__ __launch_bounds__(256, 2) void nl_plan_fused_kernel(const FusedArgs a
         // first when the encoder ticket is dry from the start, tiny K T)
         if (wave_ticket(sync + kFusedFlags + (int64_t)av.r.T * a.ntk + tk, lane) == 0) tile = (int)tk;
       }
+      if (tile >= 0) __hip_atomic_store(sync + kFusedCuState + cu, 1u, NLC_RLX_AGENT);  // this CU walks a chain
     }
-    *s_tile = tile;  // every lane of wave 0 stores the same word
+    s_tile[0] = tile;  // every lane of wave 0 stores the same words
+    s_tile[1] = (int)nth;
   }
   __syncthreads();
-  int tile = __builtin_amdgcn_readfirstlane(*s_tile);
+  int tile = __builtin_amdgcn_readfirstlane(s_tile[0]);
+  const int nth = __builtin_amdgcn_readfirstlane(s_tile[1]);
   __syncthreads();
 
-  // (Schedules that were measured and lost, profiles/r2_fused_small_shard.md: the chain's workgroup first encoding its
-  // own tile's first steps; chains that start only after a share of the encoder tiles is done; the CU's other workgroup
-  // sleeping while a chain runs.  One encoder tile is 158 us of a wave, a fifth of the launch: too coarse to place.)
-  if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);
+  // ---- schedule (trace build, K = 2048, profiles/r2_fused_small_shard.md): the chains are the launch's critical path --
+  // a chain walks a horizon step in 10.7 us alone and in ~21 us beside an encoder wave (an FP64 MFMA holds the SIMD's
+  // vector issue for 64 clocks and cannot be pre-empted, whatever the wave priorities), while the chip produces a step's
+  // latents in ~17 us.  So a chain starts at once and walks contended while the encoder ticket is young; once n_yield
+  // tiles have been drawn the OTHER workgroup of its CU stops drawing and sleeps until the chain is done, the chain
+  // finishes at full speed on banked latents, and the CUs without a chain encode the rest.  (Measured and lost: sleeping
+  // from the start -- the half chip left produces a step per 19.7 us and starves the chains; chains that start late; the
+  // chain's workgroup encoding its own first steps.)
+  if (tile >= 0) {
+    if (a.chain_first_tiles > 0) {
+      fused_encode<G>(smem, a.chain_first_tiles, -1, 0);
+      __syncthreads();  // the GRU images in LDS are dead
+    }
+    fused_rollout<HT, NT3>(tile, smem);
+    __hip_atomic_store(sync + kFusedCuState + cu, 2u, NLC_RLX_AGENT);  // (all waves, same word) wakes this CU's sleeper
+  }
 
   // ---- encoder role: one tile (horizon step t, samples 16 j .. 16 j + 15) per wavefront and ticket
   __syncthreads();  // (a rollout may just have finished in this LDS)
-  fused_encode<G>(smem);
+  fused_encode<G>(smem, 0x7fffffff, (nth != 0 && a.partner_tiles >= 0) ? (int)cu : -1, a.partner_tiles);
 
   // ---- drain: rollout tiles that have no owner yet (K/16 > roll_cap, or fewer CUs than the host assumed)
   const int first_drain = a.roll_cap < a.ntk ? a.roll_cap : a.ntk;
@@ -271,10 +304,10 @@ __global__ __launch_bounds__(256, 2) void nl_plan_fused_kernel(const FusedArgs a
         cand = cand >= a.ntk ? cand - a.ntk : cand;
         drawn = wave_ticket(sync + kFusedFlags + (int64_t)av.r.T * a.ntk + cand, lane) == 0 ? cand : -1;  // -1: owned, draw again
       }
-      *s_tile = drawn;
+      s_tile[0] = drawn;
     }
     __syncthreads();
-    tile = __builtin_amdgcn_readfirstlane(*s_tile);
+    tile = __builtin_amdgcn_readfirstlane(s_tile[0]);
     __syncthreads();
     if (tile == -2) break;
     if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);

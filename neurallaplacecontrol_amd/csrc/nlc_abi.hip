@@ -101,6 +101,8 @@ struct nlc_ctx {
   // planner options (nlc_set_option)
   int opt_rollout_variant = 0;          // 0 auto, 1 wave-per-tile, 2 latency-split (two launches), 3 fused one-launch body
   int opt_fused_roll_cap = 0;           // 0 auto (half the CUs)
+  int opt_fused_chain_first_tiles = -1; // tiles per wave a chain's workgroup encodes before it starts walking (-1 auto)
+  int opt_fused_partner_tiles = -2;     // tiles per wave after which a chain's CU partner sleeps (-1: never, -2 auto)
   int64_t opt_fused_max_samples = 2048; // auto: populations up to this size take the fused body (measured: 4096 is slower)
   int fused_blocks_per_cu = -1;         // occupancy of the fused kernel (queried once)
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): reported by the next call
@@ -406,6 +408,12 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "fused_roll_cap") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_roll_cap must be >= 0 (0 = auto)");
     c->opt_fused_roll_cap = (int)value;
+  } else if (n == "fused_chain_first_tiles") {
+    if (value < -1 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_chain_first_tiles must be in -1..64 (-1 = auto)");
+    c->opt_fused_chain_first_tiles = (int)value;
+  } else if (n == "fused_partner_tiles") {
+    if (value < -2 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_partner_tiles must be in -2..64 (-2 = auto, -1 = never)");
+    c->opt_fused_partner_tiles = (int)value;
   } else if (n == "fused_max_samples") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_max_samples must be >= 0");
     c->opt_fused_max_samples = (int64_t)value;
@@ -1557,6 +1565,15 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       // rollout workgroups start one per CU on the first CUs to arrive; by default on half the CUs at most
       fc.roll_cap = c->opt_fused_roll_cap > 0 ? c->opt_fused_roll_cap : (ncu / 2 > 0 ? ncu / 2 : 1);
       if (fc.roll_cap > fc.ntk) fc.roll_cap = fc.ntk;
+      // Schedule (profiles/r2_fused_small_shard.md): with at least ~2.25 encoder tiles per resident wavefront (K = 2048,
+      // T = 40: 2.5) every wave -- the chains' too -- encodes one tile first, and a chain's CU partner sleeps after its
+      // second tile until the chain is done (-6 % at K = 2048); with fewer tiles per wave neither helps (measured at
+      // K = 512 / 1024 / 1536), the chains start at once and nobody sleeps.
+      const bool many_tiles = (int64_t)fc.n_enc * 4 >= (int64_t)9 * ncu * bpc * 4;
+      fc.chain_first_tiles = c->opt_fused_chain_first_tiles >= 0 ? c->opt_fused_chain_first_tiles : (many_tiles ? 1 : 0);
+      const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : (many_tiles ? 2 : -1);
+      // (sleepers need CUs without a chain to produce the latents the chains wait for)
+      fc.partner_tiles = fc.roll_cap <= ncu / 2 ? partner : -1;
       if (int rc = launch_shift_perturb()) return rc;
       // every workgroup must be resident at once: a rollout workgroup waits for encoder workgroups of the same launch
       const unsigned grid = (unsigned)(ncu * bpc);

@@ -216,14 +216,19 @@ constexpr int kFusedStatEntered = 4, kFusedStatRollStart = 5, kFusedStatRollDone
 constexpr int kFusedTimeEntry = 9, kFusedTimeRollBeginFirst = 10, kFusedTimeRollBeginLast = 11, kFusedTimeRollEndFirst = 12,
               kFusedTimeRollEndLast = 13, kFusedTimeEncLast = 14;
 constexpr int kFusedCuOcc = 16;              // 2048 per-CU arrival counters (XCC_ID << 8 | SE/SH/CU id)
-constexpr int kFusedFlags = 16 + 2048;       // (T, ntk) one word per encoder tile, then one (ntk) row of rollout-tile owner
+constexpr int kFusedCuState = 16 + 2048;     // 2048 per-CU words: 1 the CU's first workgroup walks a chain, 2 it has finished
+constexpr int kFusedFlags = 16 + 4096;       // (T, ntk) one word per encoder tile, then one (ntk) row of rollout-tile owner
                                              // tickets (the first add owns the tile)
-inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)(T + 1) * (size_t)((K + 15) / 16); }
+// (+ (T, ntk) chain-step time stamps, written by the trace build only)
+inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)(2 * T + 1) * (size_t)((K + 15) / 16); }
 struct FusedCtl {   // role assignment; passed to the kernel by value
   unsigned* sync;
   unsigned* timeout_host;  // pinned host word: non-zero = a rollout workgroup gave up waiting (command lost)
   int ntk;         // 16-sample tiles per horizon step
   int n_enc;       // T * ntk encoder tiles
+  int chain_first_tiles;  // encoder tiles every wave of a chain's workgroup encodes before the chain starts
+  int partner_tiles;      // >= 0: the other workgroup of a chain's CU sleeps after this many tiles per wave until the chain
+                          // is done; < 0: it never sleeps
   int roll_cap;    // rollout workgroups that start right away (one per CU); the other tiles drain after the encoders
 };
 struct FusedArgs {   // the kernel's one by-value argument

@@ -654,15 +654,18 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("K,cap", [(2048, 0), (2048, 40), (1000, 0), (4096, 0), (600, 7), (16, 0), (2048, 200)])
-def test_fused_plan_handoff_repeated_commands(nlc, K, cap):
+@pytest.mark.parametrize("K,cap,sched", [(2048, 0, None), (2048, 40, None), (1000, 0, None), (4096, 0, None), (600, 7, None),
+                                         (16, 0, None), (2048, 200, None), (2048, 0, (0, -1)), (2048, 0, (2, 1)),
+                                         (2048, 40, (3, 0)), (1000, 0, (1, 2)), (600, 7, (1, 0)), (4096, 0, (0, 1))])
+def test_fused_plan_handoff_repeated_commands(nlc, K, cap, sched):
     """The fused body hands every 16-sample tile's GRU latents from an encoder wavefront to a rollout workgroup INSIDE
     the launch (write-through stores + flag, sc1 loads behind a barrier).  A stale or early read would show up as a
     difference to the two-launch path: 25 consecutive commands (the latent buffer is rewritten in place every command,
     so a stale line of the previous command is a wrong value), all states / costs / actions bit-identical.  cap = 40
     starts only 40 rollout workgroups at the census: the other tiles drain after the encoders, beside busy CUs.
     K = 600 / 16: the encoder ticket is dry almost at once, so census and drain workgroups race for the rollout tiles
-    (exclusive owner words); cap = 200: more census rollouts than half the CUs."""
+    (exclusive owner words); cap = 200: more census rollouts than half the CUs.  sched = (fused_chain_first_tiles,
+    fused_partner_tiles): None = the library's auto schedule (one tile first / partner sleeps after two at K = 2048)."""
     from oracle import nl_model as onl
 
     env, T = "oderl-cartpole", 40
@@ -675,6 +678,8 @@ def test_fused_plan_handoff_repeated_commands(nlc, K, cap):
         opts = {"rollout_variant": variant}
         if variant == 3 and cap:
             opts["fused_roll_cap"] = cap
+        if variant == 3 and sched is not None:
+            opts["fused_chain_first_tiles"], opts["fused_partner_tiles"] = sched
         planners[variant] = nlc.MPPIDelay(
             nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=3, planner_options=opts,

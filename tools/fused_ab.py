@@ -1,5 +1,5 @@
-"""A/B of the fused planner body on one box (tools only): python tools/fused_ab.py [roll_cap|none ...]
-NLC_LIB_PATH=<other libnlc_hip.so> selects the library; `none` leaves fused_roll_cap at the library's default."""
+"""A/B of the fused planner body on one box (tools only): python tools/fused_ab.py [<chain_first_tiles>x<partner_tiles>|none ...]
+NLC_LIB_PATH=<other libnlc_hip.so> selects the library; `none` leaves the schedule at the library's auto choice."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +14,8 @@ for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for own in sys.argv[1:] or ["none"]:
         opts = {"rollout_variant": 3}
         if own != "none":
-            opts["fused_roll_cap"] = int(own)
+            opts["fused_chain_first_tiles"] = int(own.split("x")[0])
+            opts["fused_partner_tiles"] = int(own.split("x")[1])
         p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(bench.ENV), d, nlc.noise_sigma(nu), num_samples=K,
                           horizon=bench.HORIZON, device="cuda:0", lambda_=1.0, u_min=torch.tensor(-3.0), u_max=torch.tensor(3.0),
                           u_scale=3.0, noise_rng="philox", seed=0, U_init=torch.zeros(bench.HORIZON, nu, dtype=torch.float64),

@@ -2,7 +2,7 @@
 finished after a few seconds, dumps the kernel's sync block (tickets, progress counters, census, flags) through a side
 stream and exits hard, so a hand-off bug never holds the GPU box.  The progress counters and the timeline need a library
 built with -DNLC_FUSED_TRACE=1 (make EXTRA_kernels_fused=-DNLC_FUSED_TRACE=1; NLC_LIB_PATH selects it).
-    python tools/fused_debug.py [K] [roll_cap]"""
+    python tools/fused_debug.py [K] [roll_cap] [<chain_first_tiles>x<partner_tiles>]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,12 +11,15 @@ import neurallaplacecontrol_amd as nlc
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cap = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+sched = sys.argv[3] if len(sys.argv) > 3 else None
 
 T, d, nu = bench.HORIZON, 5, 1
 model = bench.synthetic_state_dict(d, nu, bench.S_TERMS).to("cuda:0")
 opts = {"rollout_variant": 3}
 if cap:
     opts["fused_roll_cap"] = cap
+if sched is not None:
+    opts["fused_chain_first_tiles"], opts["fused_partner_tiles"] = (int(x) for x in sched.split("x"))
 p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(bench.ENV), d, nlc.noise_sigma(nu), num_samples=K, horizon=T,
                   device="cuda:0", lambda_=1.0, u_min=torch.tensor(-3.0), u_max=torch.tensor(3.0), u_scale=3.0,
                   noise_rng="philox", seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options=opts)
@@ -26,7 +29,7 @@ ab = torch.zeros(4, nu, dtype=torch.float64)
 
 def dump(tag):
     ntk = (K + 15) // 16
-    words = 16 + 2048 + (T + 1) * ntk
+    words = 16 + 4096 + (2 * T + 1) * ntk
     nd = ((words + 1) // 2 + 63) // 64 * 64
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -47,8 +50,19 @@ def dump(tag):
     occ = w[16:16 + 2048]
     nz = occ[occ != 0]
     print(tag, "CUs seen", int((occ != 0).sum()), "max WG/CU", int(nz.max()) if nz.numel() else 0, flush=True)
-    fl = w[2064:2064 + T * ntk].view(T, ntk)
+    fl = w[4112:4112 + T * ntk].view(T, ntk)
     print(tag, "flags set per horizon step:", [int(x) for x in (fl != 0).sum(1)], flush=True)
+    if os.environ.get("FUSED_TIMELINE"):
+        # trace build: flag words carry the tile's completion time, the block behind the owner row every chain's step times
+        us = lambda x: (((x.to(torch.int64) & 0xffffffff) - t0) & 0xffffffff).double() / 100.0
+        ft = us(fl)
+        print(tag, "encoder tiles of horizon step t done, us (min / median / max):",
+              [(int(ft[t].min()), int(ft[t].median()), int(ft[t].max())) for t in range(0, T, 3)], flush=True)
+        ch = us(w[4112 + (T + 1) * ntk:4112 + (2 * T + 1) * ntk].view(T, ntk))
+        print(tag, "chains past step t, us (min / median / max):",
+              [(int(ch[t].min()), int(ch[t].median()), int(ch[t].max())) for t in range(0, T, 3)], flush=True)
+        order = torch.sort(ft.reshape(-1)).values
+        print(tag, "encoder tiles finished by 100 us marks:", [int((order <= m).sum()) for m in range(100, 1001, 100)], flush=True)
 
 
 def watchdog():
