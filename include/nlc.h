@@ -83,11 +83,13 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "fused_max_samples"  auto picks the fused body up to this many local samples (default 2048: one GPU's shard of
  *                        BASELINE configs[1] at 8 GPUs; at 4096 the two-launch path measured faster)
  *   "fused_roll_cap"     rollout workgroups the fused body starts right away, one per CU (0 = auto: half the CUs)
- *   "fused_chain_first_tiles"  encoder tiles every wavefront of such a workgroup encodes before its chain starts
- *                        (-1 = auto: 1 when the launch has >= 2.25 encoder tiles per resident wavefront, else 0)
- *   "fused_partner_tiles"  the OTHER workgroup of that CU stops drawing encoder tiles after this many per wavefront and
- *                        sleeps until the chain is done (an encoder wave beside a chain doubles the chain's step time);
- *                        -1 = never, -2 = auto (2 under the same condition, else never)
+ *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
+ *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
+ *                        the latency -- 1 / 0; -1 = auto (default): up to 100 000 windows
+ *   "fused_chain_first_tiles"  encoder tiles every such workgroup encodes before its chain starts (-1 = auto: 1)
+ *   "fused_partner_tiles"  the OTHER workgroups of that CU stop drawing encoder tiles after this many each and sleep until
+ *                        the chain is done (an encoder wave beside a chain doubles the chain's step time); -1 = never,
+ *                        -2 = auto (1 .. 4 with the share of CUs that walk a chain: fit to MI355X measurements)
  * Unknown names / out-of-range values: NLC_ERR_BAD_ARG. */
 int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
 /* device properties the bench reports next to its roofline numbers */

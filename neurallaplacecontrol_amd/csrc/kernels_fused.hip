@@ -7,7 +7,7 @@
 // Here the rollout of a tile starts as soon as the latents of its FIRST horizon step exist and the encoder waves keep
 // every other SIMD (and the rollout workgroups' own idle issue slots, at lower wave priority) busy.
 //
-// Grid: 2 workgroups of 256 threads per CU, all co-resident (the host sizes the grid from the device's CU count and
+// Grid: 4 workgroups of 256 threads per CU, all co-resident (the host sizes the grid from the device's CU count and
 // this kernel's occupancy).  Roles are taken at run time and do NOT depend on dispatch order or placement for
 // correctness (only for speed):
 //   * census: the first workgroup to arrive on a CU (s_getreg HW_ID / XCC_ID -> per-CU counter) may take one of the first
@@ -173,25 +173,12 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem) {
   }
 }
 
-// One encoder tile: horizon step t of samples 16 j .. 16 j + 15, by one wavefront; the latents leave the wave as
-// write-through stores and are complete when this returns.
-template <int G>
-__device__ __forceinline__ void fused_encode_tile(const FusedArgs& a, int lane, int t, int j, double* H0, double* H1) {
-  const int q = lane >> 4, c = lane & 15;
-  const int64_t k = (int64_t)j * 16 + c;
-  const bool valid = k < a.r.K;
-  const int64_t kk = valid ? k : a.r.K - 1;
-  const double o = gru_encode_tile<G>(a.g, lane, 0, kk, t, H0, H1);
-  if (valid && q < 2) {
-    unsigned long long* dst = (unsigned long long*)(a.r.pa + ((int64_t)t * a.r.K + k) * 2 + q);
-    __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, o), NLC_RLX_AGENT);  // global_store_dwordx2 sc1
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left this wave
-}
-
-// Encoder role: this wavefront draws encoder tiles (ticket order = horizon-major: all tiles of step t before step t+1)
-// until the ticket is spent, or until it has encoded max_tiles of them (a chain's workgroup before it starts walking).
-// yield_cu >= 0 (the OTHER workgroup of a chain's CU): after yield_after tiles it stops drawing while that chain is
+// Encoder role: the WORKGROUP draws encoder tiles (ticket order = horizon-major: all tiles of step t before step t+1)
+// until the ticket is spent, or until it has encoded max_tiles of them (a chain's workgroup before it starts walking),
+// and encodes each one cooperatively -- gru_encode_tile_coop: one gate chunk per wavefront, a quarter of the latency of
+// a wave-sized tile at the same throughput (at four workgroups per CU), so that work moves between the roles in units of
+// ~40 us instead of 150-290.  Wave 0 draws the ticket, applies the head and publishes the tile.
+// yield_cu >= 0 (another workgroup of a chain's CU): after yield_after tiles it stops drawing while that chain is
 // still running (see the kernel for why).  Never sleeps while it holds a tile: a chain elsewhere may be waiting for it.
 template <int G>
 __device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yield_cu, int yield_after) {
@@ -199,42 +186,55 @@ __device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yi
   const FusedArgs& a = *(const FusedArgs*)role_args();
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c = lane & 15;
   unsigned* sync = a.ctl.sync;
-  double* H0 = smem + (size_t)wv * 2 * KSG * 64;
-  double* H1 = H0 + KSG * 64;
+  unsigned* s_ticket = reinterpret_cast<unsigned*>(smem + 4 * KSG * 64);  // behind the four hidden-state images
   for (int done = 0; done < max_tiles; ++done) {
-    if (yield_cu >= 0 && done >= yield_after) {
-      // bounded (~50 ms): nothing depends on this wait for correctness
-      for (unsigned spins = 0; spins < (1u << 14); ++spins) {
-        const unsigned st = __hip_atomic_load(sync + kFusedCuState + yield_cu, NLC_RLX_AGENT);
-        if (__builtin_amdgcn_readfirstlane(st) != 1u) break;
-        __builtin_amdgcn_s_sleep(127);
+    if (wv == 0) {
+      if (yield_cu >= 0 && done >= yield_after) {
+        // bounded (~50 ms): nothing depends on this wait for correctness
+        for (unsigned spins = 0; spins < (1u << 14); ++spins) {
+          const unsigned st = __hip_atomic_load(sync + kFusedCuState + yield_cu, NLC_RLX_AGENT);
+          if (__builtin_amdgcn_readfirstlane(st) != 1u) break;
+          __builtin_amdgcn_s_sleep(127);
+        }
       }
+      *s_ticket = wave_ticket(sync + kFusedEncTicket, lane);  // (every lane stores the same word)
     }
-    const unsigned i = wave_ticket(sync + kFusedEncTicket, lane);
+    __syncthreads();  // also: wave 0 has finished the previous tile's head before anybody zeroes the images again
+    const unsigned i = __builtin_amdgcn_readfirstlane(*s_ticket);
     if (i >= (unsigned)a.ctl.n_enc) break;
     const unsigned tr = i / (unsigned)a.ctl.ntk;
     const int t = (int)tr;
     const int j = (int)(i - tr * (unsigned)a.ctl.ntk);
-    fused_encode_tile<G>(a, lane, t, j, H0, H1);
-    if (NLC_FUSED_TRACE) {
-      // trace build: the flag word carries the tile's completion time (any non-zero value publishes the tile)
-      __hip_atomic_fetch_or(sync + kFusedFlags + i, (unsigned)__builtin_amdgcn_s_memrealtime() | 1u, NLC_RLX_AGENT);
-    } else {
-      wave_add_one(sync + kFusedFlags + i, lane);
+    const int64_t k = (int64_t)j * 16 + c;
+    const bool valid = k < a.r.K;
+    const int64_t kk = valid ? k : a.r.K - 1;
+    const double o = gru_encode_tile_coop<G>(a.g, lane, wv, 0, kk, t, smem);
+    if (wv == 0) {
+      if (valid && q < 2) {
+        unsigned long long* dst = (unsigned long long*)(a.r.pa + ((int64_t)t * a.r.K + k) * 2 + q);
+        __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, o), NLC_RLX_AGENT);  // global_store_dwordx2 sc1
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left this wave
+      if (NLC_FUSED_TRACE) {
+        // trace build: the flag word carries the tile's completion time (any non-zero value publishes the tile)
+        __hip_atomic_fetch_or(sync + kFusedFlags + i, (unsigned)__builtin_amdgcn_s_memrealtime() | 1u, NLC_RLX_AGENT);
+      } else {
+        wave_add_one(sync + kFusedFlags + i, lane);
+      }
+      if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEncDone, lane);
+      stamp_max(sync + kFusedTimeEncLast, false);
     }
-    if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEncDone, lane);
-    stamp_max(sync + kFusedTimeEncLast, false);
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
 template <int HT, int NT3, int G>
-__global__ __launch_bounds__(256, 2) void nl_plan_fused_kernel(const FusedArgs av) {
+__global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs av) {
   const FusedCtl& a = av.ctl;  // role assignment; the roles read av through role_args()
   constexpr int KSG = G / 4;  // GRU k-steps
   constexpr int KS = HT * 4;  // representation-MLP k-steps
-  constexpr int kGruDoubles = 4 * 2 * KSG * 64, kRollDoubles = 2 * KS * 64 + 8 * 64;
+  constexpr int kGruDoubles = 4 * KSG * 64 + 8, kRollDoubles = 2 * KS * 64 + 8 * 64;
   __shared__ double smem[kGruDoubles > kRollDoubles ? kGruDoubles : kRollDoubles];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -44,8 +44,41 @@ __global__ __launch_bounds__(256, G <= 64 ? 2 : 1) void gru_encode_kernel(const 
   }
 }
 
-hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s) {
+// Cooperative variant (one 16-window tile per workgroup, one gate chunk per wave: nlc_gru_tile.h): same results, a
+// quarter of the per-tile latency -- for launches with too few tiles to fill the chip with wave-sized ones.
+__global__ __launch_bounds__(256, 4) void gru_encode_coop_kernel(const GruArgs a) {
+  constexpr int KS = 16;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  __shared__ double Hc[4 * KS * 64];
+  for (int64_t tile = blockIdx.x; tile * 16 < a.N; tile += gridDim.x) {
+    const int64_t w = tile * 16 + c;
+    const bool valid = w < a.N;
+    const int64_t wc = valid ? w : a.N - 1;
+    int64_t kk = 0;
+    int tt = 0;
+    if (a.mode == 1) {
+      kk = wc / a.Tc;
+      tt = a.t0 + (int)(wc - kk * a.Tc);
+    }
+    const double o = gru_encode_tile_coop<64>(a, lane, wv, wc, kk, tt, Hc);
+    if (wv == 0 && valid && q < 2) {
+      const int64_t wo = (a.mode == 1) ? kk * a.T + tt : w;
+      a.out[wo * 2 + q] = o;
+    }
+    __syncthreads();  // the images are re-zeroed by the next tile
+  }
+}
+
+hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop) {
   if (a.N <= 0) return hipSuccess;
+  if (coop) {
+    if (g != 64) return hipErrorInvalidValue;
+    const int64_t tiles = (a.N + 15) / 16;
+    hipLaunchKernelGGL(gru_encode_coop_kernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   const unsigned grid = (unsigned)((a.N + 63) / 64);
   if (g == 64) {
     hipLaunchKernelGGL((gru_encode_kernel<64>), dim3(grid), dim3(256), 0, s, a);

@@ -101,6 +101,7 @@ struct nlc_ctx {
   // planner options (nlc_set_option)
   int opt_rollout_variant = 0;          // 0 auto, 1 wave-per-tile, 2 latency-split (two launches), 3 fused one-launch body
   int opt_fused_roll_cap = 0;           // 0 auto (half the CUs)
+  int opt_gru_coop = -1;                // stand-alone GRU encodes: cooperative (one tile per workgroup) kernel 1 / 0, -1 auto
   int opt_fused_chain_first_tiles = -1; // tiles per wave a chain's workgroup encodes before it starts walking (-1 auto)
   int opt_fused_partner_tiles = -2;     // tiles per wave after which a chain's CU partner sleeps (-1: never, -2 auto)
   int64_t opt_fused_max_samples = 2048; // auto: populations up to this size take the fused body (measured: 4096 is slower)
@@ -118,6 +119,15 @@ namespace {
 int fail(nlc_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   return code;
+}
+
+// Stand-alone GRU encode: the cooperative kernel (one 16-window tile per workgroup, gru_encode_coop_kernel) has a third of
+// the latency and, measured on the MI355X, the better time up to ~80 k windows (0.030 vs 0.093 ms at 4096, 0.427 vs
+// 0.432 ms at 81920); from 160 k windows on the wave-per-tile kernel is 2 % faster (3.14 vs 3.21 ms at 655360).
+bool gru_use_coop(const nlc_ctx* c, int64_t n_windows) {
+  if (c->g != 64) return false;
+  if (c->opt_gru_coop >= 0) return c->opt_gru_coop != 0;
+  return n_windows <= 100000;
 }
 
 #define NLC_HIP(c, expr)                                                                          \
@@ -414,6 +424,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "fused_partner_tiles") {
     if (value < -2 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_partner_tiles must be in -2..64 (-2 = auto, -1 = never)");
     c->opt_fused_partner_tiles = (int)value;
+  } else if (n == "gru_coop") {
+    if (value != 0 && value != 1 && value != -1) return fail(c, NLC_ERR_BAD_ARG, "gru_coop must be -1 (auto), 0 or 1");
+    c->opt_gru_coop = (int)value;
   } else if (n == "fused_max_samples") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_max_samples must be >= 0");
     c->opt_fused_max_samples = (int64_t)value;
@@ -748,7 +761,7 @@ extern "C" int nlc_gru_encode(nlc_ctx* c, const double* window, int64_t N, int B
   a.B = B;
   a.out = out;
   ProfScope ps(c, "gru_encode_kernel");
-  NLC_HIP(c, launch_gru_encode(a, c->g, c->stream));
+  NLC_HIP(c, launch_gru_encode(a, c->g, c->stream, gru_use_coop(c, a.N)));
   return NLC_OK;
   NLC_GUARD_END(c)
 }
@@ -780,7 +793,7 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
     a.B = B;
     a.out = pa;
     ProfScope ps(c, "gru_encode_kernel");
-    NLC_HIP(c, launch_gru_encode(a, c->g, c->stream));
+    NLC_HIP(c, launch_gru_encode(a, c->g, c->stream, gru_use_coop(c, a.N)));
   }
   if (c->md.ilt.algo == NLC_ILT_DEHOOG) {
     // staged: representation function -> F_k (re, im) in HBM -> de Hoog kernel (nonlinear in F: not an MFMA epilogue)
@@ -1465,7 +1478,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       g.N = KE * d.T;
       {
         ProfScope ps(c, "gru_encode_kernel");
-        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
       }
       double* tconst = ws + w.tconst;
       NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1546,7 +1559,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
         NLC_HIP(c, fused_max_resident_blocks(&bpc));
         c->fused_blocks_per_cu = bpc;
       }
-      const int bpc = c->fused_blocks_per_cu < 2 ? c->fused_blocks_per_cu : 2;
+      const int bpc = c->fused_blocks_per_cu < 4 ? c->fused_blocks_per_cu : 4;
       if (bpc < 1) return fail(c, NLC_ERR_HIP, "fused planner body: kernel does not fit a CU");
       const int ncu = c->prop.multiProcessorCount;
       FusedArgs f{};
@@ -1565,13 +1578,17 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       // rollout workgroups start one per CU on the first CUs to arrive; by default on half the CUs at most
       fc.roll_cap = c->opt_fused_roll_cap > 0 ? c->opt_fused_roll_cap : (ncu / 2 > 0 ? ncu / 2 : 1);
       if (fc.roll_cap > fc.ntk) fc.roll_cap = fc.ntk;
-      // Schedule (profiles/r2_fused_small_shard.md): with at least ~2.25 encoder tiles per resident wavefront (K = 2048,
-      // T = 40: 2.5) every wave -- the chains' too -- encodes one tile first, and a chain's CU partner sleeps after its
-      // second tile until the chain is done (-6 % at K = 2048); with fewer tiles per wave neither helps (measured at
-      // K = 512 / 1024 / 1536), the chains start at once and nobody sleeps.
-      const bool many_tiles = (int64_t)fc.n_enc * 4 >= (int64_t)9 * ncu * bpc * 4;
-      fc.chain_first_tiles = c->opt_fused_chain_first_tiles >= 0 ? c->opt_fused_chain_first_tiles : (many_tiles ? 1 : 0);
-      const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : (many_tiles ? 2 : -1);
+      // Schedule (profiles/r2_fused_small_shard.md).  Every workgroup -- the chains' too -- encodes one tile first.  A
+      // chain's CU partners then encode M - 1 more tiles each and sleep until the chain is done: with few chains the CUs
+      // WITHOUT one feed them alone (M = 1); the more CUs walk a chain, the longer their partners have to help.  M is an
+      // empirical fit to the best schedule measured on the MI355X at T = 40 (chains on 25 / 37.5 / 43.75 / 50 % of the
+      // CUs, K = 1024 / 1536 / 1792 / 2048: M = 1 / 2 / 3 / 4; e.g. 0.672 ms at K = 2048 against 0.723 without any of
+      // this and 0.846 with M = 1), scaled with the horizon.
+      const double f_chain = (double)fc.roll_cap / (double)ncu;
+      const double extra = (16.0 * f_chain - 4.5) * (double)d.T / 40.0;
+      const int auto_partner = 1 + (extra > 0 ? (int)extra : 0);
+      fc.chain_first_tiles = c->opt_fused_chain_first_tiles >= 0 ? c->opt_fused_chain_first_tiles : 1;
+      const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : auto_partner;
       // (sleepers need CUs without a chain to produce the latents the chains wait for)
       fc.partner_tiles = fc.roll_cap <= ncu / 2 ? partner : -1;
       if (int rc = launch_shift_perturb()) return rc;
@@ -1586,7 +1603,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       g.N = KE * d.T;
       {
         ProfScope ps(c, "gru_encode_kernel");
-        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream));
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
       }
       r.t_begin = 0;
       r.t_end = d.T;

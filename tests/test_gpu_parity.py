@@ -1414,6 +1414,41 @@ dist.destroy_process_group()
 """
 
 
+def test_gru_cooperative_kernel_bit_identical(nlc):
+    """gru_encode_coop_kernel (one 16-window tile per workgroup, one gate chunk per wavefront; what small launches and the
+    fused body's encoders run) against the wave-per-tile kernel: same chunk GEMMs in the same k order and the same gate
+    math, so every latent is bit-identical -- ragged N, both kernels forced through the option, and a two-launch planner
+    command with either."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-acrobot"]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(3, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    ctx = model.hip_ctx(torch.device("cuda:0"))
+    torch.manual_seed(9)
+    try:
+        for N in (1, 15, 16, 17, 1000, 40961):
+            win = ((torch.rand(N, 4, nu, dtype=torch.float64) * 2 - 1) * A).cuda()
+            outs = []
+            for coop in (0, 1):
+                ctx.set_option("gru_coop", coop)
+                with torch.no_grad():
+                    outs.append(model.encode_actions(win).clone())
+            assert torch.equal(outs[0], outs[1]), N
+    finally:
+        ctx.set_option("gru_coop", -1)
+    acts = []
+    state0 = nlc.initial_state("oderl-acrobot", torch.Generator().manual_seed(2))
+    for coop in (0, 1):
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-acrobot"), d, nlc.noise_sigma(nu), 700, 9, "cuda",
+                          lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=4,
+                          U_init=torch.zeros(9, nu, dtype=torch.float64), planner_options={"rollout_variant": 2, "gru_coop": coop})
+        with torch.no_grad():
+            acts.append((p.command(state0, torch.zeros(4, nu, dtype=torch.float64)).cpu(), p.states.cpu()))
+    assert torch.equal(acts[0][0], acts[1][0]) and torch.equal(acts[0][1], acts[1][1])
+
+
 _NATIVE_COLLECTIVE_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
