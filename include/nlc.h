@@ -80,9 +80,10 @@ int nlc_synchronize(nlc_ctx* ctx);
  * which hand-written rollout body a command of NLC_DYN_NL / Fourier runs):
  *   "rollout_variant"    0 auto (default) | 1 one wavefront per 16-sample tile | 2 latency-split, one workgroup per tile
  *                        | 3 fused one-launch body (GRU encode + split rollout as roles of one persistent grid)
- *   "fused_max_samples"  auto picks the fused body up to this many local samples (default 2048: one GPU's shard of
- *                        BASELINE configs[1] at 8 GPUs; at 4096 the two-launch path measured faster)
- *   "fused_roll_cap"     rollout workgroups the fused body starts right away, one per CU (0 = auto: half the CUs)
+ *   "fused_max_samples"  auto picks the fused body up to this many local samples (default 4096: one chain per CU; one
+ *                        GPU's shard of BASELINE configs[1] at 4 and 8 GPUs)
+ *   "fused_roll_cap"     rollout workgroups the fused body starts right away, one per CU (0 = auto: one per 16-sample
+ *                        tile, at most one per CU)
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 100 000 windows

@@ -100,11 +100,11 @@ struct nlc_ctx {
   hipEvent_t stage_ev = nullptr;  // recorded after the staged H2D copies of a command
   // planner options (nlc_set_option)
   int opt_rollout_variant = 0;          // 0 auto, 1 wave-per-tile, 2 latency-split (two launches), 3 fused one-launch body
-  int opt_fused_roll_cap = 0;           // 0 auto (half the CUs)
+  int opt_fused_roll_cap = 0;           // 0 auto (one chain per 16-sample tile, at most one per CU)
   int opt_gru_coop = -1;                // stand-alone GRU encodes: cooperative (one tile per workgroup) kernel 1 / 0, -1 auto
   int opt_fused_chain_first_tiles = -1; // tiles per wave a chain's workgroup encodes before it starts walking (-1 auto)
   int opt_fused_partner_tiles = -2;     // tiles per wave after which a chain's CU partner sleeps (-1: never, -2 auto)
-  int64_t opt_fused_max_samples = 2048; // auto: populations up to this size take the fused body (measured: 4096 is slower)
+  int64_t opt_fused_max_samples = 4096; // auto: populations up to this size take the fused body (one chain per CU at most)
   int fused_blocks_per_cu = -1;         // occupancy of the fused kernel (queried once)
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): reported by the next call
   // optional native collective (nlc_comm_init): an RCCL communicator over the ranks of a K-sharded planner
@@ -1576,7 +1576,8 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       fc.ntk = (int)((KE + 15) / 16);
       fc.n_enc = fc.ntk * d.T;
       // rollout workgroups start one per CU on the first CUs to arrive; by default on half the CUs at most
-      fc.roll_cap = c->opt_fused_roll_cap > 0 ? c->opt_fused_roll_cap : (ncu / 2 > 0 ? ncu / 2 : 1);
+      // chains start on distinct CUs, one per 16-sample tile (the tiles beyond the CU count drain after the encoders)
+      fc.roll_cap = c->opt_fused_roll_cap > 0 ? c->opt_fused_roll_cap : ncu;
       if (fc.roll_cap > fc.ntk) fc.roll_cap = fc.ntk;
       // Schedule (profiles/r2_fused_small_shard.md).  Every workgroup -- the chains' too -- encodes one tile first.  A
       // chain's CU partners then encode M - 1 more tiles each and sleep until the chain is done: with few chains the CUs

@@ -13,6 +13,8 @@ state = nlc.initial_state(bench.ENV, torch.Generator().manual_seed(0))
 for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for own in sys.argv[1:] or ["none"]:
         opts = {"rollout_variant": 3}
+        if os.environ.get("AB_CAP"):
+            opts["fused_roll_cap"] = int(os.environ["AB_CAP"])
         if own != "none":
             opts["fused_chain_first_tiles"] = int(own.split("x")[0])
             opts["fused_partner_tiles"] = int(own.split("x")[1])
