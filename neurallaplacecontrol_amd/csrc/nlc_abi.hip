@@ -122,12 +122,13 @@ int fail(nlc_ctx* c, int code, const std::string& msg) {
 }
 
 // Stand-alone GRU encode: the cooperative kernel (one 16-window tile per workgroup, gru_encode_coop_kernel) has a third of
-// the latency and, measured on the MI355X, the better time up to ~80 k windows (0.030 vs 0.093 ms at 4096, 0.427 vs
-// 0.432 ms at 81920); from 160 k windows on the wave-per-tile kernel is 2 % faster (3.14 vs 3.21 ms at 655360).
+// the latency and, measured on the MI355X, the better time up to ~40 k windows (0.030 vs 0.093 ms at 4096, 0.233 vs
+// 0.271 ms at 40960); at 80 k windows the two are within 2 % of each other either way, from 160 k on the wave-per-tile
+// kernel is 2 % faster (3.14 vs 3.21 ms at 655360).
 bool gru_use_coop(const nlc_ctx* c, int64_t n_windows) {
   if (c->g != 64) return false;
   if (c->opt_gru_coop >= 0) return c->opt_gru_coop != 0;
-  return n_windows <= 100000;
+  return n_windows <= 50000;
 }
 
 #define NLC_HIP(c, expr)                                                                          \
