@@ -84,6 +84,8 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        GPU's shard of BASELINE configs[1] at 4 and 8 GPUs)
  *   "fused_roll_cap"     rollout workgroups the fused body starts right away, one per CU (0 = auto: one per 16-sample
  *                        tile, at most one per CU)
+ *   "repfunc_split"      staged de Hoog planner: the per-step representation launch as one workgroup per 16-sample tile
+ *                        (1, default; 60 vs 76 us per step at K = 16384, S = 33) or one wavefront per tile (0)
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows

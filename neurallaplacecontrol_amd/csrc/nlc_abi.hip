@@ -101,6 +101,7 @@ struct nlc_ctx {
   // planner options (nlc_set_option)
   int opt_rollout_variant = 0;          // 0 auto, 1 wave-per-tile, 2 latency-split (two launches), 3 fused one-launch body
   int opt_fused_roll_cap = 0;           // 0 auto (one chain per 16-sample tile, at most one per CU)
+  int opt_repfunc_split = 1;            // staged de Hoog planner: latency-split representation kernel (h = 128)
   int opt_gru_coop = -1;                // stand-alone GRU encodes: cooperative (one tile per workgroup) kernel 1 / 0, -1 auto
   int opt_fused_chain_first_tiles = -1; // tiles per wave a chain's workgroup encodes before it starts walking (-1 auto)
   int opt_fused_partner_tiles = -2;     // tiles per wave after which a chain's CU partner sleeps (-1: never, -2 auto)
@@ -425,6 +426,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "fused_partner_tiles") {
     if (value < -2 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_partner_tiles must be in -2..64 (-2 = auto, -1 = never)");
     c->opt_fused_partner_tiles = (int)value;
+  } else if (n == "repfunc_split") {
+    if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "repfunc_split must be 0 or 1");
+    c->opt_repfunc_split = (int)value;
   } else if (n == "gru_coop") {
     if (value != 0 && value != 1 && value != -1) return fail(c, NLC_ERR_BAD_ARG, "gru_coop must be -1 (auto), 0 or 1");
     c->opt_gru_coop = (int)value;
@@ -1497,6 +1501,7 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       // F travels slot-major between the two kernels of a step: four 128-B runs per store instruction of the MFMA
       // epilogue, one full line per de Hoog load (kernels_ilt.hip, FMODE 2)
       rf.slot_major = 1;
+      rf.split = c->md.h == 128 && c->opt_repfunc_split != 0;
       IltArgs ia{nullptr, nullptr, tconst, ws + w.dx, KE, d.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol),
                  c->md.ilt.scale, rf.fre, rf.fim, 1.0, 0, 0, 0, 0, c->eidx_dev};
       StepTailArgs st{};

@@ -295,6 +295,7 @@ struct RepFuncArgs {
   // running + perturbation cost into ccarry (StepTailArgs semantics) -- and the new x is the observation
   int tail_prev;      // 0: no prologue (obs is read as given)
   StepTailArgs tail;  // tail.t = the PREVIOUS step
+  int split;          // planner path: 1 = one workgroup per 16-sample tile (nl_repfunc_split_kernel), 0 = one wave per tile
 };
 hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s);
 

@@ -201,6 +201,14 @@ __global__ __launch_bounds__(256) void nl_repfunc_kernel(const RepFuncArgs a) {
   }
 }
 
+// latency-split form of the planner's per-step launch (repfunc_split_tile, nlc_rollout.h)
+template <int HT, int NT3>
+__global__ __launch_bounds__(256, 2) void nl_repfunc_split_kernel(const RepFuncArgs a) {
+  constexpr int KS = HT * 4;
+  __shared__ double H1[KS * 64], H2[KS * 64];
+  repfunc_split_tile<HT, NT3>(a, (int64_t)blockIdx.x, H1, H2);
+}
+
 // instantiated layer-3 tile counts; other (d,S) round up to the next one (zero-padded tiles)
 #define NLC_FOR_NT3(X) X(7) X(9) X(11) X(13) X(17) X(21) X(25)
 

@@ -374,4 +374,181 @@ __device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t
   }
 }
 
+// ------------------------------------------------------------------ latency-split representation function (de Hoog path)
+// One workgroup = one 16-sample tile, as rollout_split_tile: every layer's output tiles are split over the four waves and
+// the activations are exchanged through LDS -- but the output is F_k itself (slot-major, for ilt_dehoog_kernel), written
+// by the wave that owns the layer-3 tile, so there is no third barrier.  The staged de Hoog planner launches this once per
+// horizon step: a wave-sized tile (nl_repfunc_kernel) does the whole MLP of 16 samples serially, one wave per SIMD, and
+// is latency-bound for the 75 us the launch lasts; four waves per tile at up to four workgroups per CU overlap.
+// Planner form only (constant query time folded into b1, slot-major F, optional tail of the previous step).
+template <int HT, int NT3>
+__device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t tile, double* __restrict__ H1,
+                                                   double* __restrict__ H2) {
+  constexpr int KS = HT * 4;
+  constexpr int TW = HT / 4;
+  constexpr int NTW = (NT3 + 3) / 4;
+  const NlNetArgs& n = a.net;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t k = tile * 16 + c;
+  const bool valid = k < a.N;
+  const int64_t kc = valid ? k : a.N - 1;
+  const int d = n.d;
+  const int i0 = q, i1 = 4 + q;
+  const double* ob = a.obs + (a.obs_per_sample ? kc : kc / a.Kep) * a.obs_stride;
+  const double* pa = a.pa + kc * a.pa_stride;
+  double x0 = (i0 < d) ? ob[i0] : 0.0, x1 = (i1 < d) ? ob[i1] : 0.0;
+  if (a.tail_prev) {
+    // tail of the previous horizon step, as in nl_repfunc_kernel; every wave needs the new state, wave 0 stores it
+    const StepTailArgs& s = a.tail;
+    const int64_t e = kc / s.Kep;
+    const double* src = s.first ? s.state0 + (s.state_per_sample ? kc : e) * d : s.x + kc * d;
+    if (i0 < d) x0 = src[i0] + s.dx[kc * d + i0];
+    if (i1 < d) x1 = src[i1] + s.dx[kc * d + i1];
+    if (wv == 0) {
+      double xs[NLC_MAX_D];
+#pragma unroll
+      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+      if (valid) {
+        if (i0 < d) s.x[k * d + i0] = x0;
+        if (i1 < d) s.x[k * d + i1] = x1;
+        if (s.states != nullptr) {
+          if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
+          if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
+        }
+      }
+      if (q == 0 && valid) {
+        double u[NLC_MAX_NU] = {0.0, 0.0};
+        for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
+        double pc = 0.0;
+        for (int j = 0; j < s.nu; ++j) {
+          double acj = 0.0;
+          for (int ii = 0; ii < s.nu; ++ii) {
+            double ev = s.noise[(k * s.T + s.t) * s.nu + ii];
+            if (s.noise_abs_cost) ev = fabs(ev);
+            acj += (s.lambda_ * ev) * s.sigma_inv[ii * s.nu + j];
+          }
+          pc += s.U[(e * s.T + s.t) * s.nu + j] * acj;
+        }
+        s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
+        s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
+      }
+    }
+  }
+  const double p0 = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0]
+                             : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+  const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
+                             : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+  int j3[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) j3[i] = (wv + 4 * i < NT3) ? wv + 4 * i : NT3 - 1;
+  // ---- layer 1: output tiles TW*wv .. TW*wv+TW-1
+  {
+    v4d acc[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b1, TW * wv + i, q);
+    gptr p = opaque(n.W1p + (size_t)TW * wv * 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const double b = ks == 0 ? p0 : p1;
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = mfma(p[(ks * HT + i) * 64 + lane], b, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+        H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+        H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+      }
+  }
+  __syncthreads();
+  // ---- layer 2
+  {
+    v4d acc[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b2, TW * wv + i, q);
+    gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
+    double a_cur[TW], a_nxt[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
+    double b_cur = H1[lane], b_nxt = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + HT * 64);
+#pragma unroll
+        for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
+        b_nxt = H1[(ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
+#pragma unroll
+      for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
+      b_cur = b_nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+        H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+        H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+      }
+  }
+  __syncthreads();
+  // ---- layer 3 (own tiles) + sphere -> complex, F_k stored slot-major
+  {
+    v4d o[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile(n.b3p, j3[i], q);
+    gptr p = opaque(n.W3p);
+    double a_cur[NTW], a_nxt[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
+    double b_cur = H2[lane], b_nxt = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + NT3 * 64);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
+        b_nxt = H2[(ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
+      b_cur = b_nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (wv + 4 * i < NT3) {  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int g = 2 * j3[i] + r;
+          // (same arithmetic as nl_eval's WRITE_F branch)
+          const double theta = m::tanh_d(o[i][r]) * kPi;
+          const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
+          double num, den;
+          m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+          const int idx = a.slot[4 * g + q];
+          if (valid && idx >= 0) {
+            double sn, cs;
+            m::sincos_bounded(theta, &sn, &cs);
+            const double rad = num * m::rcp_refined(den);
+            const int64_t at = (int64_t)(4 * g + q) * a.N + k;
+            a.fre[at] = rad * cs;
+            a.fim[at] = rad * sn;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace nlc

@@ -1414,6 +1414,31 @@ dist.destroy_process_group()
 """
 
 
+def test_repfunc_split_kernel_agrees_with_wave_per_tile_planner(nlc):
+    """Staged de Hoog planner: the latency-split representation launch (one workgroup per 16-sample tile) against the
+    wave-per-tile one -- same GEMM order per output tile and the same sphere map, so the two agree to rounding of the
+    differently contracted scalar code (1e-9 after the QD recurrence's amplification; the oracle comparisons of the
+    de Hoog tests run through the split form, the default) -- ragged K, several term counts."""
+    from oracle import nl_model as onl
+
+    for env, S, K, T in (("oderl-cartpole", 33, 1000, 6), ("oderl-acrobot", 9, 333, 4), ("oderl-pendulum", 21, 16, 3)):
+        st = onl.ENV_STATS[env]
+        d, nu, A = st["d"], st["nu"], st["act_high"]
+        sd = onl.make_synthetic_state_dict(6, d, nu, 128, S, st["state_std"], [A / 2], tame="dehoog")
+        model = build_model(nlc, sd, S=S, algo="dehoog")
+        state0 = nlc.initial_state(env, torch.Generator().manual_seed(2))
+        res = []
+        for split in (0, 1):
+            p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+                              u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=4,
+                              U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"repfunc_split": split})
+            with torch.no_grad():
+                acts = [p.command(state0, torch.zeros(4, nu, dtype=torch.float64)).cpu() for _ in range(2)]
+            res.append((torch.stack(acts), p.states.cpu(), p.cost_total.cpu()))
+        for a, b in zip(res[0], res[1]):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-10, err_msg=f"{env} S={S}")
+
+
 def test_gru_cooperative_kernel_bit_identical(nlc):
     """gru_encode_coop_kernel (one 16-window tile per workgroup, one gate chunk per wavefront; what small launches and the
     fused body's encoders run) against the wave-per-tile kernel: same chunk GEMMs in the same k order and the same gate

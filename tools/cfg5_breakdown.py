@@ -10,7 +10,8 @@ model = nlc.NeuralLaplaceModel(5, 1, 5, hidden_units=128, s_recon_terms=S, ilt_a
 with torch.no_grad(): model.laplace_rep_func.linear_tanh_stack[4].bias[5*S:] += -3.0
 model = model.to("cuda")
 mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-cartpole"), 5, nlc.noise_sigma(1), 16384, 40, "cuda", lambda_=1.0,
-    u_min=torch.tensor(-3.0), u_max=torch.tensor(3.0), u_scale=3.0, noise_rng="philox", U_init=torch.zeros(40,1,dtype=torch.float64), store_rollouts=False)
+    u_min=torch.tensor(-3.0), u_max=torch.tensor(3.0), u_scale=3.0, noise_rng="philox", U_init=torch.zeros(40,1,dtype=torch.float64), store_rollouts=False,
+    planner_options=dict(kv.split("=") for kv in os.environ.get("CFG5_OPTS", "").split(",") if kv))
 st, ab = nlc.initial_state("oderl-cartpole"), torch.zeros(4,1,dtype=torch.float64)
 with torch.no_grad():
     for _ in range(2): mppi.command(st, ab)
