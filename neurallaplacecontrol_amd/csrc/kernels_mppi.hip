@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
   const int64_t total = a.K * a.T;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_zero_words; i += (int64_t)gridDim.x * blockDim.x)
     a.zero_words[i] = 0u;
+  if (a.fused_shift && blockIdx.x == 0) {
+    // the staged per-command inputs (shift_U_kernel's second job)
+    for (int i = threadIdx.x; i < a.n_state_in; i += blockDim.x) a.state_dst[i] = a.state_in[i];
+    for (int i = threadIdx.x; i < a.n_abuf_in; i += blockDim.x) a.abuf_dst[i] = a.abuf_in[i];
+  }
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = idx / a.T;
@@ -65,7 +70,14 @@ __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
     }
     const bool null_action = a.sample_null_action && (ke == a.K_global - 1);
     for (int i = 0; i < a.nu; ++i) {
-      const double U = a.U_new[(e * a.T + t) * a.nu + i];
+      double U;
+      if (a.fused_shift) {
+        // U <- roll(U, -1); U[-1] = u_init (:199-200) applied on the fly; the episode's first local sample stores it
+        U = (t + 1 < a.T) ? a.U_old[(e * a.T + t + 1) * a.nu + i] : a.u_init[i];
+        if (k == e * a.Kep) a.U_new[(e * a.T + t) * a.nu + i] = U;
+      } else {
+        U = a.U_new[(e * a.T + t) * a.nu + i];
+      }
       double V = U + eps[i];
       if (null_action) V = 0.0;  // :322-323
       double Vs = V * a.u_scale;
@@ -151,20 +163,32 @@ __global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a,
     for (int s = 0; s < ns; ++s) acc += sw[s] * np[(int64_t)s * TN];
     out[1 + tj] = acc;
   }
-}
-
-// pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r).
-// One wavefront per output entry: lanes stride over the blocks, then a wave reduction.
-__global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
-  const int TN = a.T * a.nu;
+  // pass 3, by the LAST block of the episode to get here: fold the block partials (fixed order -> run-to-run
+  // deterministic) into (eta_r, S_r).  One wavefront per output entry: lanes stride over the blocks, then a wave
+  // reduction -- the arithmetic of the former weight_final_kernel, without its launch.
+  __shared__ unsigned s_last;
+  __threadfence();  // this block's partial is visible device-wide before it is counted
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned n = __hip_atomic_fetch_add(a.arrived + e, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (n + 1u == (unsigned)gridDim.x) ? 1u : 0u;
+    if (s_last) __hip_atomic_store(a.arrived + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next command
+  }
+  __syncthreads();
+  if (!s_last) return;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= 1 + TN) return;
-  const int64_t e = blockIdx.y;
-  double acc = 0.0;
-  for (int b = lane; b < a.nblk; b += 64) acc += a.block_part[(e * a.nblk + b) * (1 + TN) + i];
-  acc = wave_sum(acc);
-  if (lane == 0) a.partials[e * (2 + TN) + 1 + i] = acc;
+  for (int i = threadIdx.x >> 6; i < 1 + TN; i += 4) {
+    double acc = 0.0;
+    for (int b = lane; b < a.nblk; b += 64) {
+      // (written by other CUs during this launch: read past this CU's L1)
+      const unsigned long long v = __hip_atomic_load(
+          reinterpret_cast<const unsigned long long*>(a.block_part + ((int64_t)e * a.nblk + b) * (1 + TN) + i), __ATOMIC_RELAXED,
+          __HIP_MEMORY_SCOPE_AGENT);
+      acc += __builtin_bit_cast(double, v);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.partials[(int64_t)e * (2 + TN) + 1 + i] = acc;
+  }
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
@@ -172,7 +196,6 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
   const unsigned E = (unsigned)a.E;
   hipLaunchKernelGGL(cost_min_kernel, dim3(nmin, E), dim3(256), 0, s, a);
   hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk, E), dim3(256), 0, s, a, nmin);
-  hipLaunchKernelGGL(weight_final_kernel, dim3((1 + a.T * a.nu + 3) / 4, E), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

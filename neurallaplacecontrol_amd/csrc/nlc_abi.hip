@@ -1204,7 +1204,10 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   c->ucur = 0;
   if (c->small) hipFree(c->small);
   c->small = nullptr;
-  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 2 * (size_t)E) * sizeof(double)));
+  // (+ E words, zero between commands: arrival counters of the weight blocks, reset by the block that folds)
+  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 3 * (size_t)E) * sizeof(double)));
+  NLC_HIP(c, hipMemsetAsync(c->small, 0, (un + 3 * (size_t)E) * sizeof(double), c->stream));
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
   const size_t pin_need = (size_t)E * d->d + (size_t)E * d->B * d->nu + un + 8;
   if (pin_need > c->pinned_n) {
     if (c->pinned) hipHostFree(c->pinned);
@@ -1301,6 +1304,7 @@ static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   wa.block_part = ws + w.block_part;
   wa.partials = buf->partials;
   wa.nblk = c->nblk;
+  wa.arrived = reinterpret_cast<unsigned*>(c->small + (size_t)d.E * d.T * d.nu + 2 * (size_t)d.E);
   ProfScope ps(c, "weight_kernels");
   NLC_HIP(c, launch_weights(wa, c->stream));
   return NLC_OK;
@@ -1427,7 +1431,11 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   // (a lambda: the fused planner body's argument block rides to the device in the perturb kernel's arguments, so that
   // path fills p.blob first)
   auto launch_shift_perturb = [&]() -> int {
-    {
+    // one launch: the perturb kernel shifts U on the fly (every (k, t) thread reads U_old[t + 1]; the episode's first
+    // local sample stores the shifted row) and stores the staged inputs; shift_U_kernel only when there is nothing to
+    // perturb
+    p.fused_shift = (int64_t)p.K * p.T > 0;
+    if (!p.fused_shift) {
       ProfScope ps(c, "shift_U_kernel");
       NLC_HIP(c, launch_shift_U(p, c->stream));
     }

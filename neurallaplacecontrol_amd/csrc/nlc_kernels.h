@@ -397,6 +397,7 @@ struct PerturbArgs {
   // words the perturb kernel zeroes for a later kernel of the same command (the fused planner's sync block)
   unsigned* zero_words;
   int64_t n_zero_words;
+  int fused_shift;  // 1: the perturb kernel also does shift_U_kernel's work (U <- roll(U, -1), the staged inputs)
 };
 hipError_t launch_shift_U(const PerturbArgs& a, hipStream_t s);
 hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s);
@@ -412,6 +413,7 @@ struct WeightArgs {
   double* block_part;   // (E, nblk, 1 + T*nu)
   double* partials;     // (E, 2 + T*nu)
   int nblk;             // weight blocks per episode
+  unsigned* arrived;    // (E) zero between commands: weight blocks of the episode that have stored their partial
 };
 constexpr int kWeightBlockSamples = 64;
 // pass-1 blocks per episode (the workspace holds E * this many block minima)
