@@ -163,32 +163,20 @@ __global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a,
     for (int s = 0; s < ns; ++s) acc += sw[s] * np[(int64_t)s * TN];
     out[1 + tj] = acc;
   }
-  // pass 3, by the LAST block of the episode to get here: fold the block partials (fixed order -> run-to-run
-  // deterministic) into (eta_r, S_r).  One wavefront per output entry: lanes stride over the blocks, then a wave
-  // reduction -- the arithmetic of the former weight_final_kernel, without its launch.
-  __shared__ unsigned s_last;
-  __threadfence();  // this block's partial is visible device-wide before it is counted
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned n = __hip_atomic_fetch_add(a.arrived + e, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (n + 1u == (unsigned)gridDim.x) ? 1u : 0u;
-    if (s_last) __hip_atomic_store(a.arrived + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next command
-  }
-  __syncthreads();
-  if (!s_last) return;
+}
+
+// pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r).
+// One wavefront per output entry: lanes stride over the blocks, then a wave reduction.
+__global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
+  const int TN = a.T * a.nu;
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x >> 6; i < 1 + TN; i += 4) {
-    double acc = 0.0;
-    for (int b = lane; b < a.nblk; b += 64) {
-      // (written by other CUs during this launch: read past this CU's L1)
-      const unsigned long long v = __hip_atomic_load(
-          reinterpret_cast<const unsigned long long*>(a.block_part + ((int64_t)e * a.nblk + b) * (1 + TN) + i), __ATOMIC_RELAXED,
-          __HIP_MEMORY_SCOPE_AGENT);
-      acc += __builtin_bit_cast(double, v);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) a.partials[(int64_t)e * (2 + TN) + 1 + i] = acc;
-  }
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= 1 + TN) return;
+  const int64_t e = blockIdx.y;
+  double acc = 0.0;
+  for (int b = lane; b < a.nblk; b += 64) acc += a.block_part[(e * a.nblk + b) * (1 + TN) + i];
+  acc = wave_sum(acc);
+  if (lane == 0) a.partials[e * (2 + TN) + 1 + i] = acc;
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
@@ -196,6 +184,7 @@ hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
   const unsigned E = (unsigned)a.E;
   hipLaunchKernelGGL(cost_min_kernel, dim3(nmin, E), dim3(256), 0, s, a);
   hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk, E), dim3(256), 0, s, a, nmin);
+  hipLaunchKernelGGL(weight_final_kernel, dim3((1 + a.T * a.nu + 3) / 4, E), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -1204,10 +1204,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   c->ucur = 0;
   if (c->small) hipFree(c->small);
   c->small = nullptr;
-  // (+ E words, zero between commands: arrival counters of the weight blocks, reset by the block that folds)
-  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 3 * (size_t)E) * sizeof(double)));
-  NLC_HIP(c, hipMemsetAsync(c->small, 0, (un + 3 * (size_t)E) * sizeof(double), c->stream));
-  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  NLC_HIP(c, hipMalloc((void**)&c->small, (un + 2 * (size_t)E) * sizeof(double)));
   const size_t pin_need = (size_t)E * d->d + (size_t)E * d->B * d->nu + un + 8;
   if (pin_need > c->pinned_n) {
     if (c->pinned) hipHostFree(c->pinned);
@@ -1304,7 +1301,6 @@ static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   wa.block_part = ws + w.block_part;
   wa.partials = buf->partials;
   wa.nblk = c->nblk;
-  wa.arrived = reinterpret_cast<unsigned*>(c->small + (size_t)d.E * d.T * d.nu + 2 * (size_t)d.E);
   ProfScope ps(c, "weight_kernels");
   NLC_HIP(c, launch_weights(wa, c->stream));
   return NLC_OK;

@@ -413,7 +413,6 @@ struct WeightArgs {
   double* block_part;   // (E, nblk, 1 + T*nu)
   double* partials;     // (E, 2 + T*nu)
   int nblk;             // weight blocks per episode
-  unsigned* arrived;    // (E) zero between commands: weight blocks of the episode that have stored their partial
 };
 constexpr int kWeightBlockSamples = 64;
 // pass-1 blocks per episode (the workspace holds E * this many block minima)
