@@ -1,11 +1,11 @@
 // One-launch planner body for SMALL populations (one GPU's K/G shard of BASELINE configs[1]): the hoisted GRU encode
-// (w_nl.py:14-29, one 16-window tile per wavefront) and the latency-split T-step rollout (planners/mppi_delay.py:271-296,
+// (w_nl.py:14-29, one 16-window tile per WORKGROUP: gru_encode_tile_coop) and the latency-split T-step rollout (planners/mppi_delay.py:271-296,
 // one 16-sample tile per workgroup) run as ROLES of the same persistent grid instead of two back-to-back launches.
 //
 // Why: at K = 2048 the split rollout is 128 workgroups walking 40 strictly sequential horizon steps (0.40 ms) while
 // the other half of the chip idles, after the encode (0.42 ms, throughput-bound on the whole chip) has run alone.
-// Here the rollout of a tile starts as soon as the latents of its FIRST horizon step exist and the encoder waves keep
-// every other SIMD (and the rollout workgroups' own idle issue slots, at lower wave priority) busy.
+// Here the rollout of a tile ("chain") starts once a first bank of latents exists, the encoder workgroups keep every other
+// SIMD busy, and the ones beside a chain yield when the chain would otherwise fall behind (schedule: in the kernel).
 //
 // Grid: 4 workgroups of 256 threads per CU, all co-resident (the host sizes the grid from the device's CU count and
 // this kernel's occupancy).  Roles are taken at run time and do NOT depend on dispatch order or placement for
@@ -13,14 +13,14 @@
 //   * census: the first workgroup to arrive on a CU (s_getreg HW_ID / XCC_ID -> per-CU counter) may take one of the first
 //     roll_cap rollout tiles (census ticket + the tile's owner word), so rollout workgroups sit on distinct CUs;
 //   * everybody else takes encoder tiles from the encoder ticket, in horizon-major order (all tiles of step t before
-//     step t+1), one tile per wavefront, and publishes each tile's latents;
+//     step t+1), one tile per workgroup (one gate chunk per wavefront), and publishes each tile's latents;
 //   * when the encoder ticket runs dry the workgroup drains the rollout tiles that have no owner yet (drain ticket +
 //     owner word).
 // An encoder never waits for anything, so the grid drains even if a rollout workgroup had to give up (bounded spins).
 //
 // Hand-off of a tile's latents (256 B, (T, K, 2) horizon-major so a tile is two whole 128-B lines), following
 // cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "inter-workgroup visibility" (third row of the sc1 table):
-//   producer wave: 8-B write-through (sc1) stores of the whole lines by ONE store instruction, s_waitcnt vmcnt(0),
+//   producer (wave 0 of the encoder workgroup): 8-B write-through (sc1) stores of the whole lines by ONE store instruction, s_waitcnt vmcnt(0),
 //                  then ONE lane's agent-scope atomic add on the tile's flag word;
 //   consumer:      ONE wave polls the flag with relaxed agent loads (global_load_dword sc1), a workgroup barrier, then
 //                  EVERY load of the latents is a 16-B buffer_load ... sc1 (bypasses the CU's L1; no acquire fence).
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs a
     __hip_atomic_store(sync + kFusedCuState + cu, 2u, NLC_RLX_AGENT);  // (all waves, same word) wakes this CU's sleeper
   }
 
-  // ---- encoder role: one tile (horizon step t, samples 16 j .. 16 j + 15) per wavefront and ticket
+  // ---- encoder role: one tile (horizon step t, samples 16 j .. 16 j + 15) per workgroup and ticket
   __syncthreads();  // (a rollout may just have finished in this LDS)
   fused_encode<G>(smem, 0x7fffffff, (nth != 0 && a.partner_tiles >= 0) ? (int)cu : -1, a.partner_tiles);
 
