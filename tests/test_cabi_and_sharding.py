@@ -113,7 +113,7 @@ WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from neurallaplacecontrol_amd.sharding import (shard_range, gather_partials, slice_noise, partial_width,
-                                               replicate_from_rank0, check_same_on_all_ranks)
+                                               replicate_from_rank0, check_same_on_all_ranks, share_bytes_from_rank0)
 from oracle import envs as oenvs, mppi as omppi
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
@@ -124,6 +124,9 @@ U_own = torch.randn(T, nu, dtype=torch.float64) * 0.3
 U = replicate_from_rank0(U_own, dist.group.WORLD)
 assert (rank == 0) == bool(torch.equal(U, U_own))
 check_same_on_all_ranks((K, T, 7), dist.group.WORLD, "sizes / seed")
+# the unique id of the library's own communicator travels from rank 0 through the group the caller has (nlc_comm_init)
+uid = bytes(range(128)) if rank == 0 else None
+assert share_bytes_from_rank0(uid, 128, dist.group.WORLD) == bytes(range(128))
 try:
     check_same_on_all_ranks((K, T, 7 + rank), dist.group.WORLD, "sizes / seed")
     raise SystemExit("seed mismatch not detected")
