@@ -154,21 +154,25 @@ dist.destroy_process_group()
 """
 
 
-def test_two_rank_gloo_sharded_command(tmp_path):
-    """world_size=2 over gloo: per-shard rollout + all-gather of (beta, eta, S) + merge == unsharded command."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_gloo_sharded_command(tmp_path, world):
+    """world_size 2 and 8 (the driver's scaling run) over gloo: per-shard rollout + all-gather of (beta, eta, S) + merge ==
+    unsharded command."""
     from oracle import envs as oenvs
     from oracle import mppi as omppi
 
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    port = str(29531 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     subprocess.check_call(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29531", str(script), REPO, str(tmp_path)],
-        env=env, timeout=300,
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+         "--master-port", port, str(script), REPO, str(tmp_path)],
+        env=env, timeout=600,
     )
-    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert torch.equal(r0["U"], r1["U"]), "ranks disagree after the merge"
+    r0 = torch.load(tmp_path / "r0.pt")
+    for r in range(1, world):
+        assert torch.equal(r0["U"], torch.load(tmp_path / f"r{r}.pt")["U"]), "ranks disagree after the merge"
     # unsharded reference
     envn, K, T, A, nu, nx = "oderl-pendulum", 64, 6, 2.0, 1, 3
     torch.manual_seed(1000)  # the workers end up with RANK 0's control sequence (replicate_from_rank0)
