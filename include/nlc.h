@@ -88,7 +88,7 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        (1, default; 60 vs 76 us per step at K = 16384, S = 33) or one wavefront per tile (0)
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
- *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows
+ *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
  *   "fused_chain_first_tiles"  encoder tiles every such workgroup encodes before its chain starts (-1 = auto: 1)
  *   "fused_partner_tiles"  the OTHER workgroups of that CU stop drawing encoder tiles after this many each and sleep until
  *                        the chain is done (an encoder wave beside a chain doubles the chain's step time); -1 = never,

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256, G <= 64 ? 2 : 1) void gru_encode_kernel(const 
 
 // Cooperative variant (one 16-window tile per workgroup, one gate chunk per wave: nlc_gru_tile.h): same results, a
 // quarter of the per-tile latency -- for launches with too few tiles to fill the chip with wave-sized ones.
-__global__ __launch_bounds__(256, 4) void gru_encode_coop_kernel(const GruArgs a) {
-  constexpr int KS = 16;
+template <int G>
+__global__ __launch_bounds__(256, G <= 64 ? 4 : 2) void gru_encode_coop_kernel(const GruArgs a) {
+  constexpr int KS = G / 4;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c = lane & 15;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, 4) void gru_encode_coop_kernel(const GruArgs a
       kk = wc / a.Tc;
       tt = a.t0 + (int)(wc - kk * a.Tc);
     }
-    const double o = gru_encode_tile_coop<64>(a, lane, wv, wc, kk, tt, Hc);
+    const double o = gru_encode_tile_coop<G>(a, lane, wv, wc, kk, tt, Hc);
     if (wv == 0 && valid && q < 2) {
       const int64_t wo = (a.mode == 1) ? kk * a.T + tt : w;
       a.out[wo * 2 + q] = o;
@@ -74,9 +75,17 @@ __global__ __launch_bounds__(256, 4) void gru_encode_coop_kernel(const GruArgs a
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop) {
   if (a.N <= 0) return hipSuccess;
   if (coop) {
-    if (g != 64) return hipErrorInvalidValue;
     const int64_t tiles = (a.N + 15) / 16;
-    hipLaunchKernelGGL(gru_encode_coop_kernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(256), 0, s, a);
+    const dim3 cgrid((unsigned)(tiles < 65536 ? tiles : 65536));
+    if (g == 64) {
+      hipLaunchKernelGGL(gru_encode_coop_kernel<64>, cgrid, dim3(256), 0, s, a);
+    } else if (g == 32) {
+      hipLaunchKernelGGL(gru_encode_coop_kernel<32>, cgrid, dim3(256), 0, s, a);
+    } else if (g == 128) {
+      hipLaunchKernelGGL(gru_encode_coop_kernel<128>, cgrid, dim3(256), 0, s, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
     return hipGetLastError();
   }
   const unsigned grid = (unsigned)((a.N + 63) / 64);

@@ -122,14 +122,18 @@ int fail(nlc_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
-// Stand-alone GRU encode: the cooperative kernel (one 16-window tile per workgroup, gru_encode_coop_kernel) has a third of
-// the latency and, measured on the MI355X, the better time up to ~40 k windows (0.030 vs 0.093 ms at 4096, 0.233 vs
-// 0.271 ms at 40960); at 80 k windows the two are within 2 % of each other either way, from 160 k on the wave-per-tile
-// kernel is 2 % faster (3.14 vs 3.21 ms at 655360).
+// Stand-alone GRU encode: the cooperative kernel (one 16-window tile per workgroup, gru_encode_coop_kernel) has a fraction
+// of the latency of the wave-per-tile one at every width.  Measured on the MI355X (tools/gru_coop_probe.py):
+//   g = 64 (hidden_units 128): better up to ~40 k windows (0.030 vs 0.093 ms at 4096, 0.233 vs 0.271 ms at 40960), level
+//           at 80 k, 2 % slower from 160 k on (3.21 vs 3.14 ms at 655360);
+//   g = 32 (hidden_units 64, two of the four waves idle): better up to ~4 k windows (0.023 vs 0.037 ms), 30-45 % slower
+//           beyond 40 k;
+//   g = 128 (hidden_units 256; 64 KB of images: two workgroups per CU instead of one): better at every size (0.079 vs
+//           0.289 ms at 16 windows, 10.9 vs 11.7 ms at 655360).
 bool gru_use_coop(const nlc_ctx* c, int64_t n_windows) {
-  if (c->g != 64) return false;
   if (c->opt_gru_coop >= 0) return c->opt_gru_coop != 0;
-  return n_windows <= 50000;
+  if (c->g == 128) return true;
+  return n_windows <= (c->g == 32 ? 8192 : 50000);
 }
 
 #define NLC_HIP(c, expr)                                                                          \

@@ -209,20 +209,21 @@ __device__ __forceinline__ double gru_encode_tile(const GruArgs& a, int lane, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// COOPERATIVE tile (G = 64 only): ONE workgroup of four wavefronts encodes ONE 16-window tile, wave w owning gate
-// chunk j = w (hidden units 16 w .. 16 w + 15) of both layers.  Same arithmetic per entry as gru_encode_tile (same
-// chunk GEMMs in the same k order, same gate math): bit-identical results, a quarter of the latency per tile.  The
-// hidden-state images are shared by the workgroup and double-buffered: Hc[2 l + b][ks*64 + lane], layer l, buffer b;
-// one barrier per GRU step between the layers and one before the head.  All four waves call this with the same
-// (wc, kk, tt); wave 0 returns linear_out row q (valid for q < 2), the others return 0.
+// COOPERATIVE tile: ONE workgroup of four wavefronts encodes ONE 16-window tile, wave w owning the gate chunks w, w + 4,
+// ... (16 hidden units each) of both layers -- G = 64: one chunk per wave; G = 128: two; G = 32: waves 0 and 1 own one,
+// the other two only keep the barriers.  Same arithmetic per entry as gru_encode_tile (same chunk GEMMs in the same k
+// order, same gate math): bit-identical results, a fraction of the latency per tile.  The hidden-state images are shared
+// by the workgroup and double-buffered: Hc[(2 l + b) * KS*64 + ks*64 + lane], layer l, buffer b; one barrier per GRU step
+// between the layers and one before the head.  All four waves call this with the same (wc, kk, tt); wave 0 returns
+// linear_out row q (valid for q < 2), the others return 0.
 template <int G>
 __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lane, int wv, int64_t wc, int64_t kk, int tt,
                                                        double* __restrict__ Hc) {
-  static_assert(G == 64, "one gate chunk per wavefront: four chunks");
+  constexpr int GT = G / 16;
   constexpr int KS = G / 4;
+  constexpr int CPW = (GT + 3) / 4;  // chunks per wave
+  constexpr int IMG = KS * 64;       // one image; layer-0 buffers at Hc + {0, IMG}, layer-1 buffers at Hc + {2, 3} IMG
   const int q = lane >> 4;
-  const int j = wv;  // this wave's chunk
-  constexpr int IMG = KS * 64;  // one image; layer-0 buffers at Hc + {0, IMG}, layer-1 buffers at Hc + {2, 3} IMG
   double in_mean = 0.0, in_std = 1.0;
   if (q < a.nin) {
     in_mean = a.mean[q];
@@ -231,9 +232,15 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
   const int ab_off = (a.mode == 1) ? (int)(kk / a.Kep) * a.B : 0;
   // zero this wave's rows of the "current" images (h_0 = 0); the other buffers are written before they are read
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    Hc[(4 * j + r) * 64 + lane] = 0.0;
-    Hc[2 * IMG + (4 * j + r) * 64 + lane] = 0.0;
+  for (int i = 0; i < CPW; ++i) {
+    const int j = wv + 4 * i;
+    if (j < GT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Hc[(4 * j + r) * 64 + lane] = 0.0;
+        Hc[2 * IMG + (4 * j + r) * 64 + lane] = 0.0;
+      }
+    }
   }
   __syncthreads();
   for (int s = 0; s < a.B; ++s) {
@@ -260,34 +267,42 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
     } else if (q == 3) {
       xin = 1.0;
     }
-    // ---------------- layer 0, chunk j
-    {
-      gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
-      v4d ar = mfma(wp[lane], xin, splat(0.0));
-      v4d az = mfma(wp[64 + lane], xin, splat(0.0));
-      v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
-      v4d ahn = load_bias_tile(a.bhn0, j, q);
-      if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, H0c);
-      const v4d hold = {H0c[(4 * j + 0) * 64 + lane], H0c[(4 * j + 1) * 64 + lane],
-                        H0c[(4 * j + 2) * 64 + lane], H0c[(4 * j + 3) * 64 + lane]};
-      const v4d hn = gru_gates(ar, az, ain, ahn, hold);
+    // ---------------- layer 0, this wave's chunks (the new state goes to the OTHER buffer: no chunk waits for another)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H0n[(4 * j + r) * 64 + lane] = hn[r];
+    for (int i = 0; i < CPW; ++i) {
+      const int j = wv + 4 * i;
+      if (j < GT) {
+        gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
+        v4d ar = mfma(wp[lane], xin, splat(0.0));
+        v4d az = mfma(wp[64 + lane], xin, splat(0.0));
+        v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
+        v4d ahn = load_bias_tile(a.bhn0, j, q);
+        if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh0p + (size_t)j * KS * 3 * 64, lane, H0c);
+        const v4d hold = {H0c[(4 * j + 0) * 64 + lane], H0c[(4 * j + 1) * 64 + lane], H0c[(4 * j + 2) * 64 + lane],
+                          H0c[(4 * j + 3) * 64 + lane]};
+        const v4d hn = gru_gates(ar, az, ain, ahn, hold);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H0n[(4 * j + r) * 64 + lane] = hn[r];
+      }
     }
     __syncthreads();  // layer 0's new state is complete; everybody has read the old one
-    // ---------------- layer 1, chunk j
-    {
-      v4d ar = load_bias_tile(a.brz1, j, q);
-      v4d az = load_bias_tile(a.brz1, G / 16 + j, q);
-      v4d ain = load_bias_tile(a.bin1, j, q);
-      v4d ahn = load_bias_tile(a.bhn1, j, q);
-      chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, H0n);
-      if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, H1c);
-      const v4d hold = {H1c[(4 * j + 0) * 64 + lane], H1c[(4 * j + 1) * 64 + lane],
-                        H1c[(4 * j + 2) * 64 + lane], H1c[(4 * j + 3) * 64 + lane]};
-      const v4d hn = gru_gates(ar, az, ain, ahn, hold);
+    // ---------------- layer 1
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H1n[(4 * j + r) * 64 + lane] = hn[r];
+    for (int i = 0; i < CPW; ++i) {
+      const int j = wv + 4 * i;
+      if (j < GT) {
+        v4d ar = load_bias_tile(a.brz1, j, q);
+        v4d az = load_bias_tile(a.brz1, GT + j, q);
+        v4d ain = load_bias_tile(a.bin1, j, q);
+        v4d ahn = load_bias_tile(a.bhn1, j, q);
+        chunk_gemm<KS>(ar, az, ain, a.Wih1p + (size_t)j * KS * 3 * 64, lane, H0n);
+        if (s > 0) chunk_gemm<KS>(ar, az, ahn, a.Whh1p + (size_t)j * KS * 3 * 64, lane, H1c);
+        const v4d hold = {H1c[(4 * j + 0) * 64 + lane], H1c[(4 * j + 1) * 64 + lane], H1c[(4 * j + 2) * 64 + lane],
+                          H1c[(4 * j + 3) * 64 + lane]};
+        const v4d hn = gru_gates(ar, az, ain, ahn, hold);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H1n[(4 * j + r) * 64 + lane] = hn[r];
+      }
     }
     // (no barrier here: the next step's layer 0 touches only the layer-0 images, and its barrier orders this step's
     // layer-1 writes before the next step's layer-1 reads)

@@ -1448,21 +1448,22 @@ def test_gru_cooperative_kernel_bit_identical(nlc):
 
     st = onl.ENV_STATS["oderl-acrobot"]
     d, nu, A = st["d"], st["nu"], st["act_high"]
-    sd = onl.make_synthetic_state_dict(3, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
-    model = build_model(nlc, sd)
-    ctx = model.hip_ctx(torch.device("cuda:0"))
     torch.manual_seed(9)
-    try:
-        for N in (1, 15, 16, 17, 1000, 40961):
-            win = ((torch.rand(N, 4, nu, dtype=torch.float64) * 2 - 1) * A).cuda()
-            outs = []
-            for coop in (0, 1):
-                ctx.set_option("gru_coop", coop)
-                with torch.no_grad():
-                    outs.append(model.encode_actions(win).clone())
-            assert torch.equal(outs[0], outs[1]), N
-    finally:
-        ctx.set_option("gru_coop", -1)
+    for h in (128, 64, 256):  # GRU width 64 (one chunk per wave), 32 (two waves idle), 128 (two chunks per wave)
+        sd = onl.make_synthetic_state_dict(3, d, nu, h, 17, st["state_std"], [A / 2], tame=True)
+        model = build_model(nlc, sd)
+        ctx = model.hip_ctx(torch.device("cuda:0"))
+        try:
+            for N, B in ((1, 4), (15, 4), (16, 5), (17, 4), (1000, 3), (40961, 4)):
+                win = ((torch.rand(N, B, nu, dtype=torch.float64) * 2 - 1) * A).cuda()
+                outs = []
+                for coop in (0, 1):
+                    ctx.set_option("gru_coop", coop)
+                    with torch.no_grad():
+                        outs.append(model.encode_actions(win).clone())
+                assert torch.equal(outs[0], outs[1]), (h, N, B)
+        finally:
+            ctx.set_option("gru_coop", -1)
     acts = []
     state0 = nlc.initial_state("oderl-acrobot", torch.Generator().manual_seed(2))
     for coop in (0, 1):

@@ -7,7 +7,14 @@ import bench
 import neurallaplacecontrol_amd as nlc
 
 d, nu = 5, 1
-model = bench.synthetic_state_dict(d, nu, bench.S_TERMS).to("cuda:0")
+H = int(os.environ.get("PROBE_H", "128"))  # hidden_units: GRU width H / 2
+if H == 128:
+    model = bench.synthetic_state_dict(d, nu, bench.S_TERMS).to("cuda:0")
+else:
+    import numpy as np
+    model = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=H, s_recon_terms=17, ilt_algorithm="fourier", state_mean=np.zeros(d),
+                                   state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.5]), normalize=True,
+                                   normalize_time=True).double().to("cuda:0")
 torch.manual_seed(0)
 ctx = model.hip_ctx(torch.device("cuda:0"))
 for N in (16, 256, 4096, 1024 * 40, 2048 * 40, 4096 * 40, 8192 * 40, 16384 * 40):
@@ -25,6 +32,6 @@ for N in (16, 256, 4096, 1024 * 40, 2048 * 40, 4096 * 40, 8192 * 40, 16384 * 40)
         prof = ctx.profile_read()
         k = [v for n, v in prof.items() if "gru" in n][0]
         outs.append(o.clone()); times.append(k["total_ms"] / k["launches"])
-    print(json.dumps(dict(N=N, equal=bool(torch.equal(outs[0], outs[1])), max_abs=float((outs[0] - outs[1]).abs().max()),
+    print(json.dumps(dict(H=H, N=N, equal=bool(torch.equal(outs[0], outs[1])), max_abs=float((outs[0] - outs[1]).abs().max()),
                           ms_wave_per_tile=round(times[0], 4), ms_coop=round(times[1], 4))), flush=True)
 ctx.set_option("gru_coop", -1)
