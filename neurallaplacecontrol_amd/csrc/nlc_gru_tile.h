@@ -222,6 +222,8 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
   constexpr int GT = G / 16;
   constexpr int KS = G / 4;
   constexpr int CPW = (GT + 3) / 4;  // chunks per wave
+  constexpr bool kAllWaves = GT % 4 == 0;  // every wave owns CPW chunks: no guard (a guard the compiler cannot fold costs
+                                           // the G = 64 kernel 95 spilled VGPRs)
   constexpr int IMG = KS * 64;       // one image; layer-0 buffers at Hc + {0, IMG}, layer-1 buffers at Hc + {2, 3} IMG
   const int q = lane >> 4;
   double in_mean = 0.0, in_std = 1.0;
@@ -234,7 +236,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
     const int j = wv + 4 * i;
-    if (j < GT) {
+    if (kAllWaves || j < GT) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Hc[(4 * j + r) * 64 + lane] = 0.0;
@@ -271,7 +273,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int j = wv + 4 * i;
-      if (j < GT) {
+      if (kAllWaves || j < GT) {
         gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
         v4d ar = mfma(wp[lane], xin, splat(0.0));
         v4d az = mfma(wp[64 + lane], xin, splat(0.0));
@@ -290,7 +292,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int j = wv + 4 * i;
-      if (j < GT) {
+      if (kAllWaves || j < GT) {
         v4d ar = load_bias_tile(a.brz1, j, q);
         v4d az = load_bias_tile(a.brz1, GT + j, q);
         v4d ain = load_bias_tile(a.bin1, j, q);

@@ -17,7 +17,7 @@ else:
                                    normalize_time=True).double().to("cuda:0")
 torch.manual_seed(0)
 ctx = model.hip_ctx(torch.device("cuda:0"))
-for N in (16, 256, 4096, 1024 * 40, 2048 * 40, 4096 * 40, 8192 * 40, 16384 * 40):
+for N in [int(x) for x in os.environ.get("PROBE_N", "16,256,4096,40960,81920,163840,327680,655360").split(",")]:
     win = (torch.rand(N, 4, nu, dtype=torch.float64, device="cuda") * 2 - 1) * 3.0
     outs, times = [], []
     for coop in (0, 1):
