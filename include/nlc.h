@@ -156,6 +156,11 @@ int nlc_gru_encode(nlc_ctx* ctx, const double* window_dev, int64_t N, int B, dou
 int64_t nlc_model_workspace_bytes(nlc_ctx* ctx, int64_t N);
 int nlc_model_forward(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, const double* ts_dev,
                       int64_t N, int B, double* out_dev, void* ws_dev);
+/* The same with ONE query time for every row (what the harness closure passes: ts_pred = dt, mppi_with_model.py:74,
+ * 120): the 2S sphere-coordinate inputs of the representation MLP are then constants and are folded into its first
+ * bias on the host (once per value of ts_pred), as nlc_mppi_configure does for the fused planner.  Fourier models. */
+int nlc_model_forward_const_t(nlc_ctx* ctx, const double* obs_dev, const double* window_dev, double ts_pred, int64_t N,
+                              int B, double* out_dev, void* ws_dev);
 /* a8 alone: LaplaceRepresentationFunc.forward (w_nl.py:55-63) on N explicit input rows
  * rep_in_dev (N, 2S + d + 2) = [theta_s (S) | phi_s (S) | latent p (d+2)] -- whatever sphere coordinates the caller
  * supplies, as torchlaplace hands them to the module -- -> theta_dev, phi_dev (N, d, S) with theta = pi tanh(.),

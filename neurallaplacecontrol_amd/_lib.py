@@ -44,6 +44,7 @@ SYMBOLS = [
     "nlc_gru_encode",
     "nlc_model_workspace_bytes",
     "nlc_model_forward",
+    "nlc_model_forward_const_t",
     "nlc_rep_func",
     "nlc_rnn_blob_size",
     "nlc_set_rnn_model",
@@ -200,6 +201,7 @@ def load_library():
         lib.nlc_model_workspace_bytes.argtypes = [vp, i64]
         lib.nlc_model_workspace_bytes.restype = i64
         lib.nlc_model_forward.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp]
+        lib.nlc_model_forward_const_t.argtypes = [vp, vp, vp, dbl, i64, i32, vp, vp]
         lib.nlc_rnn_blob_size.argtypes = [P(RnnDesc)]
         lib.nlc_rnn_blob_size.restype = i64
         lib.nlc_set_rnn_model.argtypes = [vp, P(RnnDesc), vp, i64]

@@ -38,7 +38,11 @@ hipError_t launch_nl_forward_h64(const ForwardArgs& a, hipStream_t s) {
   switch (a.net.nt3) {
 #define X(N)                                                                            \
   case N:                                                                               \
-    hipLaunchKernelGGL((nl_forward_kernel<4, N>), dim3(grid), dim3(256), 0, s, a);  \
+    if (a.const_t) {                                                                        \
+      hipLaunchKernelGGL((nl_forward_kernel<4, N, false>), dim3(grid), dim3(256), 0, s, a); \
+    } else {                                                                                \
+      hipLaunchKernelGGL((nl_forward_kernel<4, N, true>), dim3(grid), dim3(256), 0, s, a);  \
+    }                                                                                       \
     break;
     NLC_FOR_NT3(X)
 #undef X

@@ -86,6 +86,9 @@ struct nlc_ctx {
   double* U[2] = {nullptr, nullptr};
   int ucur = 0;
   double* b1fold = nullptr;   // (h) device
+  double* b1fold_fwd = nullptr;          // (h) device: the same fold for nlc_model_forward_const_t's query time
+  double fwd_tn = -1.0;                  // normalised time b1fold_fwd was folded for
+  std::vector<double> fwd_fold_host;     // its host copy (kept alive for the asynchronous upload)
   double* small = nullptr;    // action (<= T*nu) + beta_eta (2)
   double tn = 0.0;
   int nblk = 0;
@@ -398,6 +401,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
   if (c->b1fold) hipFree(c->b1fold);
+  if (c->b1fold_fwd) hipFree(c->b1fold_fwd);
   if (c->small) hipFree(c->small);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->stage_ev) hipEventDestroy(c->stage_ev);
@@ -750,6 +754,7 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   N.scale = d->ilt.scale;
   N.time_div = d->time_div;
   c->has_model = true;
+  c->fwd_tn = -1.0;  // the constant-time forward's folded bias belongs to the previous weights
   c->has_mppi = false;  // a planner configured against the previous weights must be re-configured
   return NLC_OK;
   NLC_GUARD_END(c)
@@ -780,6 +785,61 @@ extern "C" int64_t nlc_model_workspace_bytes(nlc_ctx* c, int64_t N) {
   int64_t n = N * 2 + 64;  // GRU latents
   if (c && c->has_model && c->md.ilt.algo == NLC_ILT_DEHOOG) n += 2 * N * c->md.d * c->S + 64;  // F_k re/im
   return n * (int64_t)sizeof(double);
+}
+
+extern "C" int nlc_model_forward_const_t(nlc_ctx* c, const double* obs, const double* window, double ts_pred, int64_t N,
+                                         int B, double* out, void* ws) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
+  if (c->md.ilt.algo != NLC_ILT_FOURIER) return fail(c, NLC_ERR_UNSUPPORTED, "constant-time forward: fourier models only");
+  if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
+  if (!(ts_pred > 0.0)) return fail(c, NLC_ERR_BAD_ARG, "ts_pred must be > 0");
+  if (N == 0) return NLC_OK;
+  if (!obs || !window || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const double tn = ts_pred / c->md.time_div;
+  const int h = c->md.h, S = c->S;
+  if (!c->b1fold_fwd) NLC_HIP(c, hipMalloc((void**)&c->b1fold_fwd, h * sizeof(double)));
+  if (tn != c->fwd_tn) {
+    // fold the constant sphere inputs of layer 1 into its bias, as nlc_mppi_configure does for the planner
+    NLC_HIP(c, hipStreamSynchronize(c->stream));  // (an earlier upload may still read the host copy)
+    std::vector<double> sph;
+    sphere_inputs(c->md.ilt, tn, sph);
+    c->fwd_fold_host.resize(h);
+    for (int r = 0; r < h; ++r) {
+      double acc = c->b1_host[r];
+      for (int j = 0; j < 2 * S; ++j) acc += c->W1s_host[(size_t)r * 2 * S + j] * sph[j];
+      c->fwd_fold_host[r] = acc;
+    }
+    NLC_HIP(c, hipMemcpyAsync(c->b1fold_fwd, c->fwd_fold_host.data(), h * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->fwd_tn = tn;
+  }
+  double* pa = (double*)ws;
+  {
+    GruArgs a = c->gru;
+    a.mode = 0;
+    a.window = window;
+    a.N = N;
+    a.B = B;
+    a.out = pa;
+    ProfScope ps(c, "gru_encode_kernel");
+    NLC_HIP(c, launch_gru_encode(a, c->g, c->stream, gru_use_coop(c, a.N)));
+  }
+  ForwardArgs f{};
+  f.net = c->net;
+  f.net.b1 = c->b1fold_fwd;
+  f.N = N;
+  f.obs = obs;
+  f.pa = pa;
+  f.ts = nullptr;
+  f.out = out;
+  f.const_t = 1;
+  f.tn = tn;
+  ProfScope ps(c, "nl_forward_kernel");
+  NLC_HIP(c, launch_nl_forward(f, c->stream));
+  return NLC_OK;
+  NLC_GUARD_END(c)
 }
 
 extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* window, const double* ts, int64_t N,

@@ -246,6 +246,8 @@ struct ForwardArgs {
   const double* pa;   // (N, 2)
   const double* ts;   // (N) raw ts_pred
   double* out;        // (N, d)
+  int const_t;        // 1: one query time for every row -- tn below, net.b1 = the folded bias, ts unused
+  double tn;          // ts_pred / time_div of the constant-time form
 };
 hipError_t launch_nl_forward(const ForwardArgs& a, hipStream_t s);
 

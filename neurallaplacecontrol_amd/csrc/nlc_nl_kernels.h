@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs
 }
 
 // ------------------------------------------------------------------ single model forward, per-sample t
-template <int HT, int NT3>
+// GENERAL_T = false: every row shares one query time (ForwardArgs::tn; the constant sphere inputs of layer 1 are folded
+// into net.b1 on the host, as for the planner) -- no W1s k-steps, no atan2 / asin per lane
+template <int HT, int NT3, bool GENERAL_T = true>
 __global__ __launch_bounds__(256) void nl_forward_kernel(const ForwardArgs a) {
   const NlNetArgs& n = a.net;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(256) void nl_forward_kernel(const ForwardArgs a) {
                              : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
   const double p1 = (i1 < d) ? (ob[i1] - n.state_mean[i1]) / n.state_std[i1]
                              : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
-  const double tn = a.ts[kc] / n.time_div;  // w_nl.py:122
-  const v4d ax = nl_eval<HT, NT3, true>(n, lane, q, p0, p1, tn);
+  const double tn = GENERAL_T ? a.ts[kc] / n.time_div : a.tn;  // w_nl.py:122
+  const v4d ax = nl_eval<HT, NT3, GENERAL_T>(n, lane, q, p0, p1, tn);
   const double Tt = n.scale * tn;
   const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
   const double factor = exp(gamma * tn) / Tt;

@@ -39,7 +39,12 @@ class NLDynamics:
         self.ts_pred = float(t[0])
 
     def __call__(self, state, perturbed_action):
-        ts = torch.full((state.shape[0], 1), self.ts_pred, dtype=torch.float64, device=state.device)
+        # one ts_pred tensor per (batch, device), as the harness builds it once outside the loop (mppi_with_model.py:74)
+        key = (state.shape[0], str(state.device))
+        if getattr(self, "_ts_key", None) != key:
+            self._ts = torch.full((state.shape[0], 1), self.ts_pred, dtype=torch.float64, device=state.device)
+            self._ts_key = key
+        ts = self._ts
         is_nl = getattr(self.model, "_dyn_id", _lib.DYN_NL) == _lib.DYN_NL
         if is_nl and self.model.encode_obs_time and perturbed_action.shape[2] == self.model.action_dim:
             # the harness closure appends a constant time channel B-1 .. 0 (mppi_with_model.py:110-119)

@@ -1439,6 +1439,39 @@ def test_repfunc_split_kernel_agrees_with_wave_per_tile_planner(nlc):
             np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-10, err_msg=f"{env} S={S}")
 
 
+def test_model_forward_constant_time_path(nlc):
+    """model.forward with ONE query time for every row (what the harness closure passes) takes the folded-bias kernel
+    (nlc_model_forward_const_t); rows of a call with per-row times that happen to carry the same t go through the general
+    kernel and must agree with it to rounding; a Python float works too; new weights refresh the fold."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-cartpole"]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(21, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    torch.manual_seed(3)
+    N = 777
+    obs = torch.randn(N, d, dtype=torch.float64).cuda()
+    win = (torch.randn(N, 4, nu, dtype=torch.float64) * 0.7).cuda()
+    for rep in range(2):
+        for tval in (0.05, 0.11):
+            ts_const = torch.full((N, 1), tval, dtype=torch.float64, device="cuda")
+            ts_mixed = ts_const.clone()
+            ts_mixed[0, 0] = 0.2  # one different row: the whole call takes the general per-row kernel
+            with torch.no_grad():
+                a = model(obs, win, ts_const)
+                assert model._const_ts_cache[1] == tval
+                b = model(obs, win, ts_mixed)
+                c = model(obs, win, tval)
+            np.testing.assert_allclose(a[1:].cpu().numpy(), b[1:].cpu().numpy(), rtol=1e-11, atol=1e-13)
+            assert torch.equal(a, c)
+            ref = onl.nl_forward(sd, obs.cpu(), win.cpu(), ts_const.cpu(), S=17)
+            np.testing.assert_allclose(a.cpu().numpy(), ref.numpy().reshape(a.shape), rtol=1e-9, atol=1e-10)
+        # new weights: the folded bias of the constant-time path must follow
+        sd = onl.make_synthetic_state_dict(22 + rep, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+        model.load_state_dict(sd)
+
+
 def test_gru_cooperative_kernel_bit_identical(nlc):
     """gru_encode_coop_kernel (one 16-window tile per workgroup, one gate chunk per wavefront; what small launches and the
     fused body's encoders run) against the wave-per-tile kernel: same chunk GEMMs in the same k order and the same gate
