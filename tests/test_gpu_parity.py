@@ -746,6 +746,19 @@ def test_cfg4_acrobot_shard_32768x60(nlc):
     _subset_check(nlc, "oderl-acrobot", 32768, 60, 4)
 
 
+def test_cfg4_acrobot_whole_population_262144x60(nlc):
+    """BASELINE configs[3] at its WHOLE size on one GPU (the largest population any config names): acrobot, K = 262144,
+    H = 60, nu = 2 -- 64 strided samples through the oracle, weights / U / action over all 262144."""
+    _subset_check(nlc, "oderl-acrobot", 262144, 60, 4)
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_pendulum_whole_population_65536x40(nlc):
+    """BASELINE configs[2] at its whole size on one GPU: pendulum, K = 65536, H = 40, 5-row action buffer."""
+    _subset_check(nlc, "oderl-pendulum", 65536, 40, 5)
+    torch.cuda.empty_cache()
+
+
 def test_full_size_cfg5_dehoog(nlc):
     """BASELINE configs[4] at its own size: cartpole, de Hoog ILT with 33 terms, K = 16384, T = 40, on the staged
     all-HIP path.  64 strided samples through the oracle (mpmath's de Hoog recurrences with IEEE divisions; the kernel
