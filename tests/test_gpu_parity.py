@@ -853,6 +853,10 @@ def _random_shape_cases(n=14, seed=2024):
         else:
             S = int(2 * rng.randint(1, 17) + 1)
         cases.append((i, env, h, algo, S, int(rng.randint(1, 7)), int(rng.randint(1, 11)), int(rng.randint(1, 400))))
+    # the smallest problems there are: one sample, one step, a one-row window; two samples over the full horizon
+    cases.append((n, "oderl-cartpole", 128, "fourier", 17, 1, 1, 1))
+    cases.append((n + 1, "oderl-acrobot", 128, "fourier", 17, 4, 40, 2))
+    cases.append((n + 2, "oderl-pendulum", 128, "dehoog", 33, 2, 1, 1))
     return cases
 
 
