@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: MPPI planning steps/s on the Neural-Laplace-Control hot path (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          # N = 1
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: starts its own ranks as a child process
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W    # N > 1, one rank per GPU (RCCL)
+        --master-port P bench.py --gpus N --steps K --warmup W    # N > 1, one rank per GPU (RCCL): the driver's form
 
 A "step" is one ``MPPIDelay.command()`` -- the region the reference times at mppi_with_model.py:257-259 --
 on BASELINE configs[1]: oderl-cartpole (nx=5, nu=1), K=16384 samples, horizon T=40, action_buffer_size 4,
@@ -221,6 +221,33 @@ def cpu_baseline(sd, d, nu, budget_s=30.0):
     )
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv, result_fd):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child process (one rank per GPU), pass its stderr through, write its LAST stdout line -- rank 0's JSON line --
+    to the saved stdout, and return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between the ranks of one node)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    if lines:
+        os.write(result_fd, (lines[-1] + "\n").encode())
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the launched ranks printed no JSON line\n")
+        return 1
+    return proc.returncode
+
+
 def git_commit():
     try:
         return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
@@ -239,6 +266,8 @@ def main():
     ap.add_argument("--collective", choices=("torch", "native"), default="torch",
                     help="N > 1: the per-command all-gather through torch.distributed (default) or inside nlc_mppi_finish on "
                          "the library's own RCCL communicator (include/nlc.h, nlc_comm_init)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch rehearsal: start the ranks, report the environment each one sees, touch no GPU")
     ap.add_argument("--samples", type=int, default=K_SAMPLES,
                     help="override K (experiments only; the headline metric is quoted at the default 16384)")
     args = ap.parse_args()
@@ -252,11 +281,27 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # invoked bare (`python bench.py --gpus N`): start the ranks ourselves, as a CHILD process (nothing in this
+        # process has touched the GPU yet), relay its one JSON line and exit with its code
+        sys.exit(self_launch(args.gpus, sys.argv[1:], result_fd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     import torch.distributed as dist
+
+    if args.dry_launch:
+        # launch rehearsal (CPU test): every rank reports the environment torch.distributed.run gave it over a gloo
+        # group; rank 0 prints them as the one JSON line.  No GPU call is made.
+        envs = [None] * world
+        if "RANK" in os.environ:
+            dist.init_process_group("gloo")
+            dist.all_gather_object(envs, {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")})
+            dist.destroy_process_group()
+        else:
+            envs = [{"RANK": None, "LOCAL_RANK": None, "WORLD_SIZE": None, "MASTER_ADDR": None}]
+        if rank == 0:
+            os.write(result_fd, (json.dumps(dict(dry_launch=True, n_gpus=world, ranks=envs)) + "\n").encode())
+        return
 
     import neurallaplacecontrol_amd as nlc
 

@@ -197,6 +197,31 @@ def test_shard_range():
         shard_range(10, 4, 0)
 
 
+def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (the shape of the driver's N = 1 command) must start its ranks itself:
+    --dry-launch goes as far as every rank reporting the environment torch.distributed.run gave it, without a GPU call,
+    and the parent relays exactly one JSON line."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["dry_launch"] is True and rec["n_gpus"] == 2
+    assert [(r["RANK"], r["LOCAL_RANK"], r["WORLD_SIZE"]) for r in rec["ranks"]] == [("0", "0", "2"), ("1", "1", "2")]
+    assert all(r["MASTER_ADDR"] == "127.0.0.1" for r in rec["ranks"])
+    # the driver's own form (ranks already launched) must not launch again: one rank under torch.distributed.run
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29577", os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-launch"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.strip().startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["ranks"][0]["RANK"] == "0"
+
+
 def test_graft_entry_build_runs(lib):
     """The driver's build check: build() must succeed on a machine without a GPU (make is a no-op when up to date)."""
     sys.path.insert(0, REPO)
