@@ -263,9 +263,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
-    ap.add_argument("--collective", choices=("torch", "native"), default="torch",
-                    help="N > 1: the per-command all-gather through torch.distributed (default) or inside nlc_mppi_finish on "
-                         "the library's own RCCL communicator (include/nlc.h, nlc_comm_init)")
+    ap.add_argument("--collective", choices=("torch", "native"), default="native",
+                    help="N > 1: the per-command all-gather inside nlc_mppi_finish on the library's own RCCL communicator "
+                         "(include/nlc.h, nlc_comm_init; default) or through torch.distributed between the two phases")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch rehearsal: start the ranks, report the environment each one sees, touch no GPU")
     ap.add_argument("--samples", type=int, default=K_SAMPLES,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 6
+#define NLC_ABI_VERSION 7
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -89,10 +89,23 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
+ *   "fused_inline"       fused body, single planner (E <= 1): 1 (default) = the importance-weight reduction (:210-216) runs
+ *                        inside the launch after the last rollout tile, and with device noise (rng == 1) and host-side state /
+ *                        action_buffer so do the sampling and bounding (:319-328), in the encoder role -- a command is then
+ *                        two launches (this one + the merge after the shard all-gather) instead of six; 0 = separate launches.
+ *                        Same bits either way.
+ *   "fused_spin_limit"   polls (~2 us each) before a waiting wave of the fused body gives up (default 2^18, ~0.5 s)
+ *   "fused_test_drop_tile"  tests only: the encoder tile with this ticket is never published (-1 = none): forces the
+ *                        hand-off timeout and the re-run on the two-launch body
  *   "fused_chain_first_tiles"  encoder tiles every such workgroup encodes before its chain starts (-1 = auto: 1)
  *   "fused_partner_tiles"  the OTHER workgroups of that CU stop drawing encoder tiles after this many each and sleep until
  *                        the chain is done (an encoder wave beside a chain doubles the chain's step time); -1 = never,
  *                        -2 = auto (1 .. 4 with the share of CUs that walk a chain: fit to MI355X measurements)
+ * The fused body assumes the device to itself: its rollout workgroups wait for encoder workgroups of the SAME launch, so
+ * all of its workgroups must be resident at once (auto picks it only when at least two fit a CU).  Every wait is bounded: on
+ * a time-out the command is re-run on the two-launch body inside nlc_mppi_finish (single rank, library-side costs, host
+ * action pointer given) or reported as NLC_ERR_HIP, and the ctx keeps to the two-launch body from then on (setting
+ * "rollout_variant" again re-arms it).
  * Unknown names / out-of-range values: NLC_ERR_BAD_ARG. */
 int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
 /* device properties the bench reports next to its roofline numbers */
@@ -315,6 +328,9 @@ int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, c
 int nlc_comm_unique_id(void* id_out);
 int nlc_comm_init(nlc_ctx* ctx, int rank, int world, const void* id);
 int nlc_comm_destroy(nlc_ctx* ctx);
+/* Collective: every rank all-gathers its rank number over the communicator and checks the result on the host (the Python
+ * mirror runs it once after nlc_comm_init and falls back to torch.distributed's collective if any rank fails). */
+int nlc_comm_self_test(nlc_ctx* ctx);
 
 /* ---- env side of the evaluation loop: the reference steps ONE env per process on the host,
  * step_env (mppi_with_model.py:193-216) = get_action (delay buffer, :25-28) + env.integrate_system(2, g, s0)

@@ -23,8 +23,15 @@ ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5
 COMM_ID_BYTES = 128
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnlc_hip.so")
-# tools/ only (A/B builds of one kernel on one box, tools/ab_cmd.sh): another build of the SAME library
-LIB_PATH = os.environ.get("NLC_LIB_PATH", LIB_PATH)
+
+
+def use_library(path):
+    """tools/ only (A/B builds of one kernel on one box): bind another build of the SAME library.  Must be called before
+    the first ``load_library()``; the product path never reads an environment variable for this."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the library is loaded")
+    LIB_PATH = os.path.abspath(path)
 
 # every symbol include/nlc.h declares (tests check the built library exports them all)
 SYMBOLS = [
@@ -62,6 +69,7 @@ SYMBOLS = [
     "nlc_comm_unique_id",
     "nlc_comm_init",
     "nlc_comm_destroy",
+    "nlc_comm_self_test",
     "nlc_env_step",
     "nlc_env_obs",
     "nlc_profile_enable",
@@ -225,6 +233,7 @@ def load_library():
         lib.nlc_comm_unique_id.argtypes = [vp]
         lib.nlc_comm_init.argtypes = [vp, i32, i32, vp]
         lib.nlc_comm_destroy.argtypes = [vp]
+        lib.nlc_comm_self_test.argtypes = [vp]
         lib.nlc_profile_enable.argtypes = [vp, i32]
         lib.nlc_profile_reset.argtypes = [vp]
         lib.nlc_profile_count.argtypes = [vp]
@@ -281,6 +290,13 @@ class Ctx:
         if len(unique_id) != COMM_ID_BYTES:
             raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
         self.check(self.lib.nlc_comm_init(self.h, int(rank), int(world), C.c_char_p(bytes(unique_id))))
+
+    def comm_self_test(self):
+        """Collective check of the library's communicator (``nlc_comm_self_test``); raises NlcError on failure."""
+        self.check(self.lib.nlc_comm_self_test(self.h))
+
+    def comm_destroy(self):
+        self.check(self.lib.nlc_comm_destroy(self.h))
 
     def device_info(self):
         name = C.create_string_buffer(128)

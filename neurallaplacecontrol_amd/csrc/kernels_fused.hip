@@ -24,10 +24,23 @@
 //                  then ONE lane's agent-scope atomic add on the tile's flag word;
 //   consumer:      ONE wave polls the flag with relaxed agent loads (global_load_dword sc1), a workgroup barrier, then
 //                  EVERY load of the latents is a 16-B buffer_load ... sc1 (bypasses the CU's L1; no acquire fence).
-// All polled words are zeroed by the command's perturb kernel (launched before this one on the same stream).
+// All polled words are zero when the launch starts (the previous command's merge kernel, the command's own perturb kernel
+// when one runs, or a memset zeroes them).
+//
+// Round 3: for the single planner with device noise the launch is the WHOLE first phase of command():
+//   * sampling / bounding (planners/mppi_delay.py:319-328): wave 0 of encoder tile (t, j) draws the actions of its 16
+//     windows (Philox is counter-based: the four tiles that share an action draw the same value), stages them in LDS for
+//     the workgroup and publishes perturbed / noise / actions of ITS step t with the tile's latents (same flag);
+//   * U <- roll(U, -1) (:199-200) is read on the fly from the sequence before the shift; workgroup 0 stores it;
+//   * the state and the action buffer are read from the kernel-argument segment (no staging copy, no perturb kernel);
+//   * importance weights (:210-216): every rollout tile folds its costs into a running minimum and counts itself done;
+//     the first nblk workgroups out of the encoder / drain loops wait for the last tile and run one 64-sample weight
+//     block each (nlc_mppi_dev.h: the arithmetic of weight_partial_kernel, bit for bit), the last block folds the partials.
+// command() is then this launch + merge_kernel (after the shard all-gather) instead of six launches.
 #include "nlc_device.h"
 #include "nlc_gru_tile.h"
 #include "nlc_kernels.h"
+#include "nlc_mppi_dev.h"
 #include "nlc_rollout.h"
 
 namespace nlc {
@@ -58,12 +71,45 @@ struct PaHandoff {
   double cur0, cur1, nxt0, nxt1;
   int ready_upto;  // polling wave: flags of steps < ready_upto have been seen set
   static constexpr int kPollWave = 3;        // the wave with the fewest layer-3 tiles
-  static constexpr unsigned kSpinLimit = 1u << 18;  // ~1 s of polling, then give up (never hang the GPU)
+  unsigned spin_limit;                       // ~2 us per poll once it naps; then give up (never hang the GPU)
+  // in-launch sampling / weights (FusedCtl::inline_perturb / inline_weights)
+  int inl, inw, nu;
+  bool w0;                    // this wave evaluates the costs (wave 0)
+  const double* state_in;     // the command's state in the kernel-argument segment (inl)
+  const double* U_old;        // control sequence BEFORE the shift (inl)
+  const double* u_init;       // in the kernel-argument segment
+  const double* pert_g;       // perturbed / bounded noise, published by the encoder tiles of this launch (or an earlier launch)
+  const double* noise_g;
+  static_assert(NLC_MAX_NU == 2, "two named slots per value below");
+  double pc0, pc1, nc0, nc1, pn0, pn1, nn0, nn1;  // (wave 0) perturbed / noise of step t (c) and of step t + 1 (n)
 
+  __device__ __forceinline__ const double* state0(const RolloutArgs& a, int64_t kc, int ep) const {
+    return inl ? state_in : a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * a.net.d;
+  }
+  __device__ __forceinline__ double pert(const RolloutArgs&, int64_t, int, int j) const { return j == 0 ? pc0 : pc1; }
+  __device__ __forceinline__ double noise(const RolloutArgs&, int64_t, int, int i) const { return i == 0 ? nc0 : nc1; }
+  __device__ __forceinline__ double U(const RolloutArgs& a, int uoff, int t, int j) const {
+    return inl ? mppi_shifted_U(U_old, u_init, 0, T, nu, t, j) : a.U[uoff + t * a.nu + j];
+  }
+  __device__ __forceinline__ void store_cost(const RolloutArgs& a, int64_t k, double v) const {
+    if (inw) MemSc1::st(a.cost_total + k, v);
+    else a.cost_total[k] = v;
+  }
   __device__ __forceinline__ void load(int t, int64_t kc, double* a0, double* a1) const {
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((int64_t)t * K + kc) * 16), 0, /*sc1*/ 16);
     *a0 = __builtin_bit_cast(double, ((unsigned long long)v.y << 32) | v.x);
     *a1 = __builtin_bit_cast(double, ((unsigned long long)v.w << 32) | v.z);
+  }
+  // (wave 0) the sampled action and its bounded noise of step t: L1-bypassing loads, like the latents
+  __device__ __forceinline__ void load_pn(int t, int64_t kc, double* p0, double* p1, double* n0, double* n1) const {
+    if (!w0) return;
+    const int64_t at = (kc * T + t) * nu;
+    *p0 = MemSc1::ld(pert_g + at);
+    *n0 = MemSc1::ld(noise_g + at);
+    if (nu > 1) {
+      *p1 = MemSc1::ld(pert_g + at + 1);
+      *n1 = MemSc1::ld(noise_g + at + 1);
+    }
   }
   // Polling wave: wait until the flag of step t_first is set.  The FIRST look is one 64-lane gather over the flags of
   // the next steps (usually the encoders are ahead and this is the only load for many steps); while waiting only ONE
@@ -81,8 +127,7 @@ struct PaHandoff {
         ready_upto = t_first + cnt;
         return;
       }
-      if (spins > kSpinLimit) {
-        // (every lane stores the same word: no lane-divergent branch inside the polling loop)
+      if (spins > spin_limit) {
         __hip_atomic_store(sync + kFusedTimeout, 1u + (unsigned)t_first, NLC_RLX_AGENT);
         __hip_atomic_store(timeout_host, 1u + (unsigned)t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ready_upto = t_end;  // stop polling: the command is lost, the grid must still drain
@@ -102,6 +147,7 @@ struct PaHandoff {
     }
     __syncthreads();
     load(t0, kc, &cur0, &cur1);
+    load_pn(t0, kc, &pc0, &pc1, &nc0, &nc1);
   }
   __device__ __forceinline__ void after_barrier1(int t, int t_end, int wv, int lane) {
     if (wv == kPollWave && t + 1 < t_end && t + 1 >= ready_upto) wait(t + 1, t_end, lane);
@@ -110,11 +156,82 @@ struct PaHandoff {
     if (NLC_FUSED_TRACE)  // trace build: when this chain entered the last third of step t
       __hip_atomic_store(sync + kFusedFlags + (int64_t)(T + 1 + t) * ntk + tile, (unsigned)__builtin_amdgcn_s_memrealtime() | 1u,
                          NLC_RLX_AGENT);
-    if (t + 1 < t_end) load(t + 1, kc, &nxt0, &nxt1);
+    if (t + 1 < t_end) {
+      load(t + 1, kc, &nxt0, &nxt1);
+      load_pn(t + 1, kc, &pn0, &pn1, &nn0, &nn1);
+    }
   }
   __device__ __forceinline__ void advance() {
     cur0 = nxt0;
     cur1 = nxt1;
+    pc0 = pn0;
+    pc1 = pn1;
+    nc0 = nn0;
+    nc1 = nn1;
+  }
+};
+
+// give-up of any bounded wait of this launch: the command is lost (the host re-runs it on the two-launch body)
+__device__ __forceinline__ void report_timeout(unsigned* sync, unsigned* timeout_host, unsigned code) {
+  // (every lane stores the same word: no lane-divergent branch inside a polling loop)
+  __hip_atomic_store(sync + kFusedTimeout, code, NLC_RLX_AGENT);
+  __hip_atomic_store(timeout_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the kernel-argument segment as ordinary (global) memory: per-lane indexed reads of the small arrays that ride in it
+__device__ __forceinline__ const FusedArgs* args_in_memory() {
+  return (const FusedArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// Window source of the encoder role when no perturb kernel ran (FusedCtl::inline_perturb): wave 0 samples and bounds the
+// B actions of each of the tile's 16 windows -- lane group q takes history entries q, q + 4, ... -- stages the raw GRU
+// inputs in LDS (xs[(j * 16 + c) * NLC_MAX_NU + dim]) for the four waves and publishes the entry that belongs to the
+// tile's OWN step (the newest one, j = B - 1) as perturbed / noise / actions [k, t].
+struct XInline {
+  bool on;
+  double* xs;
+  __device__ __forceinline__ void prepare(const GruArgs& a, int lane, int wv, int64_t kk, int tt, bool valid) {
+    if (!on || wv != 0) return;
+    const FusedArgs* fa = args_in_memory();
+    const PerturbArgs& p = fa->p;
+    const int q = lane >> 4, c = lane & 15;
+    const int64_t ke = p.k_offset + kk;  // single planner: episode 0
+    const bool null_action = p.sample_null_action && (ke == p.K_global - 1);
+    for (int j = q; j < a.B; j += 4) {
+      const int i = tt + j;  // history index: [action_buffer[1:] ; u_scale * perturbed]
+      double v0 = 0.0, v1 = 0.0;
+      if (i < a.B - 1) {
+        v0 = fa->p.abuf_in[(1 + i) * a.nact];
+        if (a.nact > 1) v1 = fa->p.abuf_in[(1 + i) * a.nact + 1];
+      } else {
+        const int tp = i - (a.B - 1);
+        double eps[NLC_MAX_NU];
+        mppi_draw(ke, tp, p.seed, p.counter, p.nu, fa->p.mu, fa->p.chol, eps);
+#pragma unroll
+        for (int dim = 0; dim < NLC_MAX_NU; ++dim) {
+          if (dim < a.nact) {
+            const double U = mppi_shifted_U(p.U_old, fa->p.u_init, 0, p.T, p.nu, tp, dim);
+            const double V = mppi_bound(U, eps[dim], null_action, p.u_scale, p.has_bounds, fa->p.u_min[dim], fa->p.u_max[dim]);
+            if (dim == 0) v0 = a.u_scale * V;
+            else v1 = a.u_scale * V;
+            if (j == a.B - 1 && valid) {
+              const int64_t at = (kk * p.T + tp) * p.nu + dim;
+              MemSc1::st(p.perturbed + at, V);
+              MemSc1::st(p.noise + at, V - U);                                               // :328
+              if (p.actions != nullptr) p.actions[at] = (p.u_scale * V) / p.u_scale;          // :255,340
+            }
+          }
+        }
+      }
+      xs[(j * 16 + c) * NLC_MAX_NU] = v0;
+      xs[(j * 16 + c) * NLC_MAX_NU + 1] = v1;
+    }
+  }
+  __device__ __forceinline__ double raw(const GruArgs& a, int64_t wc, int64_t kk, int tt, int j_win, int q, int c,
+                                        int ab_off) const {
+    if (!on) return XDirect().raw(a, wc, kk, tt, j_win, q, c, ab_off);
+    if (q < a.nact) return xs[(j_win * 16 + c) * NLC_MAX_NU + q];
+    return (double)(a.B - 1 - j_win);
   }
 };
 
@@ -161,12 +278,37 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem) {
   src.sync = a.ctl.sync;
   src.timeout_host = a.ctl.timeout_host;
   src.ready_upto = 0;
+  src.spin_limit = a.ctl.spin_limit;
+  src.inl = a.ctl.inline_perturb;
+  src.inw = a.ctl.inline_weights;
+  src.nu = a.r.nu;
+  src.w0 = wv == 0;
+  src.state_in = args_in_memory()->p.state_in;
+  src.u_init = args_in_memory()->p.u_init;
+  src.U_old = a.p.U_old;
+  src.pert_g = a.r.perturbed;
+  src.noise_g = a.r.noise;
+  src.pc0 = src.pc1 = src.nc0 = src.nc1 = src.pn0 = src.pn1 = src.nn0 = src.nn1 = 0.0;
   // the sequential chain is the command's critical path: its waves win the issue arbitration on their SIMDs
   if (NLC_FUSED_TRACE && wv == 0) wave_add_one(a.ctl.sync + kFusedStatRollStart, lane);
   __builtin_amdgcn_s_setprio(3);
-  rollout_split_tile<HT, NT3>(a.r, (int64_t)tile, src, smem, smem + KS * 64, smem + 2 * KS * 64);
+  const double cost = rollout_split_tile<HT, NT3>(a.r, (int64_t)tile, src, smem, smem + KS * 64, smem + 2 * KS * 64);
   __builtin_amdgcn_s_setprio(0);
   if (wv == 0) {
+    if (a.ctl.inline_weights) {
+      // this tile's costs are final: fold them into the running minimum (kept as max of ~order_key, which starts from the
+      // zeroed word), drain the write-through cost stores, then count the tile done (ONE lane adds; nlc_mppi_dev.h)
+      const bool valid = (int64_t)tile * 16 + (lane & 15) < a.r.K;
+      unsigned long long key = valid ? ~f64_order_key(cost) : 0ull;
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other > key ? other : key;
+      }
+      __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a.ctl.sync + kFusedBetaKey), lane == 0 ? key : 0ull,
+                             NLC_RLX_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wave_add_one(a.ctl.sync + kFusedCostDone, lane);
+    }
     if (NLC_FUSED_TRACE) wave_add_one(a.ctl.sync + kFusedStatRollDone, lane);
     stamp_max(a.ctl.sync + kFusedTimeRollEndFirst, true);
     stamp_max(a.ctl.sync + kFusedTimeRollEndLast, false);
@@ -189,6 +331,7 @@ __device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yi
   const int q = lane >> 4, c = lane & 15;
   unsigned* sync = a.ctl.sync;
   unsigned* s_ticket = reinterpret_cast<unsigned*>(smem + 4 * KSG * 64);  // behind the four hidden-state images
+  XInline xsrc{a.ctl.inline_perturb != 0, smem + 4 * KSG * 64 + 8};      // (+ B x 16 x NLC_MAX_NU staged inputs)
   for (int done = 0; done < max_tiles; ++done) {
     if (wv == 0) {
       if (yield_cu >= 0 && done >= yield_after) {
@@ -210,8 +353,8 @@ __device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yi
     const int64_t k = (int64_t)j * 16 + c;
     const bool valid = k < a.r.K;
     const int64_t kk = valid ? k : a.r.K - 1;
-    const double o = gru_encode_tile_coop<G>(a.g, lane, wv, 0, kk, t, smem);
-    if (wv == 0) {
+    const double o = gru_encode_tile_coop<G>(a.g, lane, wv, 0, kk, t, smem, xsrc, valid);
+    if (wv == 0 && i != (unsigned)a.ctl.test_drop_tile) {
       if (valid && q < 2) {
         unsigned long long* dst = (unsigned long long*)(a.r.pa + ((int64_t)t * a.r.K + k) * 2 + q);
         __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, o), NLC_RLX_AGENT);  // global_store_dwordx2 sc1
@@ -234,7 +377,7 @@ __global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs a
   const FusedCtl& a = av.ctl;  // role assignment; the roles read av through role_args()
   constexpr int KSG = G / 4;  // GRU k-steps
   constexpr int KS = HT * 4;  // representation-MLP k-steps
-  constexpr int kGruDoubles = 4 * KSG * 64 + 8, kRollDoubles = 2 * KS * 64 + 8 * 64;
+  constexpr int kGruDoubles = 4 * KSG * 64 + 8 + kFusedMaxInlineB * 16 * NLC_MAX_NU, kRollDoubles = 2 * KS * 64 + 8 * 64;
   __shared__ double smem[kGruDoubles > kRollDoubles ? kGruDoubles : kRollDoubles];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -247,6 +390,13 @@ __global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs a
   const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
   const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID [3:0]
   const unsigned cu = ((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu);
+  if (a.inline_perturb && blockIdx.x == 0 && wv == 0) {
+    // U <- roll(U, -1); U[-1] = u_init (:199-200): everybody in this launch shifts on the fly, the merge kernel reads this
+    const PerturbArgs& p = ((const FusedArgs*)role_args())->p;
+    const FusedArgs* fa = args_in_memory();
+    for (int i = lane; i < p.T * p.nu; i += 64)
+      p.U_new[i] = mppi_shifted_U(p.U_old, fa->p.u_init, 0, p.T, p.nu, i / p.nu, i % p.nu);
+  }
   if (wv == 0) {
     int tile = -1;
     if (NLC_FUSED_TRACE) wave_add_one(sync + kFusedStatEntered, lane);
@@ -311,6 +461,43 @@ __global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs a
     __syncthreads();
     if (tile == -2) break;
     if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);
+  }
+
+  // ---- importance weights (planners/mppi_delay.py:210-216) inside the launch: the first nblk workgroups to get here take
+  // one 64-sample weight block each, wait (asleep) until every rollout tile has counted itself done -- the running
+  // minimum beta is then final -- and run weight_partial_kernel's arithmetic on it; the block that finishes last folds
+  // the block partials (weight_final_kernel's arithmetic).  Costs, noise and block partials were stored write-through
+  // inside this launch and are loaded past the L1 (MemSc1); cost_nz and the shard's partials are for the next launch.
+  if (a.inline_weights) {
+    const WeightArgs& w = ((const FusedArgs*)role_args())->w;
+    if (wv == 0) s_tile[0] = (int)wave_ticket(sync + kFusedWTicket, lane);
+    __syncthreads();
+    const int blk = __builtin_amdgcn_readfirstlane(s_tile[0]);
+    __syncthreads();
+    if (blk < w.nblk) {
+      if (wv == 0) {
+        for (unsigned spins = 0;; ++spins) {
+          const unsigned done = __hip_atomic_load(sync + kFusedCostDone, NLC_RLX_AGENT);
+          if (__builtin_amdgcn_readfirstlane(done) >= (unsigned)a.ntk) break;
+          if (spins > a.spin_limit) {
+            report_timeout(sync, a.timeout_host, 0x80000000u | (unsigned)blk);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(64);  // ~2 us
+        }
+      }
+      __syncthreads();
+      const unsigned long long mk =
+          __hip_atomic_load(reinterpret_cast<unsigned long long*>(sync + kFusedBetaKey), NLC_RLX_AGENT);
+      const double beta = f64_from_order_key(~mk);
+      weight_block<MemSc1>(w, 0, blk, beta, smem + 8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through partials have left
+      __syncthreads();
+      if (wv == 0) s_tile[0] = (int)wave_ticket(sync + kFusedWDone, lane);
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(s_tile[0]) == w.nblk - 1)
+        for (int i = wv; i < 1 + w.T * w.nu; i += 4) weight_final_entry<MemSc1>(w, 0, i, lane);
+    }
   }
   if (NLC_FUSED_TRACE && wv == 0) wave_add_one(sync + kFusedStatExited, lane);
 }

@@ -5,6 +5,7 @@
 // All of these are HBM-light streaming / reduction kernels over the (K, T, nu) noise tensor.
 #include "nlc_device.h"
 #include "nlc_kernels.h"
+#include "nlc_mppi_dev.h"
 
 namespace nlc {
 
@@ -50,21 +51,7 @@ __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
     const int64_t kg = e * a.K_global + ke;
     double eps[NLC_MAX_NU];
     if (a.rng) {
-      double z[NLC_MAX_NU];
-      static_assert(NLC_MAX_NU <= 2, "one Philox block yields two normals");
-      const u4 r = philox4x32_10(u4{(uint32_t)kg, (uint32_t)(kg >> 32), (uint32_t)t, (uint32_t)a.counter},
-                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32) ^ (uint32_t)(a.counter >> 32));
-      const double u1 = u53(r.x, r.y), u2 = u53(r.z, r.w);
-      const double rad = sqrt(-2.0 * log(u1));
-      double sn, cs;
-      m::sincos_bounded(2.0 * kPi * u2 - kPi, &sn, &cs);  // angle in (-pi, pi)
-      z[0] = rad * cs;
-      z[1] = rad * sn;
-      for (int i = 0; i < a.nu; ++i) {
-        double v = a.mu[i];
-        for (int j = 0; j <= i; ++j) v += a.chol[i * a.nu + j] * z[j];
-        eps[i] = v;
-      }
+      mppi_draw(kg, t, a.seed, a.counter, a.nu, a.mu, a.chol, eps);
     } else {
       for (int i = 0; i < a.nu; ++i) eps[i] = a.noise[idx * a.nu + i];
     }
@@ -78,11 +65,7 @@ __global__ __launch_bounds__(256) void perturb_kernel(const PerturbArgs a) {
       } else {
         U = a.U_new[(e * a.T + t) * a.nu + i];
       }
-      double V = U + eps[i];
-      if (null_action) V = 0.0;  // :322-323
-      double Vs = V * a.u_scale;
-      if (a.has_bounds) Vs = fmax(fmin(Vs, a.u_max[i]), a.u_min[i]);  // :351
-      V = Vs / a.u_scale;                                            // :326
+      const double V = mppi_bound(U, eps[i], null_action, a.u_scale, a.has_bounds, a.u_min[i], a.u_max[i]);
       a.perturbed[idx * a.nu + i] = V;
       a.noise[idx * a.nu + i] = V - U;                               // :328
       if (a.actions != nullptr) a.actions[idx * a.nu + i] = (a.u_scale * V) / a.u_scale;  // :255,340
@@ -99,15 +82,6 @@ hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ importance weights (:210-216)
-__device__ __forceinline__ double wave_min(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 // pass 1: per-block min of cost (blockIdx.y = episode in all three passes)
 __global__ __launch_bounds__(256) void cost_min_kernel(const WeightArgs a) {
   __shared__ double sm[4];
@@ -137,46 +111,15 @@ __global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a,
   __syncthreads();
   if (threadIdx.x == 0) sbeta = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
   __syncthreads();
-  const double beta = sbeta;
-  const int64_t kb = (int64_t)blockIdx.x * kWeightBlockSamples;  // within the episode
-  const int ns = (int)((a.Kep - kb < kWeightBlockSamples) ? (a.Kep - kb) : kWeightBlockSamples);
-  const int64_t k0 = (int64_t)e * a.Kep + kb;
-  const int TN = a.T * a.nu;
-  double wk = 0.0;
-  if ((int)threadIdx.x < ns) {
-    wk = exp(-(1.0 / a.lambda_) * (a.cost[k0 + threadIdx.x] - beta));  // _ensure_non_zero :12-13
-    a.cost_nz[k0 + threadIdx.x] = wk;
-    sw[threadIdx.x] = wk;
-  }
-  __syncthreads();
-  double* out = a.block_part + ((int64_t)e * a.nblk + blockIdx.x) * (1 + TN);
-  if (threadIdx.x < 64) {
-    const double es = wave_sum(wk);  // threads 0..63 hold all (<= 64) weights of the block
-    if (threadIdx.x == 0) {
-      out[0] = es;
-      if (blockIdx.x == 0) a.partials[(int64_t)e * (2 + TN)] = beta;
-    }
-  }
-  for (int tj = threadIdx.x; tj < TN; tj += 256) {
-    double acc = 0.0;
-    const double* np = a.noise + k0 * TN + tj;
-    for (int s = 0; s < ns; ++s) acc += sw[s] * np[(int64_t)s * TN];
-    out[1 + tj] = acc;
-  }
+  weight_block<MemPlain>(a, e, (int)blockIdx.x, sbeta, sw);
 }
 
 // pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r).
 // One wavefront per output entry: lanes stride over the blocks, then a wave reduction.
 __global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
-  const int TN = a.T * a.nu;
-  const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= 1 + TN) return;
-  const int64_t e = blockIdx.y;
-  double acc = 0.0;
-  for (int b = lane; b < a.nblk; b += 64) acc += a.block_part[(e * a.nblk + b) * (1 + TN) + i];
-  acc = wave_sum(acc);
-  if (lane == 0) a.partials[e * (2 + TN) + 1 + i] = acc;
+  if (i >= 1 + a.T * a.nu) return;
+  weight_final_entry<MemPlain>(a, (int64_t)blockIdx.y, i, threadIdx.x & 63);
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
@@ -196,6 +139,10 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
   const int TN = a.T * a.nu;
   const int W = 2 + TN;
   const int64_t e = blockIdx.y;
+  // the fused planner body of the NEXT command starts from zeroed tickets / flags (this launch is the last of a command)
+  for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < a.n_zero_words;
+       i += (int64_t)gridDim.x * gridDim.y * 256)
+    a.zero_words[i] = 0u;
   const double* gat = a.gathered + e * W;       // rank g's row of this episode: gat + g * E * W
   const int64_t gs = (int64_t)a.E * W;
   double beta = INFINITY;

@@ -110,7 +110,21 @@ struct nlc_ctx {
   int opt_fused_partner_tiles = -2;     // tiles per wave after which a chain's CU partner sleeps (-1: never, -2 auto)
   int64_t opt_fused_max_samples = 4096; // auto: populations up to this size take the fused body (one chain per CU at most)
   int fused_blocks_per_cu = -1;         // occupancy of the fused kernel (queried once)
-  bool fused_lost = false;              // a fused command gave up (hand-off timeout): reported by the next call
+  bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
+  int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
+  int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
+  int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
+  int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
+  const void* sync_clean_ws = nullptr;  // workspace whose fused sync block the last merge kernel left zeroed
+  bool sync_dirty = false;              // a fused launch has used the sync block since
+  // the last command's inputs, kept for a re-run on the two-launch body (nlc_mppi_finish, after a fused timeout)
+  struct LastCommand {
+    bool valid = false, inline_inputs = false, fused = false;
+    int state_per_sample = 0, rng = 0;
+    uint64_t seed = 0, counter = 0;
+    double state_in[NLC_MAX_D] = {0};
+    double abuf_in[kMaxInlineAbuf] = {0};
+  } last;
   // optional native collective (nlc_comm_init): an RCCL communicator over the ranks of a K-sharded planner
   void* comm = nullptr;
   int comm_world = 0, comm_rank = 0;
@@ -386,6 +400,31 @@ extern "C" int nlc_comm_init(nlc_ctx* c, int rank, int world, const void* id) {
   NLC_GUARD_END(c)
 }
 
+extern "C" int nlc_comm_self_test(nlc_ctx* c) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  NLC_GUARD_BEGIN
+  if (!c->comm) return fail(c, NLC_ERR_STATE, "nlc_comm_self_test: no communicator (nlc_comm_init)");
+  NLC_HIP(c, hipSetDevice(c->device));
+  const int G = c->comm_world;
+  double* dev = nullptr;
+  NLC_HIP(c, hipMalloc((void**)&dev, (size_t)(G + 1) * sizeof(double)));
+  const double mine = (double)(c->comm_rank + 1);
+  hipError_t e = hipMemcpyAsync(dev + G, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream);
+  int rc = 0;
+  if (e == hipSuccess) rc = rccl()->AllGather(dev + G, dev, 1, kNcclFloat64, c->comm, c->stream);
+  std::vector<double> got((size_t)G, 0.0);
+  if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(got.data(), dev, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(c->stream);
+  hipFree(dev);
+  if (rc != 0) return fail(c, NLC_ERR_COMM, std::string("ncclAllGather: ") + rccl()->GetErrorString(rc));
+  if (e != hipSuccess) return fail(c, NLC_ERR_HIP, std::string("nlc_comm_self_test: ") + hipGetErrorString(e));
+  for (int g = 0; g < G; ++g)
+    if (got[(size_t)g] != (double)(g + 1))
+      return fail(c, NLC_ERR_COMM, "nlc_comm_self_test: the all-gather returned the wrong rank order / values");
+  return NLC_OK;
+  NLC_GUARD_END(c)
+}
+
 extern "C" void nlc_destroy(nlc_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
@@ -425,6 +464,16 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   if (n == "rollout_variant") {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
     c->opt_rollout_variant = (int)value;
+    c->fused_lost = false;  // an explicit choice re-arms the fused body after a timeout
+  } else if (n == "fused_inline") {
+    if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "fused_inline must be 0, 1 (= 3), or the bit mask 1 weights | 2 sampling");
+    c->opt_fused_inline = (int)value == 1 ? 3 : (int)value;
+  } else if (n == "fused_spin_limit") {
+    if (value < 1 || value > 4.0e9) return fail(c, NLC_ERR_BAD_ARG, "fused_spin_limit must be in 1 .. 4e9");
+    c->opt_fused_spin_limit = (int64_t)value;
+  } else if (n == "fused_test_drop_tile") {
+    if (value < -1) return fail(c, NLC_ERR_BAD_ARG, "fused_test_drop_tile must be >= -1");
+    c->opt_fused_test_drop_tile = (int)value;
   } else if (n == "fused_roll_cap") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_roll_cap must be >= 0 (0 = auto)");
     c->opt_fused_roll_cap = (int)value;
@@ -1298,6 +1347,9 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     NLC_HIP(c, hipMemcpy(c->b1fold, bf.data(), h * sizeof(double), hipMemcpyHostToDevice));
   }
   c->has_mppi = true;
+  c->sync_clean_ws = nullptr;
+  c->sync_dirty = false;
+  c->last.valid = false;
   return NLC_OK;
   NLC_GUARD_END(c)
 }
@@ -1348,7 +1400,7 @@ static bool fused_gave_up(nlc_ctx* c) {
   return true;
 }
 
-static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
+static WeightArgs make_weight_args(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   const nlc_mppi_desc& d = c->pd;
   const WsLayout w = ws_layout(c);
   double* ws = (double*)buf->workspace;
@@ -1365,6 +1417,11 @@ static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   wa.block_part = ws + w.block_part;
   wa.partials = buf->partials;
   wa.nblk = c->nblk;
+  return wa;
+}
+
+static int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
+  const WeightArgs wa = make_weight_args(c, buf);
   ProfScope ps(c, "weight_kernels");
   NLC_HIP(c, launch_weights(wa, c->stream));
   return NLC_OK;
@@ -1397,9 +1454,10 @@ extern "C" int nlc_mppi_get_U(nlc_ctx* c, double* U) {
   return NLC_OK;
 }
 
-extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_sample, const double* abuf_host,
-                                const nlc_mppi_buffers* buf, int rng, uint64_t seed, uint64_t counter) {
-  if (!c) return NLC_ERR_BAD_ARG;
+// Phase 1 of a command.  `replay`: the command's fused launch gave up (hand-off timeout) -- run it again on the two-launch
+// body from the inputs kept in c->last / still staged in the workspace (nlc_mppi_finish).
+static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_sample, const double* abuf_host,
+                             const nlc_mppi_buffers* buf, int rng, uint64_t seed, uint64_t counter, bool replay) {
   NLC_GUARD_BEGIN
   if (!c->has_mppi) return fail(c, NLC_ERR_STATE, "planner not configured");
   const nlc_mppi_desc& d = c->pd;
@@ -1409,15 +1467,20 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
   if (d.cost_external && !buf->states) return fail(c, NLC_ERR_BAD_ARG, "cost_external needs buf->states");
   NLC_HIP(c, hipSetDevice(c->device));
-  if (fused_gave_up(c))  // (a device-resident caller never synchronised inside nlc_mppi_finish)
-    return fail(c, NLC_ERR_HIP, "fused planner body: the PREVIOUS command timed out waiting for GRU latents");
+  if (!replay && fused_gave_up(c)) {  // (a device-resident caller never synchronised inside nlc_mppi_finish)
+    c->fused_lost = true;  // from here on the two-launch body
+    return fail(c, NLC_ERR_HIP, "fused planner body: the PREVIOUS command timed out waiting inside the launch (its action "
+                                "was not valid); later commands run the two-launch body");
+  }
   const WsLayout w = ws_layout(c);
   double* ws = (double*)buf->workspace;
   double* state_dev = ws + w.state0;
   double* abuf_dev = ws + w.abuf;
   const int64_t KE = d.K * d.E;  // all local samples, episode-major
   bool inline_inputs = false;
-  if (!external && d.E > 1) {
+  if (replay) {
+    inline_inputs = c->last.inline_inputs;  // otherwise the inputs are still staged in the workspace
+  } else if (!external && d.E > 1) {
     // batched episodes: the (E,d) states and (E,B,nu) action buffers usually live on the device already (a device-side
     // env loop); hipMemcpyDefault takes either kind of pointer
     const size_t ns = (size_t)(state_per_sample ? KE : d.E) * d.d;
@@ -1474,11 +1537,6 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) p.chol[i] = d.noise_chol[i];
   p.seed = seed;
   p.counter = counter;
-  if (d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_DEHOOG) {
-    // the fused planner body's tickets / census / flags start every command at zero
-    p.zero_words = reinterpret_cast<unsigned*>(ws + w.sync);
-    p.n_zero_words = (int64_t)fused_sync_words(d.T, KE);
-  }
   if (inline_inputs) {
     p.n_state_in = d.d;
     p.n_abuf_in = d.B * d.nu;
@@ -1486,6 +1544,20 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     p.abuf_dst = abuf_dev;
     std::memcpy(p.state_in, state, (size_t)d.d * sizeof(double));
     std::memcpy(p.abuf_in, abuf_host, (size_t)d.B * d.nu * sizeof(double));
+  }
+  if (!replay) {
+    nlc_ctx::LastCommand& L = c->last;
+    L.valid = !external;
+    L.inline_inputs = inline_inputs;
+    L.fused = false;
+    L.state_per_sample = state_per_sample;
+    L.rng = rng;
+    L.seed = seed;
+    L.counter = counter;
+    if (inline_inputs) {
+      std::memcpy(L.state_in, p.state_in, sizeof(L.state_in));
+      std::memcpy(L.abuf_in, p.abuf_in, sizeof(L.abuf_in));
+    }
   }
   c->ucur ^= 1;  // from here on c->U[c->ucur] is the shifted sequence the two kernels below produce
   // (a lambda: the fused planner body's argument block rides to the device in the perturb kernel's arguments, so that
@@ -1626,15 +1698,20 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
     int variant = c->opt_rollout_variant;
     const bool fused_ok = c->md.h == 128 && c->g == 64 && c->net.nt3 <= 21 && KE * d.T * 16 < (int64_t)1 << 31;
     if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
-    if (variant == 0 && fused_ok && KE <= c->opt_fused_max_samples) variant = 3;
+    if (fused_ok && c->fused_blocks_per_cu < 0) {
+      int bpc = 0;
+      NLC_HIP(c, fused_max_resident_blocks(&bpc));
+      c->fused_blocks_per_cu = bpc;
+    }
+    // The fused body's rollout workgroups wait for encoder workgroups of the SAME launch, so every workgroup must be
+    // resident and there must be workgroups left to encode beside one chain per CU: at least two per CU.  It
+    // also assumes the device to itself (include/nlc.h): after one hand-off timeout the ctx stays on the two-launch body.
+    if (variant == 3 && c->fused_blocks_per_cu < 2)
+      return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: fewer than two workgroups of the kernel fit a CU");
+    if (variant == 0 && fused_ok && c->fused_blocks_per_cu >= 2 && KE <= c->opt_fused_max_samples) variant = 3;
+    if (variant == 3 && (replay || c->fused_lost)) variant = 2;
     if (variant == 3) {
-      if (c->fused_blocks_per_cu < 0) {
-        int bpc = 0;
-        NLC_HIP(c, fused_max_resident_blocks(&bpc));
-        c->fused_blocks_per_cu = bpc;
-      }
       const int bpc = c->fused_blocks_per_cu < 4 ? c->fused_blocks_per_cu : 4;
-      if (bpc < 1) return fail(c, NLC_ERR_HIP, "fused planner body: kernel does not fit a CU");
       const int ncu = c->prop.multiProcessorCount;
       FusedArgs f{};
       f.r = r;
@@ -1666,11 +1743,34 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
       const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : auto_partner;
       // (sleepers need CUs without a chain to produce the latents the chains wait for)
       fc.partner_tiles = fc.roll_cap <= ncu / 2 ? partner : -1;
-      if (int rc = launch_shift_perturb()) return rc;
+      fc.spin_limit = (unsigned)c->opt_fused_spin_limit;
+      fc.test_drop_tile = c->opt_fused_test_drop_tile;
+      // Single planner: the weight reduction runs inside the launch, and with device noise and the command's inputs in
+      // the kernel arguments so does the sampling -- command() is then this launch + merge_kernel.
+      fc.inline_weights = (c->opt_fused_inline & 1) && d.E == 1 && !d.cost_external;
+      fc.inline_perturb = (c->opt_fused_inline & 2) && d.E == 1 && inline_inputs && rng == 1 && d.B <= kFusedMaxInlineB;
+      unsigned* sync_words = reinterpret_cast<unsigned*>(ws + w.sync);
+      const size_t n_sync = fused_sync_words(d.T, KE);
+      if (fc.inline_perturb) {
+        // tickets / flags start at zero: the previous command's merge kernel left them so (else: one memset)
+        if (c->sync_clean_ws != buf->workspace) NLC_HIP(c, hipMemsetAsync(sync_words, 0, n_sync * sizeof(unsigned), c->stream));
+      } else {
+        p.zero_words = sync_words;
+        p.n_zero_words = (int64_t)n_sync;
+        if (int rc = launch_shift_perturb()) return rc;
+      }
+      c->sync_clean_ws = nullptr;
+      c->sync_dirty = true;
+      c->last.fused = true;
+      f.p = p;
+      if (fc.inline_weights) f.w = make_weight_args(c, buf);
       // every workgroup must be resident at once: a rollout workgroup waits for encoder workgroups of the same launch
       const unsigned grid = (unsigned)(ncu * bpc);
-      ProfScope ps(c, "nl_plan_fused_kernel");
-      NLC_HIP(c, launch_nl_plan_fused(f, c->g, grid, c->stream));
+      {
+        ProfScope ps(c, "nl_plan_fused_kernel");
+        NLC_HIP(c, launch_nl_plan_fused(f, c->g, grid, c->stream));
+      }
+      if (fc.inline_weights) return NLC_OK;
     } else {
       if (int rc = launch_shift_perturb()) return rc;
       g.t0 = 0;
@@ -1777,6 +1877,12 @@ extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_s
   NLC_GUARD_END(c)
 }
 
+extern "C" int nlc_mppi_rollout(nlc_ctx* c, const double* state, int state_per_sample, const double* abuf_host,
+                                const nlc_mppi_buffers* buf, int rng, uint64_t seed, uint64_t counter) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  return mppi_rollout_impl(c, state, state_per_sample, abuf_host, buf, rng, seed, counter, false);
+}
+
 extern "C" int nlc_mppi_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
@@ -1836,15 +1942,41 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   // on the host's critical path is the stream synchronisation
   double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;
   m.action_pinned = action_host ? pin_act : nullptr;
-  {
+  auto launch_merge_now = [&]() -> int {
+    if (c->sync_dirty && buf->workspace) {
+      // last launch of the command: leave the fused body's tickets / flags zeroed for the next one
+      m.zero_words = reinterpret_cast<unsigned*>((double*)buf->workspace + ws_layout(c).sync);
+      m.n_zero_words = (int64_t)fused_sync_words(d.T, d.K * d.E);
+    }
     ProfScope ps(c, "merge_kernel");
     NLC_HIP(c, launch_merge(m, c->stream));
-  }
+    if (m.zero_words) {
+      c->sync_clean_ws = buf->workspace;
+      c->sync_dirty = false;
+    }
+    return NLC_OK;
+  };
+  if (int rc = launch_merge_now()) return rc;
   if (action_host) {
     const size_t na = (size_t)d.E * d.u_per_command * d.nu;
     NLC_HIP(c, hipStreamSynchronize(c->stream));
-    if (fused_gave_up(c))
-      return fail(c, NLC_ERR_HIP, "fused planner body: a rollout workgroup timed out waiting for GRU latents; command lost");
+    if (fused_gave_up(c)) {
+      // A wave of the fused body gave up waiting for another workgroup of its launch (the device was not this planner's
+      // alone, or fewer workgroups were resident than the host assumed): the command's result is not valid.  This ctx
+      // runs the two-launch body from now on; a single-rank command with library-side costs is re-run on it right here.
+      c->fused_lost = true;
+      if (G != 1 || d.cost_external || !c->last.valid || !c->last.fused || !buf->workspace || !buf->partials)
+        return fail(c, NLC_ERR_HIP, "fused planner body: a workgroup timed out waiting inside the launch; command lost "
+                                    "(later commands run the two-launch body)");
+      c->fused_fallbacks += 1;
+      c->ucur ^= 1;  // back to the control sequence before this command's shift (the ping-pong partner is untouched)
+      const nlc_ctx::LastCommand L = c->last;
+      if (int rc = mppi_rollout_impl(c, L.state_in, L.state_per_sample, L.abuf_in, buf, L.rng, L.seed, L.counter, true)) return rc;
+      m.U = c->U[c->ucur];
+      if (gathered == nullptr || G == 1) m.gathered = buf->partials;
+      if (int rc = launch_merge_now()) return rc;
+      NLC_HIP(c, hipStreamSynchronize(c->stream));
+    }
     std::memcpy(action_host, pin_act, na * sizeof(double));
   }
   return NLC_OK;

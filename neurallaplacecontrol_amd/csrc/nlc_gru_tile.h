@@ -216,9 +216,27 @@ __device__ __forceinline__ double gru_encode_tile(const GruArgs& a, int lane, in
 // by the workgroup and double-buffered: Hc[(2 l + b) * KS*64 + ks*64 + lane], layer l, buffer b; one barrier per GRU step
 // between the layers and one before the head.  All four waves call this with the same (wc, kk, tt); wave 0 returns
 // linear_out row q (valid for q < 2), the others return 0.
-template <int G>
+// Where a window's raw (un-normalised) inputs come from is a policy of the cooperative tile:
+//   XDirect  the explicit window tensor (mode 0) / the MPPI history over the perturbed-action tensor an EARLIER launch
+//            wrote (mode 1) -- gru_encode_coop_kernel, and the fused planner body behind a perturb kernel
+//   (kernels_fused.hip) XInline: the fused planner body samples and bounds the actions itself
+// Interface: prepare() is called by all four waves before the tile's first barrier; raw() after it, by lanes q < nin.
+struct XDirect {
+  __device__ __forceinline__ void prepare(const GruArgs&, int, int, int64_t, int, bool) {}
+  __device__ __forceinline__ double raw(const GruArgs& a, int64_t wc, int64_t kk, int tt, int j_win, int q, int c,
+                                        int ab_off) const {
+    if (a.mode == 0) return a.window[(wc * a.B + j_win) * a.nin + q];
+    const int i = tt + j_win;
+    if (q < a.nact)
+      return (i < a.B - 1) ? a.abuf[(ab_off + 1 + i) * a.nact + q]
+                           : a.u_scale * a.perturbed[(kk * a.T + (i - (a.B - 1))) * a.nact + q];
+    return (double)(a.B - 1 - j_win);  // encode_obs_time model: the harness's constant time channel
+  }
+};
+
+template <int G, class XS = XDirect>
 __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lane, int wv, int64_t wc, int64_t kk, int tt,
-                                                       double* __restrict__ Hc) {
+                                                       double* __restrict__ Hc, XS xs = XS(), bool valid = true) {
   constexpr int GT = G / 16;
   constexpr int KS = G / 4;
   constexpr int CPW = (GT + 3) / 4;  // chunks per wave
@@ -232,6 +250,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
     in_std = a.std[q];
   }
   const int ab_off = (a.mode == 1) ? (int)(kk / a.Kep) * a.B : 0;
+  xs.prepare(a, lane, wv, kk, tt, valid);
   // zero this wave's rows of the "current" images (h_0 = 0); the other buffers are written before they are read
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
@@ -254,17 +273,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
     const int j_win = a.B - 1 - s;
     double xin = 0.0;
     if (q < a.nin) {
-      double raw;
-      if (a.mode == 0) {
-        raw = a.window[(wc * a.B + j_win) * a.nin + q];
-      } else {
-        const int i = tt + j_win;
-        if (q < a.nact)
-          raw = (i < a.B - 1) ? a.abuf[(ab_off + 1 + i) * a.nact + q]
-                              : a.u_scale * a.perturbed[(kk * a.T + (i - (a.B - 1))) * a.nact + q];
-        else
-          raw = (double)(a.B - 1 - j_win);
-      }
+      const double raw = xs.raw(a, wc, kk, tt, j_win, q, lane & 15, ab_off);
       xin = (raw - in_mean) / in_std;
     } else if (q == 3) {
       xin = 1.0;

@@ -204,41 +204,6 @@ struct RolloutArgs {
 };
 hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s, int force_variant = 0);
 
-// One-launch planner body for small populations (kernels_fused.hip): GRU encode + split rollout as roles of one grid.
-// `sync` is a block of unsigned words the command's perturb kernel zeroes:
-constexpr int kFusedEncTicket = 0, kFusedRollTicket = 1, kFusedTimeout = 2, kFusedCensusTicket = 3;
-// progress counters (diagnostics; one relaxed atomic add each): workgroups entered / rollout tiles started / finished /
-// encoder tiles published / workgroups exited
-constexpr int kFusedStatEntered = 4, kFusedStatRollStart = 5, kFusedStatRollDone = 6, kFusedStatEncDone = 7, kFusedStatExited = 8;
-// timeline (low 32 bits of the 100 MHz s_memrealtime counter; "first" values are stored complemented so that the zeroed
-// word works with atomic max): first entry, first / last rollout past its first hand-off, first / last rollout done,
-// last encoder tile published
-constexpr int kFusedTimeEntry = 9, kFusedTimeRollBeginFirst = 10, kFusedTimeRollBeginLast = 11, kFusedTimeRollEndFirst = 12,
-              kFusedTimeRollEndLast = 13, kFusedTimeEncLast = 14;
-constexpr int kFusedCuOcc = 16;              // 2048 per-CU arrival counters (XCC_ID << 8 | SE/SH/CU id)
-constexpr int kFusedCuState = 16 + 2048;     // 2048 per-CU words: 1 the CU's first workgroup walks a chain, 2 it has finished
-constexpr int kFusedFlags = 16 + 4096;       // (T, ntk) one word per encoder tile, then one (ntk) row of rollout-tile owner
-                                             // tickets (the first add owns the tile)
-// (+ (T, ntk) chain-step time stamps, written by the trace build only)
-inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)(2 * T + 1) * (size_t)((K + 15) / 16); }
-struct FusedCtl {   // role assignment; passed to the kernel by value
-  unsigned* sync;
-  unsigned* timeout_host;  // pinned host word: non-zero = a rollout workgroup gave up waiting (command lost)
-  int ntk;         // 16-sample tiles per horizon step
-  int n_enc;       // T * ntk encoder tiles
-  int chain_first_tiles;  // encoder tiles every wave of a chain's workgroup encodes before the chain starts
-  int partner_tiles;      // >= 0: the other workgroup of a chain's CU sleeps after this many tiles per wave until the chain
-                          // is done; < 0: it never sleeps
-  int roll_cap;    // rollout workgroups that start right away (one per CU); the other tiles drain after the encoders
-};
-struct FusedArgs {   // the kernel's one by-value argument
-  RolloutArgs r;   // r.pa: the (T, K, 2) HORIZON-major latent tensor (written and read inside the launch)
-  GruArgs g;       // mode 1 fields filled in; g.out unused
-  FusedCtl ctl;
-};
-hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, hipStream_t s);
-hipError_t fused_max_resident_blocks(int* blocks_per_cu);
-
 struct ForwardArgs {
   NlNetArgs net;
   int64_t N;
@@ -432,7 +397,60 @@ struct MergeArgs {
   double* action;          // (E, u_per_command * nu) device
   double* action_pinned;   // same, in pinned host memory the kernel stores to directly (NULL = not wanted)
   double* beta_eta;        // (E, 2) device: merged beta, eta
+  unsigned* zero_words;    // words zeroed for the NEXT command (the fused planner body's sync block); may be NULL
+  int64_t n_zero_words;
 };
 hipError_t launch_merge(const MergeArgs& a, hipStream_t s);
+
+// One-launch planner body for small populations (kernels_fused.hip): GRU encode + split rollout as roles of one grid,
+// and -- for the single planner with device noise -- the command's sampling / bounding (in the encoder role) and its
+// importance-weight reduction (after the last rollout tile) as further phases of the same launch.
+// `sync` is a block of unsigned words that is zero when the launch starts (zeroed by the previous command's merge kernel,
+// by the command's own perturb kernel when that still runs, or by a memset):
+constexpr int kFusedEncTicket = 0, kFusedRollTicket = 1, kFusedTimeout = 2, kFusedCensusTicket = 3;
+// progress counters (diagnostics; one relaxed atomic add each): workgroups entered / rollout tiles started / finished /
+// encoder tiles published / workgroups exited
+constexpr int kFusedStatEntered = 4, kFusedStatRollStart = 5, kFusedStatRollDone = 6, kFusedStatEncDone = 7, kFusedStatExited = 8;
+// timeline (low 32 bits of the 100 MHz s_memrealtime counter; "first" values are stored complemented so that the zeroed
+// word works with atomic max): first entry, first / last rollout past its first hand-off, first / last rollout done,
+// last encoder tile published
+constexpr int kFusedTimeEntry = 9, kFusedTimeRollBeginFirst = 10, kFusedTimeRollBeginLast = 11, kFusedTimeRollEndFirst = 12,
+              kFusedTimeRollEndLast = 13, kFusedTimeEncLast = 14;
+constexpr int kFusedCuOcc = 16;              // 2048 per-CU arrival counters (XCC_ID << 8 | SE/SH/CU id)
+constexpr int kFusedCuState = 16 + 2048;     // 2048 per-CU words: 1 the CU's first workgroup walks a chain, 2 it has finished
+// in-launch weight reduction: rollout tiles whose costs are final / weight-block ticket / weight blocks done; the running
+// max of ~order_key(cost) (= min cost) as one 8-byte word
+constexpr int kFusedCostDone = 16 + 4096, kFusedWTicket = 16 + 4097, kFusedWDone = 16 + 4098, kFusedBetaKey = 16 + 4100;
+constexpr int kFusedFlags = 16 + 4096 + 16;  // (T, ntk) one word per encoder tile, then one (ntk) row of rollout-tile owner
+                                             // tickets (the first add owns the tile)
+// (+ (T, ntk) chain-step time stamps, written by the trace build only)
+inline size_t fused_sync_words(int T, int64_t K) { return (size_t)kFusedFlags + (size_t)(2 * T + 1) * (size_t)((K + 15) / 16); }
+constexpr int kFusedMaxInlineB = 8;  // action-buffer rows the in-launch sampling stages in LDS
+struct FusedCtl {   // role assignment; passed to the kernel by value
+  unsigned* sync;
+  unsigned* timeout_host;  // pinned host word: non-zero = a rollout workgroup gave up waiting (command lost)
+  int ntk;         // 16-sample tiles per horizon step
+  int n_enc;       // T * ntk encoder tiles
+  int chain_first_tiles;  // encoder tiles every wave of a chain's workgroup encodes before the chain starts
+  int partner_tiles;      // >= 0: the other workgroup of a chain's CU sleeps after this many tiles per wave until the chain
+                          // is done; < 0: it never sleeps
+  int roll_cap;    // rollout workgroups that start right away (one per CU); the other tiles drain after the encoders
+  int inline_perturb;  // 1: no perturb kernel ran -- encoder tile (t, j) samples / bounds the actions of its windows
+                       // (FusedArgs::p, device Philox) and publishes perturbed / noise / actions of step t with its latents;
+                       // the command's state and action_buffer are read from the kernel arguments (p.state_in / p.abuf_in)
+  int inline_weights;  // 1: the importance-weight reduction (FusedArgs::w) runs after the last rollout tile
+  unsigned spin_limit; // polls before a waiting wave gives up (the command is then lost and reported)
+  int test_drop_tile;  // tests only: the encoder tile with this ticket is never published (-1: none)
+};
+struct FusedArgs {   // the kernel's one by-value argument
+  RolloutArgs r;   // r.pa: the (T, K, 2) HORIZON-major latent tensor (written and read inside the launch)
+  GruArgs g;       // mode 1 fields filled in; g.out unused
+  PerturbArgs p;   // inline_perturb
+  WeightArgs w;    // inline_weights
+  FusedCtl ctl;
+};
+hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, hipStream_t s);
+hipError_t fused_max_resident_blocks(int* blocks_per_cu);
+
 
 }  // namespace nlc

@@ -155,7 +155,7 @@ NLC_HD double cos_poly(double y) {
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   // 1 - z/2 + z^2 p with the rounding error of (1 - hz) folded back in (as fdlibm does)
-  return w + (((1.0 - w) - hz) + z * z * p);
+  return w + fma(z * z, p, (1.0 - w) - hz);  // (explicit: the same bits under -ffp-contract=off and =fast)
 }
 
 constexpr double kPio2Hi = 1.57079632679489655800e+00;

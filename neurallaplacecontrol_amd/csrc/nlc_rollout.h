@@ -155,10 +155,13 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 //   PaDirect   the (K, T, 2) tensor an earlier launch wrote (nl_rollout_split_kernel)
 //   PaHandoff  (kernels_fused.hip) tiles published by encoder workgroups of the SAME launch, behind per-tile flags
 // Policy interface (all calls are made by all four waves, in this order per horizon step t):
+//   state0(a, kc, ep)            where the rollout's start state is read from
 //   begin(t0, wv, lane, kc)      before the loop; leaves the latents of step t0 in cur0/cur1
 //   after_barrier1(t, ...)       between the first and second barrier of step t   (poll for step t+1)
 //   after_barrier2(t, ...)       after the second barrier of step t               (issue the loads of step t+1)
+//   pert / noise / U (wave 0)    the sampled action, its bounded noise and the nominal control of step t
 //   advance()                    end of step t: the latents of step t+1 become cur0/cur1
+//   store_cost(a, k, v)          (wave 0, lane group 0) the sample's total cost
 struct PaDirect {
   const double* pa;
   int T;
@@ -168,6 +171,17 @@ struct PaDirect {
     *a0 = p[0];
     *a1 = p[1];
   }
+  __device__ __forceinline__ const double* state0(const RolloutArgs& a, int64_t kc, int ep) const {
+    return a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * a.net.d;
+  }
+  __device__ __forceinline__ double pert(const RolloutArgs& a, int64_t kc, int t, int j) const {
+    return a.perturbed[(kc * a.T + t) * a.nu + j];
+  }
+  __device__ __forceinline__ double noise(const RolloutArgs& a, int64_t kc, int t, int i) const {
+    return a.noise[(kc * a.T + t) * a.nu + i];
+  }
+  __device__ __forceinline__ double U(const RolloutArgs& a, int uoff, int t, int j) const { return a.U[uoff + t * a.nu + j]; }
+  __device__ __forceinline__ void store_cost(const RolloutArgs& a, int64_t k, double v) const { a.cost_total[k] = v; }
   __device__ __forceinline__ void begin(int t0, int, int, int64_t kc) { load(t0, kc, &cur0, &cur1); }
   __device__ __forceinline__ void after_barrier1(int, int, int, int) {}
   __device__ __forceinline__ void after_barrier2(int t, int t_end, int64_t kc) {
@@ -179,9 +193,10 @@ struct PaDirect {
   }
 };
 
+// Returns the sample's total cost (meaningful in wave 0 when the launch runs the last horizon chunk).
 template <int HT, int NT3, class PA>
-__device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t tile, PA& src, double* __restrict__ H1,
-                                                   double* __restrict__ H2, double* __restrict__ AX) {
+__device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64_t tile, PA& src, double* __restrict__ H1,
+                                                     double* __restrict__ H2, double* __restrict__ AX) {
   constexpr int KS = HT * 4;           // k-steps over the hidden dimension
   constexpr int TW = HT / 4;           // layer-1/2 output tiles per wave
   constexpr int NTW = (NT3 + 3) / 4;   // layer-3 output tiles per wave (tile j = wave + 4 i)
@@ -198,7 +213,7 @@ __device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t
   const bool first_chunk = a.t_begin == 0, last_chunk = a.t_end == a.T;
   const int ep = (int)(kc / a.Kep);  // episode of this lane's sample (0 for the single planner)
   const int uoff = ep * a.T * a.nu;
-  const double* st = first_chunk ? a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * d : a.xcarry + kc * d;
+  const double* st = first_chunk ? src.state0(a, kc, ep) : a.xcarry + kc * d;
   if (i0 < d) {
     x0 = st[i0];
     m0 = n.state_mean[i0];
@@ -345,15 +360,15 @@ __device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t
       for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
       double u[NLC_MAX_NU] = {0.0, 0.0};
       double pc = 0.0;
-      for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(kc * a.T + t) * a.nu + j];
+      for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * src.pert(a, kc, t, j);
       for (int j = 0; j < a.nu; ++j) {
         double acj = 0.0;
         for (int i = 0; i < a.nu; ++i) {
-          double e = a.noise[(kc * a.T + t) * a.nu + i];
+          double e = src.noise(a, kc, t, i);
           if (a.noise_abs_cost) e = fabs(e);
           acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
         }
-        pc += a.U[uoff + t * a.nu + j] * acj;
+        pc += src.U(a, uoff, t, j) * acj;
       }
       cost += running_cost(a.env, xs, u, a.nu);
       pcost += pc;
@@ -362,7 +377,7 @@ __device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t
   }
   if (wv == 0 && valid) {
     if (last_chunk) {
-      if (q == 0) a.cost_total[k] = cost + pcost;
+      if (q == 0) src.store_cost(a, k, cost + pcost);
     } else {
       if (i0 < d) a.xcarry[k * d + i0] = x0;
       if (i1 < d) a.xcarry[k * d + i1] = x1;
@@ -372,6 +387,7 @@ __device__ __forceinline__ void rollout_split_tile(const RolloutArgs& a, int64_t
       }
     }
   }
+  return cost + pcost;
 }
 
 // ------------------------------------------------------------------ latency-split representation function (de Hoog path)

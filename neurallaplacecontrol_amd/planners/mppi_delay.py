@@ -23,15 +23,20 @@ command), ``compute_device``, ``store_rollouts``.
 """
 
 import ctypes as C
-import os
 
 import torch
 from torch.distributions.multivariate_normal import MultivariateNormal
 
 from .. import _lib
 from ..envs import EnvCost, NLDynamics, OracleDynamics
-from ..sharding import (check_same_on_all_ranks, gather_partials, replicate_from_rank0, shard_range, share_bytes_from_rank0,
+from ..sharding import (all_ranks_agree, check_same_on_all_ranks, gather_partials, replicate_from_rank0, shard_range, share_bytes_from_rank0,
                         slice_noise)
+
+
+def _backend_is_rccl(group):
+    import torch.distributed as dist
+
+    return str(dist.get_backend(group)).lower() == "nccl"
 
 
 def _per_dim(v, nu, name):
@@ -195,22 +200,42 @@ class MPPIDelay:
         # every planner owns its ctx: U and the folded layer-1 bias live there, so two planners over one model
         # must not share one (the model's own ctx serves model.forward only)
         self.ctx = _lib.Ctx(self.cd.index)
-        # tuning knobs of include/nlc.h (nlc_set_option); the NLC_* environment variables are read ONCE, here
-        opts = {"rollout_variant": os.environ.get("NLC_ROLLOUT_VARIANT"), "fused_roll_cap": os.environ.get("NLC_FUSED_ROLL_CAP"),
-                "fused_max_samples": os.environ.get("NLC_FUSED_MAX_SAMPLES"),
-                "native_collective": os.environ.get("NLC_NATIVE_COLLECTIVE")}
-        opts.update(planner_options or {})
+        # tuning knobs of include/nlc.h (nlc_set_option) come from `planner_options` only: no environment variable is read,
+        # so the ranks of a sharded planner cannot silently differ
+        opts = dict(planner_options or {})
         # "native_collective": the per-command all-gather runs inside nlc_mppi_finish on the library's own RCCL
-        # communicator (include/nlc.h, nlc_comm_init) instead of torch.distributed between the two phases
-        self.native_collective = bool(float(opts.pop("native_collective") or 0)) and self.pg is not None
+        # communicator (include/nlc.h, nlc_comm_init) instead of torch.distributed between the two phases.  Default
+        # (None): on whenever the group's backend is RCCL ("nccl") -- no host hop between the rollout and the action.
+        nat = opts.pop("native_collective", None)
+        if nat is None:
+            nat = self.pg is not None and _backend_is_rccl(self.pg)
+        self.native_collective = bool(float(nat)) and self.pg is not None
         for name, value in opts.items():
             if value is not None:
                 self.ctx.set_option(name, float(value))
         if self.native_collective:
             uid = share_bytes_from_rank0(self.ctx.comm_unique_id() if self.rank == 0 else None, _lib.COMM_ID_BYTES, self.pg,
                                          self.cd)
-            with torch.cuda.device(self.cd):
-                self.ctx.comm_init(self.rank, self.G, uid)
+            ok = 1
+            try:
+                with torch.cuda.device(self.cd):
+                    self.ctx.use_torch_stream()
+                    self.ctx.comm_init(self.rank, self.G, uid)
+                    self.ctx.comm_self_test()  # one all-gather of the rank numbers, checked on the host
+            except _lib.NlcError as err:
+                if planner_options and planner_options.get("native_collective"):
+                    raise  # asked for explicitly
+                ok, self._native_error = 0, str(err)
+            if not all_ranks_agree(ok, self.pg, self.cd):
+                # the default is a preference: if any rank could not bring the communicator up, every rank uses the
+                # collective of the group the caller gave us
+                import warnings
+
+                warnings.warn("neurallaplacecontrol_amd: library-owned RCCL communicator unavailable "
+                              f"({getattr(self, '_native_error', 'failed on another rank')}); using torch.distributed's all-gather")
+                self.native_collective = False
+                with torch.cuda.device(self.cd):
+                    self.ctx.comm_destroy()
         self._model_key = None
         self._B = None
         self._buf = None

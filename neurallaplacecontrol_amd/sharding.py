@@ -81,3 +81,14 @@ def share_bytes_from_rank0(payload, nbytes, group, compute_device=None):
         t = t.to(compute_device)
     dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
     return bytes(t.cpu().tolist())
+
+
+def all_ranks_agree(flag, group, compute_device=None):
+    """True iff `flag` is truthy on EVERY rank of `group` (a min-all-reduce of one number)."""
+    import torch.distributed as dist
+
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+    if dist.get_backend(group) != "gloo" and compute_device is not None:
+        t = t.to(compute_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.cpu().item() > 0.5)

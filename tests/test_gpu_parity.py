@@ -626,7 +626,7 @@ def test_full_size_cfg2_properties(nlc):
 
 
 @pytest.mark.parametrize("env,K,T", [("oderl-cartpole", 1024, 20), ("oderl-acrobot", 4096, 12), ("oderl-pendulum", 16400, 6)])
-def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
+def test_rollout_kernel_variants_agree(nlc, env, K, T):
     """Wave-per-tile (1), latency-split (2: 4 waves per 16-sample tile, LDS exchange) and fused one-launch (3: GRU encode
     and split rollout as roles of one persistent grid, latents handed over inside the launch) rollout bodies: same
     numbers; 2 and 3 share every arithmetic instruction, so they must agree bit for bit."""
@@ -642,9 +642,9 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T, monkeypatch):
     state, ab = nlc.initial_state(env), torch.randn(4, nu, dtype=torch.float64)
     out = {}
     for variant in ("1", "2", "3"):
-        monkeypatch.setenv("NLC_ROLLOUT_VARIANT", variant)
         mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
-                             lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+                             lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(),
+                             planner_options={"rollout_variant": int(variant)})
         mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
         act = mppi.command(state, ab)
         out[variant] = (act.clone(), mppi.states.clone(), mppi.cost_total.clone())
@@ -693,6 +693,87 @@ def test_fused_plan_handoff_repeated_commands(nlc, K, cap, sched):
         assert torch.equal(planners[2].cost_total, planners[3].cost_total), step
         ab = torch.roll(ab, -1, 0)
         ab[-1] = acts[2].cpu()
+
+
+@pytest.mark.parametrize("K,env,sample_null", [(2048, "oderl-cartpole", False), (1000, "oderl-acrobot", True),
+                                               (4096, "oderl-pendulum", False), (48, "oderl-cartpole", True)])
+def test_fused_inline_sampling_and_weights_bit_identical(nlc, K, env, sample_null):
+    """Round 3: with device noise the fused body also samples / bounds the actions (encoder role) and reduces the importance
+    weights (after the last rollout tile) INSIDE its launch -- command() = that launch + merge_kernel.  Everything the
+    command produces must equal, bit for bit, what the launch-per-step bodies produce: the two-launch body (2) and the fused
+    body behind its own perturb / weight launches (fused_inline = 0).  12 consecutive commands: perturbed actions, bounded
+    noise, actions, states, costs, weights, omega, U and the returned action; a 5-row action buffer and nu = 2 included."""
+    from oracle import nl_model as onl
+
+    T = 40 if K > 100 else 9
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    B = 5 if env == "oderl-pendulum" else 4
+    planners = {}
+    for name, opts in (("two", {"rollout_variant": 2}), ("fused_sep", {"rollout_variant": 3, "fused_inline": 0}),
+                       ("fused_inl", {"rollout_variant": 3, "fused_inline": 1})):
+        planners[name] = nlc.MPPIDelay(
+            nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=0.7,
+            u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=11,
+            sample_null_action=sample_null, planner_options=opts, U_init=torch.zeros(T, nu, dtype=torch.float64),
+        )
+    state = nlc.initial_state(env)
+    ab = torch.randn(B, nu, dtype=torch.float64)
+    for step in range(12):
+        acts = {n: p.command(state, ab) for n, p in planners.items()}
+        ref = planners["two"]
+        for n in ("fused_sep", "fused_inl"):
+            p = planners[n]
+            assert torch.equal(acts["two"], acts[n]), (n, step)
+            for attr in ("perturbed_action", "noise", "actions", "states", "cost_total", "cost_total_non_zero", "omega", "U"):
+                assert torch.equal(getattr(ref, attr), getattr(p, attr)), (n, attr, step)
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = acts["two"]
+    kernels = {n: set(p.ctx.profile_read()) for n, p in planners.items()}  # (empty: profiling is off) -- names checked below
+    for n, p in planners.items():
+        p.ctx.profile_reset()
+        p.ctx.profile(True)
+        p.command(state, ab)
+        p.ctx.profile(False)
+        kernels[n] = set(p.ctx.profile_read())
+    assert kernels["fused_inl"] == {"nl_plan_fused_kernel", "merge_kernel"}, kernels
+    assert kernels["fused_sep"] == {"perturb_kernel", "nl_plan_fused_kernel", "weight_kernels", "merge_kernel"}, kernels
+
+
+def test_fused_timeout_reruns_command_on_two_launch_body(nlc):
+    """a hand-off time-out of the fused body must not lose the command.  `fused_test_drop_tile` keeps one
+    encoder tile from ever being published, so a rollout workgroup gives up after `fused_spin_limit` polls; nlc_mppi_finish
+    then re-runs the command on the two-launch body (same inputs, the control sequence before the shift) -- the action
+    equals the one a two-launch planner returns, and the ctx stays on the two-launch body afterwards."""
+    from oracle import nl_model as onl
+
+    env, K, T = "oderl-cartpole", 512, 12
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+
+    def make(opts):
+        return nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=5,
+                             planner_options=opts, U_init=torch.zeros(T, nu, dtype=torch.float64))
+
+    ref = make({"rollout_variant": 2})
+    bad = make({"rollout_variant": 3, "fused_test_drop_tile": 37, "fused_spin_limit": 3000})
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    for step in range(3):
+        a_ref, a_bad = ref.command(state, ab), bad.command(state, ab)
+        assert torch.equal(a_ref, a_bad), step
+        assert torch.equal(ref.cost_total, bad.cost_total) and torch.equal(ref.U, bad.U), step
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = a_ref
+    bad.ctx.profile_reset()
+    bad.ctx.profile(True)
+    bad.command(state, ab)
+    bad.ctx.profile(False)
+    assert "nl_plan_fused_kernel" not in bad.ctx.profile_read(), "the ctx must stay on the two-launch body after a time-out"
 
 
 def _subset_check(nlc, env, K, T, B, n_check=64, seed=0, S=17, algo="fourier", tol=1e-7, weights_seed=0, tame=True):

@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 import neurallaplacecontrol_amd as nlc
+if os.environ.get("NLC_LIB_PATH"):  # tools only: another build of the same library
+    from neurallaplacecontrol_amd import _lib as _nlc_lib
+    _nlc_lib.use_library(os.environ["NLC_LIB_PATH"])
 
 K = int(os.environ.get("AB_K", "2048"))
 d, nu = 5, 1

@@ -8,6 +8,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 import neurallaplacecontrol_amd as nlc
+FLAGS = 16 + 4096 + 16  # kFusedFlags (csrc/nlc_kernels.h)
+if os.environ.get("NLC_LIB_PATH"):  # tools only: another build of the same library
+    from neurallaplacecontrol_amd import _lib as _nlc_lib
+    _nlc_lib.use_library(os.environ["NLC_LIB_PATH"])
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cap = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -29,7 +33,7 @@ ab = torch.zeros(4, nu, dtype=torch.float64)
 
 def dump(tag):
     ntk = (K + 15) // 16
-    words = 16 + 4096 + (2 * T + 1) * ntk
+    words = FLAGS + (2 * T + 1) * ntk
     nd = ((words + 1) // 2 + 63) // 64 * 64
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -50,7 +54,7 @@ def dump(tag):
     occ = w[16:16 + 2048]
     nz = occ[occ != 0]
     print(tag, "CUs seen", int((occ != 0).sum()), "max WG/CU", int(nz.max()) if nz.numel() else 0, flush=True)
-    fl = w[4112:4112 + T * ntk].view(T, ntk)
+    fl = w[FLAGS:FLAGS + T * ntk].view(T, ntk)
     print(tag, "flags set per horizon step:", [int(x) for x in (fl != 0).sum(1)], flush=True)
     if os.environ.get("FUSED_TIMELINE"):
         # trace build: flag words carry the tile's completion time, the block behind the owner row every chain's step times
@@ -58,7 +62,7 @@ def dump(tag):
         ft = us(fl)
         print(tag, "encoder tiles of horizon step t done, us (min / median / max):",
               [(int(ft[t].min()), int(ft[t].median()), int(ft[t].max())) for t in range(0, T, 3)], flush=True)
-        ch = us(w[4112 + (T + 1) * ntk:4112 + (2 * T + 1) * ntk].view(T, ntk))
+        ch = us(w[FLAGS + (T + 1) * ntk:FLAGS + (2 * T + 1) * ntk].view(T, ntk))
         print(tag, "chains past step t, us (min / median / max):",
               [(int(ch[t].min()), int(ch[t].median()), int(ch[t].max())) for t in range(0, T, 3)], flush=True)
         order = torch.sort(ft.reshape(-1)).values
