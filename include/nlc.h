@@ -89,11 +89,14 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
- *   "fused_inline"       fused body, single planner (E <= 1): 1 (default) = the importance-weight reduction (:210-216) runs
- *                        inside the launch after the last rollout tile, and with device noise (rng == 1) and host-side state /
- *                        action_buffer so do the sampling and bounding (:319-328), in the encoder role -- a command is then
- *                        two launches (this one + the merge after the shard all-gather) instead of six; 0 = separate launches.
- *                        Same bits either way.
+ *   "fused_blocks_per_cu"  fused body: the instance compiled for 3 (168 VGPRs) or 4 (128 VGPRs) workgroups per CU; 0 = auto
+ *                        (3 while rollout chains sit on at most half of the CUs, else 4)
+ *   "fused_inline"       fused body, single planner (E <= 1), bit mask: 1 = the importance-weight reduction (:210-216) runs
+ *                        inside the launch (every rollout tile folds its 16 samples when their costs are final, the last one
+ *                        folds the tiles); 2 = with device noise (rng == 1) and host-side state / action_buffer the sampling
+ *                        and bounding (:319-328) run in the encoder role; 3 (default; 1 is accepted as 3) = both -- a command
+ *                        is then two launches (this one + the merge after the shard all-gather) instead of five; 0 = separate
+ *                        launches.  Same bits either way.
  *   "fused_spin_limit"   polls (~2 us each) before a waiting wave of the fused body gives up (default 2^18, ~0.5 s)
  *   "fused_test_drop_tile"  tests only: the encoder tile with this ticket is never published (-1 = none): forces the
  *                        hand-off timeout and the re-run on the two-launch body

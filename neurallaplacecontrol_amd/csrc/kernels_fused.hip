@@ -33,9 +33,10 @@
 //     the workgroup and publishes perturbed / noise / actions of ITS step t with the tile's latents (same flag);
 //   * U <- roll(U, -1) (:199-200) is read on the fly from the sequence before the shift; workgroup 0 stores it;
 //   * the state and the action buffer are read from the kernel-argument segment (no staging copy, no perturb kernel);
-//   * importance weights (:210-216): every rollout tile folds its costs into a running minimum and counts itself done;
-//     the first nblk workgroups out of the encoder / drain loops wait for the last tile and run one 64-sample weight
-//     block each (nlc_mppi_dev.h: the arithmetic of weight_partial_kernel, bit for bit), the last block folds the partials.
+//   * importance weights (:210-216): a rollout tile IS a weight tile (nlc_mppi_dev.h) -- wave 0 folds its 16 samples
+//     (beta_b, eta_b, S_b) the moment their costs are final and counts the tile done; the workgroup whose count comes
+//     last folds the tile partials into the shard's (beta_r, eta_r, S_r): the arithmetic of weight_tile_kernel /
+//     weight_rank_kernel, bit for bit.
 // command() is then this launch + merge_kernel (after the shard all-gather) instead of six launches.
 #include "nlc_device.h"
 #include "nlc_gru_tile.h"
@@ -91,10 +92,7 @@ struct PaHandoff {
   __device__ __forceinline__ double U(const RolloutArgs& a, int uoff, int t, int j) const {
     return inl ? mppi_shifted_U(U_old, u_init, 0, T, nu, t, j) : a.U[uoff + t * a.nu + j];
   }
-  __device__ __forceinline__ void store_cost(const RolloutArgs& a, int64_t k, double v) const {
-    if (inw) MemSc1::st(a.cost_total + k, v);
-    else a.cost_total[k] = v;
-  }
+  __device__ __forceinline__ void store_cost(const RolloutArgs& a, int64_t k, double v) const { a.cost_total[k] = v; }
   __device__ __forceinline__ void load(int t, int64_t kc, double* a0, double* a1) const {
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((int64_t)t * K + kc) * 16), 0, /*sc1*/ 16);
     *a0 = __builtin_bit_cast(double, ((unsigned long long)v.y << 32) | v.x);
@@ -262,6 +260,14 @@ __device__ __forceinline__ fused_args_cptr role_args() {
   return p;
 }
 
+// The weight folds run once per rollout tile / once per launch: real calls, so that their registers (sixteen loads in
+// flight, ocml's exp) are allocated apart from the roles' -- inlined at both rollout call sites they cost the kernel 600
+// spilled VGPRs and 30 us per launch (measured).
+__device__ __attribute__((noinline)) void fused_weight_tile(const WeightArgs w, int tile, int lane, double cost, bool valid) {
+  weight_tile<MemSc1>(w, 0, (int64_t)tile, lane, cost, valid);
+}
+__device__ __attribute__((noinline)) void fused_weight_rank(const WeightArgs w, double* lds) { weight_rank<MemSc1>(w, 0, lds); }
+
 template <int HT, int NT3>
 __device__ __forceinline__ void fused_rollout(int tile, double* smem) {
   constexpr int KS = HT * 4;
@@ -294,21 +300,23 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem) {
   __builtin_amdgcn_s_setprio(3);
   const double cost = rollout_split_tile<HT, NT3>(a.r, (int64_t)tile, src, smem, smem + KS * 64, smem + 2 * KS * 64);
   __builtin_amdgcn_s_setprio(0);
-  if (wv == 0) {
-    if (a.ctl.inline_weights) {
-      // this tile's costs are final: fold them into the running minimum (kept as max of ~order_key, which starts from the
-      // zeroed word), drain the write-through cost stores, then count the tile done (ONE lane adds; nlc_mppi_dev.h)
+  if (a.ctl.inline_weights) {
+    // this tile's costs are final: fold its 16 samples (weight_tile), drain the write-through partial, count the tile
+    // done (ONE lane adds); the workgroup whose add comes last folds all tile partials into the shard's partials
+    int* s_last = reinterpret_cast<int*>(smem);  // (H1 region: dead since the last step's second barrier)
+    if (wv == 0) {
       const bool valid = (int64_t)tile * 16 + (lane & 15) < a.r.K;
-      unsigned long long key = valid ? ~f64_order_key(cost) : 0ull;
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o, 64);
-        key = other > key ? other : key;
-      }
-      __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a.ctl.sync + kFusedBetaKey), lane == 0 ? key : 0ull,
-                             NLC_RLX_AGENT);
+      fused_weight_tile(a.w, tile, lane, cost, valid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      wave_add_one(a.ctl.sync + kFusedCostDone, lane);
+      s_last[0] = (int)wave_ticket(a.ctl.sync + kFusedCostDone, lane);
     }
+    __syncthreads();
+    const bool last = __builtin_amdgcn_readfirstlane(s_last[0]) == a.ctl.ntk - 1;
+    __syncthreads();
+    if (last) fused_weight_rank(a.w, smem + 8);
+    __syncthreads();
+  }
+  if (wv == 0) {
     if (NLC_FUSED_TRACE) wave_add_one(a.ctl.sync + kFusedStatRollDone, lane);
     stamp_max(a.ctl.sync + kFusedTimeRollEndFirst, true);
     stamp_max(a.ctl.sync + kFusedTimeRollEndLast, false);
@@ -372,8 +380,12 @@ __device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yi
   }
 }
 
-template <int HT, int NT3, int G>
-__global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs av) {
+// BPC = workgroups per CU the instance is compiled for.  4: 128 VGPRs, the rollout role spills 110 of them (its sphere
+// map wants ~200) but four cooperative encoder tiles per CU hide each other's latencies -- the better trade when most CUs
+// walk a chain (K > 2048 on 256 CUs).  3: 168 VGPRs, 34 spills: chains 5 % faster per horizon step; better up to one
+// chain on half the CUs (K = 1024: 0.527 vs 0.571 ms, K = 2048: 0.674 vs 0.709 ms; profiles/r3_fused_small_shard.md).
+template <int HT, int NT3, int G, int BPC>
+__global__ __launch_bounds__(256, BPC) void nl_plan_fused_kernel(const FusedArgs av) {
   const FusedCtl& a = av.ctl;  // role assignment; the roles read av through role_args()
   constexpr int KSG = G / 4;  // GRU k-steps
   constexpr int KS = HT * 4;  // representation-MLP k-steps
@@ -463,56 +475,25 @@ __global__ __launch_bounds__(256, 4) void nl_plan_fused_kernel(const FusedArgs a
     if (tile >= 0) fused_rollout<HT, NT3>(tile, smem);
   }
 
-  // ---- importance weights (planners/mppi_delay.py:210-216) inside the launch: the first nblk workgroups to get here take
-  // one 64-sample weight block each, wait (asleep) until every rollout tile has counted itself done -- the running
-  // minimum beta is then final -- and run weight_partial_kernel's arithmetic on it; the block that finishes last folds
-  // the block partials (weight_final_kernel's arithmetic).  Costs, noise and block partials were stored write-through
-  // inside this launch and are loaded past the L1 (MemSc1); cost_nz and the shard's partials are for the next launch.
-  if (a.inline_weights) {
-    const WeightArgs& w = ((const FusedArgs*)role_args())->w;
-    if (wv == 0) s_tile[0] = (int)wave_ticket(sync + kFusedWTicket, lane);
-    __syncthreads();
-    const int blk = __builtin_amdgcn_readfirstlane(s_tile[0]);
-    __syncthreads();
-    if (blk < w.nblk) {
-      if (wv == 0) {
-        for (unsigned spins = 0;; ++spins) {
-          const unsigned done = __hip_atomic_load(sync + kFusedCostDone, NLC_RLX_AGENT);
-          if (__builtin_amdgcn_readfirstlane(done) >= (unsigned)a.ntk) break;
-          if (spins > a.spin_limit) {
-            report_timeout(sync, a.timeout_host, 0x80000000u | (unsigned)blk);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(64);  // ~2 us
-        }
-      }
-      __syncthreads();
-      const unsigned long long mk =
-          __hip_atomic_load(reinterpret_cast<unsigned long long*>(sync + kFusedBetaKey), NLC_RLX_AGENT);
-      const double beta = f64_from_order_key(~mk);
-      weight_block<MemSc1>(w, 0, blk, beta, smem + 8);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through partials have left
-      __syncthreads();
-      if (wv == 0) s_tile[0] = (int)wave_ticket(sync + kFusedWDone, lane);
-      __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(s_tile[0]) == w.nblk - 1)
-        for (int i = wv; i < 1 + w.T * w.nu; i += 4) weight_final_entry<MemSc1>(w, 0, i, lane);
-    }
-  }
   if (NLC_FUSED_TRACE && wv == 0) wave_add_one(sync + kFusedStatExited, lane);
 }
 
-hipError_t fused_max_resident_blocks(int* blocks_per_cu) {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)nl_plan_fused_kernel<8, 11, 64>, 256, 0);
+hipError_t fused_max_resident_blocks(int bpc_built, int* blocks_per_cu) {
+  const void* f = bpc_built == 3 ? (const void*)nl_plan_fused_kernel<8, 11, 64, 3> : (const void*)nl_plan_fused_kernel<8, 11, 64, 4>;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, 0);
 }
 
-hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, hipStream_t s) {
+hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, int bpc_built, hipStream_t s) {
   if (a.r.K <= 0) return hipSuccess;
-  if (a.r.net.h != 128 || g != 64) return hipErrorInvalidValue;
+  if (a.r.net.h != 128 || g != 64 || (bpc_built != 3 && bpc_built != 4)) return hipErrorInvalidValue;
   switch (a.r.net.nt3) {
-#define X(N)                                                                                          \
-  case N:                                                                                             \
-    hipLaunchKernelGGL((nl_plan_fused_kernel<8, N, 64>), dim3(grid), dim3(256), 0, s, a);         \
+#define X(N)                                                                                                 \
+  case N:                                                                                                    \
+    if (bpc_built == 3) {                                                                                    \
+      hipLaunchKernelGGL((nl_plan_fused_kernel<8, N, 64, 3>), dim3(grid), dim3(256), 0, s, a);           \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL((nl_plan_fused_kernel<8, N, 64, 4>), dim3(grid), dim3(256), 0, s, a);           \
+    }                                                                                                        \
     break;
     X(7) X(9) X(11) X(13) X(17) X(21)
 #undef X

@@ -82,52 +82,66 @@ hipError_t launch_perturb(const PerturbArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ importance weights (:210-216)
-// pass 1: per-block min of cost (blockIdx.y = episode in all three passes)
-__global__ __launch_bounds__(256) void cost_min_kernel(const WeightArgs a) {
-  __shared__ double sm[4];
-  double v = INFINITY;
-  const double* cost = a.cost + (int64_t)blockIdx.y * a.Kep;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.Kep; i += (int64_t)gridDim.x * 256)
-    v = fmin(v, cost[i]);
-  v = wave_min(v);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    a.block_min[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
+// Two launches (arithmetic and its fixed order: nlc_mppi_dev.h): one wavefront per 16-sample tile, then one workgroup per
+// episode folds the tile partials into the shard's (beta_r, eta_r, S_r).  blockIdx.y = episode.
+__global__ __launch_bounds__(256) void weight_tile_kernel(const WeightArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.nblk) return;
+  const int64_t e = blockIdx.y;
+  const int64_t ks = b * kWeightTile + (lane & 15);  // within the episode
+  const bool valid = ks < a.Kep;
+  const double cost = valid ? a.cost[e * a.Kep + ks] : 0.0;
+  weight_tile<MemPlain>(a, e, b, lane, cost, valid);
 }
-
-// pass 2: w_k = exp(-(c_k - beta)/lambda); per-block partial eta and S[t,j] = sum_k w_k eps[k,t,j].
-// A block owns kWeightBlockSamples consecutive samples; thread tj < T*nu walks them with coalesced
-// reads of eps[k, :, :] rows and the weights broadcast from LDS (wavefront-uniform).
-__global__ __launch_bounds__(256) void weight_partial_kernel(const WeightArgs a, int nmin) {
-  __shared__ double sw[kWeightBlockSamples];
-  __shared__ double sbeta;
-  __shared__ double sm[4];
-  double v = INFINITY;
-  const int e = blockIdx.y;
-  for (int i = threadIdx.x; i < nmin; i += 256) v = fmin(v, a.block_min[(int64_t)e * nmin + i]);
-  v = wave_min(v);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) sbeta = fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
-  __syncthreads();
-  weight_block<MemPlain>(a, e, (int)blockIdx.x, sbeta, sw);
+// small populations: one workgroup per episode folds all chunks (weight_rank)
+__global__ __launch_bounds__(256) void weight_rank_kernel(const WeightArgs a) {
+  __shared__ double lds[kWeightRankLds];
+  weight_rank<MemPlain>(a, (int64_t)blockIdx.y, lds);
 }
-
-// pass 3: fold the block partials (fixed order -> run-to-run deterministic) into (eta_r, S_r).
-// One wavefront per output entry: lanes stride over the blocks, then a wave reduction.
-__global__ __launch_bounds__(256) void weight_final_kernel(const WeightArgs a) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= 1 + a.T * a.nu) return;
-  weight_final_entry<MemPlain>(a, (int64_t)blockIdx.y, i, threadIdx.x & 63);
+// large populations: one workgroup per 64-tile chunk, then one per episode adds the chunk values in ascending order --
+// the same additions in the same order as weight_rank
+__global__ __launch_bounds__(256) void weight_chunk_kernel(const WeightArgs a) {
+  __shared__ double lds[kWeightRankLds];
+  const int64_t e = blockIdx.y;
+  const int j = blockIdx.x, lane = threadIdx.x & 63, TN = a.T * a.nu;
+  const double beta = weight_beta<MemPlain>(a, e, lds);
+  for (int i0 = 0; i0 < 1 + TN; i0 += 64) {
+    const double c = weight_chunk<MemPlain>(a, e, j, i0, beta, lds);
+    if (threadIdx.x < 64 && i0 + lane < 1 + TN) a.chunk_part[(e * gridDim.x + j) * (2 + TN) + 1 + i0 + lane] = c;
+  }
+  if (threadIdx.x == 0) a.chunk_part[(e * gridDim.x + j) * (2 + TN)] = beta;
+}
+__global__ __launch_bounds__(128) void weight_final_kernel(const WeightArgs a, int nch) {
+#pragma clang fp contract(off)
+  const int64_t e = blockIdx.y;
+  const int TN = a.T * a.nu, W = 2 + TN;
+  const double* cp = a.chunk_part + e * nch * W;
+  for (int i = threadIdx.x; i < 1 + TN; i += 128) {
+    double tot = 0.0;
+    for (int j0 = 0; j0 < nch; j0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) v[s] = j0 + s < nch ? cp[(int64_t)(j0 + s) * W + 1 + i] : 0.0;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (j0 + s < nch) tot += v[s];
+    }
+    a.partials[e * W + 1 + i] = tot;
+  }
+  if (threadIdx.x == 0) a.partials[e * W] = cp[0];
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {
-  const int nmin = weight_min_blocks(a.Kep);
   const unsigned E = (unsigned)a.E;
-  hipLaunchKernelGGL(cost_min_kernel, dim3(nmin, E), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(weight_partial_kernel, dim3(a.nblk, E), dim3(256), 0, s, a, nmin);
-  hipLaunchKernelGGL(weight_final_kernel, dim3((1 + a.T * a.nu + 3) / 4, E), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(weight_tile_kernel, dim3((a.nblk + 3) / 4, E), dim3(256), 0, s, a);
+  const int nch = weight_chunks(a.nblk);
+  if (nch <= 4) {
+    hipLaunchKernelGGL(weight_rank_kernel, dim3(1, E), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(weight_chunk_kernel, dim3(nch, E), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(weight_final_kernel, dim3(1, E), dim3(128), 0, s, a, nch);
+  }
   return hipGetLastError();
 }
 
@@ -166,21 +180,17 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
       a.beta_eta[e * 2 + 1] = eta;
     }
   }
-  // omega / cost_total_non_zero relative to the GLOBAL beta
-  if (threadIdx.x == 0) {
-    s_scale_self = (a.G == 1) ? 1.0 : exp(-(gat[a.rank * gs] - beta) / a.lambda_);
-    s_eta = eta;
-  }
+  // cost_total_non_zero = exp(-(c - beta)/lambda) with the GLOBAL beta (_ensure_non_zero :12-13, :213) and omega (:214)
+  if (threadIdx.x == 0) s_eta = eta;
+  (void)s_scale_self;
   __syncthreads();
-  const double sc = s_scale_self, inv = 1.0 / s_eta;
+  const double inv = 1.0 / s_eta;
+  const double* cost = a.cost + e * a.Kep;
   double* cost_nz = a.cost_nz + e * a.Kep;
   double* omega = a.omega != nullptr ? a.omega + e * a.Kep : nullptr;
   for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.Kep; k += (int64_t)gridDim.x * 256) {
-    double w = cost_nz[k];
-    if (a.G != 1) {
-      w *= sc;
-      cost_nz[k] = w;
-    }
+    const double w = exp(-(1.0 / a.lambda_) * (cost[k] - beta));
+    cost_nz[k] = w;
     if (omega != nullptr) omega[k] = inv * w;
   }
 }

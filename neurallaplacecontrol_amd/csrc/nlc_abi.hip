@@ -109,7 +109,9 @@ struct nlc_ctx {
   int opt_fused_chain_first_tiles = -1; // tiles per wave a chain's workgroup encodes before it starts walking (-1 auto)
   int opt_fused_partner_tiles = -2;     // tiles per wave after which a chain's CU partner sleeps (-1: never, -2 auto)
   int64_t opt_fused_max_samples = 4096; // auto: populations up to this size take the fused body (one chain per CU at most)
-  int fused_blocks_per_cu = -1;         // occupancy of the fused kernel (queried once)
+  int fused_blocks_per_cu = -1;         // occupancy of the fused kernel's 4-per-CU instance (queried once)
+  int fused_blocks_per_cu3 = -1;        // ... of its 3-per-CU instance
+  int opt_fused_blocks_per_cu = 0;      // 0 auto (3 while chains sit on at most half of the CUs, else 4), 3 or 4
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
   int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
@@ -465,6 +467,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
     c->opt_rollout_variant = (int)value;
     c->fused_lost = false;  // an explicit choice re-arms the fused body after a timeout
+  } else if (n == "fused_blocks_per_cu") {
+    if (value != 0 && value != 3 && value != 4) return fail(c, NLC_ERR_BAD_ARG, "fused_blocks_per_cu must be 0 (auto), 3 or 4");
+    c->opt_fused_blocks_per_cu = (int)value;
   } else if (n == "fused_inline") {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "fused_inline must be 0, 1 (= 3), or the bit mask 1 weights | 2 sampling");
     c->opt_fused_inline = (int)value == 1 ? 3 : (int)value;
@@ -1328,7 +1333,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   std::memset(c->pinned, 0, c->pinned_n * sizeof(double));
   c->pd = *d;
   c->pd.E = E;
-  c->nblk = (int)((d->K + kWeightBlockSamples - 1) / kWeightBlockSamples);
+  c->nblk = weight_tiles(d->K);
   if (d->dynamics == NLC_DYN_NL) {
     // constant prediction time => the 2S sphere-coordinate inputs of layer 1 are constants: fold into the bias
     c->tn = d->ts_pred / c->md.time_div;
@@ -1356,7 +1361,7 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 
 namespace {
 struct WsLayout {
-  size_t block_min, block_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, rq, sync, total;
+  size_t tile_part, chunk_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, rq, sync, total;
 };
 WsLayout ws_layout(const nlc_ctx* c) {
   const nlc_mppi_desc& d = c->pd;
@@ -1368,8 +1373,8 @@ WsLayout ws_layout(const nlc_ctx* c) {
     return o;
   };
   const size_t KE = (size_t)d.K * d.E;  // all local samples
-  w.block_min = take((size_t)d.E * 256);
-  w.block_part = take((size_t)d.E * c->nblk * (1 + (size_t)d.T * d.nu));
+  w.tile_part = take((size_t)d.E * c->nblk * (2 + (size_t)d.T * d.nu));
+  w.chunk_part = take((size_t)d.E * ((c->nblk + 63) / 64) * (2 + (size_t)d.T * d.nu));
   w.pa = take(d.dynamics == NLC_DYN_NL ? KE * d.T * 2 : 0);
   w.state0 = take(d.dynamics == NLC_DYN_EXTERNAL ? 0 : KE * d.d);
   w.abuf = take((size_t)d.E * d.B * d.nu);
@@ -1412,9 +1417,8 @@ static WeightArgs make_weight_args(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   wa.lambda_ = d.lambda_;
   wa.cost = buf->cost_total;
   wa.noise = buf->noise;
-  wa.cost_nz = buf->cost_nz;
-  wa.block_min = ws + w.block_min;
-  wa.block_part = ws + w.block_part;
+  wa.tile_part = ws + w.tile_part;
+  wa.chunk_part = ws + w.chunk_part;
   wa.partials = buf->partials;
   wa.nblk = c->nblk;
   return wa;
@@ -1700,8 +1704,10 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
     if (fused_ok && c->fused_blocks_per_cu < 0) {
       int bpc = 0;
-      NLC_HIP(c, fused_max_resident_blocks(&bpc));
+      NLC_HIP(c, fused_max_resident_blocks(4, &bpc));
       c->fused_blocks_per_cu = bpc;
+      NLC_HIP(c, fused_max_resident_blocks(3, &bpc));
+      c->fused_blocks_per_cu3 = bpc;
     }
     // The fused body's rollout workgroups wait for encoder workgroups of the SAME launch, so every workgroup must be
     // resident and there must be workgroups left to encode beside one chain per CU: at least two per CU.  It
@@ -1711,8 +1717,12 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     if (variant == 0 && fused_ok && c->fused_blocks_per_cu >= 2 && KE <= c->opt_fused_max_samples) variant = 3;
     if (variant == 3 && (replay || c->fused_lost)) variant = 2;
     if (variant == 3) {
-      const int bpc = c->fused_blocks_per_cu < 4 ? c->fused_blocks_per_cu : 4;
       const int ncu = c->prop.multiProcessorCount;
+      const int ntk_all = (int)((KE + 15) / 16);
+      // instance: three workgroups per CU (168 VGPRs) while chains sit on at most half of the CUs, else four (128 VGPRs)
+      int built = c->opt_fused_blocks_per_cu ? c->opt_fused_blocks_per_cu : (2 * ntk_all <= ncu ? 3 : 4);
+      if (built == 3 && c->fused_blocks_per_cu3 < 3) built = 4;
+      const int bpc = built == 3 ? 3 : (c->fused_blocks_per_cu < 4 ? c->fused_blocks_per_cu : 4);
       FusedArgs f{};
       f.r = r;
       f.r.t_begin = 0;
@@ -1738,7 +1748,14 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
       // this and 0.846 with M = 1), scaled with the horizon.
       const double f_chain = (double)fc.roll_cap / (double)ncu;
       const double extra = (16.0 * f_chain - 4.5) * (double)d.T / 40.0;
-      const int auto_partner = 1 + (extra > 0 ? (int)extra : 0);
+      int auto_partner = 1 + (extra > 0 ? (int)extra : 0);
+      if (built == 3) {
+        // two partners per chain CU instead of three: measured best M = 1 / 1 / 2 / 6 at chains on 12.5 / 25 / 37.5 / 50 %
+        // of the CUs (K = 512 / 1024 / 1536 / 2048, T = 40; 0.521 / 0.527 / 0.563 / 0.674 ms per launch)
+        // (K = 1280 / 1792, 31 / 44 %: M = 1 / 4; linear in between)
+        const double m3 = f_chain <= 0.3125 ? 1.0 : 1.0 + 26.7 * (f_chain - 0.3125);
+        auto_partner = (int)(1.0 + (m3 - 1.0) * (double)d.T / 40.0);
+      }
       fc.chain_first_tiles = c->opt_fused_chain_first_tiles >= 0 ? c->opt_fused_chain_first_tiles : 1;
       const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : auto_partner;
       // (sleepers need CUs without a chain to produce the latents the chains wait for)
@@ -1768,7 +1785,7 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
       const unsigned grid = (unsigned)(ncu * bpc);
       {
         ProfScope ps(c, "nl_plan_fused_kernel");
-        NLC_HIP(c, launch_nl_plan_fused(f, c->g, grid, c->stream));
+        NLC_HIP(c, launch_nl_plan_fused(f, c->g, grid, built, c->stream));
       }
       if (fc.inline_weights) return NLC_OK;
     } else {
@@ -1938,6 +1955,8 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   m.omega = buf->omega;
   m.action = buf->action ? buf->action : c->small;
   m.beta_eta = c->small + (size_t)d.E * d.T * d.nu;
+  if (!buf->cost_total) return fail(c, NLC_ERR_BAD_ARG, "NULL buf->cost_total");
+  m.cost = buf->cost_total;
   // the returned action is stored by the kernel straight into pinned (host-coherent) memory: the only thing left
   // on the host's critical path is the stream synchronisation
   double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;

@@ -375,15 +375,13 @@ struct WeightArgs {
   double lambda_;
   const double* cost;   // (E, Kep)
   const double* noise;  // (E, Kep, T, nu)
-  double* cost_nz;      // (E, Kep)
-  double* block_min;    // (E, nmin)
-  double* block_part;   // (E, nblk, 1 + T*nu)
+  double* tile_part;    // (E, nblk, 2 + T*nu): (beta_b, eta_b, S_b) of every 16-sample tile
+  double* chunk_part;   // (E, ceil(nblk/64), 2 + T*nu): 64-tile chunk sums (large populations: launch_weights)
   double* partials;     // (E, 2 + T*nu)
-  int nblk;             // weight blocks per episode
+  int nblk;             // weight tiles per episode
 };
-constexpr int kWeightBlockSamples = 64;
-// pass-1 blocks per episode (the workspace holds E * this many block minima)
-inline int weight_min_blocks(int64_t Kep) { return (int)((Kep + 255) / 256 < 256 ? (Kep + 255) / 256 : 256); }
+constexpr int kWeightTile = 16;  // = the rollout kernels' MFMA tile: a tile's samples become final together
+inline int weight_tiles(int64_t Kep) { return (int)((Kep + kWeightTile - 1) / kWeightTile); }
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s);
 
 struct MergeArgs {
@@ -392,11 +390,12 @@ struct MergeArgs {
   double lambda_, u_scale;
   const double* gathered;  // (G, E, 2 + T*nu)
   double* U;               // (E, T, nu) updated in place
-  double* cost_nz;         // (E, Kep) rescaled to the global beta
+  double* cost_nz;         // (E, Kep) out
   double* omega;           // (E, Kep) or NULL
   double* action;          // (E, u_per_command * nu) device
   double* action_pinned;   // same, in pinned host memory the kernel stores to directly (NULL = not wanted)
   double* beta_eta;        // (E, 2) device: merged beta, eta
+  const double* cost;      // (E, Kep) total costs: cost_nz = exp(-(cost - beta)/lambda) with the merged beta
   unsigned* zero_words;    // words zeroed for the NEXT command (the fused planner body's sync block); may be NULL
   int64_t n_zero_words;
 };
@@ -418,9 +417,8 @@ constexpr int kFusedTimeEntry = 9, kFusedTimeRollBeginFirst = 10, kFusedTimeRoll
               kFusedTimeRollEndLast = 13, kFusedTimeEncLast = 14;
 constexpr int kFusedCuOcc = 16;              // 2048 per-CU arrival counters (XCC_ID << 8 | SE/SH/CU id)
 constexpr int kFusedCuState = 16 + 2048;     // 2048 per-CU words: 1 the CU's first workgroup walks a chain, 2 it has finished
-// in-launch weight reduction: rollout tiles whose costs are final / weight-block ticket / weight blocks done; the running
-// max of ~order_key(cost) (= min cost) as one 8-byte word
-constexpr int kFusedCostDone = 16 + 4096, kFusedWTicket = 16 + 4097, kFusedWDone = 16 + 4098, kFusedBetaKey = 16 + 4100;
+// in-launch weight reduction: rollout tiles whose weight-tile partial has been published
+constexpr int kFusedCostDone = 16 + 4096;
 constexpr int kFusedFlags = 16 + 4096 + 16;  // (T, ntk) one word per encoder tile, then one (ntk) row of rollout-tile owner
                                              // tickets (the first add owns the tile)
 // (+ (T, ntk) chain-step time stamps, written by the trace build only)
@@ -449,8 +447,9 @@ struct FusedArgs {   // the kernel's one by-value argument
   WeightArgs w;    // inline_weights
   FusedCtl ctl;
 };
-hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, hipStream_t s);
-hipError_t fused_max_resident_blocks(int* blocks_per_cu);
+// bpc_built: the instance compiled for 3 or 4 workgroups per CU (kernels_fused.hip)
+hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, int bpc_built, hipStream_t s);
+hipError_t fused_max_resident_blocks(int bpc_built, int* blocks_per_cu);
 
 
 }  // namespace nlc

@@ -85,50 +85,117 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// One weight block = kWeightBlockSamples consecutive samples of episode e, handled by a 256-thread workgroup:
-// w_k = exp(-(c_k - beta)/lambda) -> cost_nz; partial eta and S[t,j] = sum_k w_k eps[k,t,j] -> block_part.  Thread tj
-// < T*nu walks the block's samples with coalesced reads of the eps[k, :, :] rows, the weights broadcast from LDS.
-// `sw`: kWeightBlockSamples doubles of LDS.  M: how cost / noise are loaded and block_part is stored (see above).
+// Two levels, so that a 16-sample rollout tile can fold its own samples the moment its costs are final (the fused planner
+// body does, inside its launch) and every path produces the same bits:
+//   tile b (kWeightTile consecutive samples of episode e):   beta_b = min c,  w_s = exp(-(c_s - beta_b)/lambda),
+//                                                            eta_b = sum w_s,  S_b[t,j] = sum_s w_s eps[s,t,j]
+//   rank (all nblk tiles of the episode):  beta = min beta_b,  scale_b = exp(-(beta_b - beta)/lambda),
+//                                          eta = sum scale_b eta_b,  S = sum scale_b S_b          -> partials (beta, eta, S)
+// -- the same rescaling the shard merge applies between ranks.  cost_nz / omega come from merge_kernel.
+// tile_part layout: (E, nblk, 2 + T*nu) = (beta_b, eta_b, S_b[T*nu]).
+//
+// weight_tile: ONE wavefront.  `cost`: the cost of sample (lane & 15) of the tile in every lane (any value where !valid).
 template <class M>
-__device__ __forceinline__ void weight_block(const WeightArgs& a, int e, int blk, double beta, double* sw) {
+__device__ __forceinline__ void weight_tile(const WeightArgs& a, int64_t e, int64_t b, int lane, double cost, bool valid) {
 #pragma clang fp contract(off)
-  const int64_t kb = (int64_t)blk * kWeightBlockSamples;  // within the episode
-  const int ns = (int)((a.Kep - kb < kWeightBlockSamples) ? (a.Kep - kb) : kWeightBlockSamples);
-  const int64_t k0 = (int64_t)e * a.Kep + kb;
   const int TN = a.T * a.nu;
-  double wk = 0.0;
-  if ((int)threadIdx.x < ns) {
-    wk = exp(-(1.0 / a.lambda_) * (M::ld(a.cost + k0 + threadIdx.x) - beta));  // _ensure_non_zero :12-13
-    a.cost_nz[k0 + threadIdx.x] = wk;
-    sw[threadIdx.x] = wk;
+  const int64_t k0 = e * a.Kep + b * kWeightTile;              // first sample of the tile (flat index)
+  const int64_t left = a.Kep - b * kWeightTile;
+  const int ns = (int)(left < kWeightTile ? left : kWeightTile);
+  double beta = valid ? cost : INFINITY;
+  for (int o = 8; o > 0; o >>= 1) beta = fmin(beta, __shfl_xor(beta, o, 64));
+  const double w = valid ? exp(-(1.0 / a.lambda_) * (cost - beta)) : 0.0;  // _ensure_non_zero :12-13
+  double eta = w;
+  for (int o = 8; o > 0; o >>= 1) eta += __shfl_xor(eta, o, 64);
+  double* out = a.tile_part + (e * a.nblk + b) * (2 + TN);
+  if (lane == 0) {
+    M::st(out, beta);
+    M::st(out + 1, eta);
   }
-  __syncthreads();
-  double* out = a.block_part + ((int64_t)e * a.nblk + blk) * (1 + TN);
-  if (threadIdx.x < 64) {
-    const double es = wave_sum(wk);  // threads 0..63 hold all (<= 64) weights of the block
-    if (threadIdx.x == 0) {
-      M::st(out, es);
-      if (blk == 0) a.partials[(int64_t)e * (2 + TN)] = beta;
-    }
-  }
-  for (int tj = threadIdx.x; tj < TN; tj += 256) {
+  for (int tj0 = 0; tj0 < TN; tj0 += 64) {
+    const int tj = tj0 + lane;
+    const bool on = tj < TN;
     double acc = 0.0;
-    const double* np = a.noise + k0 * TN + tj;
-    for (int s = 0; s < ns; ++s) acc += sw[s] * M::ld(np + (int64_t)s * TN);
-    M::st(out + 1 + tj, acc);
+#pragma unroll 1
+    for (int s0 = 0; s0 < kWeightTile; s0 += 8) {
+      double ev[8];  // eight loads in flight (M may be an ordered access), then their multiply-adds in sample order
+#pragma unroll
+      for (int s = 0; s < 8; ++s) ev[s] = (on && s0 + s < ns) ? M::ld(a.noise + (k0 + s0 + s) * TN + tj) : 0.0;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const double ws = __shfl(w, s0 + s, 64);
+        if (s0 + s < ns) acc += ws * ev[s];
+      }
+    }
+    if (on) M::st(out + 2 + tj, acc);
   }
 }
 
-// Entry i (0: eta, 1 + tj: S[tj]) of the shard's partials: the block partials folded in a fixed order (run-to-run
-// deterministic) by ONE wavefront -- lanes stride over the blocks, then a wave reduction.
+// Rank fold.  Fixed order (independent of the launch shape): tiles in CHUNKS of 64; within a chunk wavefront w adds the 16
+// tiles 16 w .. 16 w + 15 in ascending order (lane i owning entry i: 0 eta, 1 + tj S[tj]; loads issued eight at a time), the chunk's value is ((s0 + s1) + s2) + s3, and the chunks are added in ascending
+// order.  weight_chunk: one 256-thread workgroup, one chunk, entries i0 .. i0 + 63; returns the chunk's value in the lanes
+// of wavefront 0.  `lds`: kWeightRankLds doubles.  beta: the minimum over ALL tiles of the episode.
+constexpr int kWeightChunk = 64;
+constexpr int kWeightRankLds = 64 + 8 + 4 * 64;
+__host__ __device__ inline int weight_chunks(int nblk) { return (nblk + kWeightChunk - 1) / kWeightChunk; }
 template <class M>
-__device__ __forceinline__ void weight_final_entry(const WeightArgs& a, int64_t e, int i, int lane) {
+__device__ __forceinline__ double weight_chunk(const WeightArgs& a, int64_t e, int j, int i0, double beta, double* lds) {
 #pragma clang fp contract(off)
-  const int TN = a.T * a.nu;
+  const int TN = a.T * a.nu, W = 2 + TN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double* part = a.tile_part + e * a.nblk * W;
+  double* s_scale = lds;       // [64] exp(-(beta_b - beta)/lambda) of the chunk's tiles
+  double* s_acc = lds + 72;    // [4][64]
+  const int i = i0 + lane;
+  const bool on = i < 1 + TN;
+  __syncthreads();  // (the previous chunk's s_scale / s_acc have been read)
+  if (tid < kWeightChunk && j * kWeightChunk + tid < a.nblk)
+    s_scale[tid] = exp(-(1.0 / a.lambda_) * (M::ld(part + (int64_t)(j * kWeightChunk + tid) * W) - beta));
+  __syncthreads();
+  const int b0 = j * kWeightChunk + 16 * wv;
   double acc = 0.0;
-  for (int b = lane; b < a.nblk; b += 64) acc += M::ld(a.block_part + (e * a.nblk + b) * (1 + TN) + i);
-  acc = wave_sum(acc);
-  if (lane == 0) a.partials[e * (2 + TN) + 1 + i] = acc;
+#pragma unroll 1
+  for (int s0 = 0; s0 < 16; s0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = (on && b0 + s0 + s < a.nblk) ? M::ld(part + (int64_t)(b0 + s0 + s) * W + 1 + i) : 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (b0 + s0 + s < a.nblk) acc += s_scale[16 * wv + s0 + s] * v[s];
+  }
+  s_acc[wv * 64 + lane] = acc;
+  __syncthreads();
+  return ((s_acc[lane] + s_acc[64 + lane]) + s_acc[128 + lane]) + s_acc[192 + lane];
+}
+// minimum of the tile minima of episode e (exact, so its order is free); `lds`: 4 doubles at lds + 64
+template <class M>
+__device__ __forceinline__ double weight_beta(const WeightArgs& a, int64_t e, double* lds) {
+  const int W = 2 + a.T * a.nu;
+  const int tid = threadIdx.x;
+  const double* part = a.tile_part + e * a.nblk * W;
+  double bmin = INFINITY;
+  for (int b = tid; b < a.nblk; b += 256) bmin = fmin(bmin, M::ld(part + (int64_t)b * W));
+  bmin = wave_min(bmin);
+  __syncthreads();
+  if ((tid & 63) == 0) lds[64 + (tid >> 6)] = bmin;
+  __syncthreads();
+  return fmin(fmin(lds[64], lds[65]), fmin(lds[66], lds[67]));
+}
+// weight_rank: ONE workgroup folds every chunk of episode e into the shard's partials (the fused planner body's last
+// rollout tile; small populations).  Same arithmetic as weight_chunk_kernel + weight_final_kernel.
+template <class M>
+__device__ __forceinline__ void weight_rank(const WeightArgs& a, int64_t e, double* lds) {
+#pragma clang fp contract(off)
+  const int TN = a.T * a.nu, W = 2 + TN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double beta = weight_beta<M>(a, e, lds);
+  const int nch = weight_chunks(a.nblk);
+  for (int i0 = 0; i0 < 1 + TN; i0 += 64) {
+    double tot = 0.0;
+    for (int j = 0; j < nch; ++j) tot += weight_chunk<M>(a, e, j, i0, beta, lds);
+    if (wv == 0 && i0 + lane < 1 + TN) a.partials[e * W + 1 + i0 + lane] = tot;
+  }
+  if (threadIdx.x == 0) a.partials[e * W] = beta;
 }
 
 // order-preserving map double -> uint64 (a < b  <=>  key(a) < key(b)) and back: min over doubles by integer atomics.

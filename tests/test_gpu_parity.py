@@ -713,7 +713,9 @@ def test_fused_inline_sampling_and_weights_bit_identical(nlc, K, env, sample_nul
     B = 5 if env == "oderl-pendulum" else 4
     planners = {}
     for name, opts in (("two", {"rollout_variant": 2}), ("fused_sep", {"rollout_variant": 3, "fused_inline": 0}),
-                       ("fused_inl", {"rollout_variant": 3, "fused_inline": 1})):
+                       ("fused_inl", {"rollout_variant": 3, "fused_inline": 1}),
+                       ("fused_w3", {"rollout_variant": 3, "fused_blocks_per_cu": 3}),
+                       ("fused_w4", {"rollout_variant": 3, "fused_blocks_per_cu": 4, "fused_inline": 2})):
         planners[name] = nlc.MPPIDelay(
             nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=0.7,
             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=11,
@@ -724,7 +726,7 @@ def test_fused_inline_sampling_and_weights_bit_identical(nlc, K, env, sample_nul
     for step in range(12):
         acts = {n: p.command(state, ab) for n, p in planners.items()}
         ref = planners["two"]
-        for n in ("fused_sep", "fused_inl"):
+        for n in ("fused_sep", "fused_inl", "fused_w3", "fused_w4"):
             p = planners[n]
             assert torch.equal(acts["two"], acts[n]), (n, step)
             for attr in ("perturbed_action", "noise", "actions", "states", "cost_total", "cost_total_non_zero", "omega", "U"):
