@@ -47,60 +47,73 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2d fma2(v2d a, v2d b, v2d c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2d splat2(double x) { return v2d{x, x}; }
-__device__ __forceinline__ v2d rcp_refined2(v2d d) {
-  // v_rcp_f64 (~2^-24) + one cubic step r (1 + e + e^2), e = 1 - d r: 3 FMAs, <= 1 ulp (tools/rcp_probe.hip)
-  const v2d r = {__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
-  const v2d e = fma2(-d, r, splat2(1.0));
-  return fma2(r, fma2(e, e, e), r);
+// ---- exponentials of the gate math (instruction count, the GRU kernel's FP64 VALU adds to its MFMA time)
+// e^r = 1 + r + r^2 q(r) on |r| <= ln2/2 with q of degree 7 (Chebyshev interpolation of (e^r - 1 - r)/r^2: relative error
+// 7.4e-14 -- the gates feed a tanh / a convex combination, the parity bar is 1e-5 and the tests hold 1e-9), evaluated as one
+// Horner chain of nine FMAs ((q r + 1) r + 1).  The reduction uses ONE ln2 constant (|n| ln2 2^-53 <= 3e-14 for every
+// argument that matters), the integer is the low word of the 1.5 * 2^52-shifted sum (no v_rndne / v_cvt).
+__device__ __forceinline__ v2d exp_poly2(v2d r) {
+  v2d q = splat2(0x1.72ad458027fbcp-19);
+  q = fma2(q, r, splat2(0x1.a136bf03ec612p-16));
+  q = fma2(q, r, splat2(0x1.a019c36bc053cp-13));
+  q = fma2(q, r, splat2(0x1.6c166bde96885p-10));
+  q = fma2(q, r, splat2(0x1.111111170bc08p-7));
+  q = fma2(q, r, splat2(0x1.55555565c7e0ep-5));
+  q = fma2(q, r, splat2(0x1.5555555554f96p-3));
+  q = fma2(q, r, splat2(0x1.fffffffffe062p-2));
+  q = fma2(q, r, splat2(1.0));
+  return fma2(q, r, splat2(1.0));
 }
-__device__ __forceinline__ v2d expm1_poly2(v2d r) {
-  v2d q = splat2(0x1.af38a9b0ec855p-26);
-  q = fma2(q, r, splat2(0x1.289185613a3d6p-22));
-  q = fma2(q, r, splat2(0x1.71de0dae63bb3p-19));
-  q = fma2(q, r, splat2(0x1.a019b90d2ae7ap-16));
-  q = fma2(q, r, splat2(0x1.a01a01a7c41d5p-13));
-  q = fma2(q, r, splat2(0x1.6c16c1788bd90p-10));
-  q = fma2(q, r, splat2(0x1.11111111109b3p-7));
-  q = fma2(q, r, splat2(0x1.5555555553d63p-5));
-  q = fma2(q, r, splat2(0x1.5555555555556p-3));
-  q = fma2(q, r, splat2(0x1.0000000000001p-1));
-  return fma2(q * r, r, r);
-}
-__device__ __forceinline__ v2d exp_reduce2(v2d y, v2i* n) {
-  // round-to-nearest by the 1.5 * 2^52 shift; the integer is the low word of the shifted sum (no v_rndne / v_cvt)
+__device__ __forceinline__ v2d exp2n2(v2d y) {  // e^y, y <= 170; flushes to 0 below ~-745
   const v2d sh = fma2(y, splat2(1.44269504088896338700e+00), splat2(6755399441055744.0));
   const v2d fn = sh - splat2(6755399441055744.0);
-  v2d r = fma2(-fn, splat2(6.93147180369123816490e-01), y);
-  r = fma2(-fn, splat2(1.90821492927058770002e-10), r);
-  *n = v2i{__double2loint(sh.x), __double2loint(sh.y)};
+  const v2d r = fma2(-fn, splat2(6.93147180559945286227e-01), y);
+  const v2d p = exp_poly2(r);
+  return v2d{ldexp(p.x, __double2loint(sh.x)), ldexp(p.y, __double2loint(sh.y))};
+}
+// (v_min / v_max spelled out: through the builtins the compiler first canonicalises every operand with a v_max_f64 x, x, x
+// of its own -- 96 extra FP64 instructions per GRU step and lane)
+__device__ __forceinline__ double min_neg(double x, double hi) {  // min(-x, hi)
+  double r;
+  asm("v_min_f64 %0, -%1, %2" : "=v"(r) : "v"(x), "s"(hi));
   return r;
 }
-// 1 + e^{-x} for either sign (e^{-x} >= 0, nothing cancels).  The argument is clamped to +-350 so that the product
-// of two such terms stays finite (below -350 the true sigmoid is < 1e-152 and this returns ~1e-152).
-__device__ __forceinline__ v2d one_plus_exp_neg2(v2d x) {
-  const v2d y = __builtin_elementwise_min(__builtin_elementwise_max(-x, splat2(-350.0)), splat2(350.0));
-  v2i n;
-  const v2d r = exp_reduce2(y, &n);
-  const v2d p = splat2(1.0) + expm1_poly2(r);
-  const v2d e = {ldexp(p.x, n.x), ldexp(p.y, n.y)};
-  return splat2(1.0) + e;
+__device__ __forceinline__ double max_raw(double x, double lo) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lo));
+  return r;
 }
-// the reset and update gates share ONE reciprocal: sigmoid(a) = B / (A B), sigmoid(b) = A / (A B) with
-// A = 1 + e^{-a}, B = 1 + e^{-b}  (three multiplies instead of a second v_rcp_f64 + refinement)
+__device__ __forceinline__ double rcp_refined1(double d) {
+  // v_rcp_f64 (~2^-24) + one cubic step r (1 + e + e^2), e = 1 - d r: 3 FMAs, <= 1 ulp (tools/rcp_probe.hip)
+  const double r = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r, 1.0);
+  return fma(r, fma(e, e, e), r);
+}
+// 1 + e^{-x} for either sign (e^{-x} >= 0, nothing cancels).  The argument is clamped from above at 170 so that the
+// product of FOUR such terms stays finite (beyond it the true sigmoid is < 1e-73 and this returns ~1e-74); no clamp from
+// below: for very negative arguments v_ldexp_f64 flushes the term to 0 and the result is exactly 1.
+__device__ __forceinline__ v2d one_plus_exp_neg2(v2d x) {
+  return splat2(1.0) + exp2n2(v2d{min_neg(x.x, 170.0), min_neg(x.y, 170.0)});
+}
+// the reset and update gates of TWO hidden units share ONE reciprocal: with A = 1 + e^{-a}, B = 1 + e^{-b} per unit and
+// R = 1 / (A0 B0 A1 B1), sigmoid(a_i) = B_i / (A_i B_i) = B_i (A_j B_j) R  (v_rcp_f64 is quarter rate: one + its three
+// refinement FMAs replaced by three multiplies)
 __device__ __forceinline__ void sigmoid_pair2(v2d a, v2d b, v2d* sa, v2d* sb) {
   const v2d A = one_plus_exp_neg2(a), B = one_plus_exp_neg2(b);
-  const v2d R = rcp_refined2(A * B);
-  *sa = B * R;
-  *sb = A * R;
+  const v2d P = A * B;
+  const double R = rcp_refined1(P.x * P.y);
+  const v2d inv = v2d{P.y, P.x} * splat2(R);  // (1 / P.x, 1 / P.y)
+  *sa = B * inv;
+  *sb = A * inv;
 }
+// tanh of two values, one reciprocal: t_i = (1 - e_i) / (1 + e_i), e = e^{-2|x|} in (0, 1], denominators in [1, 2].
+// (1 - e is exact near 0 up to e's own rounding: absolute error ~1e-16, which is what a gate needs.)
 __device__ __forceinline__ v2d tanh2(v2d x) {
-  const v2d y = __builtin_elementwise_max(-2.0 * __builtin_elementwise_abs(x), splat2(-745.0));
-  v2i n;
-  const v2d r = exp_reduce2(y, &n);
-  const v2d p = expm1_poly2(r);
-  const v2d two_n = {ldexp(1.0, n.x), ldexp(1.0, n.y)};
-  const v2d em = fma2(two_n, p, two_n - splat2(1.0));
-  const v2d t = -em * rcp_refined2(splat2(2.0) + em);
+  const v2d y2 = -2.0 * __builtin_elementwise_abs(x);
+  const v2d e = exp2n2(v2d{max_raw(y2.x, -745.0), max_raw(y2.y, -745.0)});
+  const v2d num = splat2(1.0) - e, d = splat2(1.0) + e;
+  const double R = rcp_refined1(d.x * d.y);
+  const v2d t = (num * v2d{d.y, d.x}) * splat2(R);
   return __builtin_elementwise_copysign(t, x);
 }
 
