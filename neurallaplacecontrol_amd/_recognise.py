@@ -1,0 +1,154 @@
+"""Recognising the reference harness's LITERAL closures.
+
+The reference hands ``MPPIDelay`` two Python callables built in ``mppi_with_model.py``:
+
+* ``dynamics`` -- a local function closing over ``model`` and ``ts_pred`` (``state + model(state, window, ts_pred)``,
+  :103-122), or ``functools.partial(<env>_dynamics_dt_delay, ts=ts_pred, delay=..., friction=...)`` (:129-143);
+* ``running_cost`` -- a local function closing over ``env`` (``-(env.diff_obs_reward_(state, exp_reward=False) +
+  env.diff_ac_reward_(action))`` on its default branch, :145-171).
+
+A closure is opaque to a HIP kernel, but its free variables are not: this module looks at ``__closure__`` /
+``functools.partial`` and proposes the fused objects of :mod:`.envs` (``NLDynamics`` / ``OracleDynamics`` / ``EnvCost``)
+that WOULD compute the same thing.  A proposal is only a candidate: ``MPPIDelay`` verifies it at its first ``command()``
+by running one short command both ways on the command's own state and action buffer and switches to the fused path only
+if rollout states and costs agree (``probe_equivalence``); otherwise it stays on the generic path, silently correct.
+Nothing here executes or imports reference code: only attribute and type inspection of objects the caller passed in.
+"""
+
+import functools
+import inspect
+
+import torch
+
+from .envs import EnvCost, NLDynamics, OracleDynamics
+
+_ORACLE_FUNCS = {
+    "cartpole_dynamics_dt_delay": "oderl-cartpole",
+    "pendulum_dynamics_dt_delay": "oderl-pendulum",
+    "acrobot_dynamics_dt_delay": "oderl-acrobot",
+}
+_ENV_CLASS_HINTS = (("cartpole", "oderl-cartpole"), ("pendulum", "oderl-pendulum"), ("acrobot", "oderl-acrobot"))
+
+
+def _free_variables(fn):
+    """name -> value of a function's closure cells (empty cells skipped)."""
+    out = {}
+    if not inspect.isfunction(fn) or fn.__closure__ is None:
+        return out
+    for name, cell in zip(fn.__code__.co_freevars, fn.__closure__):
+        try:
+            out[name] = cell.cell_contents
+        except ValueError:  # empty cell
+            pass
+    return out
+
+
+def _constant_scalar(v):
+    """float(v) if `v` is a number or a tensor / array whose entries are all equal, else None."""
+    if isinstance(v, bool):
+        return None
+    if isinstance(v, (int, float)):
+        return float(v)
+    try:
+        t = torch.as_tensor(v).detach().reshape(-1)
+    except Exception:
+        return None
+    if t.numel() == 0 or not (t.dtype.is_floating_point or t.dtype in (torch.int32, torch.int64)):
+        return None
+    t = t.to("cpu", torch.float64)
+    return float(t[0]) if bool((t == t[0]).all()) else None
+
+
+def _model_twin(obj):
+    """The package's model mirror for `obj`: the object itself if it is one of ours, a converted twin if it looks like
+    the reference's ``w_nl.NeuralLaplaceModel`` (same sub-modules / attributes), else None."""
+    from .nl_model import NeuralLaplaceModel
+    from .node_model import NODE
+    from .rnn_model import RNN, DeltaTRNN
+
+    if isinstance(obj, (NeuralLaplaceModel, DeltaTRNN, RNN, NODE)):
+        return obj
+    if isinstance(obj, torch.nn.Module) and type(obj).__name__ == "NeuralLaplaceModel" and hasattr(obj, "laplace_rep_func"):
+        try:
+            return NeuralLaplaceModel.from_reference(obj)
+        except Exception:
+            return None
+    return None
+
+
+def candidate_dynamics(fn):
+    """An ``NLDynamics`` / ``OracleDynamics`` that `fn` appears to compute, or None."""
+    if isinstance(fn, (NLDynamics, OracleDynamics)):
+        return fn
+    if isinstance(fn, functools.partial):
+        env = _ORACLE_FUNCS.get(getattr(fn.func, "__name__", ""))
+        if env is None or fn.args:
+            return None
+        kw = dict(fn.keywords or {})
+        ts = _constant_scalar(kw.pop("ts", None))
+        delay = kw.pop("delay", None)
+        friction = bool(kw.pop("friction", False))
+        if ts is None or not isinstance(delay, int) or kw:
+            return None
+        return OracleDynamics(env, ts=ts, delay=delay, friction=friction)
+    free = _free_variables(fn)
+    if not free:
+        return None
+    models = [(n, m) for n, m in ((n, _model_twin(v)) for n, v in free.items()) if m is not None]
+    if len(models) != 1:
+        return None
+    # the prediction time: the free variable the harness calls ts_pred, else the only constant-valued tensor / number
+    if "ts_pred" in free:
+        ts = _constant_scalar(free["ts_pred"])
+    else:
+        consts = [c for c in (_constant_scalar(v) for n, v in free.items() if n != models[0][0] and not isinstance(v, (str, torch.device))) if c is not None]
+        ts = consts[0] if len(consts) == 1 else None
+    if ts is None or not (ts > 0.0):
+        return None
+    try:
+        return NLDynamics(models[0][1], ts)
+    except Exception:
+        return None
+
+
+def candidate_cost(fn):
+    """An ``EnvCost`` that `fn` appears to compute (the harness closure's default branch), or None."""
+    if isinstance(fn, EnvCost):
+        return fn
+    free = _free_variables(fn)
+    if not free:
+        return None
+    # non-default branches (state_constraint / change_goal) are NOT the plain env cost
+    for flag in ("state_constraint", "change_goal"):
+        if free.get(flag):
+            return None
+    envs = [v for v in free.values() if hasattr(v, "diff_obs_reward_") and hasattr(v, "diff_ac_reward_")]
+    if len(envs) != 1:
+        return None
+    cls = type(envs[0]).__name__.lower()
+    for hint, name in _ENV_CLASS_HINTS:
+        if hint in cls:
+            return EnvCost(name)
+    return None
+
+
+def probe_equivalence(make_planner, literal, candidate, state, action_buffer, K, nu, horizon=4, rtol=1e-9, atol=1e-10):
+    """One short command on the command's own state / action buffer through the literal callables (generic path) and
+    through the candidate objects (fused path), on the SAME noise draw (a private generator: the caller's RNG stream is
+    not touched).  True iff rollout states and total costs agree.  Any exception on either side -> False."""
+    try:
+        gen = torch.Generator().manual_seed(0x5EED)
+        raw = torch.randn(K, horizon, nu, dtype=torch.float64, generator=gen) * 0.5
+        out = []
+        for dyn, cost in (literal, candidate):
+            p = make_planner(dyn, cost, horizon)
+            p.noise_dist = type("Replay", (), {"sample": staticmethod(lambda shape, raw=raw: raw.to(p.d))})()
+            with torch.no_grad():
+                p.command(state, action_buffer)
+            out.append((p.states.detach().cpu(), p.cost_total.detach().cpu()))
+        (s0, c0), (s1, c1) = out
+        if s0.shape != s1.shape or not bool(torch.isfinite(s0).all()) or not bool(torch.isfinite(c0).all()):
+            return False
+        return bool(torch.allclose(s0, s1, rtol=rtol, atol=atol)) and bool(torch.allclose(c0, c1, rtol=rtol, atol=atol))
+    except Exception:
+        return False

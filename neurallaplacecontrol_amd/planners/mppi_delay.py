@@ -27,7 +27,7 @@ import ctypes as C
 import torch
 from torch.distributions.multivariate_normal import MultivariateNormal
 
-from .. import _lib
+from .. import _lib, _recognise
 from ..envs import EnvCost, NLDynamics, OracleDynamics
 from ..sharding import (all_ranks_agree, check_same_on_all_ranks, gather_partials, replicate_from_rank0, shard_range, share_bytes_from_rank0,
                         slice_noise)
@@ -129,8 +129,6 @@ class MPPIDelay:
         self.rollout_var_cost = rollout_var_cost
         self.rollout_var_discount = rollout_var_discount
         self.step_dependency = step_dependent_dynamics
-        self.F = dynamics
-        self.running_cost = running_cost
         self.terminal_state_cost = terminal_state_cost
         self.sample_null_action = sample_null_action
         self.noise_abs_cost = noise_abs_cost
@@ -141,7 +139,7 @@ class MPPIDelay:
         self.noise_rng = noise_rng
         self.seed = int(seed)
         self._commands = 0
-        self.store_rollouts = store_rollouts
+        self._store_rollouts_arg = store_rollouts
 
         # ---- K-sharding over a process group
         self.pg = process_group
@@ -153,45 +151,28 @@ class MPPIDelay:
             self.G, self.rank = 1, 0
         self.k_offset, self.K_local = shard_range(self.K, self.G, self.rank)
 
-        # fused dynamics: the whole T-step rollout is one HIP kernel (Fourier models), or the staged all-HIP path
-        # (rep-func kernel -> de Hoog kernel -> state kernel per horizon step) for de Hoog models
-        self.fused_dynamics = (
-            isinstance(dynamics, (NLDynamics, OracleDynamics))
-            and not step_dependent_dynamics
-            # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
-            # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
-            and not (encode_obs_time and not isinstance(dynamics, OracleDynamics))
-            and not (
-                isinstance(dynamics, NLDynamics)
-                and getattr(dynamics.model, "ilt_algorithm", "fourier") not in ("fourier", "dehoog")
-            )
-        )
-        # fused: the running cost is evaluated inside the rollout kernel as well (EnvCost, no terminal cost)
-        self.fused = self.fused_dynamics and isinstance(running_cost, EnvCost) and terminal_state_cost is None
-        # otherwise, with fused dynamics, the cost callables (the harness's state_constraint / change_goal closures,
-        # a terminal cost, ...) run on the stored device states after the rollout: the states do not depend on them
-        self.cost_external = self.fused_dynamics and not self.fused
-        if self.cost_external:
-            self.store_rollouts = True  # the cost callables read the stored states
-        if self.M > 1:
-            # rollout_samples M > 1 (reference :291-292, 310).  The reference never replicates the state M times: its M
-            # cost rows are copies and ``c.var(dim=0)`` is the variance of the running cost OVER THE K SAMPLES, one number
-            # per horizon step -- every sample's cost gets the same rollout_var_cost * sum_t var_t * discount^t.  Softmax
-            # weights, U and the action do not see a constant shift; it is added to .cost_total after the command, from
-            # the stored rollout.
-            if process_group is not None:
-                raise NotImplementedError("rollout_samples > 1 with a K-sharded planner (the variance is over the whole population)")
-            if int(getattr(self, "E", 1)) > 1:
-                raise NotImplementedError("rollout_samples > 1 with BatchedMPPIDelay")
-            self.store_rollouts = True
-        if isinstance(dynamics, OracleDynamics) and not self.fused_dynamics:
-            raise NotImplementedError("OracleDynamics needs the default rollout options (no step-dependent dynamics)")
+        self._F_callable = dynamics  # what get_rollouts() replays through (reference :358-381)
+        self._decide_mode(dynamics, running_cost)
+        # The reference harness's LITERAL closures (mppi_with_model.py:103-122, 129-143, 145-171): look inside them for a
+        # model + constant ts_pred / an oracle partial / an env, and -- once verified at the first command() by a short
+        # probe run both ways (_recognise.probe_equivalence) -- plan on the fused path instead of the generic one.
+        self._candidate = None
+        opts_in = dict(planner_options or {})
+        self.recognised = False  # True once literal closures have been verified and replaced by their fused twins
+        if (bool(float(opts_in.pop("recognise_closures", 1))) and not self.fused_dynamics and not step_dependent_dynamics
+                and self.E == 1 and type(self) is MPPIDelay):
+            cd = _recognise.candidate_dynamics(dynamics)
+            if cd is not None:
+                self._candidate = (cd, _recognise.candidate_cost(running_cost) or running_cost)
+        planner_options = opts_in
 
         if compute_device is None:
+            model_holder = dynamics if isinstance(dynamics, NLDynamics) else (
+                self._candidate[0] if self._candidate is not None and isinstance(self._candidate[0], NLDynamics) else None)
             if self.d.type == "cuda":
                 compute_device = self.d
-            elif isinstance(dynamics, NLDynamics) and next(dynamics.model.parameters()).is_cuda:
-                compute_device = next(dynamics.model.parameters()).device
+            elif model_holder is not None and next(model_holder.model.parameters()).is_cuda:
+                compute_device = next(model_holder.model.parameters()).device
         if not torch.cuda.is_available():
             raise RuntimeError("neurallaplacecontrol_amd.MPPIDelay needs an AMD MI355X; there is no CPU path")
         self.cd = torch.device(compute_device) if compute_device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -250,6 +231,68 @@ class MPPIDelay:
                                     "num_samples / horizon / nu / seed / noise_rng", self.cd)
         # T x nu control sequence; defaults to a noise draw (consumes the RNG like the reference :161-164)
         self.U = U_init if U_init is not None else self.noise_dist.sample(self._lead(self.T))
+
+    def _decide_mode(self, dynamics, running_cost):
+        """Which planner path the (dynamics, running_cost) pair runs on: fused / fused dynamics + cost callables / generic."""
+        self.F = dynamics
+        self.running_cost = running_cost
+        self.store_rollouts = self._store_rollouts_arg
+        # fused dynamics: the whole T-step rollout is one HIP kernel (Fourier models), or the staged all-HIP path
+        # (rep-func kernel -> de Hoog kernel -> state kernel per horizon step) for de Hoog models
+        self.fused_dynamics = (
+            isinstance(dynamics, (NLDynamics, OracleDynamics))
+            and not self.step_dependency
+            # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
+            # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
+            and not (self.encode_obs_time and not isinstance(dynamics, OracleDynamics))
+            and not (
+                isinstance(dynamics, NLDynamics)
+                and getattr(dynamics.model, "ilt_algorithm", "fourier") not in ("fourier", "dehoog")
+            )
+        )
+        # fused: the running cost is evaluated inside the rollout kernel as well (EnvCost, no terminal cost)
+        self.fused = self.fused_dynamics and isinstance(running_cost, EnvCost) and self.terminal_state_cost is None
+        # otherwise, with fused dynamics, the cost callables (the harness's state_constraint / change_goal closures,
+        # a terminal cost, ...) run on the stored device states after the rollout: the states do not depend on them
+        self.cost_external = self.fused_dynamics and not self.fused
+        if self.cost_external:
+            self.store_rollouts = True  # the cost callables read the stored states
+        if self.M > 1:
+            # rollout_samples M > 1 (reference :291-292, 310).  The reference never replicates the state M times: its M
+            # cost rows are copies and ``c.var(dim=0)`` is the variance of the running cost OVER THE K SAMPLES, one number
+            # per horizon step -- every sample's cost gets the same rollout_var_cost * sum_t var_t * discount^t.  Softmax
+            # weights, U and the action do not see a constant shift; it is added to .cost_total after the command, from
+            # the stored rollout.
+            if self.pg is not None:
+                raise NotImplementedError("rollout_samples > 1 with a K-sharded planner (the variance is over the whole population)")
+            if int(getattr(self, "E", 1)) > 1:
+                raise NotImplementedError("rollout_samples > 1 with BatchedMPPIDelay")
+            self.store_rollouts = True
+        if isinstance(dynamics, OracleDynamics) and not self.fused_dynamics:
+            raise NotImplementedError("OracleDynamics needs the default rollout options (no step-dependent dynamics)")
+
+    def _verify_candidate(self, state, action_buffer):
+        """First command(): run the literal closures and the recognised fused objects on one short probe command (this
+        command's state and action buffer, a private noise draw) and switch to the fused path iff they agree."""
+        cand, self._candidate = self._candidate, None
+        literal = (self.F, self.running_cost)
+
+        def make(dyn, cost, horizon):
+            return MPPIDelay(
+                dyn, cost, self.nx, self.noise_sigma if self.nu > 1 else self.noise_sigma.view(1, 1), self.K, horizon,
+                device=self.d, terminal_state_cost=self.terminal_state_cost, lambda_=self.lambda_, noise_mu=self.noise_mu,
+                u_min=self.u_min, u_max=self.u_max, u_init=self.u_init, U_init=torch.zeros(horizon, self.nu, dtype=torch.float64),
+                u_scale=self.u_scale, sample_null_action=self.sample_null_action, noise_abs_cost=self.noise_abs_cost,
+                encode_obs_time=self.encode_obs_time, dt=self.dt, compute_device=self.cd, store_rollouts=True,
+                planner_options={"recognise_closures": 0},
+            )
+
+        ok = _recognise.probe_equivalence(make, literal, cand, state, action_buffer, self.K, self.nu)
+        if self.pg is not None and self.G > 1:
+            ok = all_ranks_agree(ok, self.pg, self.cd)
+        self.recognised = bool(ok)
+        if ok:
+            self._decide_mode(*cand)
 
     def _lead(self, *shape):
         """Shape with the leading episode dimension of a batched planner."""
@@ -403,6 +446,8 @@ class MPPIDelay:
             raise ValueError("action_buffer must be (B, nu)")
         lib, ctx = self.ctx.lib, self.ctx
         rng = 1 if self.noise_rng == "philox" else 0
+        if self._candidate is not None:
+            self._verify_candidate(state, action_buffer)
         with torch.cuda.device(self.cd):
             ctx.use_torch_stream()  # before any (re)configuration: its uploads are ordered on this stream too
             self._ensure_configured(ab.shape[0])
@@ -453,7 +498,8 @@ class MPPIDelay:
 
     # ------------------------------------------------------------------ generic callables (reference :232-313)
     def _dynamics(self, state, u, t):
-        return self.F(state, u, t) if self.step_dependency else self.F(state, u)
+        F = self.F if not isinstance(self.F, OracleDynamics) else self._F_callable
+        return F(state, u, t) if self.step_dependency else F(state, u)
 
     def _running_cost(self, state, u):
         return self.running_cost(state, u)

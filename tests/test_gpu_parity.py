@@ -435,6 +435,145 @@ def test_mppi_nl_dynamics_vs_reference_golden(nlc, env):
     check_command_steps(nlc, g, make)
 
 
+class _EnvStandIn:
+    """What the harness's running_cost closure needs of an env: the two reward methods (class names as in
+    envs/oderl/envs/ct*.py; the arithmetic comes from the oracle's restatement of those methods)."""
+
+    def __init__(self, env_name):
+        self.env_name = env_name
+
+    def diff_obs_reward_(self, state, exp_reward=False, **kw):
+        from oracle import envs as oenvs
+
+        assert not kw, "default branch only"
+        nu = oenvs.ACT_DIM[self.env_name]
+        return -oenvs.RUNNING_COST[self.env_name](state, torch.zeros(state.shape[:-1] + (nu,), dtype=state.dtype, device=state.device))
+
+    def diff_ac_reward_(self, action):
+        return -(1e-4 if self.env_name == "oderl-acrobot" else 0.01) * (action * action).sum(-1)
+
+
+def _literal_harness_closures(env_name, model=None, ts_pred=None, delay=None, device="cuda", action_buffer_size=4):
+    """dynamics / running_cost built the way mppi_with_model.py:103-122, 129-143, 145-171 builds them (default branches):
+    a local function closing over `model` and `ts_pred`, or functools.partial(<env>_dynamics_dt_delay, ts=, delay=,
+    friction=), and a local function closing over `env`."""
+    import functools
+
+    from oracle import envs as oenvs
+
+    env = type({"oderl-cartpole": "CTCartpole", "oderl-pendulum": "CTPendulum", "oderl-acrobot": "CTAcrobot"}[env_name],
+               (_EnvStandIn,), {})(env_name)
+    state_constraint = change_goal = False
+    encode_obs_time, model_name = False, "nl"
+    if model is not None:
+
+        def dynamics(state, perturbed_action, encode_obs_time=encode_obs_time, action_buffer_size=action_buffer_size,
+                     model_name=model_name):
+            if encode_obs_time and model_name == "nl":
+                perturbed_action = torch.cat(
+                    (perturbed_action, torch.flip(torch.arange(action_buffer_size, device=device), (0,))
+                     .view(1, action_buffer_size, 1).repeat(perturbed_action.shape[0], 1, 1)), dim=2)
+            state_diff_pred = model(state, perturbed_action, ts_pred)
+            state_out = state + state_diff_pred
+            return state_out
+    else:
+
+        def oracle_fn(state, perturbed_action, ts, delay, friction=False):
+            return oenvs.ORACLE_DYNAMICS[env_name](state, perturbed_action, ts.to(state.device), delay, friction)
+
+        oracle_fn.__name__ = env_name.split("-")[1] + "_dynamics_dt_delay"
+        dynamics = functools.partial(oracle_fn, ts=ts_pred, delay=delay, friction=False)
+
+    def running_cost(state, action):
+        if state_constraint:
+            reward = env.diff_obs_reward_(state, exp_reward=False, state_constraint=state_constraint) + env.diff_ac_reward_(action)
+        elif change_goal:
+            reward = env.diff_obs_reward_(state, exp_reward=False, change_goal=change_goal) + env.diff_ac_reward_(action)
+        else:
+            reward = env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action)
+        cost = -reward
+        return cost
+
+    return dynamics, running_cost
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_literal_nl_closures_are_recognised_and_plan_fused_g3(nlc, env):
+    """an UNMODIFIED harness -- dynamics / running_cost are the literal closures of mppi_with_model.py
+    (a local function over model + ts_pred, a local function over env) -- gets the fused planner: the constructor finds the
+    model, the constant prediction time and the env inside the closures, the first command() verifies the candidates
+    against the closures on a probe, and from then on `mppi.fused is True`.  Results: G3 (reference MPPIDelay + reference
+    model) at the fused path's tolerance; the caller's torch RNG stream is not touched by the probe."""
+    g = np.load(f"{GOLD}/g3_nl_{env}.npz")
+    model = build_model(nlc, load_sd(g))
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    ts_pred = torch.tensor(0.05, device="cuda", dtype=torch.double).view(1, 1).repeat(K, 1)
+    made = []
+
+    def make(U0):
+        dyn, cost = _literal_harness_closures("oderl-" + env, model=model, ts_pred=ts_pred)
+        p = nlc.MPPIDelay(dyn, cost, d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0)
+        assert not p.fused and p._candidate is not None  # recognised, not yet verified
+        made.append(p)
+        return p
+
+    torch.manual_seed(123)
+    before = torch.random.get_rng_state()
+    with torch.no_grad():
+        check_command_steps(nlc, g, make)
+    assert torch.equal(before, torch.random.get_rng_state()), "the probe must not consume the caller's RNG stream"
+    p = made[0]
+    assert p.fused is True and p.recognised is True and isinstance(p.F, nlc.NLDynamics) and isinstance(p.running_cost, nlc.EnvCost)
+    p.ctx.profile_reset()
+    p.ctx.profile(True)
+    p.command(g["s1_state"], T64(g["s1_action_buffer"]))
+    p.ctx.profile(False)
+    assert any(k in p.ctx.profile_read() for k in ("nl_plan_fused_kernel", "nl_rollout_kernel")), p.ctx.profile_read()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "g1_*_d[02].npz"))))
+def test_literal_oracle_partial_is_recognised_and_plans_fused_g1(nlc, path):
+    """The harness's oracle branch: functools.partial(<env>_dynamics_dt_delay, ts=ts_pred, delay=, friction=) -> fused
+    oracle rollout, G1 parity (real reference MPPIDelay / oracle.py / env rewards)."""
+    g = np.load(path)
+    env = "oderl-" + os.path.basename(path).split("_")[2]
+    K, T, nx, nu, A, delay = int(g["K"]), int(g["T"]), int(g["nx"]), int(g["nu"]), float(g["A"]), int(g["delay"])
+    ts_pred = torch.tensor(0.05, dtype=torch.double).view(1, 1).repeat(K, 1)
+    made = []
+
+    def make(U0):
+        dyn, cost = _literal_harness_closures(env, ts_pred=ts_pred, delay=delay)
+        p = nlc.MPPIDelay(dyn, cost, nx, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0)
+        made.append(p)
+        return p
+
+    check_command_steps(nlc, g, make)
+    assert made[0].fused is True and isinstance(made[0].F, nlc.OracleDynamics)
+
+
+def test_closure_that_differs_from_its_candidate_stays_generic(nlc):
+    """The probe is the decision: a closure over a model + constant ts_pred that ALSO does something else (here: clamps the
+    state) is recognised as a candidate, fails the probe and keeps the generic path with the closure's own semantics."""
+    g = np.load(f"{GOLD}/g3_nl_cartpole.npz")
+    model = build_model(nlc, load_sd(g))
+    K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
+    ts_pred = torch.full((K, 1), 0.05, dtype=torch.double, device="cuda")
+
+    def dynamics(state, perturbed_action):
+        return (state + model(state, perturbed_action, ts_pred)).clamp(-0.5, 0.5)
+
+    cost = nlc.EnvCost("oderl-cartpole")
+    with torch.no_grad():
+        p = nlc.MPPIDelay(dynamics, cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A),
+                          u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64))
+        assert p._candidate is not None
+        p.command(g["s0_state"], T64(g["s0_action_buffer"]))
+    assert p.fused is False and p.recognised is False and p.F is dynamics
+    assert float(p.states.abs().max()) <= 0.5
+
+
 @pytest.mark.parametrize("env", ["cartpole", "acrobot"])
 def test_mppi_generic_callables_match_fused(nlc, env):
     """The external-callable path (reference contract: arbitrary closures) equals the fused path."""

@@ -63,3 +63,83 @@ def test_weights_key_detects_every_kind_of_weight_change(make):
     assert m._weights_key() == k5
     m.mark_weights_dirty()
     assert m._weights_key() != k5
+
+
+# --------------------------------------------------------------------------- literal harness closures
+def _harness_style_closures(model, env, ts_pred, device="cpu", encode_obs_time=False, action_buffer_size=4, model_name="nl",
+                            state_constraint=False, change_goal=False):
+    """Closures of the SHAPE the reference harness builds (mppi_with_model.py:103-122, 145-171): same free variables."""
+
+    def dynamics(state, perturbed_action, encode_obs_time=encode_obs_time, action_buffer_size=action_buffer_size,
+                 model_name=model_name):
+        if encode_obs_time and model_name == "nl":
+            perturbed_action = torch.cat(
+                (perturbed_action, torch.flip(torch.arange(action_buffer_size, device=device), (0,))
+                 .view(1, action_buffer_size, 1).repeat(perturbed_action.shape[0], 1, 1)), dim=2)
+        state_diff_pred = model(state, perturbed_action, ts_pred)
+        return state + state_diff_pred
+
+    def running_cost(state, action):
+        if state_constraint:
+            reward = env.diff_obs_reward_(state, exp_reward=False, state_constraint=state_constraint) + env.diff_ac_reward_(action)
+        elif change_goal:
+            reward = env.diff_obs_reward_(state, exp_reward=False, change_goal=change_goal) + env.diff_ac_reward_(action)
+        else:
+            reward = env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action)
+        return -reward
+
+    return dynamics, running_cost
+
+
+def test_recognise_literal_harness_closures_without_gpu():
+    """Free-variable inspection only (no GPU, nothing executed): a model + constant ts_pred -> NLDynamics candidate, an
+    oracle partial -> OracleDynamics, an env on the default reward branch -> EnvCost; anything else -> no candidate."""
+    import functools
+
+    import numpy as np
+
+    import neurallaplacecontrol_amd as nlc
+    from neurallaplacecontrol_amd import _recognise as R
+
+    model = nlc.NeuralLaplaceModel(5, 1, 5, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier",
+                                   state_mean=np.zeros(5), state_std=np.ones(5), action_mean=np.array([0]),
+                                   action_std=np.array([1.5]), normalize=True, normalize_time=True).double()
+
+    class CTCartpole:  # stand-in with the two methods the closure calls (class name as in envs/oderl/envs/ctcartpole.py)
+        def diff_obs_reward_(self, s, exp_reward=False, **kw):
+            return -s.pow(2).sum(-1)
+
+        def diff_ac_reward_(self, a):
+            return -0.01 * a.pow(2).sum(-1)
+
+    ts_pred = torch.tensor(0.05, dtype=torch.double).view(1, 1).repeat(64, 1)
+    dyn, cost = _harness_style_closures(model, CTCartpole(), ts_pred)
+    cd, cc = R.candidate_dynamics(dyn), R.candidate_cost(cost)
+    assert isinstance(cd, nlc.NLDynamics) and cd.model is model and cd.ts_pred == 0.05
+    assert isinstance(cc, nlc.EnvCost) and cc.env_name == "oderl-cartpole"
+    # non-default reward branches are not the plain env cost; a varying ts_pred is not a constant prediction time
+    _, cost_sc = _harness_style_closures(model, CTCartpole(), ts_pred, state_constraint=True)
+    assert R.candidate_cost(cost_sc) is None
+    dyn_var, _ = _harness_style_closures(model, CTCartpole(), torch.linspace(0.01, 0.05, 64, dtype=torch.double).view(-1, 1))
+    assert R.candidate_dynamics(dyn_var) is None
+    # two models in the closure: ambiguous -> no candidate; plain lambdas without free variables -> none
+    other = model
+
+    def two(state, w, m1=None):
+        return model(state, w, ts_pred) + other(state, w, ts_pred) * 0
+
+    assert R.candidate_dynamics(two) is None
+    assert R.candidate_dynamics(lambda s, w: s) is None and R.candidate_cost(lambda s, u: s.sum(-1)) is None
+    # oracle partial, as mppi_with_model.py:129-143 builds it
+
+    def cartpole_dynamics_dt_delay(state, perturbed_action, ts, delay, friction=False):
+        return state
+
+    od = R.candidate_dynamics(functools.partial(cartpole_dynamics_dt_delay, ts=ts_pred, delay=2, friction=True))
+    assert isinstance(od, nlc.OracleDynamics) and (od.env_name, od.ts, od.delay, od.friction) == ("oderl-cartpole", 0.05, 2, True)
+    assert R.candidate_dynamics(functools.partial(cartpole_dynamics_dt_delay, ts=ts_pred, delay=2, extra=1)) is None
+
+    def some_other_name(state, perturbed_action, ts, delay, friction=False):
+        return state
+
+    assert R.candidate_dynamics(functools.partial(some_other_name, ts=ts_pred, delay=0)) is None
