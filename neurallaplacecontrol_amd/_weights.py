@@ -37,6 +37,13 @@ class WeightsKeyMixin:
     def _weights_key_extra(self):
         return ()
 
+    def _apply(self, fn, *args, **kwargs):
+        # .float().double() / .half().double() / .to(...) re-allocate through `param.data = fn(param.data)`: the Parameter
+        # object and its version counter survive and the caching allocator may hand back the very block just freed, so
+        # (data_ptr, _version) can stay equal although the values were rounded.  Conversions are rare: bump.
+        self._wk_dirty += 1
+        return super()._apply(fn, *args, **kwargs)
+
     def mark_weights_dirty(self):
         """Force the next planner command / forward to re-upload the weights (needed after a ``.data`` write)."""
         self._wk_dirty += 1

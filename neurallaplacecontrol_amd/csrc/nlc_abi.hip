@@ -575,7 +575,9 @@ static int linear_tables(nlc_ctx* c, const nlc_ilt_desc* d, const double** tab) 
     }
   }
   if (!c->lin_tab) NLC_HIP(c, hipMalloc((void**)&c->lin_tab, (size_t)4 * kMaxTerms * sizeof(double)));
-  NLC_HIP(c, hipStreamSynchronize(c->stream));  // a kernel of an earlier call may still read the old tables
+  // a kernel of an earlier call may still read the old tables -- on ANY stream the ctx was bound to since (the Python
+  // mirror rebinds it to torch's current stream every call): this rare path waits for the whole device
+  NLC_HIP(c, hipDeviceSynchronize());
   NLC_HIP(c, hipMemcpy(c->lin_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
   c->lin_algo = d->algo;
   c->lin_S = S;
@@ -857,7 +859,9 @@ extern "C" int nlc_model_forward_const_t(nlc_ctx* c, const double* obs, const do
   if (!c->b1fold_fwd) NLC_HIP(c, hipMalloc((void**)&c->b1fold_fwd, h * sizeof(double)));
   if (tn != c->fwd_tn) {
     // fold the constant sphere inputs of layer 1 into its bias, as nlc_mppi_configure does for the planner
-    NLC_HIP(c, hipStreamSynchronize(c->stream));  // (an earlier upload may still read the host copy)
+    // an earlier upload may still read the host copy, and a forward launched on a PREVIOUSLY bound stream may still read
+    // the folded bias: a new query time is rare, so wait for the whole device
+    NLC_HIP(c, hipDeviceSynchronize());
     std::vector<double> sph;
     sphere_inputs(c->md.ilt, tn, sph);
     c->fwd_fold_host.resize(h);

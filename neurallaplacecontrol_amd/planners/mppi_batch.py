@@ -89,6 +89,8 @@ class BatchedMPPIDelay(MPPIDelay):
             else:
                 act = torch.empty(E, self.u_per_command * nu, dtype=torch.float64)
                 ctx.check(lib.nlc_mppi_finish(ctx.h, _lib.ptr(self._partials), 1, 0, C.byref(self._buf), _lib.ptr(act)))
+            if self.M > 1 and self.rollout_var_cost != 0:
+                self._add_rollout_var_cost()  # one variance per episode (reference :291-292, 310)
         action = act.view(E, self.u_per_command, nu)
         if self.u_per_command == 1:
             action = action[:, 0]

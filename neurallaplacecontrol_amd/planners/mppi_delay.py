@@ -15,6 +15,10 @@ lambda_ u_scale``).  Everything numeric runs in HIP kernels behind ``libnlc_hip.
 * generic path -- arbitrary dynamics callables (the reference's contract): sampling, bounding, weighting and the
   U update are the same HIP kernels; the T-step loop calls the user's callables on device tensors.
 
+With a ``process_group`` every rank must make the SAME sequence of calls: the constructor, ``reset()`` and every assignment
+to ``.U`` are collective (U is replicated from rank 0 by a broadcast, so that the ranks' copies cannot drift), ``command()``
+contains the one all-gather of the shard partials.  Calling any of them on a subset of ranks deadlocks.
+
 Extra keyword-only arguments (not in the reference): ``noise_rng`` ("torch": draw with
 ``MultivariateNormal`` on ``device`` exactly like the reference, so a CPU-seeded run reproduces the
 reference's noise bit for bit; "philox": draw inside the perturb kernel), ``seed``, ``process_group``
@@ -263,10 +267,8 @@ class MPPIDelay:
             # per horizon step -- every sample's cost gets the same rollout_var_cost * sum_t var_t * discount^t.  Softmax
             # weights, U and the action do not see a constant shift; it is added to .cost_total after the command, from
             # the stored rollout.
-            if self.pg is not None:
-                raise NotImplementedError("rollout_samples > 1 with a K-sharded planner (the variance is over the whole population)")
-            if int(getattr(self, "E", 1)) > 1:
-                raise NotImplementedError("rollout_samples > 1 with BatchedMPPIDelay")
+            # K-sharded: the variance is a statistic of the WHOLE population -- two tiny all-reduces per command (the
+            # per-step sums, then the per-step squared deviations); BatchedMPPIDelay: one variance per episode.
             self.store_rollouts = True
         if isinstance(dynamics, OracleDynamics) and not self.fused_dynamics:
             raise NotImplementedError("OracleDynamics needs the default rollout options (no step-dependent dynamics)")
@@ -505,13 +507,30 @@ class MPPIDelay:
         return self.running_cost(state, u)
 
     def _add_rollout_var_cost(self):
-        """cost_total += rollout_var_cost * sum_t Var_k[c_t] * discount^t (reference :291-292, 310; see __init__)."""
+        """cost_total += rollout_var_cost * sum_t Var_k[c_t] * discount^t (reference :291-292, 310; see _decide_mode).
+        The sample axis is the second-to-last of the leading dims ((K) or (E, K)); with a process group the variance is
+        taken over all ranks' samples (torch.var's two passes: the mean, then the squared deviations, each all-reduced)."""
         A = self.u_scale * self._perturbed
-        var = torch.zeros((), dtype=torch.float64, device=self.cd)
-        for t in range(self.T):
-            c = self._running_cost(self._states[:, t], A[:, t])
-            var = var + c.var(dim=0) * (self.rollout_var_discount**t)
-        self._cost_total += var * self.rollout_var_cost
+        kdim = 0 if self.E == 1 else 1
+        c = torch.stack([self._running_cost(self._states.select(kdim + 1, t), A.select(kdim + 1, t)) for t in range(self.T)], dim=-1)
+        disc = torch.tensor([self.rollout_var_discount**t for t in range(self.T)], dtype=torch.float64, device=c.device)
+        if self.pg is None or self.G == 1:
+            var = c.var(dim=kdim)  # (T) or (E, T)
+        else:
+            import torch.distributed as dist
+
+            def allsum(t):
+                if dist.get_backend(self.pg) == "gloo" and t.is_cuda:
+                    h = t.cpu()
+                    dist.all_reduce(h, group=self.pg)
+                    return h.to(t.device)
+                dist.all_reduce(t, group=self.pg)
+                return t
+
+            mean = allsum(c.sum(dim=kdim)) / self.K
+            var = allsum(((c - mean.unsqueeze(kdim)) ** 2).sum(dim=kdim)) / (self.K - 1)
+        shift = (var * disc).sum(dim=-1) * self.rollout_var_cost  # () or (E)
+        self._cost_total += shift if self.E == 1 else shift.unsqueeze(1)
 
     def _external_cost(self):
         """cost_external: the fused rollout left the states (K, T, nx) and the perturbation cost (:343-344) on the

@@ -1648,6 +1648,14 @@ for name, dyn in (("nl", n.NLDynamics(model, 0.05)), ("oracle", n.OracleDynamics
     with torch.no_grad():
         acts = [p.command(state, ab).cpu() for _ in range(3)]
     out[name] = dict(acts=torch.stack(acts), U=p.U.cpu(), noise=p.noise.cpu(), omega=p.omega.cpu())
+# rollout_samples > 1 under the group: the variance term is a statistic of the WHOLE population (two small all-reduces)
+p = n.MPPIDelay(n.OracleDynamics("oderl-cartpole", 0.05, 1), n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda",
+                lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                noise_rng="philox", seed=22, process_group=dist.group.WORLD, rollout_samples=3, rollout_var_cost=0.7,
+                rollout_var_discount=0.9)
+with torch.no_grad():
+    a = p.command(state, ab).cpu()
+out["varcost"] = dict(acts=a, cost=p.cost_total.cpu())
 torch.save(out, os.path.join(sys.argv[2], f"r{rank}.pt"))
 dist.destroy_process_group()
 """
@@ -1861,6 +1869,45 @@ def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
         np.testing.assert_allclose(both.numpy(), p.noise.numpy(), rtol=0, atol=1e-12)
         np.testing.assert_allclose(torch.cat((r0[name]["omega"], r1[name]["omega"])).numpy(), p.omega.numpy(),
                                    rtol=1e-9, atol=1e-15)
+    # rollout_samples = 3 with a variance cost: sharded == unsharded (the reference's statistic over all K samples)
+    p = nlc.MPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 1), nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K,
+                      T, "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                      U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=22, rollout_samples=3,
+                      rollout_var_cost=0.7, rollout_var_discount=0.9)
+    a = p.command(state, ab)
+    np.testing.assert_allclose(r0["varcost"]["acts"].numpy(), a.numpy(), rtol=1e-10, atol=1e-12)
+    both = torch.cat((r0["varcost"]["cost"], r1["varcost"]["cost"]))
+    np.testing.assert_allclose(both.numpy(), p.cost_total.numpy(), rtol=1e-11, atol=1e-11)
+    plain = nlc.MPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 1), nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K,
+                          T, "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                          U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=22)
+    plain.command(state, ab)
+    shift = p.cost_total - plain.cost_total
+    assert float(shift.min()) > 1e-6 and float(shift.max() - shift.min()) < 1e-9  # one constant, as in the reference
+
+
+def test_batched_planner_rollout_samples_per_episode_variance(nlc):
+    """rollout_samples > 1 in BatchedMPPIDelay: episode e gets ITS population's variance term, exactly what a single
+    MPPIDelay with the same options computes for it (reference mppi_delay.py:291-292, 310)."""
+    env, K, T, E, A = "oderl-pendulum", 200, 7, 3, 2.0
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, rollout_samples=2, rollout_var_cost=0.5,
+              rollout_var_discount=0.8)
+    torch.manual_seed(9)
+    raw = torch.randn(E, K, T, 1, dtype=torch.float64)
+    U0 = torch.randn(E, T, 1, dtype=torch.float64) * 0.3
+    states = torch.stack([nlc.initial_state(env) + 0.05 * e for e in range(E)])
+    abs_ = torch.randn(E, 4, 1, dtype=torch.float64)
+    b = nlc.BatchedMPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 3, nlc.noise_sigma(1), E, K, T, "cpu",
+                             U_init=U0.clone(), **kw)
+    b.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+    acts = b.command(states, abs_)
+    for e in range(E):
+        p = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 3, nlc.noise_sigma(1), K, T, "cpu",
+                          U_init=U0[e].clone(), **kw)
+        p.noise_dist = type("R", (), {"sample": staticmethod(lambda shape, e=e: raw[e])})()
+        a = p.command(states[e], abs_[e])
+        assert torch.equal(a, acts[e])
+        np.testing.assert_allclose(b.cost_total[e].numpy(), p.cost_total.numpy(), rtol=1e-13, atol=1e-13)
 
 
 # --------------------------------------------------------------------------- G5: encode_obs_time variants
