@@ -111,6 +111,7 @@ struct nlc_ctx {
   int64_t opt_fused_max_samples = 4096; // auto: populations up to this size take the fused body (one chain per CU at most)
   int fused_blocks_per_cu = -1;         // occupancy of the fused kernel's 4-per-CU instance (queried once)
   int fused_blocks_per_cu3 = -1;        // ... of its 3-per-CU instance
+  int fused_occ_h = 0;                  // hidden width the two occupancies were queried for
   int opt_fused_blocks_per_cu = 0;      // 0 auto (3 while chains sit on at most half of the CUs, else 4), 3 or 4
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
   int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
@@ -1704,14 +1705,19 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     }
     // rollout_variant (nlc_set_option): 0 auto, 1 wave-per-tile, 2 latency-split, 3 fused one-launch body
     int variant = c->opt_rollout_variant;
-    const bool fused_ok = c->md.h == 128 && c->g == 64 && c->net.nt3 <= 21 && KE * d.T * 16 < (int64_t)1 << 31;
+    const int h_ = c->md.h;
+    const bool fused_ok = (h_ == 64 || h_ == 128 || h_ == 256) && 2 * c->g == h_ && c->net.nt3 <= 21 &&
+                          KE * d.T * 16 < (int64_t)1 << 31;
     if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
-    if (fused_ok && c->fused_blocks_per_cu < 0) {
+    // instances per width: 3 and 4 workgroups per CU at hidden_units 64 / 128, 2 at 256 (68 KB of LDS per workgroup)
+    const int bpc_hi = h_ == 256 ? 2 : 4, bpc_lo = h_ == 256 ? 2 : 3;
+    if (fused_ok && (c->fused_blocks_per_cu < 0 || c->fused_occ_h != h_)) {
       int bpc = 0;
-      NLC_HIP(c, fused_max_resident_blocks(4, &bpc));
+      NLC_HIP(c, fused_max_resident_blocks(h_, bpc_hi, &bpc));
       c->fused_blocks_per_cu = bpc;
-      NLC_HIP(c, fused_max_resident_blocks(3, &bpc));
+      NLC_HIP(c, fused_max_resident_blocks(h_, bpc_lo, &bpc));
       c->fused_blocks_per_cu3 = bpc;
+      c->fused_occ_h = h_;
     }
     // The fused body's rollout workgroups wait for encoder workgroups of the SAME launch, so every workgroup must be
     // resident and there must be workgroups left to encode beside one chain per CU: at least two per CU.  It
@@ -1726,7 +1732,9 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
       // instance: three workgroups per CU (168 VGPRs) while chains sit on at most half of the CUs, else four (128 VGPRs)
       int built = c->opt_fused_blocks_per_cu ? c->opt_fused_blocks_per_cu : (2 * ntk_all <= ncu ? 3 : 4);
       if (built == 3 && c->fused_blocks_per_cu3 < 3) built = 4;
-      const int bpc = built == 3 ? 3 : (c->fused_blocks_per_cu < 4 ? c->fused_blocks_per_cu : 4);
+      if (h_ == 256) built = 2;
+      const int bpc = built == bpc_lo ? (c->fused_blocks_per_cu3 < bpc_lo ? c->fused_blocks_per_cu3 : bpc_lo)
+                                      : (c->fused_blocks_per_cu < bpc_hi ? c->fused_blocks_per_cu : bpc_hi);
       FusedArgs f{};
       f.r = r;
       f.r.t_begin = 0;
@@ -1753,7 +1761,7 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
       const double f_chain = (double)fc.roll_cap / (double)ncu;
       const double extra = (16.0 * f_chain - 4.5) * (double)d.T / 40.0;
       int auto_partner = 1 + (extra > 0 ? (int)extra : 0);
-      if (built == 3) {
+      if (built <= 3) {
         // two partners per chain CU instead of three: measured best M = 1 / 1 / 2 / 6 at chains on 12.5 / 25 / 37.5 / 50 %
         // of the CUs (K = 512 / 1024 / 1536 / 2048, T = 40; 0.521 / 0.527 / 0.563 / 0.674 ms per launch)
         // (K = 1280 / 1792, 31 / 44 %: M = 1 / 4; linear in between)

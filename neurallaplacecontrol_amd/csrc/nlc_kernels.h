@@ -449,7 +449,7 @@ struct FusedArgs {   // the kernel's one by-value argument
 };
 // bpc_built: the instance compiled for 3 or 4 workgroups per CU (kernels_fused.hip)
 hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, int bpc_built, hipStream_t s);
-hipError_t fused_max_resident_blocks(int bpc_built, int* blocks_per_cu);
+hipError_t fused_max_resident_blocks(int h, int bpc_built, int* blocks_per_cu);
 
 
 }  // namespace nlc

@@ -764,8 +764,10 @@ def test_full_size_cfg2_properties(nlc):
     np.testing.assert_allclose(action.cpu().numpy(), (U_after[0] * A).numpy(), rtol=1e-10, atol=1e-13)
 
 
-@pytest.mark.parametrize("env,K,T", [("oderl-cartpole", 1024, 20), ("oderl-acrobot", 4096, 12), ("oderl-pendulum", 16400, 6)])
-def test_rollout_kernel_variants_agree(nlc, env, K, T):
+@pytest.mark.parametrize("env,K,T,h", [("oderl-cartpole", 1024, 20, 128), ("oderl-acrobot", 4096, 12, 128),
+                                        ("oderl-pendulum", 16400, 6, 128), ("oderl-cartpole", 2048, 40, 64),
+                                        ("oderl-pendulum", 1000, 40, 256), ("oderl-acrobot", 600, 9, 64)])
+def test_rollout_kernel_variants_agree(nlc, env, K, T, h):
     """Wave-per-tile (1), latency-split (2: 4 waves per 16-sample tile, LDS exchange) and fused one-launch (3: GRU encode
     and split rollout as roles of one persistent grid, latents handed over inside the launch) rollout bodies: same
     numbers; 2 and 3 share every arithmetic instruction, so they must agree bit for bit."""
@@ -773,7 +775,7 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T):
 
     st = onl.ENV_STATS[env]
     d, nu, A = st["d"], st["nu"], st["act_high"]
-    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    sd = onl.make_synthetic_state_dict(0, d, nu, h, 17, st["state_std"], [A / 2], tame=True)
     model = build_model(nlc, sd)
     torch.manual_seed(4)
     raw = torch.randn(K, T, nu, dtype=torch.float64)
@@ -1050,7 +1052,7 @@ def test_other_hidden_widths_forward_and_planner(nlc, h, S, algo):
     tsk = torch.full((K, 1), 0.05, dtype=torch.float64)
     ref = omppi.mppi_command(U0.clone(), state, ab, raw.clone(), onl.nl_dynamics(sd, tsk, S=S, ilt_algorithm=algo),
                              oenvs.RUNNING_COST[env], d, torch.inverse(sig), 1.0, A, torch.tensor(-A), torch.tensor(A))
-    for variant in ((1, 2) if algo == "fourier" else (0,)):
+    for variant in ((1, 2, 3) if algo == "fourier" else (0,)):  # 3: the fused one-launch body exists for every width
         mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, sig, K, T, "cpu", lambda_=1.0,
                              u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(),
                              planner_options={"rollout_variant": variant})
@@ -1136,7 +1138,7 @@ def test_other_hidden_widths_vs_reference_golden(nlc, name):
         model = build_model(nlc, sd, S=S)
         got = model(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda()).cpu()
         np.testing.assert_allclose(got.numpy(), g["fwd_out"], **TOL)
-        for variant in (1, 2):
+        for variant in (1, 2, 3):
             def make(U0, variant=variant):
                 return nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), num_samples=K,
                                      horizon=T, device="cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A),
