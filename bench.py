@@ -39,7 +39,7 @@ ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
 # newest committed PMC summary (separate rocprofv3 --pmc passes: tools/collect_profiles.sh + tools/pmc_summarize.py)
-PMC_CANDIDATES = ("r2_pmc_kernels.json", "r1k_pmc_kernels.json")
+PMC_CANDIDATES = ("r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
 # library kernel (nlc_profile_read name) -> key of the PMC summary; the summary's "_meta.kernel_names" must list a
 # rocprof kernel name containing the library name, or the traffic figure belongs to some other build
 PMC_KEYS = {"gru_encode_kernel": "gru_encode", "nl_rollout_kernel": "nl_rollout", "ilt_fourier_kernel": "ilt_fourier",
@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--collective", choices=("torch", "native"), default="native",
                     help="N > 1: the per-command all-gather inside nlc_mppi_finish on the library's own RCCL communicator "
                          "(include/nlc.h, nlc_comm_init; default) or through torch.distributed between the two phases")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed commands for this long during set-up (clock ramp from idle), before the W warm-up steps")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch rehearsal: start the ranks, report the environment each one sees, touch no GPU")
     ap.add_argument("--samples", type=int, default=K_SAMPLES,
@@ -337,6 +339,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, before the W warm-up steps and outside every timed region: planner construction above, and `--preheat-ms` of
+    # untimed commands so that a short run (the driver's K = 20) does not time the GPU's clock ramp from idle (at one
+    # 8-GPU shard, 0.7 ms per step, 50 cold steps measured 0.74 ms per step where a 200-step loop measures 0.71)
+    t_heat = time.perf_counter()
+    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+        abuf = step(abuf)
     for _ in range(args.warmup):
         abuf = step(abuf)
     fence()
@@ -484,7 +492,7 @@ def main():
         dtype="f64",
         data="synthetic",
         config=dict(workload=workload, samples_per_gpu=k_local, noise="device Philox4x32-10", device=info["name"],
-                    commit=git_commit(),
+                    commit=git_commit(), preheat_ms=args.preheat_ms,
                     collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
                                                         if args.collective == "native" else
                                                         "rccl all-gather via torch.distributed between the two phases")),

@@ -4,7 +4,7 @@
 # headline bench, the cfg5 (de Hoog) planner and one 8-GPU shard (K = 2048, fused body).
 #   NLC_COMMIT=$(git rev-parse --short HEAD) /usr/local/graft/bin/gpurun --timeout 1100 -- "NLC_COMMIT=$NLC_COMMIT tools/collect_profiles.sh r2"
 set -o pipefail
-TAG=${1:-r2x}
+TAG=${1:-r3x}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

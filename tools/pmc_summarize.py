@@ -15,7 +15,7 @@ import json
 import sys
 
 KEYS = ("gru_encode", "nl_plan_fused", "nl_rollout", "nl_repfunc", "ilt_fourier_bwd", "ilt_fourier", "ilt_dehoog", "perturb",
-        "weight_partial", "oracle_rollout", "rnn_encode", "rnn_rollout", "merge", "step_tail")
+        "weight_tile", "weight_rank", "weight_chunk", "weight_final", "oracle_rollout", "rnn_encode", "rnn_rollout", "merge", "step_tail")
 
 
 def short(name):
