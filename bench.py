@@ -320,7 +320,9 @@ def main():
     sd_cpu = {k: v.detach().cpu().to(torch.float64) for k, v in model.state_dict().items()}
     planner = nlc.MPPIDelay(
         nlc.NLDynamics(model, 0.05), nlc.EnvCost(ENV), d, nlc.noise_sigma(nu), num_samples=K_total, horizon=HORIZON,
-        device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A_HIGH), u_max=torch.tensor(A_HIGH), u_scale=A_HIGH,
+        # device="cpu": U and the returned action live on the host, as the harness's env.step needs them (the merge kernel
+        # stores the action straight into pinned host memory); every kernel runs on compute_device
+        device="cpu", compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A_HIGH), u_max=torch.tensor(A_HIGH), u_scale=A_HIGH,
         noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(HORIZON, nu, dtype=torch.float64),
         planner_options={"native_collective": int(args.collective == "native")},
     )

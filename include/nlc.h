@@ -89,6 +89,11 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
+ *   "host_spin"          nlc_mppi_finish with action_host (single planner): 1 (default) = the merge kernel stores a sequence
+ *                        number behind the action in pinned host memory and the host spins on that word (sub-microsecond
+ *                        hand-over, one busy core for the length of a command) instead of sleeping in hipStreamSynchronize
+ *                        (an interrupt wake-up: 10-20 us per command); 0 = hipStreamSynchronize.  After the call the action is
+ *                        valid; the stream may still be finishing omega / cost_nz (stream-ordered for every later call).
  *   "fused_blocks_per_cu"  fused body: the instance compiled for 3 (168 VGPRs) or 4 (128 VGPRs) workgroups per CU; 0 = auto
  *                        (3 while rollout chains sit on at most half of the CUs, else 4)
  *   "fused_inline"       fused body, single planner (E <= 1), bit mask: 1 = the importance-weight reduction (:210-216) runs

@@ -179,6 +179,13 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
       a.beta_eta[e * 2] = beta;
       a.beta_eta[e * 2 + 1] = eta;
     }
+    if (a.seq_pinned != nullptr) {
+      // the action words above have left this workgroup (every thread drains its stores, then the barrier); ONE
+      // system-scope store tells the spinning host that they are in its memory
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(a.seq_pinned, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   // cost_total_non_zero = exp(-(c - beta)/lambda) with the GLOBAL beta (_ensure_non_zero :12-13, :213) and omega (:214)
   if (threadIdx.x == 0) s_eta = eta;

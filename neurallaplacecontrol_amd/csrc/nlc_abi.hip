@@ -115,6 +115,9 @@ struct nlc_ctx {
   int opt_fused_blocks_per_cu = 0;      // 0 auto (3 while chains sit on at most half of the CUs, else 4), 3 or 4
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
   int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
+  int opt_host_spin = 1;                // nlc_mppi_finish with a host action pointer: spin on a pinned word the merge kernel
+                                        // stores (1) instead of hipStreamSynchronize (0)
+  unsigned long long host_seq = 0;      // sequence number of the last command handed to the spin protocol
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
   int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
   int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
@@ -468,6 +471,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
     c->opt_rollout_variant = (int)value;
     c->fused_lost = false;  // an explicit choice re-arms the fused body after a timeout
+  } else if (n == "host_spin") {
+    if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "host_spin must be 0 or 1");
+    c->opt_host_spin = (int)value;
   } else if (n == "fused_blocks_per_cu") {
     if (value != 0 && value != 3 && value != 4) return fail(c, NLC_ERR_BAD_ARG, "fused_blocks_per_cu must be 0 (auto), 3 or 4");
     c->opt_fused_blocks_per_cu = (int)value;
@@ -1973,7 +1979,28 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   // on the host's critical path is the stream synchronisation
   double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;
   m.action_pinned = action_host ? pin_act : nullptr;
+  // host wait: spin on a pinned sequence word (single planner) or hipStreamSynchronize
+  unsigned long long* seq_word = reinterpret_cast<unsigned long long*>(fused_timeout_word(c) + 1);
+  const bool spin = action_host && c->opt_host_spin && d.E == 1 && !c->profiling;
+  auto wait_for_action = [&]() -> int {
+    if (spin) {
+      const unsigned long long want = c->host_seq;
+      const volatile unsigned long long* w = seq_word;
+      for (unsigned long long it = 0; it < 400000000ull; ++it) {  // ~ seconds: then fall back to the runtime's wait
+        if (*w == want) return NLC_OK;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+    }
+    NLC_HIP(c, hipStreamSynchronize(c->stream));
+    return NLC_OK;
+  };
   auto launch_merge_now = [&]() -> int {
+    if (spin) {
+      m.seq_pinned = seq_word;
+      m.seq = ++c->host_seq;
+    }
     if (c->sync_dirty && buf->workspace) {
       // last launch of the command: leave the fused body's tickets / flags zeroed for the next one
       m.zero_words = reinterpret_cast<unsigned*>((double*)buf->workspace + ws_layout(c).sync);
@@ -1990,7 +2017,7 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   if (int rc = launch_merge_now()) return rc;
   if (action_host) {
     const size_t na = (size_t)d.E * d.u_per_command * d.nu;
-    NLC_HIP(c, hipStreamSynchronize(c->stream));
+    if (int rc = wait_for_action()) return rc;
     if (fused_gave_up(c)) {
       // A wave of the fused body gave up waiting for another workgroup of its launch (the device was not this planner's
       // alone, or fewer workgroups were resident than the host assumed): the command's result is not valid.  This ctx
@@ -2006,7 +2033,7 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
       m.U = c->U[c->ucur];
       if (gathered == nullptr || G == 1) m.gathered = buf->partials;
       if (int rc = launch_merge_now()) return rc;
-      NLC_HIP(c, hipStreamSynchronize(c->stream));
+      if (int rc = wait_for_action()) return rc;
     }
     std::memcpy(action_host, pin_act, na * sizeof(double));
   }

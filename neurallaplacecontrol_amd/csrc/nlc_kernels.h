@@ -398,6 +398,10 @@ struct MergeArgs {
   const double* cost;      // (E, Kep) total costs: cost_nz = exp(-(cost - beta)/lambda) with the merged beta
   unsigned* zero_words;    // words zeroed for the NEXT command (the fused planner body's sync block); may be NULL
   int64_t n_zero_words;
+  // single planner, host action wanted: after action_pinned the kernel stores `seq` here (pinned, system scope) -- the host
+  // spins on this word instead of sleeping in hipStreamSynchronize (an interrupt wake-up costs 10-20 us per command)
+  unsigned long long* seq_pinned;
+  unsigned long long seq;
 };
 hipError_t launch_merge(const MergeArgs& a, hipStream_t s);
 
