@@ -115,6 +115,7 @@ struct nlc_ctx {
   int opt_fused_blocks_per_cu = 0;      // 0 auto (3 while chains sit on at most half of the CUs, else 4), 3 or 4
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
   int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
+  double opt_fused_tile_step_ratio = 0.0;  // > 0: the adaptive partner rule (measured slower: profiles/r3_fused_small_shard.md); 0 = static schedule
   int opt_host_spin = 1;                // nlc_mppi_finish with a host action pointer: spin on a pinned word the merge kernel
                                         // stores (1) instead of hipStreamSynchronize (0)
   unsigned long long host_seq = 0;      // sequence number of the last command handed to the spin protocol
@@ -471,6 +472,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
     c->opt_rollout_variant = (int)value;
     c->fused_lost = false;  // an explicit choice re-arms the fused body after a timeout
+  } else if (n == "fused_tile_step_ratio") {
+    if (value < 0 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_tile_step_ratio must be in 0 .. 64 (0 = static schedule)");
+    c->opt_fused_tile_step_ratio = value;
   } else if (n == "host_spin") {
     if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "host_spin must be 0 or 1");
     c->opt_host_spin = (int)value;
@@ -1774,10 +1778,19 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
         const double m3 = f_chain <= 0.3125 ? 1.0 : 1.0 + 26.7 * (f_chain - 0.3125);
         auto_partner = (int)(1.0 + (m3 - 1.0) * (double)d.T / 40.0);
       }
+      // experiment (round 3, option "fused_tile_step_ratio" > 0): partners sleep unless the chain-free CUs alone would
+      // finish the remaining encoder tiles later than the chain finishes its remaining steps (the kernel's feedback
+      // rule).  Measured SLOWER than the static schedule at every K (K = 2048: 0.83 vs 0.67 ms): the rule balances the
+      // finishing times but not the ORDER -- the chains consume a horizon step per 11.5 us, the chain-free CUs produce one
+      // per 15 us, so the chains starve behind the encoder front while their partners sleep; default off.
+      const bool adaptive = c->opt_fused_partner_tiles == -2 && c->opt_fused_tile_step_ratio > 0.0;
+      fc.adaptive_q8 = adaptive ? (int)(256.0 * c->opt_fused_tile_step_ratio) : 0;
+      fc.pool_wgs = (ncu - fc.roll_cap) * bpc;
+      if (adaptive) auto_partner = 1;  // every partner encodes one tile first, then the rule decides
       fc.chain_first_tiles = c->opt_fused_chain_first_tiles >= 0 ? c->opt_fused_chain_first_tiles : 1;
       const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : auto_partner;
       // (sleepers need CUs without a chain to produce the latents the chains wait for)
-      fc.partner_tiles = fc.roll_cap <= ncu / 2 ? partner : -1;
+      fc.partner_tiles = (adaptive || fc.roll_cap <= ncu / 2) ? partner : -1;
       fc.spin_limit = (unsigned)c->opt_fused_spin_limit;
       fc.test_drop_tile = c->opt_fused_test_drop_tile;
       // Single planner: the weight reduction runs inside the launch, and with device noise and the command's inputs in

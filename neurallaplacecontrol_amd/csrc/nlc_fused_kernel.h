@@ -62,6 +62,9 @@ __device__ __forceinline__ void stamp_max(unsigned* w, bool complement) {
   const unsigned t = (unsigned)__builtin_amdgcn_s_memrealtime();
   __hip_atomic_fetch_max(w, complement ? ~t : t, NLC_RLX_AGENT);
 }
+// per-CU state word (kFusedCuState): 0 no chain, 2 the CU's chain has finished, >= kChainWalking: walking, at horizon step
+// (word - kChainWalking)
+constexpr unsigned kChainWalking = 16u;
 // GRU latents published by encoder workgroups of this launch (see the file header for the protocol)
 struct PaHandoff {
   __amdgpu_buffer_rsrc_t rsrc;  // over paT (T, K, 2)
@@ -76,6 +79,7 @@ struct PaHandoff {
   unsigned spin_limit;                       // ~2 us per poll once it naps; then give up (never hang the GPU)
   // in-launch sampling / weights (FusedCtl::inline_perturb / inline_weights)
   int inl, inw, nu;
+  unsigned* cu_state;         // this CU's state word when the chain was taken at the census (partners read it), else NULL
   bool w0;                    // this wave evaluates the costs (wave 0)
   const double* state_in;     // the command's state in the kernel-argument segment (inl)
   const double* U_old;        // control sequence BEFORE the shift (inl)
@@ -152,6 +156,8 @@ struct PaHandoff {
     if (wv == kPollWave && t + 1 < t_end && t + 1 >= ready_upto) wait(t + 1, t_end, lane);
   }
   __device__ __forceinline__ void after_barrier2(int t, int t_end, int64_t kc) {
+    // progress of this chain for its CU's sleeping partners (one relaxed store per horizon step, every lane the same word)
+    if (w0 && cu_state != nullptr) __hip_atomic_store(cu_state, kChainWalking + (unsigned)(t + 1), NLC_RLX_AGENT);
     if (NLC_FUSED_TRACE)  // trace build: when this chain entered the last third of step t
       __hip_atomic_store(sync + kFusedFlags + (int64_t)(T + 1 + t) * ntk + tile, (unsigned)__builtin_amdgcn_s_memrealtime() | 1u,
                          NLC_RLX_AGENT);
@@ -270,7 +276,7 @@ static __device__ __attribute__((noinline)) void fused_weight_tile(const WeightA
 static __device__ __attribute__((noinline)) void fused_weight_rank(const WeightArgs w, double* lds) { weight_rank<MemSc1>(w, 0, lds); }
 
 template <int HT, int NT3>
-__device__ __forceinline__ void fused_rollout(int tile, double* smem) {
+__device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* cu_state = nullptr) {
   constexpr int KS = HT * 4;
   const FusedArgs& a = *(const FusedArgs*)role_args();
   const int lane = threadIdx.x & 63;
@@ -289,6 +295,7 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem) {
   src.inl = a.ctl.inline_perturb;
   src.inw = a.ctl.inline_weights;
   src.nu = a.r.nu;
+  src.cu_state = cu_state;
   src.w0 = wv == 0;
   src.state_in = args_in_memory()->p.state_in;
   src.u_init = args_in_memory()->p.u_init;
@@ -344,10 +351,23 @@ __device__ __forceinline__ void fused_encode(double* smem, int max_tiles, int yi
   for (int done = 0; done < max_tiles; ++done) {
     if (wv == 0) {
       if (yield_cu >= 0 && done >= yield_after) {
-        // bounded (~50 ms): nothing depends on this wait for correctness
+        // A chain's CU partner (see the kernel).  While the chain walks (state >= kChainWalking + its horizon step) the
+        // partner sleeps -- an encoder wave beside a chain doubles the chain's step time -- UNLESS the workgroups on
+        // chain-free CUs could not finish the remaining encoder tiles before the chain is through anyway:
+        //   remaining tiles * (tile time / chain step time) > remaining chain steps * pool workgroups   -> help.
+        // (adaptive = the default schedule: both sides of the inequality shrink as the launch proceeds, so the two roles end
+        // together whatever their actual speeds; static schedules -- sleep after a fixed tile count -- for the A/B tools.)
+        // Bounded (~50 ms): nothing depends on this wait for correctness.
         for (unsigned spins = 0; spins < (1u << 14); ++spins) {
-          const unsigned st = __hip_atomic_load(sync + kFusedCuState + yield_cu, NLC_RLX_AGENT);
-          if (__builtin_amdgcn_readfirstlane(st) != 1u) break;
+          const unsigned st = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sync + kFusedCuState + yield_cu, NLC_RLX_AGENT));
+          if (st < kChainWalking) break;  // no chain here (any more)
+          if (a.ctl.adaptive_q8 > 0) {
+            const unsigned drawn = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sync + kFusedEncTicket, NLC_RLX_AGENT));
+            const long long rem_tiles = (long long)a.ctl.n_enc - (long long)drawn;
+            const long long rem_steps = (long long)a.r.T - (long long)(st - kChainWalking);
+            if (rem_tiles <= 0) break;  // nothing left to draw: fall through to the ticket (it ends the role)
+            if (rem_tiles * a.ctl.adaptive_q8 > rem_steps * a.ctl.pool_wgs * 256) break;  // the pool alone is too slow: help
+          }
           __builtin_amdgcn_s_sleep(127);
         }
       }
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(256, BPC) void nl_plan_fused_kernel(const FusedArgs
         // first when the encoder ticket is dry from the start, tiny K T)
         if (wave_ticket(sync + kFusedFlags + (int64_t)av.r.T * a.ntk + tk, lane) == 0) tile = (int)tk;
       }
-      if (tile >= 0) __hip_atomic_store(sync + kFusedCuState + cu, 1u, NLC_RLX_AGENT);  // this CU walks a chain
+      if (tile >= 0) __hip_atomic_store(sync + kFusedCuState + cu, kChainWalking, NLC_RLX_AGENT);  // this CU walks a chain
     }
     s_tile[0] = tile;  // every lane of wave 0 stores the same words
     s_tile[1] = (int)nth;
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256, BPC) void nl_plan_fused_kernel(const FusedArgs
       fused_encode<G>(smem, a.chain_first_tiles, -1, 0);
       __syncthreads();  // the GRU images in LDS are dead
     }
-    fused_rollout<HT, NT3>(tile, smem);
+    fused_rollout<HT, NT3>(tile, smem, sync + kFusedCuState + cu);
     __hip_atomic_store(sync + kFusedCuState + cu, 2u, NLC_RLX_AGENT);  // (all waves, same word) wakes this CU's sleeper
   }
 

@@ -437,6 +437,8 @@ struct FusedCtl {   // role assignment; passed to the kernel by value
   int partner_tiles;      // >= 0: the other workgroup of a chain's CU sleeps after this many tiles per wave until the chain
                           // is done; < 0: it never sleeps
   int roll_cap;    // rollout workgroups that start right away (one per CU); the other tiles drain after the encoders
+  int adaptive_q8; // > 0: partners sleep / help by the feedback rule of fused_encode; value = 256 * (tile time / chain step time)
+  int pool_wgs;    // workgroups on CUs without a chain (they encode throughout)
   int inline_perturb;  // 1: no perturb kernel ran -- encoder tile (t, j) samples / bounds the actions of its windows
                        // (FusedArgs::p, device Philox) and publishes perturbed / noise / actions of step t with its latents;
                        // the command's state and action_buffer are read from the kernel arguments (p.state_in / p.abuf_in)

@@ -7,6 +7,20 @@
 #include "nlc_envcost.h"
 #include "nlc_kernels.h"
 
+// hidden-layer activation of the representation MLP.  The short form of nlc_math.h (tanh_pair_fast: 20 % fewer FP64
+// instructions, 1.5e-13 absolute) was measured on one box against the few-ulp tanh_pair_d (round 3, tools/bench_ab.sh with
+// -DNLC_HIDDEN_TANH_FAST=1): nl_rollout_kernel 1.234 -> 1.223 ms at K = 16384 (-0.25 % of the command), but the fused
+// small-shard body 0.673 -> 0.687 ms at K = 2048 under every static schedule (+2 %): the chains are latency-bound, not
+// instruction-bound.  Not shipped.
+#ifndef NLC_HIDDEN_TANH_FAST
+#define NLC_HIDDEN_TANH_FAST 0
+#endif
+#if NLC_HIDDEN_TANH_FAST
+#define NLC_HIDDEN_TANH_PAIR m::tanh_pair_fast
+#else
+#define NLC_HIDDEN_TANH_PAIR m::tanh_pair_d
+#endif
+
 namespace nlc {
 
 // ------------------------------------------------------------------ one model evaluation
@@ -81,7 +95,7 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
       double ta, tb;
-      m::tanh_pair_d(h1[j][r], h1[j][r + 1], &ta, &tb);
+      NLC_HIDDEN_TANH_PAIR(h1[j][r], h1[j][r + 1], &ta, &tb);
       h1[j][r] = ta;
       h1[j][r + 1] = tb;
     }
@@ -95,7 +109,7 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
       double ta, tb;
-      m::tanh_pair_d(h2[j][r], h2[j][r + 1], &ta, &tb);
+      NLC_HIDDEN_TANH_PAIR(h2[j][r], h2[j][r + 1], &ta, &tb);
       h2[j][r] = ta;
       h2[j][r + 1] = tb;
     }
@@ -259,7 +273,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           double ta, tb;
-          m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+          NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
           H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
           H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
         }
@@ -295,7 +309,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           double ta, tb;
-          m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+          NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
           H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
           H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
         }
@@ -476,7 +490,7 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         double ta, tb;
-        m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+        NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
         H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
         H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
       }
@@ -511,7 +525,7 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         double ta, tb;
-        m::tanh_pair_d(acc[i][r], acc[i][r + 1], &ta, &tb);
+        NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
         H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
         H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
       }

@@ -42,3 +42,10 @@ void nlc_t_sin_mpio2(const double* x, double* y, long n) {
   }
 }
 }
+extern "C" {
+// round 3: the rollout kernels' hidden-layer activation (instruction count over ulps): pairs (x[i], x[i + 1])
+void nlc_t_tanh_pair_fast(const double* x, double* y, long n) {
+  for (long i = 0; i + 1 < n; i += 2) nlc::m::tanh_pair_fast(x[i], x[i + 1], &y[i], &y[i + 1]);
+  if (n & 1) { double t; nlc::m::tanh_pair_fast(x[n - 1], 0.0, &y[n - 1], &t); }
+}
+}

@@ -18,6 +18,10 @@ for rep in range(int(os.environ.get("AB_REPS", "2"))):
         opts = {"rollout_variant": 3}
         if os.environ.get("AB_CAP"):
             opts["fused_roll_cap"] = int(os.environ["AB_CAP"])
+        if os.environ.get("AB_RATIO"):
+            opts["fused_tile_step_ratio"] = float(os.environ["AB_RATIO"])
+        if os.environ.get("AB_BPC"):
+            opts["fused_blocks_per_cu"] = int(os.environ["AB_BPC"])
         if own != "none":
             opts["fused_chain_first_tiles"] = int(own.split("x")[0])
             opts["fused_partner_tiles"] = int(own.split("x")[1])
@@ -50,5 +54,5 @@ for rep in range(int(os.environ.get("AB_REPS", "2"))):
         p.ctx.profile(False)
         prof = p.ctx.profile_read()
         k = prof["nl_plan_fused_kernel"]
-        print(json.dumps(dict(lib=os.environ.get("NLC_LIB_PATH", "tree"), K=K, own=own, ms_per_command=round(ms, 4),
+        print(json.dumps(dict(ratio=os.environ.get("AB_RATIO"), bpc=os.environ.get("AB_BPC"), K=K, own=own, ms_per_command=round(ms, 4),
                               fused_ms=round(k["total_ms"] / k["launches"], 4))), flush=True)
