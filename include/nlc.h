@@ -89,6 +89,13 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
+ *   "dehoog_streams"     staged de Hoog planner (NLC_ILT_DEHOOG models): the population is cut into this many contiguous parts
+ *                        whose per-step launches run on streams of their own -- one part's FP64-VALU-bound QD pass beside
+ *                        another part's MFMA-bound representation launch; 0 = auto (2 from 8192 samples), 1 = one stream.
+ *                        Same bits for every value.
+ *   "dehoog_gru_chunks"  the same planner: GRU encode in this many horizon chunks on a further stream, beside the step chain
+ *                        (cooperative kernel at reduced occupancy, "dehoog_gru_lds_pad" bytes of unused LDS); 0 / 1 (default):
+ *                        one launch up front -- measured no faster (the chip is busy either way).
  *   "host_spin"          nlc_mppi_finish with action_host (single planner): 1 (default) = the merge kernel stores a sequence
  *                        number behind the action in pinned host memory and the host spins on that word (sub-microsecond
  *                        hand-over, one busy core for the length of a command) instead of sleeping in hipStreamSynchronize

@@ -72,17 +72,20 @@ __global__ __launch_bounds__(256, G <= 64 ? 4 : 2) void gru_encode_coop_kernel(c
   }
 }
 
-hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop) {
+// lds_pad_bytes (cooperative form only): unused dynamic LDS that lowers the kernel's occupancy, for launches that are
+// meant to SHARE the CUs with another stream's kernels (the staged de Hoog planner encodes later horizon chunks beside its
+// step chain: two encoder workgroups per CU instead of four leave registers and issue slots for the chain's kernels)
+hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop, unsigned lds_pad_bytes) {
   if (a.N <= 0) return hipSuccess;
   if (coop) {
     const int64_t tiles = (a.N + 15) / 16;
     const dim3 cgrid((unsigned)(tiles < 65536 ? tiles : 65536));
     if (g == 64) {
-      hipLaunchKernelGGL(gru_encode_coop_kernel<64>, cgrid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gru_encode_coop_kernel<64>, cgrid, dim3(256), lds_pad_bytes, s, a);
     } else if (g == 32) {
-      hipLaunchKernelGGL(gru_encode_coop_kernel<32>, cgrid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gru_encode_coop_kernel<32>, cgrid, dim3(256), lds_pad_bytes, s, a);
     } else if (g == 128) {
-      hipLaunchKernelGGL(gru_encode_coop_kernel<128>, cgrid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gru_encode_coop_kernel<128>, cgrid, dim3(256), lds_pad_bytes, s, a);
     } else {
       return hipErrorInvalidValue;
     }

@@ -115,6 +115,14 @@ struct nlc_ctx {
   int opt_fused_blocks_per_cu = 0;      // 0 auto (3 while chains sit on at most half of the CUs, else 4), 3 or 4
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
   int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
+  int opt_dehoog_gru_chunks = 0;        // staged de Hoog planner: GRU encode in this many horizon chunks beside the step chain (0 / 1: one launch up front)
+  int opt_dehoog_gru_lds_pad = 49152;   // unused dynamic LDS of those chunk launches (bytes): 32 KB + 48 KB -> two workgroups per CU
+  hipStream_t gru_stream = nullptr;
+  std::vector<hipEvent_t> ev_gru;
+  int opt_dehoog_streams = 0;           // staged de Hoog planner: parts of the population on streams of their own (0 auto)
+  std::vector<hipStream_t> aux_streams;
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_join;
   double opt_fused_tile_step_ratio = 0.0;  // > 0: the adaptive partner rule (measured slower: profiles/r3_fused_small_shard.md); 0 = static schedule
   int opt_host_spin = 1;                // nlc_mppi_finish with a host action pointer: spin on a pinned word the merge kernel
                                         // stores (1) instead of hipStreamSynchronize (0)
@@ -451,6 +459,11 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   if (c->small) hipFree(c->small);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->stage_ev) hipEventDestroy(c->stage_ev);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (hipEvent_t e : c->ev_join) hipEventDestroy(e);
+  for (hipStream_t s2 : c->aux_streams) hipStreamDestroy(s2);
+  for (hipEvent_t e : c->ev_gru) hipEventDestroy(e);
+  if (c->gru_stream) hipStreamDestroy(c->gru_stream);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   hipStreamDestroy(c->own_stream);
   delete c;
@@ -472,6 +485,15 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
     c->opt_rollout_variant = (int)value;
     c->fused_lost = false;  // an explicit choice re-arms the fused body after a timeout
+  } else if (n == "dehoog_gru_chunks") {
+    if (value < 0 || value > 8 || value != (int)value) return fail(c, NLC_ERR_BAD_ARG, "dehoog_gru_chunks must be 0 .. 8");
+    c->opt_dehoog_gru_chunks = (int)value;
+  } else if (n == "dehoog_gru_lds_pad") {
+    if (value < 0 || value > 120000) return fail(c, NLC_ERR_BAD_ARG, "dehoog_gru_lds_pad must be in 0 .. 120000 bytes");
+    c->opt_dehoog_gru_lds_pad = (int)value;
+  } else if (n == "dehoog_streams") {
+    if (value < 0 || value > 4 || value != (int)value) return fail(c, NLC_ERR_BAD_ARG, "dehoog_streams must be 0 (auto), 1, 2, 3 or 4");
+    c->opt_dehoog_streams = (int)value;
   } else if (n == "fused_tile_step_ratio") {
     if (value < 0 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_tile_step_ratio must be in 0 .. 64 (0 = static schedule)");
     c->opt_fused_tile_step_ratio = value;
@@ -1637,15 +1659,45 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     if (c->md.ilt.algo == NLC_ILT_DEHOOG) {
       // staged de Hoog planner path (BASELINE configs[4]): hoisted GRU, then per horizon step three launches --
       // representation function -> F_k, de Hoog ILT -> dx, state/cost tail.  Everything stays on the device.
-      g.t0 = 0;
-      g.Tc = d.T;
-      g.N = KE * d.T;
-      {
+      // GRU encode: one launch up front, or (round 3, option "dehoog_gru_chunks" C > 1) C horizon chunks on a stream of
+      // their own that run BESIDE the step chain -- the chain's launches wait for the chunk that holds their horizon step.
+      // The chunks use the cooperative kernel at reduced occupancy (lds_pad) so that the chain's workgroups find room.
+      int C = d.E == 1 ? c->opt_dehoog_gru_chunks : 1;
+      if (C == 0) C = 1;  // auto: off
+      if (C > d.T) C = d.T;
+      if (C > 8) C = 8;
+      const int Tc = (d.T + C - 1) / C;
+      if (C == 1) {
+        g.t0 = 0;
+        g.Tc = d.T;
+        g.N = KE * d.T;
         ProfScope ps(c, "gru_encode_kernel");
         NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
       }
       double* tconst = ws + w.tconst;
       NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      if (C > 1) {
+        if (!c->gru_stream) NLC_HIP(c, hipStreamCreateWithFlags(&c->gru_stream, hipStreamNonBlocking));
+        if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        while ((int)c->ev_gru.size() < C) {
+          hipEvent_t e2 = nullptr;
+          NLC_HIP(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+          c->ev_gru.push_back(e2);
+        }
+        NLC_HIP(c, hipEventRecord(c->ev_fork, c->stream));  // behind the perturb kernel and the staged inputs
+        NLC_HIP(c, hipStreamWaitEvent(c->gru_stream, c->ev_fork, 0));
+        for (int ch = 0; ch < C; ++ch) {
+          g.t0 = ch * Tc;
+          g.Tc = (g.t0 + Tc <= d.T) ? Tc : d.T - g.t0;
+          if (g.Tc <= 0) break;
+          g.N = KE * g.Tc;
+          {
+            ProfScope ps(c, "gru_encode_kernel", c->gru_stream, true);
+            NLC_HIP(c, launch_gru_encode(g, c->g, c->gru_stream, true, (unsigned)c->opt_dehoog_gru_lds_pad));
+          }
+          NLC_HIP(c, hipEventRecord(c->ev_gru[ch], c->gru_stream));
+        }
+      }
       RepFuncArgs rf{};
       rf.net = r.net;
       rf.N = KE;
@@ -1685,31 +1737,107 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
       st.states = buf->states;
       st.cost_total = buf->cost_total;
       // two launches per horizon step: [tail of step t-1 +] representation function -> F, then de Hoog -> dx; the tail
-      // of the LAST step is a launch of its own
-      for (int t = 0; t < d.T; ++t) {
-        rf.obs = state_dev;
-        rf.obs_per_sample = (t == 0) ? state_per_sample : 1;
-        rf.pa = pa + (size_t)t * 2;
-        rf.tail_prev = t > 0;
-        if (t > 0) {
-          rf.tail = st;
-          rf.tail.t = t - 1;
-          rf.tail.first = t - 1 == 0;
-          rf.tail.last = 0;
+      // of the LAST step is a launch of its own.
+      // Round 3: the population is cut into P contiguous parts (multiples of 64 samples) whose 2 T + 1 launches run on P
+      // streams.  A sample's chain never leaves its part, so the parts need no ordering among themselves, and the two
+      // kernels of a step bound different pipes -- the representation launch the FP64 MFMA (util 0.42: dependent layers),
+      // the QD launch the FP64 VALU at 1.25 wavefronts per SIMD (active 0.39) -- so while one part's QD pass runs, another
+      // part's representation launch fills the matrix pipe (option "dehoog_streams": 1 = one stream, as before).
+      int P = d.E == 1 ? c->opt_dehoog_streams : 1;
+      if (P == 0) P = KE >= 8192 ? 2 : 1;  // auto
+      if (P > 4) P = 4;
+      while (P > 1 && KE / P < 1024) --P;
+      if (P > 1) {
+        while ((int)c->aux_streams.size() < P - 1) {
+          hipStream_t s2 = nullptr;
+          NLC_HIP(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+          c->aux_streams.push_back(s2);
         }
-        {
-          ProfScope ps(c, "nl_repfunc_kernel");
-          NLC_HIP(c, launch_nl_repfunc(rf, c->stream));
+        if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        while ((int)c->ev_join.size() < P - 1) {
+          hipEvent_t e2 = nullptr;
+          NLC_HIP(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+          c->ev_join.push_back(e2);
         }
-        ProfScope ps(c, "ilt_dehoog_kernel");
-        NLC_HIP(c, launch_ilt_dehoog(ia, c->stream));
+        NLC_HIP(c, hipEventRecord(c->ev_fork, c->stream));  // behind the GRU encode and the staged inputs
+        for (int h = 1; h < P; ++h) NLC_HIP(c, hipStreamWaitEvent(c->aux_streams[h - 1], c->ev_fork, 0));
       }
-      st.t = d.T - 1;
-      st.first = d.T == 1;
-      st.last = 1;
+      // part h: samples [off_h, off_h + n_h)
+      int64_t off_h[4], n_h[4];
       {
-        ProfScope ps(c, "step_tail_kernel");
-        NLC_HIP(c, launch_step_tail(st, c->stream));
+        const int64_t per = ((KE / P) + 63) / 64 * 64;
+        for (int h = 0; h < P; ++h) {
+          off_h[h] = (int64_t)h * per < KE ? (int64_t)h * per : KE;
+          n_h[h] = (h == P - 1) ? KE - off_h[h] : (off_h[h] + per <= KE ? per : KE - off_h[h]);
+        }
+      }
+      const size_t f_per_sample = 8 * (size_t)c->net.nt3;
+      auto part = [&](int h, RepFuncArgs& rfp, IltArgs& iap, StepTailArgs& stp) {
+        const int64_t o = off_h[h], n = n_h[h];
+        stp = st;
+        stp.K = n;
+        stp.Kep = P > 1 ? n : d.K;
+        stp.state0 = state_dev + (state_per_sample ? o * d.d : 0);
+        stp.x = st.x + o * d.d;
+        stp.dx = st.dx + o * d.d;
+        stp.ccarry = st.ccarry + o * 2;
+        stp.perturbed = st.perturbed + o * d.T * d.nu;
+        stp.noise = st.noise + o * d.T * d.nu;
+        stp.states = st.states ? st.states + o * d.T * d.d : nullptr;
+        stp.cost_total = st.cost_total + o;
+        rfp = rf;
+        rfp.N = n;
+        rfp.Kep = stp.Kep;
+        rfp.fre = rf.fre + (size_t)o * f_per_sample;  // slot-major (8 nt3, n) block of the part
+        rfp.fim = rf.fim + (size_t)o * f_per_sample;
+        iap = ia;
+        iap.N = n;
+        iap.x = ia.x + o * d.d;
+        iap.fre = rfp.fre;
+        iap.fim = rfp.fim;
+      };
+      RepFuncArgs rfs[4];
+      IltArgs ias[4];
+      StepTailArgs sts[4];
+      for (int h = 0; h < P; ++h) part(h, rfs[h], ias[h], sts[h]);
+      for (int t = 0; t < d.T; ++t) {
+        for (int h = 0; h < P; ++h) {
+          if (n_h[h] <= 0) continue;
+          hipStream_t sh = h == 0 ? c->stream : c->aux_streams[h - 1];
+          if (C > 1 && t % Tc == 0) NLC_HIP(c, hipStreamWaitEvent(sh, c->ev_gru[t / Tc], 0));  // latents of this chunk
+          RepFuncArgs& rp = rfs[h];
+          rp.obs = sts[h].state0;
+          rp.obs_per_sample = (t == 0) ? state_per_sample : 1;
+          rp.pa = pa + ((size_t)off_h[h] * d.T + (size_t)t) * 2;
+          rp.tail_prev = t > 0;
+          if (t > 0) {
+            rp.tail = sts[h];
+            rp.tail.t = t - 1;
+            rp.tail.first = t - 1 == 0;
+            rp.tail.last = 0;
+          }
+          {
+            ProfScope ps(c, "nl_repfunc_kernel", sh, true);
+            NLC_HIP(c, launch_nl_repfunc(rp, sh));
+          }
+          ProfScope ps(c, "ilt_dehoog_kernel", sh, true);
+          NLC_HIP(c, launch_ilt_dehoog(ias[h], sh));
+        }
+      }
+      for (int h = 0; h < P; ++h) {
+        if (n_h[h] <= 0) continue;
+        hipStream_t sh = h == 0 ? c->stream : c->aux_streams[h - 1];
+        sts[h].t = d.T - 1;
+        sts[h].first = d.T == 1;
+        sts[h].last = 1;
+        {
+          ProfScope ps(c, "step_tail_kernel", sh, true);
+          NLC_HIP(c, launch_step_tail(sts[h], sh));
+        }
+        if (h > 0) {
+          NLC_HIP(c, hipEventRecord(c->ev_join[h - 1], sh));
+          NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+        }
       }
       return d.cost_external ? NLC_OK : run_weights(c, buf);
     }

@@ -103,7 +103,7 @@ struct GruArgs {
   double bo[2];
   double* out;  // (N, 2)
 };
-hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop = false);
+hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop = false, unsigned lds_pad_bytes = 0);
 
 // ------------------------------------------------------------------ Delta-t RNN baseline (train_utils.py:589-631)
 // One-layer forward GRU over the action window (hidden H) + the hidden part of linear_out: q = W_out[:, :H] h_last.

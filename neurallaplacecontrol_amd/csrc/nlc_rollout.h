@@ -440,14 +440,13 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
       double xs[NLC_MAX_D];
 #pragma unroll
       for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
-      if (valid) {
-        if (i0 < d) s.x[k * d + i0] = x0;
-        if (i1 < d) s.x[k * d + i1] = x1;
-        if (s.states != nullptr) {
-          if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
-          if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
-        }
+      if (valid && s.states != nullptr) {
+        if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
+        if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
       }
+      // (the carried state s.x is stored BEHIND the first barrier below: the other three waves read it above, and a
+      // store from here could overtake their loads -- seen as wrong states from the third horizon step on once another
+      // stream's kernels shared the CUs, round 3)
       if (q == 0 && valid) {
         double u[NLC_MAX_NU] = {0.0, 0.0};
         for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
@@ -496,6 +495,10 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
       }
   }
   __syncthreads();
+  if (a.tail_prev && wv == 0 && valid) {  // every wave has read the previous state: now it may be replaced
+    if (i0 < d) a.tail.x[k * d + i0] = x0;
+    if (i1 < d) a.tail.x[k * d + i1] = x1;
+  }
   // ---- layer 2
   {
     v4d acc[TW];

@@ -1663,6 +1663,38 @@ dist.destroy_process_group()
 """
 
 
+def test_dehoog_planner_parts_on_streams_bit_identical(nlc):
+    """Staged de Hoog planner, round 3: the population cut into P contiguous parts whose launches run on P streams
+    (`dehoog_streams`).  A sample's chain never leaves its part and no kernel's per-sample arithmetic depends on the launch
+    shape, so P = 1 / 2 / 3 / 4 must give the same bits -- states, costs, weights, action -- over consecutive commands; ragged
+    K (the last part is shorter, a part boundary inside a 64-sample QD block is impossible by construction)."""
+    from oracle import nl_model as onl
+
+    env, K, T, S = "oderl-cartpole", 4416 + 37, 9, 33
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(6, d, nu, 128, S, st["state_std"], [A / 2], tame="dehoog")
+    model = build_model(nlc, sd, S=S, algo="dehoog")
+    planners = {P: nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                                 u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=4,
+                                 U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"dehoog_streams": P})
+                for P in (1, 2, 3, 4)}
+    # + the GRU encode in horizon chunks on a stream of its own, beside the chains (cooperative kernel: same bits)
+    planners[5] = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                                u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=4,
+                                U_init=torch.zeros(T, nu, dtype=torch.float64),
+                                planner_options={"dehoog_streams": 2, "dehoog_gru_chunks": 4})
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    for step in range(3):
+        acts = {P: p.command(state, ab) for P, p in planners.items()}
+        for P in (2, 3, 4, 5):
+            assert torch.equal(acts[1], acts[P]), (P, step)
+            for attr in ("states", "cost_total", "omega", "U", "perturbed_action"):
+                assert torch.equal(getattr(planners[1], attr), getattr(planners[P], attr)), (P, attr, step)
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = acts[1]
+
+
 def test_repfunc_split_kernel_agrees_with_wave_per_tile_planner(nlc):
     """Staged de Hoog planner: the latency-split representation launch (one workgroup per 16-sample tile) against the
     wave-per-tile one -- same GEMM order per output tile and the same sphere map, so the two agree to rounding of the
