@@ -263,9 +263,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
-    ap.add_argument("--collective", choices=("torch", "native"), default="native",
+    ap.add_argument("--collective", choices=("auto", "torch", "native"), default="auto",
                     help="N > 1: the per-command all-gather inside nlc_mppi_finish on the library's own RCCL communicator "
-                         "(include/nlc.h, nlc_comm_init; default) or through torch.distributed between the two phases")
+                         "(include/nlc.h, nlc_comm_init) or through torch.distributed between the two phases; auto (default) "
+                         "= the library's, falling back to torch's if any rank cannot bring the communicator up")
+    ap.add_argument("--planner-opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="extra planner_options entries (experiments), e.g. --planner-opt host_spin=0")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed commands for this long during set-up (clock ramp from idle), before the W warm-up steps")
     ap.add_argument("--dry-launch", action="store_true",
@@ -324,7 +327,8 @@ def main():
         # stores the action straight into pinned host memory); every kernel runs on compute_device
         device="cpu", compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A_HIGH), u_max=torch.tensor(A_HIGH), u_scale=A_HIGH,
         noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(HORIZON, nu, dtype=torch.float64),
-        planner_options={"native_collective": int(args.collective == "native")},
+        planner_options=dict({} if args.collective == "auto" else {"native_collective": int(args.collective == "native")},
+                             **{kv.split("=", 1)[0]: float(kv.split("=", 1)[1]) for kv in args.planner_opt}),
     )
     state = nlc.initial_state(ENV, torch.Generator().manual_seed(0))
     abuf = torch.zeros(ABUF, nu, dtype=torch.float64)
@@ -496,7 +500,7 @@ def main():
         config=dict(workload=workload, samples_per_gpu=k_local, noise="device Philox4x32-10", device=info["name"],
                     commit=git_commit(), preheat_ms=args.preheat_ms,
                     collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
-                                                        if args.collective == "native" else
+                                                        if planner.native_collective else
                                                         "rccl all-gather via torch.distributed between the two phases")),
         roofline=roofline,
         roofline_ilt=ilt,
