@@ -58,6 +58,14 @@ __device__ __forceinline__ cplx csqrt_(cplx z) {
 // FMODE 2 (planner path): F is SLOT-major (8*nt3, N) as the representation kernel's MFMA epilogue stores it; a wavefront
 // owns 64 consecutive samples of ONE dim, so term k of its rows is one full 512-B line -- no LDS, no barrier, and the
 // kernel reads exactly the bytes it needs (row-major rows of 33 doubles straddle the 17-term chunks: 1.8x the traffic).
+// Round 3, the 1.8x re-read of the row-major modes -- two single-read forms were built and measured on
+// N = 655 360, d = 5, S = 33 (1.31 ms, 3.17 GB at the fabric counter as shipped): staging by ROW GROUPS (the flat 32-row half
+// of the block read once, coalesced, through the same 17 KB of LDS) with (a) all S terms of a lane's row pulled into
+// registers: 256 VGPRs, 104 spilled, 1.54 ms and 0.7 GB of scratch WRITES per launch; (b) only the high terms M + 1 .. 2M in
+// registers and the low ones back in LDS: 168 spilled.  The pending terms and the growing QD diagonal do fit one budget on
+// paper (at most 2M complex together), but not in the allocator's hands, and a full LDS image (34 KB per wavefront) means
+// one wave per SIMD, i.e. the FP64 VALU -- the kernel's actual bound -- at half rate.  The chunked form stays; the planner
+// path (FMODE 2) reads exactly its bytes.
 template <int M, int CH, int W, int FMODE>
 __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
   constexpr int S = 2 * M + 1;
