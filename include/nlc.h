@@ -89,6 +89,13 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
+ *   "horizon_chunks"     Fourier planner, wave-per-tile body (more than 8192 local samples): the GRU encode in this many horizon
+ *                        chunks on a low-priority stream of its own, each chunk's rollout launch behind its event, so that the
+ *                        encoder of later steps runs beside the rollout of earlier ones (one wave of each kernel fits a SIMD:
+ *                        216 + 288 VGPRs).  1 (default) = one encode launch, one rollout launch.  Same bits for every value;
+ *                        measured 4.224 vs 4.270 ms at 3 chunks (K = 16384) -- the two kernels leave each other little to fill
+ *                        (95 % / 85 % of the issue slots busy), and per-launch times of overlapped kernels say nothing about
+ *                        either, so the default and the reported roofline stay with the two plain launches.
  *   "dehoog_streams"     staged de Hoog planner (NLC_ILT_DEHOOG models): the population is cut into this many contiguous parts
  *                        whose per-step launches run on streams of their own -- one part's FP64-VALU-bound QD pass beside
  *                        another part's MFMA-bound representation launch; 0 = auto (2 from 8192 samples), 1 = one stream.

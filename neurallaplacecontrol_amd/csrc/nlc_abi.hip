@@ -115,6 +115,7 @@ struct nlc_ctx {
   int opt_fused_blocks_per_cu = 0;      // 0 auto (3 while chains sit on at most half of the CUs, else 4), 3 or 4
   bool fused_lost = false;              // a fused command gave up (hand-off timeout): later commands take the two-launch body
   int64_t fused_fallbacks = 0;          // commands re-run on the two-launch body after such a timeout
+  int opt_horizon_chunks = 1;           // Fourier planner, wave-per-tile body (K > 8192): GRU encode of later horizon chunks beside the rollout of earlier ones
   int opt_dehoog_gru_chunks = 0;        // staged de Hoog planner: GRU encode in this many horizon chunks beside the step chain (0 / 1: one launch up front)
   int opt_dehoog_gru_lds_pad = 49152;   // unused dynamic LDS of those chunk launches (bytes): 32 KB + 48 KB -> two workgroups per CU
   hipStream_t gru_stream = nullptr;
@@ -485,6 +486,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 3) return fail(c, NLC_ERR_BAD_ARG, "rollout_variant must be 0 (auto), 1, 2 or 3");
     c->opt_rollout_variant = (int)value;
     c->fused_lost = false;  // an explicit choice re-arms the fused body after a timeout
+  } else if (n == "horizon_chunks") {
+    if (value < 1 || value > 8 || value != (int)value) return fail(c, NLC_ERR_BAD_ARG, "horizon_chunks must be 1 .. 8");
+    c->opt_horizon_chunks = (int)value;
   } else if (n == "dehoog_gru_chunks") {
     if (value < 0 || value > 8 || value != (int)value) return fail(c, NLC_ERR_BAD_ARG, "dehoog_gru_chunks must be 0 .. 8");
     c->opt_dehoog_gru_chunks = (int)value;
@@ -1949,17 +1953,63 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
       if (fc.inline_weights) return NLC_OK;
     } else {
       if (int rc = launch_shift_perturb()) return rc;
-      g.t0 = 0;
-      g.Tc = d.T;
-      g.N = KE * d.T;
-      {
-        ProfScope ps(c, "gru_encode_kernel");
-        NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
+      // Horizon chunks (round 3, option "horizon_chunks"): the encoder input does not depend on the state, so the GRU
+      // encode of horizon steps [c Tc, (c + 1) Tc) can run on a stream of its own while the rollout walks the chunk before
+      // it.  The two kernels bound different things -- the encoder the FP64 MFMA pipe (95 % busy, two waves per SIMD), the
+      // wave-per-tile rollout the latency of ONE wave per SIMD (85 % busy) -- and since round 3 one wave of each fits a
+      // SIMD's registers (216 + 288 <= 512), so the encoder fills the rollout's issue bubbles.  State and cost sums travel
+      // between the rollout's chunk launches in xcarry / ccarry: same bits as the single launch.
+      int C = (variant != 2 && KE > 8192 && d.E == 1) ? c->opt_horizon_chunks : 1;
+      if (C < 1) C = 1;
+      if (C > d.T) C = d.T;
+      if (C > 8) C = 8;
+      if (C == 1) {
+        g.t0 = 0;
+        g.Tc = d.T;
+        g.N = KE * d.T;
+        {
+          ProfScope ps(c, "gru_encode_kernel");
+          NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
+        }
+        r.t_begin = 0;
+        r.t_end = d.T;
+        ProfScope ps(c, "nl_rollout_kernel");
+        NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
+      } else {
+        const int Tc = (d.T + C - 1) / C;
+        if (!c->gru_stream) {
+          int lo = 0, hi = 0;
+          (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = lowest priority: the rollout's workgroups go first
+          NLC_HIP(c, hipStreamCreateWithPriority(&c->gru_stream, hipStreamNonBlocking, lo));
+        }
+        if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        while ((int)c->ev_gru.size() < C) {
+          hipEvent_t e2 = nullptr;
+          NLC_HIP(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+          c->ev_gru.push_back(e2);
+        }
+        NLC_HIP(c, hipEventRecord(c->ev_fork, c->stream));  // behind the perturb kernel and the staged inputs
+        NLC_HIP(c, hipStreamWaitEvent(c->gru_stream, c->ev_fork, 0));
+        for (int ch = 0; ch < C; ++ch) {
+          g.t0 = ch * Tc;
+          g.Tc = (g.t0 + Tc <= d.T) ? Tc : d.T - g.t0;
+          if (g.Tc <= 0) break;
+          g.N = KE * g.Tc;
+          {
+            ProfScope ps(c, "gru_encode_kernel", c->gru_stream, true);
+            NLC_HIP(c, launch_gru_encode(g, c->g, c->gru_stream, false));
+          }
+          NLC_HIP(c, hipEventRecord(c->ev_gru[ch], c->gru_stream));
+        }
+        for (int ch = 0; ch < C; ++ch) {
+          r.t_begin = ch * Tc;
+          r.t_end = (r.t_begin + Tc <= d.T) ? r.t_begin + Tc : d.T;
+          if (r.t_begin >= r.t_end) break;
+          NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_gru[ch], 0));
+          ProfScope ps(c, "nl_rollout_kernel");
+          NLC_HIP(c, launch_nl_rollout(r, c->stream, 1));
+        }
       }
-      r.t_begin = 0;
-      r.t_end = d.T;
-      ProfScope ps(c, "nl_rollout_kernel");
-      NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
     }
   } else if (d.dynamics == NLC_DYN_NODE) {
     NodeRolloutArgs r{};

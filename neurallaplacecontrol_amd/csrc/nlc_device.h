@@ -64,6 +64,33 @@ __device__ __forceinline__ void gemm_acc(v4d (&acc)[MT], const double* __restric
   }
 }
 
+// The same for MT consecutive output tiles m0 .. m0 + MT - 1 of a matrix packed with MTOT tiles per k-step (a layer's output
+// tiles processed in two halves: half the accumulators and half the prefetch registers live at a time; per tile the
+// MFMA sequence over k is unchanged, so the results are the same bits).
+template <int MT, int MTOT, int KS, typename BF>
+__device__ __forceinline__ void gemm_acc_part(v4d (&acc)[MT], const double* __restrict__ Wp, int m0, int lane, BF bfrag) {
+  double a_cur[MT], a_nxt[MT];
+  gptr p = opaque(Wp + (size_t)m0 * 64);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_cur[m] = p[m * 64 + lane];
+  double b_cur = bfrag(0), b_nxt = 0.0;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+      p = opaque(p + MTOT * 64);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_nxt[m] = p[m * 64 + lane];
+      b_nxt = bfrag(ks + 1);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = mfma(a_cur[m], b_cur, acc[m]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    b_cur = b_nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // bias tile: lane (q = lane >> 4) reg r holds feature 16 j + 4 r + q
 __device__ __forceinline__ v4d load_bias_tile(const double* __restrict__ b, int j, int q) {
   const double* p = b + 16 * j + q;

@@ -3,6 +3,8 @@
 // rollout of one 16-sample tile by the four waves of a workgroup (rollout_split_tile).  Reference call sites and the
 // dataflow are described at the top of kernels_nl.hip.
 #pragma once
+#include <type_traits>
+
 #include "nlc_device.h"
 #include "nlc_envcost.h"
 #include "nlc_kernels.h"
@@ -114,45 +116,61 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
       h2[j][r + 1] = tb;
     }
 
-  v4d o[NT3];
-#pragma unroll
-  for (int j = 0; j < NT3; ++j) o[j] = load_bias_tile(n.b3p, j, q);
-  gemm_acc<NT3, KS>(o, n.W3p, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
-
-  // sphere -> complex, keep the component the Fourier phase i^k selects, then sum over k by MFMA
+  // Layer 3 in two halves of its output tiles (round 3): half the accumulators and prefetch registers live at a time --
+  // the wave-per-tile rollout kernel drops under 256 VGPRs, so one of its waves fits a SIMD beside a GRU-encoder wave
+  // (horizon chunks of the two kernels running side by side, nlc_abi.hip).  Same MFMA sequence per tile, same ILT sum
+  // order: same bits.
   v4d ax[1];
   ax[0] = splat(0.0);
   gptr cp = opaque(n.Cp);
+  auto epilogue = [&](auto& o, auto J0, auto NJ) {
 #pragma unroll
-  for (int j = 0; j < NT3; ++j) {
+    for (int jj = 0; jj < decltype(NJ)::value; ++jj) {
+      const int j = decltype(J0)::value + jj;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int g = 2 * j + r;
-      // (not paired: a saturated phi must be EXACTLY pi/2 to reproduce the reference's clamped |F|)
-      const double theta = m::tanh_d(o[j][r]) * kPi;                               // w_nl.py:59
-      const double phi = m::tanh_d(o[j][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
-      // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
-      double num, den;
-      m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
-      if constexpr (WRITE_F) {
-        const int idx = fo->slot[4 * g + q];
-        if (fo->row >= 0 && idx >= 0 && fo->angles) {
-          fo->fre[fo->row * fo->dS + idx] = theta;  // the module's own outputs (theta, phi), w_nl.py:59-63
-          fo->fim[fo->row * fo->dS + idx] = phi;
-        } else if (fo->row >= 0 && idx >= 0) {
-          double sn, cs;
-          m::sincos_bounded(theta, &sn, &cs);
-          const double rad = num * m::rcp_refined(den);
-          const int64_t at = fo->n_rows > 0 ? (int64_t)(4 * g + q) * fo->n_rows + fo->row : fo->row * fo->dS + idx;
-          fo->fre[at] = rad * cs;
-          fo->fim[at] = rad * sn;
+      for (int r = 0; r < 2; ++r) {
+        const int g = 2 * j + r;
+        // (not paired: a saturated phi must be EXACTLY pi/2 to reproduce the reference's clamped |F|)
+        const double theta = m::tanh_d(o[jj][r]) * kPi;                               // w_nl.py:59
+        const double phi = m::tanh_d(o[jj][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
+        // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
+        double num, den;
+        m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+        if constexpr (WRITE_F) {
+          const int idx = fo->slot[4 * g + q];
+          if (fo->row >= 0 && idx >= 0 && fo->angles) {
+            fo->fre[fo->row * fo->dS + idx] = theta;  // the module's own outputs (theta, phi), w_nl.py:59-63
+            fo->fim[fo->row * fo->dS + idx] = phi;
+          } else if (fo->row >= 0 && idx >= 0) {
+            double sn, cs;
+            m::sincos_bounded(theta, &sn, &cs);
+            const double rad = num * m::rcp_refined(den);
+            const int64_t at = fo->n_rows > 0 ? (int64_t)(4 * g + q) * fo->n_rows + fo->row : fo->row * fo->dS + idx;
+            fo->fre[at] = rad * cs;
+            fo->fim[at] = rad * sn;
+          }
+        } else {
+          (void)num;
+          (void)den;
+          ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
         }
-      } else {
-        (void)num;
-        (void)den;
-        ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
       }
     }
+  };
+  constexpr int NA = (NT3 + 1) / 2, NB = NT3 - NA;
+  {
+    v4d o[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) o[j] = load_bias_tile(n.b3p, j, q);
+    gemm_acc_part<NA, NT3, KS>(o, n.W3p, 0, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
+    epilogue(o, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+  }
+  {
+    v4d o[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) o[j] = load_bias_tile(n.b3p, NA + j, q);
+    gemm_acc_part<NB, NT3, KS>(o, n.W3p, NA, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
+    epilogue(o, std::integral_constant<int, NA>{}, std::integral_constant<int, NB>{});
   }
   return ax[0];
 }

@@ -795,6 +795,33 @@ def test_rollout_kernel_variants_agree(nlc, env, K, T, h):
         assert torch.equal(a, b)
 
 
+def test_horizon_chunks_pipeline_bit_identical(nlc):
+    """Round 3: GRU encode of later horizon chunks on a stream of its own beside the rollout of earlier chunks (wave-per-tile
+    body, K > 8192).  The rollout carries state and cost sums between its chunk launches exactly, the encoder's windows do
+    not depend on the chunking: same bits as the single launch, over consecutive commands (the chunks of one command must
+    also not run into the next command's sampling)."""
+    from oracle import nl_model as onl
+
+    env, K, T = "oderl-cartpole", 16384 + 48, 40
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    planners = {C: nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                                 u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=9,
+                                 U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"horizon_chunks": C})
+                for C in (1, 2, 3, 8)}
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    for step in range(4):
+        acts = {C: p.command(state, ab) for C, p in planners.items()}
+        for C in (2, 3, 8):
+            assert torch.equal(acts[1], acts[C]), (C, step)
+            for attr in ("states", "cost_total", "omega", "U"):
+                assert torch.equal(getattr(planners[1], attr), getattr(planners[C], attr)), (C, attr, step)
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = acts[1]
+
+
 @pytest.mark.parametrize("K,cap,sched", [(2048, 0, None), (2048, 40, None), (1000, 0, None), (4096, 0, None), (600, 7, None),
                                          (16, 0, None), (2048, 200, None), (2048, 0, (0, -1)), (2048, 0, (2, 1)),
                                          (2048, 40, (3, 0)), (1000, 0, (1, 2)), (600, 7, (1, 0)), (4096, 0, (0, 1))])
