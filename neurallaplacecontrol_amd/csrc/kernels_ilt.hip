@@ -93,6 +93,31 @@ hipError_t launch_ilt_linear(const IltLinArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// backward: x = (1/t) sum_k (wr_k R_k cos(theta_k) - wi_k R_k sin(theta_k)),  R = tan(phi/2 + pi/4),  R' = (1 + R^2) / 2:
+//   d x / d theta_k = -(1/t) R (wr sin + wi cos),    d x / d phi_k = (1/t) (wr cos - wi sin) (1 + R^2) / 2
+// One thread per (row, term) element: reads theta, phi, writes both gradients, fully coalesced (the reference trains the
+// representation function through whichever ilt_algorithm is configured, train_utils.py:388-407).
+__global__ __launch_bounds__(256) void ilt_linear_bwd_kernel(const IltLinBwdArgs a) {
+  const int64_t total = a.N * a.d * a.S;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / a.S;
+    const int k = (int)(e - row * a.S);
+    const double rad = m::tan_0_halfpi(a.phi[e] / 2.0 + kPi / 4.0);
+    double sn, cs;
+    m::sincos_bounded(a.theta[e], &sn, &cs);
+    const double g = a.gx[row] / a.t[row / a.d];
+    a.gtheta[e] = -g * rad * (a.wr[k] * sn + a.wi[k] * cs);
+    a.gphi[e] = g * (a.wr[k] * cs - a.wi[k] * sn) * (0.5 * (1.0 + rad * rad));
+  }
+}
+hipError_t launch_ilt_linear_bwd(const IltLinBwdArgs& a, hipStream_t s) {
+  const int64_t total = a.N * a.d * a.S;
+  if (total <= 0) return hipSuccess;
+  const int64_t want = (total + 255) / 256;
+  hipLaunchKernelGGL(ilt_linear_bwd_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ Fourier series
 // x[n,c] = e^{gamma t}/T * sum_k w_k Re(F_k e^{i pi k/scale}),  w_0 = 1/2, t/T = 1/scale for every t.
 // Rows (n,c) are contiguous runs of S doubles in theta/phi.  A block streams ROWS rows with perfectly

@@ -679,11 +679,21 @@ extern "C" int nlc_ilt_reconstruct_backward(nlc_ctx* c, const nlc_ilt_desc* d, c
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
   if (int r = check_ilt(c, d)) return r;
-  if (d->algo != NLC_ILT_FOURIER) return fail(c, NLC_ERR_UNSUPPORTED, "backward is implemented for the Fourier ILT only");
+  if (d->algo == NLC_ILT_DEHOOG)
+    return fail(c, NLC_ERR_UNSUPPORTED, "backward: fourier, fixed_tablot and stehfest have HIP kernels; de Hoog differentiates as "
+                                        "PyTorch-ROCm tensor ops in the Python mirror");
   if (N < 0 || dd < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or d");
   if (N == 0) return NLC_OK;
   if (!theta || !phi || !t || !grad_x || !grad_theta || !grad_phi) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
+  if (d->algo == NLC_ILT_FIXED_TALBOT || d->algo == NLC_ILT_STEHFEST) {
+    const double* tab = nullptr;
+    if (int r = linear_tables(c, d, &tab)) return r;
+    IltLinBwdArgs la{theta, phi, t, grad_x, grad_theta, grad_phi, N, dd, d->terms, tab + 2 * d->terms, tab + 3 * d->terms};
+    ProfScope ps(c, "ilt_linear_bwd_kernel");
+    NLC_HIP(c, launch_ilt_linear_bwd(la, c->stream));
+    return NLC_OK;
+  }
   IltBwdArgs a{theta, phi, t, grad_x, grad_theta, grad_phi, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, 0, 0};
   ProfScope ps(c, "ilt_fourier_bwd_kernel");
   NLC_HIP(c, launch_ilt_fourier_bwd(a, c->stream));

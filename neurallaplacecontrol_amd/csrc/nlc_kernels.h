@@ -71,6 +71,20 @@ struct IltLinArgs {
   const double* wi;
 };
 hipError_t launch_ilt_linear(const IltLinArgs& a, hipStream_t s);
+// backward of the same with respect to theta / phi (round 3): gx (N, d) upstream gradient -> gtheta, gphi (N, d, S)
+struct IltLinBwdArgs {
+  const double* theta;
+  const double* phi;
+  const double* t;
+  const double* gx;
+  double* gtheta;
+  double* gphi;
+  int64_t N;
+  int d, S;
+  const double* wr;
+  const double* wi;
+};
+hipError_t launch_ilt_linear_bwd(const IltLinBwdArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ GRU action encoder (a7)
 // Action source: either an explicit window tensor (N, B, nin), or the MPPI history

@@ -159,8 +159,8 @@ def _dehoog_autograd(theta, phi, t, desc):
 def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=None):
     """theta, phi: (N, d, S) representation-function outputs, t: (N,) -> x (N, d).
 
-    Differentiable with respect to theta / phi: Fourier through the HIP backward kernel, de Hoog through PyTorch-ROCm
-    tensor ops (training path only; the no-grad forward is the HIP kernel)."""
+    Differentiable with respect to theta / phi: Fourier, fixed Talbot and Stehfest through HIP backward kernels, de Hoog
+    through PyTorch-ROCm tensor ops (training path only; the no-grad forward is the HIP kernel)."""
     dev = compute_device(theta, phi, t)
     needs_grad = torch.is_grad_enabled() and (
         (torch.is_tensor(theta) and theta.requires_grad) or (torch.is_tensor(phi) and phi.requires_grad)
@@ -176,9 +176,7 @@ def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=No
     if needs_grad:
         if desc.algo == 1:
             return _dehoog_autograd(theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc)
-        if desc.algo != 0:
-            raise NotImplementedError("autograd through the ILT is implemented for ilt_algorithm 'fourier' (HIP backward "
-                                      "kernel) and 'dehoog' (PyTorch-ROCm tensor ops)")
+        # fourier, fixed_tablot, stehfest: HIP forward + HIP backward kernels behind one autograd Function
         return _IltFn.apply(
             theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc, ctx
         )

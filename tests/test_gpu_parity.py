@@ -107,6 +107,31 @@ def test_ilt_fourier_backward_vs_autograd_of_oracle(nlc, d, S, N):
             np.testing.assert_allclose(a.cpu().numpy() / sc, b.numpy() / sc, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("algo,S", [("fixed_tablot", 11), ("fixed_tablot", 24), ("stehfest", 8), ("stehfest", 16)])
+def test_ilt_linear_backward_vs_autograd_of_oracle(nlc, algo, S):
+    """Round 3: HIP backward of the two linear ILT algorithms (ilt_linear_bwd_kernel behind the same autograd Function as the
+    Fourier one) against torch autograd through the CPU restatement; ragged N."""
+    from oracle import ilt as oilt
+
+    N, d = 777, 5
+    g = torch.Generator().manual_seed(S)
+    theta = ((torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi).requires_grad_()
+    phi = ((torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi / 2 * 0.9).requires_grad_()
+    t = torch.rand(N, dtype=torch.float64, generator=g) * 2 + 0.05
+    gx = torch.randn(N, d, dtype=torch.float64, generator=g)
+    ref = oilt.ilt_from_sphere(theta, phi, t, algo)
+    rt, rp = torch.autograd.grad(ref, (theta, phi), gx)
+    th_d, ph_d = theta.detach().cuda().requires_grad_(), phi.detach().cuda().requires_grad_()
+    got = nlc.ilt_reconstruct(th_d, ph_d, t.cuda(), algo)
+    assert got.requires_grad
+    sc = float(ref.detach().abs().max())
+    np.testing.assert_allclose(got.detach().cpu().numpy() / sc, ref.detach().numpy() / sc, rtol=1e-9, atol=1e-11)
+    gt, gp = torch.autograd.grad(got, (th_d, ph_d), gx.cuda())
+    for a, b in ((gt, rt), (gp, rp)):
+        sc = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy() / sc, b.numpy() / sc, rtol=1e-9, atol=1e-12)
+
+
 def test_laplace_reconstruct_trains_rep_func_through_hip_ilt(nlc):
     """Gradients reach the representation function's weights AND the latent p through laplace_reconstruct
     (the training path of w_nl.py:137-144), equal to autograd through the CPU restatement."""
@@ -140,10 +165,11 @@ def test_laplace_reconstruct_trains_rep_func_through_hip_ilt(nlc):
     for a, b in zip((lin_d.weight.grad, lin_d.bias.grad, p_d.grad), ref_grads):
         sc = float(b.abs().max())
         np.testing.assert_allclose(a.cpu().numpy() / sc, b.numpy() / sc, rtol=1e-8, atol=1e-11)
-    with pytest.raises(NotImplementedError):  # no reverse mode for the two linear algorithms
-        nlc.ilt_reconstruct(torch.zeros(2, 1, 16, dtype=torch.float64, device="cuda", requires_grad=True),
+    # (the two linear algorithms have a HIP backward as well since round 3: test_ilt_linear_backward_vs_autograd_of_oracle)
+    x = nlc.ilt_reconstruct(torch.zeros(2, 1, 16, dtype=torch.float64, device="cuda", requires_grad=True),
                             torch.zeros(2, 1, 16, dtype=torch.float64, device="cuda"),
                             torch.full((2,), 0.1, dtype=torch.float64, device="cuda"), "stehfest")
+    assert x.requires_grad
 
 
 def test_ilt_fourier_full_bench_size_vs_oracle(nlc):
