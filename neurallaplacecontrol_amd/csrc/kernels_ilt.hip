@@ -93,6 +93,37 @@ hipError_t launch_ilt_linear(const IltLinArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Planner path (round 3): F_k = (re, im) arrives SLOT-major (8*nt3, N) from the representation kernel's MFMA epilogue,
+// as for the de Hoog planner (kernels_dehoog.hip, FMODE 2): a wavefront owns 64 consecutive samples of ONE dim, term k of
+// its rows is one full 512-B line per array, and the kernel reads exactly d * S * 16 B per sample.  Same summation order
+// as ilt_linear_kernel.  t is one device scalar (the planner's constant prediction time).
+__global__ __launch_bounds__(64) void ilt_linear_slot_kernel(const IltLinSlotArgs a) {
+  const int lane = threadIdx.x;
+  const int64_t nsb = (a.N + 63) / 64;
+  const int64_t nblk = nsb * a.d;
+  const double t = a.t[0];
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int cdim = (int)(blk % a.d);
+    const int64_t n = (blk / a.d) * 64 + lane;
+    if (n >= a.N) continue;
+    const int* ei = a.eidx + cdim * a.S;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < a.S; ++k) {
+      const int64_t at = (int64_t)ei[k] * a.N + n;
+      acc += a.wr[k] * a.fre[at] - a.wi[k] * a.fim[at];
+    }
+    a.x[n * a.d + cdim] = acc / t;
+  }
+}
+hipError_t launch_ilt_linear_slot(const IltLinSlotArgs& a, hipStream_t s) {
+  if (a.N <= 0 || a.d <= 0) return hipSuccess;
+  if (!a.fre || !a.fim || !a.eidx || !a.wr || !a.wi || !a.t || !a.x) return hipErrorInvalidValue;
+  const int64_t want = (a.N + 63) / 64 * a.d;
+  hipLaunchKernelGGL(ilt_linear_slot_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
 // backward: x = (1/t) sum_k (wr_k R_k cos(theta_k) - wi_k R_k sin(theta_k)),  R = tan(phi/2 + pi/4),  R' = (1 + R^2) / 2:
 //   d x / d theta_k = -(1/t) R (wr sin + wi cos),    d x / d phi_k = (1/t) (wr cos - wi sin) (1 + R^2) / 2
 // One thread per (row, term) element: reads theta, phi, writes both gradients, fully coalesced (the reference trains the

@@ -256,6 +256,9 @@ int64_t blob_size(const nlc_model_desc* d) {
          h * h + h + 2 * d->d * S * h + 2 * d->d * S;
 }
 
+}  // namespace
+static void linear_tables_host(int algo, int S, std::vector<double>& h);
+namespace {
 bool is_device_ptr(const void* p) {
   hipPointerAttribute_t at{};
   if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -266,9 +269,20 @@ bool is_device_ptr(const void* p) {
 }
 
 void sphere_inputs(const nlc_ilt_desc& ilt, double tn, std::vector<double>& sph) {
-  // [theta_s(0..S-1) | phi_s(0..S-1)] of s_k = gamma + i pi k / T
+  // [theta_s(0..S-1) | phi_s(0..S-1)] of s_k = gamma + i pi k / T (Fourier, de Hoog) or s_k = node_k / t (linear algorithms)
   const int S = ilt.terms;
   sph.assign(2 * S, 0.0);
+  if (ilt.algo == NLC_ILT_FIXED_TALBOT || ilt.algo == NLC_ILT_STEHFEST) {
+    std::vector<double> tab;
+    linear_tables_host(ilt.algo, S, tab);
+    for (int k = 0; k < S; ++k) {
+      const double re = tab[k] / tn, im = tab[S + k] / tn;
+      sph[k] = std::atan2(im, re);
+      const double a2 = re * re + im * im;
+      sph[S + k] = std::asin((a2 - 1.0) / (a2 + 1.0));
+    }
+    return;
+  }
   const double Tt = ilt.scale * tn;
   const double gamma = ilt.alpha - std::log(ilt.tol) / (ilt.scale * Tt);
   for (int k = 0; k < S; ++k) {
@@ -574,15 +588,10 @@ static int check_ilt(nlc_ctx* c, const nlc_ilt_desc* d) {
 
 // nodes and weights of the linear algorithms (mpmath 1.3.0 calculus/inverselaplace.py: FixedTalbot.calc_laplace_parameter /
 // calc_time_domain_solution, Stehfest._coeff), uploaded once per (algorithm, terms): [node_re | node_im | w_re | w_im]
-static int linear_tables(nlc_ctx* c, const nlc_ilt_desc* d, const double** tab) {
-  const int S = d->terms;
-  if (c->lin_tab && c->lin_algo == d->algo && c->lin_S == S) {
-    *tab = c->lin_tab;
-    return NLC_OK;
-  }
-  std::vector<double> h((size_t)4 * S, 0.0);
+static void linear_tables_host(int algo, int S, std::vector<double>& h) {
+  h.assign((size_t)4 * S, 0.0);
   double *nr = h.data(), *ni = nr + S, *wr = ni + S, *wi = wr + S;
-  if (d->algo == NLC_ILT_FIXED_TALBOT) {
+  if (algo == NLC_ILT_FIXED_TALBOT) {
     const int M = S;
     const double r = 2.0 * M / 5.0;
     nr[0] = r;
@@ -611,6 +620,15 @@ static int linear_tables(nlc_ctx* c, const nlc_ilt_desc* d, const double** tab) 
       wr[k - 1] = (double)(((k + M2) % 2 ? -1.0L : 1.0L) * z * (long double)M_LN2);
     }
   }
+}
+static int linear_tables(nlc_ctx* c, const nlc_ilt_desc* d, const double** tab) {
+  const int S = d->terms;
+  if (c->lin_tab && c->lin_algo == d->algo && c->lin_S == S) {
+    *tab = c->lin_tab;
+    return NLC_OK;
+  }
+  std::vector<double> h;
+  linear_tables_host(d->algo, S, h);
   if (!c->lin_tab) NLC_HIP(c, hipMalloc((void**)&c->lin_tab, (size_t)4 * kMaxTerms * sizeof(double)));
   // a kernel of an earlier call may still read the old tables -- on ANY stream the ctx was bound to since (the Python
   // mirror rebinds it to torch's current stream every call): this rare path waits for the whole device
@@ -709,13 +727,14 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   NLC_GUARD_BEGIN
   if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
   if (int r = check_ilt(c, &d->ilt)) return r;
-  if (d->ilt.algo != NLC_ILT_FOURIER && d->ilt.algo != NLC_ILT_DEHOOG)
-    return fail(c, NLC_ERR_UNSUPPORTED, "fused model kernels: ilt_algorithm must be fourier or dehoog");
+  // (fixed_tablot / stehfest models: GRU encoder, representation kernel and the staged planner; their model.forward runs
+  // staged in the Python mirror)
   if (d->h != 64 && d->h != 128 && d->h != 256)
     return fail(c, NLC_ERR_UNSUPPORTED, "hidden_units must be 64, 128 or 256 (the kernels are instantiated for these widths)");
   if (d->d < 1 || d->d > 6) return fail(c, NLC_ERR_UNSUPPORTED, "state_dim must be in 1..6");
   if (d->nin < 1 || d->nin > NLC_MAX_NIN) return fail(c, NLC_ERR_UNSUPPORTED, "GRU input dim must be in 1..3");
-  if (d->ilt.scale != 2.0) return fail(c, NLC_ERR_UNSUPPORTED, "fused model path needs ILT scale == 2");
+  const bool linear_algo = d->ilt.algo == NLC_ILT_FIXED_TALBOT || d->ilt.algo == NLC_ILT_STEHFEST;
+  if (!linear_algo && d->ilt.scale != 2.0) return fail(c, NLC_ERR_UNSUPPORTED, "fused model path needs ILT scale == 2");
   if (n != blob_size(d)) return fail(c, NLC_ERR_BAD_SHAPE, "weight blob size mismatch");
   NLC_HIP(c, hipSetDevice(c->device));
   const int g = d->h / 2, S = d->ilt.terms, P = d->d + 2, h = d->h, dd = d->d, nin = d->nin;
@@ -954,6 +973,8 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
   if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
   if (c->md.ilt.algo == NLC_ILT_DEHOOG && (c->S < 3 || c->S > 33 || c->S % 2 == 0))
     return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be odd, 3 .. 33 (2M+1 terms)");
+  if (c->md.ilt.algo != NLC_ILT_DEHOOG && c->md.ilt.algo != NLC_ILT_FOURIER)
+    return fail(c, NLC_ERR_UNSUPPORTED, "nlc_model_forward: fourier and dehoog models (the linear algorithms' query points depend on t per sample: run nlc_gru_encode, the representation function and nlc_ilt staged)");
   if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
   if (N == 0) return NLC_OK;
   if (!obs || !window || !ts || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
@@ -1431,7 +1452,7 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.abuf = take((size_t)d.E * d.B * d.nu);
   w.xcarry = take(d.dynamics == NLC_DYN_NL ? KE * d.d : 0);
   w.ccarry = take(d.dynamics == NLC_DYN_NL ? KE * 2 : 0);
-  const bool dh = d.dynamics == NLC_DYN_NL && c->md.ilt.algo == NLC_ILT_DEHOOG;
+  const bool dh = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER;  // staged: de Hoog and the linear algorithms
   w.fre = take(dh ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
   w.fim = take(dh ? KE * 8 * (size_t)c->net.nt3 : 0);
   w.dx = take(dh ? KE * d.d : 0);
@@ -1630,7 +1651,7 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     NLC_HIP(c, launch_perturb(p, c->stream));
     return NLC_OK;
   };
-  const bool nl_fourier = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_DEHOOG;
+  const bool nl_fourier = d.dynamics == NLC_DYN_NL && c->md.ilt.algo == NLC_ILT_FOURIER;
   if (!nl_fourier)
     if (int rc = launch_shift_perturb()) return rc;
   if (external) return NLC_OK;  // the caller runs the horizon loop, then nlc_mppi_weights
@@ -1670,9 +1691,14 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     r.cost_total = buf->cost_total;
     r.xcarry = ws + w.xcarry;
     r.ccarry = ws + w.ccarry;
-    if (c->md.ilt.algo == NLC_ILT_DEHOOG) {
+    if (c->md.ilt.algo != NLC_ILT_FOURIER) {
       // staged de Hoog planner path (BASELINE configs[4]): hoisted GRU, then per horizon step three launches --
       // representation function -> F_k, de Hoog ILT -> dx, state/cost tail.  Everything stays on the device.
+      // fixed_tablot / stehfest models (round 3) take the same path with the slot-major linear ILT in de Hoog's place.
+      const bool dehoog = c->md.ilt.algo == NLC_ILT_DEHOOG;
+      const double* lin_tab = nullptr;
+      if (!dehoog)
+        if (int rc = linear_tables(c, &c->md.ilt, &lin_tab)) return rc;
       // GRU encode: one launch up front, or (round 3, option "dehoog_gru_chunks" C > 1) C horizon chunks on a stream of
       // their own that run BESIDE the step chain -- the chain's launches wait for the chunk that holds their horizon step.
       // The chunks use the cooperative kernel at reduced occupancy (lds_pad) so that the chain's workgroups find room.
@@ -1834,8 +1860,15 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
             ProfScope ps(c, "nl_repfunc_kernel", sh, true);
             NLC_HIP(c, launch_nl_repfunc(rp, sh));
           }
-          ProfScope ps(c, "ilt_dehoog_kernel", sh, true);
-          NLC_HIP(c, launch_ilt_dehoog(ias[h], sh));
+          if (dehoog) {
+            ProfScope ps(c, "ilt_dehoog_kernel", sh, true);
+            NLC_HIP(c, launch_ilt_dehoog(ias[h], sh));
+          } else {
+            const IltArgs& ih = ias[h];
+            const IltLinSlotArgs il{ih.fre, ih.fim, ih.eidx, ih.t, ih.x, ih.N, ih.d, ih.S, lin_tab + 2 * ih.S, lin_tab + 3 * ih.S};
+            ProfScope ps(c, "ilt_linear_slot_kernel", sh, true);
+            NLC_HIP(c, launch_ilt_linear_slot(il, sh));
+          }
         }
       }
       for (int h = 0; h < P; ++h) {

@@ -71,6 +71,19 @@ struct IltLinArgs {
   const double* wi;
 };
 hipError_t launch_ilt_linear(const IltLinArgs& a, hipStream_t s);
+// the same sum over F_k = (re, im) held SLOT-major (8*nt3, N) (staged planner path; see IltArgs::eidx)
+struct IltLinSlotArgs {
+  const double* fre;  // (8*nt3, N)
+  const double* fim;
+  const int* eidx;    // (d*S): slot of term k of dim c
+  const double* t;    // one device scalar: the normalised prediction time
+  double* x;          // (N, d)
+  int64_t N;
+  int d, S;
+  const double* wr;   // (S) device tables
+  const double* wi;
+};
+hipError_t launch_ilt_linear_slot(const IltLinSlotArgs& a, hipStream_t s);
 // backward of the same with respect to theta / phi (round 3): gx (N, d) upstream gradient -> gtheta, gphi (N, d, S)
 struct IltLinBwdArgs {
   const double* theta;

@@ -198,10 +198,9 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
         d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)
         desc = _lib.ModelDesc()
         desc.d, desc.nin, desc.h = d, nin, self.hidden_units
-        # the fused kernels exist for fourier / dehoog; a model with another algorithm still uses this ctx for its GRU
-        # encoder (encode_actions), so its weights are packed under a Fourier descriptor of the same term count
-        fused_algo = self.ilt_algorithm in ("fourier", "dehoog")
-        desc.ilt = _lib.ilt_desc(self.ilt_algorithm if fused_algo else "fourier", self.s_recon_terms, self.ilt_options if fused_algo else None)
+        # fourier / dehoog: fused forward and planner kernels; fixed_tablot / stehfest: GRU encoder, representation kernel
+        # and the staged planner path (their model.forward runs staged in _forward below)
+        desc.ilt = _lib.ilt_desc(self.ilt_algorithm, self.s_recon_terms, self.ilt_options)
         f64 = lambda t: t.detach().to("cpu", torch.float64).reshape(-1)  # noqa: E731
         if self.normalize:
             sm, ss = f64(self.state_mean), f64(self.state_std)
@@ -290,8 +289,6 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
         """Grad-mode forward (the reference trains through ``model(...)``, ``train_utils.py:388-407``): the op sequence of
         ``w_nl.py:117-145`` with the GRU encoder and the representation MLP on PyTorch-ROCm (their backward is
         autograd's) and the line integral in HIP, forward AND backward (``nlc_ilt_reconstruct_backward``)."""
-        if self.ilt_algorithm not in ("fourier", "dehoog"):
-            raise NotImplementedError("training through the ILT is implemented for ilt_algorithm 'fourier' and 'dehoog'")
         dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
         if next(self.parameters()).device != dev:
             raise RuntimeError("training forward: move the model to the GPU first (model.to('cuda'))")

@@ -242,17 +242,13 @@ class MPPIDelay:
         self.running_cost = running_cost
         self.store_rollouts = self._store_rollouts_arg
         # fused dynamics: the whole T-step rollout is one HIP kernel (Fourier models), or the staged all-HIP path
-        # (rep-func kernel -> de Hoog kernel -> state kernel per horizon step) for de Hoog models
+        # (rep-func kernel -> ILT kernel -> state kernel per horizon step) for de Hoog, fixed_tablot and stehfest models
         self.fused_dynamics = (
             isinstance(dynamics, (NLDynamics, OracleDynamics))
             and not self.step_dependency
             # the collector's encode_obs_time variant only appends a time-stamp channel to the window; oracle
             # dynamics ignore it (oracle.py:23 takes [:, -(delay+1), :nu]), an NL model consumes it -> generic path
             and not (self.encode_obs_time and not isinstance(dynamics, OracleDynamics))
-            and not (
-                isinstance(dynamics, NLDynamics)
-                and getattr(dynamics.model, "ilt_algorithm", "fourier") not in ("fourier", "dehoog")
-            )
         )
         # fused: the running cost is evaluated inside the rollout kernel as well (EnvCost, no terminal cost)
         self.fused = self.fused_dynamics and isinstance(running_cost, EnvCost) and self.terminal_state_cost is None

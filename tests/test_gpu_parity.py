@@ -409,6 +409,38 @@ def test_model_trains_through_hip_ilt(nlc, env):
     np.testing.assert_allclose(after.cpu().numpy(), twin.cpu().numpy(), rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("algo,S", [("fixed_tablot", 11), ("stehfest", 8)])
+def test_model_with_linear_ilt_trains_through_hip_ilt(nlc, algo, S):
+    """The same for a model configured with fixed_tablot / stehfest (the reference trains through whichever
+    ilt_algorithm its config names, train_utils.py:388-407): forward and every parameter gradient vs the restatement."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS["oderl-pendulum"]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(5, d, nu, 128, S, st["state_std"], [A / 2], tame=True)
+    g = torch.Generator().manual_seed(23)
+    N = 77
+    obs = torch.randn(N, d, dtype=torch.float64, generator=g) * torch.tensor(st["state_std"])
+    win = (torch.rand(N, 4, nu, dtype=torch.float64, generator=g) * 2 - 1) * A
+    ts = torch.rand(N, 1, dtype=torch.float64, generator=g) * 0.08 + 0.02
+    target = torch.randn(N, d, dtype=torch.float64, generator=g)
+    names = [k for k in sd if k.startswith(("action_encoder.", "laplace_rep_func."))]
+    leaves = {k: (v.clone().requires_grad_() if k in names else v) for k, v in sd.items()}
+    ref = onl.nl_forward(leaves, obs, win, ts, S=S, ilt_algorithm=algo)
+    ((ref - target) ** 2).mean().backward()
+    model = build_model(nlc, sd, S=S, algo=algo)
+    model.train()
+    got = model(obs.cuda(), win.cuda(), ts.cuda())
+    assert got.requires_grad
+    sc = float(ref.detach().abs().max())
+    np.testing.assert_allclose(got.detach().cpu().numpy() / sc, ref.detach().numpy().reshape(got.shape) / sc, rtol=1e-7, atol=1e-9)
+    ((got - target.cuda().reshape(got.shape)) ** 2).mean().backward()
+    for k, p_ in model.named_parameters():
+        ref_g = leaves[k].grad
+        sc = float(ref_g.abs().max()) + 1e-300
+        np.testing.assert_allclose(p_.grad.cpu().numpy() / sc, ref_g.numpy() / sc, rtol=1e-6, atol=1e-8, err_msg=k)
+
+
 # --------------------------------------------------------------------------- planner (a1-a4, a10-a12)
 def check_command_steps(nlc, g, make_planner, tol=TOL):
     mppi = None
@@ -1269,7 +1301,7 @@ def test_ilt_linear_algorithms_vs_oracle(nlc, algo, S):
 
 def test_model_with_linear_ilt_and_cme_constructor(nlc):
     """A NeuralLaplaceModel configured with fixed_tablot runs (HIP GRU -> torch rep func -> HIP ILT) and plans on the
-    generic path; with "cme" the constructor snaps the term count like the reference (w_nl.py:86-88) and the forward
+    staged all-HIP path (representation kernel -> slot-major linear ILT -> state kernel per horizon step); with "cme" the constructor snaps the term count like the reference (w_nl.py:86-88) and the forward
     says why the method cannot run here."""
     from oracle import nl_model as onl
 
@@ -1285,12 +1317,23 @@ def test_model_with_linear_ilt_and_cme_constructor(nlc):
         got = model(obs.cuda(), win.cuda(), ts.cuda()).cpu()
     scale = float(ref.abs().max())
     np.testing.assert_allclose(got.numpy(), ref.numpy().reshape(got.shape), rtol=1e-7, atol=1e-9 * scale)
-    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-pendulum"), d, nlc.noise_sigma(nu), 64, 3, "cpu",
-                         lambda_=1.0, u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), u_scale=2.0)
-    assert not mppi.fused_dynamics  # generic path: the model's forward is the dynamics callable
-    with torch.no_grad():
-        act = mppi.command(nlc.initial_state("oderl-pendulum"), torch.zeros(4, nu, dtype=torch.float64))
-    assert torch.isfinite(act).all()
+    # planner: the staged all-HIP path (round 3) against the generic path, whose dynamics callable is the model's forward
+    K, T = 200, 5
+    raw = torch.randn(K, T, nu, dtype=torch.float64) * 0.5
+    state, ab = nlc.initial_state("oderl-pendulum"), torch.randn(4, nu, dtype=torch.float64) * 0.3
+    out = {}
+    dyn_obj = nlc.NLDynamics(model, 0.05)
+    for name, dyn in (("staged", dyn_obj), ("generic", lambda s_, w_: dyn_obj(s_, w_))):
+        mppi = nlc.MPPIDelay(dyn, nlc.EnvCost("oderl-pendulum"), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                             u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), u_scale=2.0,
+                             U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"recognise_closures": 0})
+        assert mppi.fused == (name == "staged")
+        mppi.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+        with torch.no_grad():
+            act = mppi.command(state, ab)
+        out[name] = (mppi.states.clone(), mppi.cost_total.clone(), act.clone())
+    for a, b in zip(out["staged"], out["generic"]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-6, atol=1e-8)
     cme = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=33, ilt_algorithm="cme", state_mean=np.zeros(d),
                                  state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]))
     assert cme.s_recon_terms == 31 and cme.laplace_rep_func.linear_tanh_stack[4].out_features == 2 * d * 31

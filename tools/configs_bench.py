@@ -21,7 +21,15 @@ CONFIGS = [  # (label, env, delay -> action_buffer rows, K, T, gpus, ilt, S)
 ]
 
 
-def rate(env, B, K, T, algo, S, steps):
+# the other closed-form values of the reference's nl_ilt_algorithm knob (config.py:36) at configs[1]'s shape: the staged
+# all-HIP planner path (round 3) beside the generic path (model.forward as the dynamics callable) it replaces
+EXTRA = [
+    ("cartpole K=16384 H=40 fixed_tablot S=17", "oderl-cartpole", 4, 16384, 40, "fixed_tablot", 17),
+    ("cartpole K=16384 H=40 stehfest S=16", "oderl-cartpole", 4, 16384, 40, "stehfest", 16),
+]
+
+
+def rate(env, B, K, T, algo, S, steps, generic=False):
     d, nu, A, std = STATS[env]
     torch.manual_seed(0)
     model = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=S, ilt_algorithm=algo, state_mean=np.zeros(d),
@@ -30,9 +38,12 @@ def rate(env, B, K, T, algo, S, steps):
     with torch.no_grad():
         model.laplace_rep_func.linear_tanh_stack[4].bias[d * S:] += -3.0  # "trained-like" taming
     model = model.to("cuda")
-    mppi = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+    dyn = nlc.NLDynamics(model, 0.05)
+    mppi = nlc.MPPIDelay((lambda s_, w_: dyn(s_, w_)) if generic else dyn, nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
-                         U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False)
+                         U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False,
+                         planner_options={"recognise_closures": 0})
+    assert mppi.fused != generic
     st, ab = nlc.initial_state(env, torch.Generator().manual_seed(0)), torch.zeros(B, nu, dtype=torch.float64)
     with torch.no_grad():
         for _ in range(2):
@@ -48,10 +59,15 @@ def rate(env, B, K, T, algo, S, steps):
 
 
 out = []
-for label, env, B, K, T, G, algo, S in CONFIGS:
+only_extra = "--extra-only" in sys.argv
+for label, env, B, K, T, G, algo, S in ([] if only_extra else CONFIGS):
     row = dict(config=label, full_population_one_gpu=rate(env, B, K, T, algo, S, 10 if K > 100000 else 20))
     if G > 1:
         row[f"per_gpu_share_K_over_{G}"] = rate(env, B, K // G, T, algo, S, 20)
+    out.append(row)
+    print(row, file=sys.stderr, flush=True)
+for label, env, B, K, T, algo, S in EXTRA:
+    row = dict(config=label, staged_hip_path=rate(env, B, K, T, algo, S, 20), generic_path=rate(env, B, K, T, algo, S, 5, generic=True))
     out.append(row)
     print(row, file=sys.stderr, flush=True)
 print(json.dumps(dict(metric="MPPI planning steps/s per BASELINE config, one MI355X, f64", results=out)))
