@@ -154,11 +154,12 @@ int nlc_ilt_rep_inputs(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* p_d
 int nlc_ilt_reconstruct(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* theta_dev, const double* phi_dev,
                         const double* t_dev, int64_t N, int d, double* x_dev);
 
-/* Backward of nlc_ilt_reconstruct with respect to the representation-function outputs (Fourier, fixed Talbot, Stehfest;
- * de Hoog: NLC_ERR_UNSUPPORTED -- the Python mirror differentiates it as tensor ops): the
+/* Backward of nlc_ilt_reconstruct with respect to the representation-function outputs, every algorithm: the
  * reference trains the rep func THROUGH torchlaplace.laplace_reconstruct by autograd (train_utils.py:388-407 ->
  * w_nl.py:137-144).  grad_x_dev (N, d) upstream gradient -> grad_theta_dev, grad_phi_dev (N, d, S).  No gradient
- * with respect to t.  HBM-bound streaming kernel; algorithmic bytes 4dS*8 per point. */
+ * with respect to t.  Fourier / fixed Talbot / Stehfest: HBM-bound streaming kernels, algorithmic bytes 4dS*8 per point.
+ * de Hoog: reverse mode through the quotient-difference table, taped in stream-ordered scratch of the call
+ * (hipMallocAsync / hipFreeAsync on the bound stream: about 19 KB per row in flight at S = 33, at most 2.4 GB). */
 int nlc_ilt_reconstruct_backward(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* theta_dev,
                                  const double* phi_dev, const double* t_dev, const double* grad_x_dev, int64_t N,
                                  int d, double* grad_theta_dev, double* grad_phi_dev);

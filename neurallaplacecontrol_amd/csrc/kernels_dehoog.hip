@@ -2,40 +2,13 @@
 // torchlaplace.laplace_reconstruct (external; call site w_nl.py:137-144), restated from mpmath 1.3.0
 // calculus/inverselaplace.py:476-531 (parity unpinned vs upstream, see oracle/ilt.py).  Any odd number of terms
 // S = 2M + 1 <= 33.  A translation unit of its own: 16 term counts x 3 input layouts of a fully unrolled kernel.
+#include "nlc_cplx.h"
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
 namespace nlc {
 
 // ------------------------------------------------------------------ de Hoog, Knight & Stokes
-struct cplx {
-  double re, im;
-};
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
-}
-// a / b = a conj(b) / |b|^2 with ONE refined reciprocal (v_rcp_f64 + one cubic refinement step, <= 1 ulp) instead of two IEEE
-// divisions (v_div_scale / v_div_fmas / v_div_fixup sequences with their VCC hazards): the QD table needs ~M^2 of
-// these per row, and they were 55 % of the kernel's issue slots.
-__device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
-  const double inv = m::rcp_refined(b.re * b.re + b.im * b.im);
-  return {(a.re * b.re + a.im * b.im) * inv, (a.im * b.re - a.re * b.im) * inv};
-}
-__device__ __forceinline__ cplx csqrt_(cplx z) {
-  // principal branch
-  const double mag = hypot(z.re, z.im);
-  double re = sqrt(0.5 * (mag + fabs(z.re)));
-  double im = (re == 0.0) ? 0.0 : 0.5 * z.im / re;
-  if (z.re < 0.0) {
-    const double t = re;
-    re = fabs(im);
-    im = copysign(t, z.im);
-  }
-  return {re, im};
-}
-
 // One thread per (point, dim) row; a block is one wavefront = 64 rows.
 //
 // The QD table is built anti-diagonal by anti-diagonal ("progressive" form): Laplace term a_n extends every column

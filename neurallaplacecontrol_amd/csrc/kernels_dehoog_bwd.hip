@@ -1,0 +1,244 @@
+// Backward of the de Hoog, Knight & Stokes ILT with respect to the representation-function outputs (theta, phi): the
+// reference trains through torchlaplace.laplace_reconstruct with whichever ilt_algorithm its config names
+// (train_utils.py:388-407 -> w_nl.py:137-144).  Reverse mode through the quotient-difference table of the forward kernel
+// (kernels_dehoog.hip; mpmath 1.3.0 calculus/inverselaplace.py:476-531), one thread per (point, dim) row.
+//
+// The forward keeps ONE diagonal of the table in registers; reverse mode needs every entry again -- M (M + 1) q's and M^2
+// e's, 8.4 KB per row at M = 16 -- so this kernel rebuilds the table column by column into a TAPE in HBM scratch (the
+// mpmath column sweep: same rhombus rules, same operands per entry as the forward's diagonal sweep), then walks the
+// columns back with the adjoints in a second region of the same scratch.  The scratch belongs to the launch: the grid is
+// persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries are [entry][lane] so every access is one
+// 1-KB line per wavefront.  A training batch (some thousand rows) keeps its slabs in L2 / MALL; the kernel is a
+// latency-bound chain of complex divisions either way.
+//
+// Adjoint convention: for a real loss L and a complex intermediate w, wbar = dL/dRe(w) + i dL/dIm(w); then for
+// holomorphic w = f(u): ubar += wbar conj(f'(u)).
+#include "nlc_cplx.h"
+#include "nlc_device.h"
+#include "nlc_kernels.h"
+
+namespace nlc {
+
+namespace {
+
+struct DhLayout {
+  int M;
+  // value tape
+  __host__ __device__ int q(int r, int i) const { return (r - 1) * (2 * M + 2 - r) + i; }                 // r = 1..M, i = 0..2(M-r)+1
+  __host__ __device__ int e(int r, int i) const { return M * (M + 1) + (r - 1) * (2 * M + 1 - r) + i; }   // r = 1..M, i = 0..2(M-r)
+  __host__ __device__ int a(int i) const { return M * (M + 1) + M * M + i; }                              // i = 0..2M
+  __host__ __device__ int A(int i) const { return M * (M + 1) + M * M + (2 * M + 1) + (i + 1); }          // i = -1..2M-1
+  __host__ __device__ int B(int i) const { return M * (M + 1) + M * M + 2 * (2 * M + 1) + (i + 1); }      // i = -1..2M-1
+  __host__ __device__ int n_values() const { return M * (M + 1) + M * M + 3 * (2 * M + 1); }
+  // adjoints: same q / e / a indices, offset by n_values()
+  __host__ __device__ int n_adjoints() const { return M * (M + 1) + M * M + (2 * M + 1); }
+  __host__ __device__ int entries() const { return n_values() + n_adjoints(); }
+};
+
+struct Tape {
+  double2* base;  // this wavefront's slab, [entry][lane]
+  int lane;
+  __device__ __forceinline__ cplx ld(int e) const {
+    const double2 v = base[(size_t)e * 64 + lane];
+    return {v.x, v.y};
+  }
+  __device__ __forceinline__ void st(int e, cplx v) const { base[(size_t)e * 64 + lane] = make_double2(v.re, v.im); }
+  __device__ __forceinline__ void add(int e, cplx v) const {
+    double2* p = base + (size_t)e * 64 + lane;
+    const double2 o = *p;
+    *p = make_double2(o.x + v.re, o.y + v.im);
+  }
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdArgs a) {
+  const int lane = threadIdx.x;
+  const int M = (a.S - 1) / 2;
+  const DhLayout L{M};
+  const int nv = L.n_values();
+  const int64_t rows_total = a.N * a.d;
+  const int64_t nblk = (rows_total + 63) / 64;
+  const Tape tp{reinterpret_cast<double2*>(a.scratch) + (size_t)blockIdx.x * L.entries() * 64, lane};
+  const cplx one = {1.0, 0.0}, zero = {0.0, 0.0};
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t row = blk * 64 + lane;
+    if (row >= rows_total) continue;  // (no barriers in this kernel: a lane may skip)
+    const double t = a.t[row / a.d] / a.t_div;
+    const double Tt = a.scale * t;
+    const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
+    const double ang = kPi * (t / Tt);
+    const cplx z = {cos(ang), sin(ang)};
+    const double* th = a.theta + row * a.S;
+    const double* ph = a.phi + row * a.S;
+
+    // ---------------------------------------------------------------- forward, taped
+    // a_k = F_k = R e^{i theta}, R = tan(phi/2 + pi/4); a_0 enters halved.  Column 1: q_1^(i) = a_{i+1} / a_i
+    {
+      cplx prev = zero;
+      for (int k = 0; k <= 2 * M; ++k) {
+        const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
+        double sn, cs;
+        m::sincos_bounded(th[k], &sn, &cs);
+        cplx ak = {rad * cs, rad * sn};
+        if (k == 0) ak = cscale(ak, 0.5);
+        tp.st(L.a(k), ak);
+        if (k > 0) tp.st(L.q(1, k - 1), cdiv(ak, prev));
+        prev = ak;
+      }
+    }
+    for (int r = 1; r <= M; ++r) {
+      const int mr = 2 * (M - r) + 1;
+      // e_r^(i) = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)
+      cplx qlo = tp.ld(L.q(r, 0));
+      for (int i = 0; i < mr; ++i) {
+        const cplx qhi = tp.ld(L.q(r, i + 1));
+        const cplx eprev = r > 1 ? tp.ld(L.e(r - 1, i + 1)) : zero;
+        tp.st(L.e(r, i), cadd(csub(qhi, qlo), eprev));
+        qlo = qhi;
+      }
+      if (r != M) {
+        // q_(r+1)^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)
+        cplx elo = tp.ld(L.e(r, 0));
+        for (int i = 0; i < mr - 1; ++i) {
+          const cplx ehi = tp.ld(L.e(r, i + 1));
+          tp.st(L.q(r + 1, i), cdiv(cmul(tp.ld(L.q(r, i + 1)), ehi), elo));
+          elo = ehi;
+        }
+      }
+    }
+    // continued fraction: d_0 = a_0, d_(2r-1) = -q_r^(0), d_(2r) = -e_r^(0);  A_i = A_(i-1) + d_i z A_(i-2)
+    auto dcoef = [&](int i) -> cplx {
+      if (i == 0) return tp.ld(L.a(0));
+      return cneg((i & 1) ? tp.ld(L.q((i + 1) / 2, 0)) : tp.ld(L.e(i / 2, 0)));
+    };
+    cplx A_prev = zero, A_cur = dcoef(0), B_prev = one, B_cur = one;
+    tp.st(L.A(-1), A_prev);
+    tp.st(L.A(0), A_cur);
+    tp.st(L.B(-1), B_prev);
+    tp.st(L.B(0), B_cur);
+    for (int i = 1; i <= 2 * M - 1; ++i) {
+      const cplx dz = cmul(dcoef(i), z);
+      const cplx An = cadd(A_cur, cmul(dz, A_prev)), Bn = cadd(B_cur, cmul(dz, B_prev));
+      A_prev = A_cur;
+      A_cur = An;
+      B_prev = B_cur;
+      B_cur = Bn;
+      tp.st(L.A(i), A_cur);
+      tp.st(L.B(i), B_cur);
+    }
+    const cplx d_last = dcoef(2 * M - 1), d_end = dcoef(2 * M);
+    const cplx brem = cscale(cadd(one, cmul(csub(d_last, d_end), z)), 0.5);
+    const cplx uoverb = cdiv(cmul(d_end, z), brem);  // inner - 1
+    const cplx sq = csqrt_(cadd(one, uoverb));
+    const cplx sm1 = csub(sq, one);
+    const cplx rem = cmul(brem, sm1);
+    const cplx An = cadd(A_cur, cmul(rem, A_prev));
+    const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
+    const cplx res = cdiv(An, Bn);
+
+    // ---------------------------------------------------------------- backward
+    for (int e = 0; e < L.n_adjoints(); ++e) tp.st(nv + e, zero);
+    const double G = a.gx[row] * (exp(gamma * t) / Tt);  // x = e^{gamma t} / T Re(res)
+    const cplx g_res = {G, 0.0};
+    // res = An / Bn
+    const cplx g_An = cdiv(g_res, cconj(Bn));
+    const cplx g_Bn = cneg(cmul(g_An, cconj(res)));
+    // An = A_cur + rem A_prev,  Bn = B_cur + rem B_prev
+    cplx gA1 = g_An, gA0 = cmul(g_An, cconj(rem));  // adjoints of (A_(2M-1), A_(2M-2))
+    cplx gB1 = g_Bn, gB0 = cmul(g_Bn, cconj(rem));
+    const cplx g_rem = cadd(cmul(g_An, cconj(A_prev)), cmul(g_Bn, cconj(B_prev)));
+    // rem = brem (sq - 1);  sq = sqrt(inner);  inner = 1 + (d_end z) / brem
+    cplx g_brem = cmul(g_rem, cconj(sm1));
+    const cplx g_sq = cmul(g_rem, cconj(brem));
+    const cplx g_inner = cdiv(g_sq, cscale(cconj(sq), 2.0));
+    const cplx g_u = cdiv(g_inner, cconj(brem));
+    g_brem = csub(g_brem, cmul(g_inner, cconj(cdiv(uoverb, brem))));
+    cplx g_dend = cmul(g_u, cconj(z));
+    // brem = (1 + (d_last - d_end) z) / 2
+    const cplx g_diff = cscale(cmul(g_brem, cconj(z)), 0.5);
+    cplx g_dlast = g_diff;
+    g_dend = csub(g_dend, g_diff);
+    // d_(2M) = -e_M^(0)
+    tp.add(nv + L.e(M, 0), cneg(g_dend));
+    // recurrence, i = 2M-1 .. 1
+    for (int i = 2 * M - 1; i >= 1; --i) {
+      const cplx di = dcoef(i);
+      const cplx Am2 = tp.ld(L.A(i - 2)), Bm2 = tp.ld(L.B(i - 2));
+      cplx g_di = cadd(cmul(gA1, cconj(cmul(z, Am2))), cmul(gB1, cconj(cmul(z, Bm2))));
+      if (i == 2 * M - 1) g_di = cadd(g_di, g_dlast);
+      const cplx cdz = cconj(cmul(di, z));
+      const cplx gAm2 = cmul(gA1, cdz), gBm2 = cmul(gB1, cdz);
+      gA0 = cadd(gA0, gA1);
+      gB0 = cadd(gB0, gB1);
+      gA1 = gA0;
+      gA0 = gAm2;
+      gB1 = gB0;
+      gB0 = gBm2;
+      // d_i = -q_r^(0) (i = 2r-1) or -e_r^(0) (i = 2r)
+      tp.add(nv + ((i & 1) ? L.q((i + 1) / 2, 0) : L.e(i / 2, 0)), cneg(g_di));
+    }
+    // A_0 = d_0 = a_0 (A_(-1), B_0, B_(-1) are constants)
+    tp.add(nv + L.a(0), gA1);
+    // table, columns r = M .. 1
+    for (int r = M; r >= 1; --r) {
+      const int mr = 2 * (M - r) + 1;
+      if (r != M) {
+        for (int i = 0; i < mr - 1; ++i) {
+          const cplx gw = tp.ld(nv + L.q(r + 1, i));
+          const cplx qv = tp.ld(L.q(r, i + 1)), ehi = tp.ld(L.e(r, i + 1)), elo = tp.ld(L.e(r, i));
+          const double inv = m::rcp_refined(elo.re * elo.re + elo.im * elo.im);
+          const cplx ielo = {elo.re * inv, -elo.im * inv};  // 1 / e_r^(i)
+          const cplx ratio = cmul(ehi, ielo);
+          const cplx qi = cmul(qv, ielo);
+          tp.add(nv + L.q(r, i + 1), cmul(gw, cconj(ratio)));
+          tp.add(nv + L.e(r, i + 1), cmul(gw, cconj(qi)));
+          tp.add(nv + L.e(r, i), cneg(cmul(gw, cconj(cmul(qi, ratio)))));
+        }
+      }
+      for (int i = 0; i < mr; ++i) {
+        const cplx g = tp.ld(nv + L.e(r, i));
+        tp.add(nv + L.q(r, i + 1), g);
+        tp.add(nv + L.q(r, i), cneg(g));
+        if (r > 1) tp.add(nv + L.e(r - 1, i + 1), g);
+      }
+    }
+    // column 1: q_1^(i) = a_(i+1) / a_i
+    for (int i = 0; i < 2 * M; ++i) {
+      const cplx g = tp.ld(nv + L.q(1, i));
+      const cplx ai = tp.ld(L.a(i)), q1 = tp.ld(L.q(1, i));
+      const cplx ga_hi = cdiv(g, cconj(ai));
+      tp.add(nv + L.a(i + 1), ga_hi);
+      tp.add(nv + L.a(i), cneg(cmul(ga_hi, cconj(q1))));
+    }
+    // F_k = R (cos theta + i sin theta), R = tan(phi/2 + pi/4), dR/dphi = (1 + R^2) / 2;  a_0 = F_0 / 2
+    for (int k = 0; k <= 2 * M; ++k) {
+      cplx gF = tp.ld(nv + L.a(k));
+      if (k == 0) gF = cscale(gF, 0.5);
+      const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
+      double sn, cs;
+      m::sincos_bounded(th[k], &sn, &cs);
+      a.gtheta[row * a.S + k] = rad * (gF.im * cs - gF.re * sn);
+      a.gphi[row * a.S + k] = (gF.re * cs + gF.im * sn) * (0.5 * (1.0 + rad * rad));
+    }
+  }
+}
+
+int64_t ilt_dehoog_bwd_scratch_bytes(int64_t N, int d, int S, unsigned* grid_out) {
+  const int64_t nblk = (N * d + 63) / 64;
+  const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
+  if (grid_out) *grid_out = grid;
+  const DhLayout L{(S - 1) / 2};
+  return (int64_t)grid * L.entries() * 64 * (int64_t)sizeof(double2);
+}
+
+hipError_t launch_ilt_dehoog_bwd(const IltDehoogBwdArgs& a, hipStream_t s) {
+  if (a.N * a.d <= 0) return hipSuccess;
+  if (a.S < 3 || a.S > 33 || (a.S & 1) == 0 || !a.scratch) return hipErrorInvalidValue;
+  unsigned grid = 0;
+  ilt_dehoog_bwd_scratch_bytes(a.N, a.d, a.S, &grid);
+  hipLaunchKernelGGL(ilt_dehoog_bwd_kernel, dim3(grid), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace nlc

@@ -697,13 +697,28 @@ extern "C" int nlc_ilt_reconstruct_backward(nlc_ctx* c, const nlc_ilt_desc* d, c
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_GUARD_BEGIN
   if (int r = check_ilt(c, d)) return r;
-  if (d->algo == NLC_ILT_DEHOOG)
-    return fail(c, NLC_ERR_UNSUPPORTED, "backward: fourier, fixed_tablot and stehfest have HIP kernels; de Hoog differentiates as "
-                                        "PyTorch-ROCm tensor ops in the Python mirror");
+  if (d->algo == NLC_ILT_DEHOOG && (d->terms < 3 || d->terms > 33 || d->terms % 2 == 0))
+    return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be odd, 3 .. 33 (2M+1 terms)");
   if (N < 0 || dd < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or d");
   if (N == 0) return NLC_OK;
   if (!theta || !phi || !t || !grad_x || !grad_theta || !grad_phi) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
+  if (d->algo == NLC_ILT_DEHOOG) {
+    // the QD tape lives in stream-ordered scratch of this launch (no ctx state: calls on different streams do not share it)
+    const int64_t bytes = ilt_dehoog_bwd_scratch_bytes(N, dd, d->terms, nullptr);
+    void* scratch = nullptr;
+    NLC_HIP(c, hipMallocAsync(&scratch, (size_t)bytes, c->stream));
+    IltDehoogBwdArgs da{theta, phi, t, grad_x, grad_theta, grad_phi, N, dd, d->terms, d->alpha, std::log(d->tol), d->scale, 1.0, scratch};
+    hipError_t le;
+    {
+      ProfScope ps(c, "ilt_dehoog_bwd_kernel");
+      le = launch_ilt_dehoog_bwd(da, c->stream);
+    }
+    const hipError_t fe = hipFreeAsync(scratch, c->stream);
+    NLC_HIP(c, le);
+    NLC_HIP(c, fe);
+    return NLC_OK;
+  }
   if (d->algo == NLC_ILT_FIXED_TALBOT || d->algo == NLC_ILT_STEHFEST) {
     const double* tab = nullptr;
     if (int r = linear_tables(c, d, &tab)) return r;

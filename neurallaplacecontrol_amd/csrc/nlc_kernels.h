@@ -98,6 +98,22 @@ struct IltLinBwdArgs {
   const double* wi;
 };
 hipError_t launch_ilt_linear_bwd(const IltLinBwdArgs& a, hipStream_t s);
+// backward of the de Hoog ILT with respect to theta / phi (round 3; kernels_dehoog_bwd.hip): reverse mode through the QD
+// table, which the kernel tapes in `scratch` (ilt_dehoog_bwd_scratch_bytes(N, d, S) bytes, owned by the launch)
+struct IltDehoogBwdArgs {
+  const double* theta;  // (N, d, S)
+  const double* phi;
+  const double* t;      // (N)
+  const double* gx;     // (N, d)
+  double* gtheta;       // (N, d, S)
+  double* gphi;
+  int64_t N;
+  int d, S;
+  double alpha, log_tol, scale, t_div;
+  void* scratch;
+};
+int64_t ilt_dehoog_bwd_scratch_bytes(int64_t N, int d, int S, unsigned* grid_out);
+hipError_t launch_ilt_dehoog_bwd(const IltDehoogBwdArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ GRU action encoder (a7)
 // Action source: either an explicit window tensor (N, B, nin), or the MPPI history

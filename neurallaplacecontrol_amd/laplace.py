@@ -90,7 +90,7 @@ def _ilt_forward(theta_d, phi_d, t_d, desc, ctx):
 class _IltFn(torch.autograd.Function):
     """``nlc_ilt_reconstruct`` with ``nlc_ilt_reconstruct_backward`` as its vector-Jacobian product, so the
     representation function trains through the HIP line integral as it does through torchlaplace
-    (``train_utils.py:388-407`` -> ``w_nl.py:137-144``).  Fourier ILT only; no gradient with respect to t."""
+    (``train_utils.py:388-407`` -> ``w_nl.py:137-144``).  No gradient with respect to t."""
 
     @staticmethod
     def forward(fctx, theta, phi, t_d, desc, ctx):
@@ -117,50 +117,11 @@ class _IltFn(torch.autograd.Function):
         return g_theta, g_phi, None, None, None
 
 
-def _dehoog_autograd(theta, phi, t, desc):
-    """de Hoog reconstruction as differentiable PyTorch-ROCm tensor ops (complex128), used ONLY when theta / phi require
-    grad: the reference trains the representation function through whatever ilt_algorithm is configured
-    (train_utils.py:388-407 -> w_nl.py:137-144), and reverse mode through the O(M^2) quotient-difference table is the
-    training path, not the planning hot path (the no-grad forward is the HIP kernel ilt_dehoog_kernel).
-    Same recurrences as that kernel: mpmath 1.3.0 calculus/inverselaplace.py:476-531."""
-    import math
-
-    S = theta.shape[-1]
-    M = (S - 1) // 2
-    t = t.to(torch.float64).view(-1, 1)
-    T = desc.scale * t
-    gamma = desc.alpha - math.log(desc.tol) / (desc.scale * T)
-    r = torch.tan(phi / 2.0 + math.pi / 4.0)
-    fp = torch.complex(r * torch.cos(theta), r * torch.sin(theta))  # (N, d, S)
-    a = [fp[..., 0] / 2.0] + [fp[..., i] for i in range(1, S)]
-    q = [a[i + 1] / a[i] for i in range(2 * M)]       # column r = 1
-    e = [torch.zeros_like(a[0]) for _ in range(S)]    # column r = 0
-    d = [a[0], -q[0]]
-    for rr in range(1, M + 1):
-        mr = 2 * (M - rr) + 1
-        e = [q[i + 1] - q[i] + e[i + 1] for i in range(mr)]
-        d.append(-e[0])
-        if rr != M:
-            q = [q[i + 1] * e[i + 1] / e[i] for i in range(mr - 1)]
-            d.append(-q[0])
-    ang = math.pi * (t / T)
-    z = torch.complex(torch.cos(ang), torch.sin(ang))
-    A_prev, A_cur = torch.zeros_like(d[0]), d[0]
-    B_prev, B_cur = torch.ones_like(d[0]), torch.ones_like(d[0])
-    for i in range(1, 2 * M):
-        A_prev, A_cur = A_cur, A_cur + d[i] * A_prev * z
-        B_prev, B_cur = B_cur, B_cur + d[i] * B_prev * z
-    brem = (1.0 + (d[2 * M - 1] - d[2 * M]) * z) / 2.0
-    rem = brem * (torch.sqrt(1.0 + d[2 * M] * z / brem) - 1.0)
-    res = (A_cur + rem * A_prev) / (B_cur + rem * B_prev)
-    return torch.exp(gamma * t) / T * res.real
-
-
 def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=None):
     """theta, phi: (N, d, S) representation-function outputs, t: (N,) -> x (N, d).
 
-    Differentiable with respect to theta / phi: Fourier, fixed Talbot and Stehfest through HIP backward kernels, de Hoog
-    through PyTorch-ROCm tensor ops (training path only; the no-grad forward is the HIP kernel)."""
+    Differentiable with respect to theta / phi for every algorithm: HIP forward and HIP backward kernels behind one
+    autograd Function (de Hoog: reverse mode through the quotient-difference table, ``kernels_dehoog_bwd.hip``)."""
     dev = compute_device(theta, phi, t)
     needs_grad = torch.is_grad_enabled() and (
         (torch.is_tensor(theta) and theta.requires_grad) or (torch.is_tensor(phi) and phi.requires_grad)
@@ -174,9 +135,7 @@ def ilt_reconstruct(theta, phi, t, ilt_algorithm="fourier", options=None, ctx=No
     desc = _lib.ilt_desc(ilt_algorithm, S, options)
     ctx = ctx or default_ctx(dev.index)
     if needs_grad:
-        if desc.algo == 1:
-            return _dehoog_autograd(theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc)
-        # fourier, fixed_tablot, stehfest: HIP forward + HIP backward kernels behind one autograd Function
+        # HIP forward + HIP backward kernels behind one autograd Function
         return _IltFn.apply(
             theta.to(device=dev, dtype=torch.float64), phi.to(device=dev, dtype=torch.float64), t_d, desc, ctx
         )

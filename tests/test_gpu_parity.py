@@ -409,15 +409,15 @@ def test_model_trains_through_hip_ilt(nlc, env):
     np.testing.assert_allclose(after.cpu().numpy(), twin.cpu().numpy(), rtol=1e-12, atol=1e-14)
 
 
-@pytest.mark.parametrize("algo,S", [("fixed_tablot", 11), ("stehfest", 8)])
-def test_model_with_linear_ilt_trains_through_hip_ilt(nlc, algo, S):
-    """The same for a model configured with fixed_tablot / stehfest (the reference trains through whichever
+@pytest.mark.parametrize("algo,S", [("fixed_tablot", 11), ("stehfest", 8), ("dehoog", 9)])
+def test_model_with_linear_ilt_trains_through_hip_ilt(nlc, monkeypatch, algo, S):
+    """The same for a model configured with fixed_tablot / stehfest / dehoog (the reference trains through whichever
     ilt_algorithm its config names, train_utils.py:388-407): forward and every parameter gradient vs the restatement."""
     from oracle import nl_model as onl
 
     st = onl.ENV_STATS["oderl-pendulum"]
     d, nu, A = st["d"], st["nu"], st["act_high"]
-    sd = onl.make_synthetic_state_dict(5, d, nu, 128, S, st["state_std"], [A / 2], tame=True)
+    sd = onl.make_synthetic_state_dict(5, d, nu, 128, S, st["state_std"], [A / 2], tame="dehoog" if algo == "dehoog" else True)
     g = torch.Generator().manual_seed(23)
     N = 77
     obs = torch.randn(N, d, dtype=torch.float64, generator=g) * torch.tensor(st["state_std"])
@@ -426,6 +426,12 @@ def test_model_with_linear_ilt_trains_through_hip_ilt(nlc, algo, S):
     target = torch.randn(N, d, dtype=torch.float64, generator=g)
     names = [k for k in sd if k.startswith(("action_encoder.", "laplace_rep_func."))]
     leaves = {k: (v.clone().requires_grad_() if k in names else v) for k, v in sd.items()}
+    if algo == "dehoog":  # the oracle's de Hoog writes its table in place: differentiate the functional twin instead
+        from oracle import ilt as oilt
+
+        plain = onl.nl_forward(sd, obs, win, ts, S=S, ilt_algorithm=algo)
+        monkeypatch.setitem(oilt.LINE_INTEGRATE, "dehoog", dehoog_line_integrate_functional)
+        np.testing.assert_allclose(onl.nl_forward(sd, obs, win, ts, S=S, ilt_algorithm=algo).numpy(), plain.numpy(), rtol=1e-9, atol=1e-11)
     ref = onl.nl_forward(leaves, obs, win, ts, S=S, ilt_algorithm=algo)
     ((ref - target) ** 2).mean().backward()
     model = build_model(nlc, sd, S=S, algo=algo)
@@ -1369,41 +1375,75 @@ def test_rollout_samples_vs_reference_golden(nlc, env):
     check_command_steps(nlc, g, lambda U0: make(U0, fused=False))
 
 
-def test_dehoog_autograd_path(nlc):
-    """Training through a de Hoog model (the reference trains through whatever ilt_algorithm is configured,
-    train_utils.py:388-407): with grad-requiring theta / phi ilt_reconstruct runs the de Hoog recurrences as PyTorch-ROCm
-    tensor ops.  Its forward must equal the HIP kernel's and the oracle's; its reverse-mode gradient must be consistent
-    with forward mode (<g, J v> = <J^T g, v>) -- finite differences cannot resolve the QD table's conditioning."""
-    import torch.autograd.forward_ad as fwAD
+def dehoog_line_integrate_functional(f_real, f_imag, t, T, gamma):
+    """oracle/ilt.py's dehoog_line_integrate (same signature, same recurrences) written without in-place tensor writes, so
+    that torch.autograd can differentiate it on the CPU: the reference gradient of the HIP backward kernel.  Callers
+    check its forward against the oracle's before trusting its gradient."""
+    import math
 
+    S = f_real.shape[-1]
+    M = (S - 1) // 2
+    fp = torch.complex(f_real, f_imag)
+    t, T, gamma = (v.squeeze(-1) if torch.is_tensor(v) and v.dim() == fp.dim() else v for v in (t, T, gamma))
+    a = [fp[..., 0] / 2.0] + [fp[..., i] for i in range(1, S)]
+    q = [a[i + 1] / a[i] for i in range(2 * M)]
+    e = [torch.zeros_like(a[0]) for _ in range(S)]
+    dco = [a[0], -q[0]]
+    for rr in range(1, M + 1):
+        mr = 2 * (M - rr) + 1
+        e = [q[i + 1] - q[i] + e[i + 1] for i in range(mr)]
+        dco.append(-e[0])
+        if rr != M:
+            q = [q[i + 1] * e[i + 1] / e[i] for i in range(mr - 1)]
+            dco.append(-q[0])
+    ang = math.pi * (t / T)
+    z = torch.complex(torch.cos(ang), torch.sin(ang))
+    A_prev, A_cur = torch.zeros_like(dco[0]), dco[0]
+    B_prev, B_cur = torch.ones_like(dco[0]), torch.ones_like(dco[0])
+    for i in range(1, 2 * M):
+        A_prev, A_cur = A_cur, A_cur + dco[i] * A_prev * z
+        B_prev, B_cur = B_cur, B_cur + dco[i] * B_prev * z
+    brem = (1.0 + (dco[2 * M - 1] - dco[2 * M]) * z) / 2.0
+    rem = brem * (torch.sqrt(1.0 + dco[2 * M] * z / brem) - 1.0)
+    res = (A_cur + rem * A_prev) / (B_cur + rem * B_prev)
+    return torch.exp(gamma * t) / T * res.real
+
+
+@pytest.mark.parametrize("S,N,d", [(3, 5, 1), (5, 70, 3), (17, 203, 3), (33, 129, 5)])
+def test_dehoog_autograd_path(nlc, monkeypatch, S, N, d):
+    """Training through a de Hoog model (the reference trains through whatever ilt_algorithm is configured,
+    train_utils.py:388-407): with grad-requiring theta / phi, ilt_reconstruct runs the same HIP forward kernel and, in
+    backward, ilt_dehoog_bwd_kernel -- reverse mode through the quotient-difference table.  Gradients against autograd
+    through the CPU restatement, on generic (random) Laplace terms: a rational F of low degree makes the table degenerate
+    (e -> rounding noise), where no two roundings of the algorithm agree on a derivative."""
     from oracle import ilt as oilt
 
-    torch.manual_seed(5)
-    N, d, S = 40, 3, 17
-    t = torch.rand(N, dtype=torch.float64) * 2 + 0.05
-    alpha, tol, scale = oilt.ilt_options("dehoog")
-    sr, si, _, _ = oilt.query_points(t, S, alpha, tol, scale)
-    s = torch.complex(sr, si).unsqueeze(1)
-    a = torch.rand(N, d, 1, dtype=torch.float64) + 0.5
-    F = 1.0 / (s + a)
-    theta, phi = oilt.complex_to_sphere(F.real, F.imag)
-    ref = oilt.ilt_from_sphere(theta, phi, t, "dehoog")
+    g = torch.Generator().manual_seed(100 + S)
+    t = torch.rand(N, dtype=torch.float64, generator=g) * 2 + 0.05
+    theta = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * 3.0
+    phi = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * 1.2
+    w = torch.randn(N, d, dtype=torch.float64, generator=g)
+    tho, pho = theta.clone().requires_grad_(), phi.clone().requires_grad_()
+    ref_inplace = oilt.ilt_from_sphere(theta, phi, t, "dehoog")
+    monkeypatch.setitem(oilt.LINE_INTEGRATE, "dehoog", dehoog_line_integrate_functional)
+    ref = oilt.ilt_from_sphere(tho, pho, t, "dehoog")
+    np.testing.assert_allclose(ref.detach().numpy(), ref_inplace.numpy(), rtol=1e-7, atol=1e-9)  # (vectorised vs per-entry complex ops)
+    (ref * w).sum().backward()
     hip = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), "dehoog")
     th, ph = theta.cuda().requires_grad_(), phi.cuda().requires_grad_()
     x = nlc.ilt_reconstruct(th, ph, t.cuda(), "dehoog")
     assert x.requires_grad
-    np.testing.assert_allclose(x.detach().cpu().numpy(), ref.numpy(), rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(x.detach().cpu().numpy(), hip.cpu().numpy(), rtol=1e-7, atol=1e-9)
-    g = torch.randn_like(x)
-    gth, gph = torch.autograd.grad(x, (th, ph), g)
+    np.testing.assert_array_equal(x.detach().cpu().numpy(), hip.cpu().numpy())
+    # rows whose table is well conditioned in the oracle itself (a near-zero e somewhere amplifies rounding differences
+    # of value AND gradient alike): judged by the forward agreement
+    ok = ((x.detach().cpu() - ref.detach()).abs() <= 1e-9 * (1.0 + ref.detach().abs())).all(dim=1)
+    assert ok.float().mean() > 0.9
+    gth, gph = torch.autograd.grad(x, (th, ph), w.cuda())
     assert torch.isfinite(gth).all() and torch.isfinite(gph).all()
-    vth, vph = torch.randn_like(gth), torch.randn_like(gph)
-    with fwAD.dual_level():
-        xd = nlc.laplace._dehoog_autograd(fwAD.make_dual(theta.cuda(), vth), fwAD.make_dual(phi.cuda(), vph), t.cuda(),
-                                          nlc._lib.ilt_desc("dehoog", S))
-        jv = fwAD.unpack_dual(xd).tangent
-    lhs, rhs = float((g * jv).sum()), float((gth * vth).sum() + (gph * vph).sum())
-    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)  # (the two modes round the QD table differently)
+    for got_, ref_ in ((gth, tho.grad), (gph, pho.grad)):
+        got_, ref_ = got_.cpu()[ok], ref_[ok]
+        sc = ref_.abs().amax(dim=(1, 2), keepdim=True) + 1e-300
+        np.testing.assert_allclose((got_ / sc).numpy(), (ref_ / sc).numpy(), rtol=1e-5, atol=1e-7)
 
 
 def test_error_paths_raise(nlc):
