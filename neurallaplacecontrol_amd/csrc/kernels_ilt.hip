@@ -155,6 +155,12 @@ hipError_t launch_ilt_linear_bwd(const IltLinBwdArgs& a, hipStream_t s) {
 // coalesced loads (lane i <-> flat element i), parks the per-element contribution in LDS and lets one
 // thread per row add its S terms (row stride padded odd: conflict-free ds_read_b64).
 
+// Round 3, measured and not kept: a LINE-ALIGNED form (tiles of 256 rows = S passes of exactly 256 consecutive doubles, so
+// every wavefront load is four whole 128-B lines instead of straddling a fifth as the 2040-B passes of S = 17 do; the lane's
+// term index then advances per pass and its phase constants are rebuilt from k with five integer instructions; 117 VGPRs,
+// no scratch, wait counts 14-18): 0.192-0.209 ms against 0.188-0.194 ms for this kernel on the same box, and this kernel
+// at S = 16 (2048-B passes) moves its bytes only 6 % faster than at S = 17 -- line straddling is not what holds the
+// stream at 84 % of the bare read rate.
 // DBG: 0 = product; 1 / 2 = timing experiments (memory only / arithmetic only), instantiated by the tools build only
 // (-DNLC_ILT_EXPERIMENTS=1)
 // ITERS > 0: passes per tile known at compile time -> the pass loop is fully unrolled (straight-line code is
@@ -196,6 +202,17 @@ __device__ __forceinline__ IltLane ilt_lane(int k, double scale) {
     L.wk = wk;
   }
   L.half_m = 0.5 * L.dm;
+  return L;
+}
+// fixed Talbot / Stehfest on the same stream (round 3): w_re Re F - w_im Im F = |w| R cos(theta + arg w), so a linear
+// algorithm is the general-phase path with psi_k = arg w_k, weight |w_k| (a real weight keeps its sign and psi = 0) and the
+// row scale 1/t
+__device__ __forceinline__ IltLane ilt_lane_linear(double wr, double wi) {
+  IltLane L;
+  L.psi = wi == 0.0 ? 0.0 : atan2(wi, wr);
+  L.wk = wi == 0.0 ? wr : hypot(wr, wi);
+  L.dm = 0.0;
+  L.half_m = 0.0;
   return L;
 }
 // the trig constants, each pinned in an SGPR pair for the whole kernel
@@ -247,7 +264,7 @@ __device__ __forceinline__ double ilt_row_scale(const IltArgs& a, double t) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // 4 waves per SIMD (<= 128 VGPRs) where the unrolled tile fits without spilling, 3 otherwise
-template <int DBG, int ITERS>
+template <int DBG, int ITERS, bool LIN = false>
 __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_fourier_kernel(const IltArgs a) {
   extern __shared__ double val[];  // [rows][SP]
   const int S = a.S;
@@ -258,12 +275,13 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
   const int act = rpp * S;
   const bool active = (int)threadIdx.x < act;
   const int k = (int)threadIdx.x % S, rloc = (int)threadIdx.x / S;
-  const IltLane L = ilt_lane(k, a.scale);
+  const IltLane L = LIN ? ilt_lane_linear(a.lin_wr[k], a.lin_wi[k]) : ilt_lane(k, a.scale);
   const m::IltTrigK K = ilt_trig_k_sgpr();
   const double psi = L.psi;
   const int64_t rows_total = a.N * a.d;
   const int64_t nblk = (rows_total + rows - 1) / rows;
   constexpr int UB = 8;  // pipeline depth in passes; the launcher makes iters a multiple of UB
+  auto row_scale = [&](double t) { return LIN ? m::rcp_refined(t) : ilt_row_scale(a, t); };
   int64_t blk = blockIdx.x;
 
   if constexpr (ITERS > 0) {
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
         const double* v = val + threadIdx.x * SP;
         double acc = 0.0;
         for (int kk = 0; kk < S; ++kk) acc += v[kk];
-        a.x[row0 + threadIdx.x] = ilt_row_scale(a, t_row) * acc;
+        a.x[row0 + threadIdx.x] = row_scale(t_row) * acc;
       }
       lds_barrier();
     }
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
       double acc = 0.0;
       for (int kk = 0; kk < S; ++kk) acc += v[kk];
       const int64_t row = row0 + threadIdx.x;
-      a.x[row] = ilt_row_scale(a, a.t[row / a.d]) * acc;
+      a.x[row] = row_scale(a.t[row / a.d]) * acc;
     }
     __syncthreads();
   }
@@ -397,6 +415,9 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   const int64_t rows_total = a.N * a.d;
   if (rows_total <= 0) return hipSuccess;
   if (a.S > 256) return hipErrorInvalidValue;
+#if NLC_ILT_EXPERIMENTS
+  if (a.lin_wr != nullptr && std::getenv("NLC_ILT_LINEAR_ROWS")) return hipErrorInvalidValue;  // time the one-thread-per-row kernel
+#endif
   // rows per block tile = rpp * iters: one thread per row for the final sum (<= 256), LDS tile under 60 KiB
   const int SP = a.S | 1;
   a.rpp = 256 / a.S;
@@ -433,6 +454,18 @@ hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
     case 24: hipLaunchKernelGGL((ilt_fourier_kernel<D, 24>), dim3(grid), dim3(256), shmem, s, a); break; \
     case 32: hipLaunchKernelGGL((ilt_fourier_kernel<D, 32>), dim3(grid), dim3(256), shmem, s, a); break; \
     default: hipLaunchKernelGGL((ilt_fourier_kernel<D, 0>), dim3(grid), dim3(256), shmem, s, a); break;  \
+  }
+  if (a.lin_wr != nullptr) {
+    // fixed Talbot / Stehfest: the same stream with per-term phase and weight from the algorithm's tables
+    if (a.lin_wi == nullptr) return hipErrorInvalidValue;
+    switch (a.iters) {
+      case 8: hipLaunchKernelGGL((ilt_fourier_kernel<0, 8, true>), dim3(grid), dim3(256), shmem, s, a); break;
+      case 16: hipLaunchKernelGGL((ilt_fourier_kernel<0, 16, true>), dim3(grid), dim3(256), shmem, s, a); break;
+      case 24: hipLaunchKernelGGL((ilt_fourier_kernel<0, 24, true>), dim3(grid), dim3(256), shmem, s, a); break;
+      case 32: hipLaunchKernelGGL((ilt_fourier_kernel<0, 32, true>), dim3(grid), dim3(256), shmem, s, a); break;
+      default: hipLaunchKernelGGL((ilt_fourier_kernel<0, 0, true>), dim3(grid), dim3(256), shmem, s, a); break;
+    }
+    return hipGetLastError();
   }
 #if NLC_ILT_EXPERIMENTS
   if (a.dbg == 1) {

@@ -675,9 +675,23 @@ extern "C" int nlc_ilt_reconstruct(nlc_ctx* c, const nlc_ilt_desc* d, const doub
   if (d->algo == NLC_ILT_FIXED_TALBOT || d->algo == NLC_ILT_STEHFEST) {
     const double* tab = nullptr;
     if (int r = linear_tables(c, d, &tab)) return r;
-    IltLinArgs la{theta, phi, t, x, N, dd, d->terms, tab + 2 * d->terms, tab + 3 * d->terms};
-    ProfScope ps(c, "ilt_linear_kernel");
-    NLC_HIP(c, launch_ilt_linear(la, c->stream));
+    // the Fourier kernel's coalesced stream with the algorithm's per-term phase and weight (round 3); the one-thread-per-row
+    // kernel remains for a term count the stream's tiling does not take
+    a.lin_wr = tab + 2 * d->terms;
+    a.lin_wi = tab + 3 * d->terms;
+    hipError_t le;
+    {
+      ProfScope ps(c, "ilt_linear_stream_kernel");
+      le = launch_ilt_fourier(a, c->stream);
+    }
+    if (le == hipErrorInvalidValue) {
+      (void)hipGetLastError();
+      IltLinArgs la{theta, phi, t, x, N, dd, d->terms, a.lin_wr, a.lin_wi};
+      ProfScope ps(c, "ilt_linear_kernel");
+      NLC_HIP(c, launch_ilt_linear(la, c->stream));
+    } else {
+      NLC_HIP(c, le);
+    }
   } else if (d->algo == NLC_ILT_FOURIER) {
     ProfScope ps(c, "ilt_fourier_kernel");
     NLC_HIP(c, launch_ilt_fourier(a, c->stream));

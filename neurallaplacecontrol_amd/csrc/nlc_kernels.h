@@ -28,6 +28,10 @@ struct IltArgs {
   // contiguous, as the representation kernel's MFMA epilogue stores them -- and eidx[c*S + k] names the slot of term k
   // of dim c; one wavefront then owns 64 consecutive samples of ONE dim and every load is a full 512-B line
   const int* eidx;
+  // Fourier kernel as the stream of the linear algorithms (fixed Talbot / Stehfest): when non-NULL, the (S) device tables
+  // w_re, w_im replace the Fourier phase and weights and the row scale is 1/t
+  const double* lin_wr;
+  const double* lin_wi;
 };
 hipError_t launch_ilt_fourier(const IltArgs& a, hipStream_t s);
 // backward of the Fourier ILT with respect to theta / phi (training through laplace_reconstruct)
