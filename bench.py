@@ -423,6 +423,23 @@ def main():
                                algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
                                frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=tr2, traffic_source=tr2_src)
         del theta, phi
+        # fixed Talbot at the Fourier kernel's shape: the same coalesced stream with the algorithm's per-term phase / weight
+        theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
+        phi = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.9
+        for _ in range(2):
+            nlc.ilt_reconstruct(theta, phi, tt, "fixed_tablot")
+        ictx.profile_reset()
+        ictx.profile(True)
+        for _ in range(10):
+            nlc.ilt_reconstruct(theta, phi, tt, "fixed_tablot")
+        torch.cuda.synchronize()
+        ictx.profile(False)
+        p = ictx.profile_read()["ilt_linear_stream_kernel"]
+        ms4 = p["total_ms"] / p["launches"]
+        ilt["fixed_tablot17"] = dict(bound="hbm", kernel="ilt_fourier_kernel<.., LIN> (ilt_linear_stream_kernel)", avg_launch_ms=ms4,
+                                     points=N, algorithmic_bytes=nbytes, achieved=nbytes / (ms4 * 1e-3) / 1e9, unit="GB/s",
+                                     frac=nbytes / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
+        del theta, phi
         # backward of the Fourier ILT (training through laplace_reconstruct): reads theta, phi, writes both gradients
         theta = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi).requires_grad_()
         phi = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.99).requires_grad_()
