@@ -183,9 +183,8 @@ typedef struct {
  *   linear_tanh_stack.0.weight (h,2S+d+2) .0.bias (h) .2.weight (h,h) .2.bias (h)
  *   .4.weight (2dS,h) .4.bias (2dS)
  * n_doubles must equal nlc_model_blob_size(desc).  The ctx repacks them into MFMA fragment order.
- * desc->ilt.algo: NLC_ILT_FOURIER / NLC_ILT_DEHOOG models run every entry point below; NLC_ILT_FIXED_TALBOT / NLC_ILT_STEHFEST
- * models run nlc_gru_encode, nlc_rep_func and the planner (NLC_DYN_NL, staged path) -- nlc_model_forward* return
- * NLC_ERR_UNSUPPORTED for them (their query points depend on each row's t: run the stages, as the Python mirror does). */
+ * desc->ilt.algo: every implemented algorithm runs nlc_gru_encode, nlc_rep_func, nlc_model_forward and the planner
+ * (NLC_DYN_NL; Fourier: fused rollout kernel, the others: staged all-HIP path); nlc_model_forward_const_t is Fourier only. */
 int64_t nlc_model_blob_size(const nlc_model_desc* desc);
 int nlc_set_model(nlc_ctx* ctx, const nlc_model_desc* desc, const double* weights_host, int64_t n_doubles);
 /* ReverseGRUEncoder.forward on the model's normalised input: window_dev (N, B, nin) raw

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void rep_inputs_kernel(const RepInArgs a) {
     if (col >= 2 * a.S) {
       v = a.p[b * a.P + (col - 2 * a.S)];
     } else {
-      const double t = a.t_batched ? a.t[row] : a.t[j];
+      const double t = (a.t_batched ? a.t[row] : a.t[j]) / (a.t_div > 0.0 ? a.t_div : 1.0);
       const double Tt = a.scale * t;
       const int k = col < a.S ? col : col - a.S;
       double gamma, im;
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
   const int64_t rows_total = a.N * a.d;
   const int64_t nblk = (rows_total + rows - 1) / rows;
   constexpr int UB = 8;  // pipeline depth in passes; the launcher makes iters a multiple of UB
-  auto row_scale = [&](double t) { return LIN ? m::rcp_refined(t) : ilt_row_scale(a, t); };
+  // (LIN: t_div is the model's time normalisation when the model forward drives this kernel, 1 otherwise)
+  auto row_scale = [&](double t) { return LIN ? m::div_fast(a.t_div, t) : ilt_row_scale(a, t); };
   int64_t blk = blockIdx.x;
 
   if constexpr (ITERS > 0) {

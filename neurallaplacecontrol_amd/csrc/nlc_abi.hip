@@ -649,7 +649,7 @@ extern "C" int nlc_ilt_rep_inputs(nlc_ctx* c, const nlc_ilt_desc* d, const doubl
   if (B * Tt == 0) return NLC_OK;
   if (!p || !t || !out) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
   NLC_HIP(c, hipSetDevice(c->device));
-  RepInArgs a{p, t, out, B, Tt, P, d->terms, t_batched, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr};
+  RepInArgs a{p, t, out, B, Tt, P, d->terms, t_batched, d->alpha, std::log(d->tol), d->scale, nullptr, nullptr, 1.0};
   if (d->algo == NLC_ILT_FIXED_TALBOT || d->algo == NLC_ILT_STEHFEST) {
     const double* tab = nullptr;
     if (int r = linear_tables(c, d, &tab)) return r;
@@ -756,8 +756,7 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   NLC_GUARD_BEGIN
   if (!d || !w) return fail(c, NLC_ERR_BAD_ARG, "NULL desc or weights");
   if (int r = check_ilt(c, &d->ilt)) return r;
-  // (fixed_tablot / stehfest models: GRU encoder, representation kernel and the staged planner; their model.forward runs
-  // staged in the Python mirror)
+  // (fixed_tablot / stehfest models: staged all-HIP forward and planner, like de Hoog)
   if (d->h != 64 && d->h != 128 && d->h != 256)
     return fail(c, NLC_ERR_UNSUPPORTED, "hidden_units must be 64, 128 or 256 (the kernels are instantiated for these widths)");
   if (d->d < 1 || d->d > 6) return fail(c, NLC_ERR_UNSUPPORTED, "state_dim must be in 1..6");
@@ -935,6 +934,8 @@ extern "C" int64_t nlc_model_workspace_bytes(nlc_ctx* c, int64_t N) {
   if (N < 0) return -1;
   int64_t n = N * 2 + 64;  // GRU latents
   if (c && c->has_model && c->md.ilt.algo == NLC_ILT_DEHOOG) n += 2 * N * c->md.d * c->S + 64;  // F_k re/im
+  if (c && c->has_model && (c->md.ilt.algo == NLC_ILT_FIXED_TALBOT || c->md.ilt.algo == NLC_ILT_STEHFEST))
+    n += 2 * N * c->md.d * c->S + 2 * N * c->S + 128;  // theta / phi rows + per-row sphere inputs
   return n * (int64_t)sizeof(double);
 }
 
@@ -1002,8 +1003,6 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
   if (!c->has_model) return fail(c, NLC_ERR_STATE, "nlc_set_model has not been called");
   if (c->md.ilt.algo == NLC_ILT_DEHOOG && (c->S < 3 || c->S > 33 || c->S % 2 == 0))
     return fail(c, NLC_ERR_UNSUPPORTED, "dehoog: ilt_reconstruction_terms must be odd, 3 .. 33 (2M+1 terms)");
-  if (c->md.ilt.algo != NLC_ILT_DEHOOG && c->md.ilt.algo != NLC_ILT_FOURIER)
-    return fail(c, NLC_ERR_UNSUPPORTED, "nlc_model_forward: fourier and dehoog models (the linear algorithms' query points depend on t per sample: run nlc_gru_encode, the representation function and nlc_ilt staged)");
   if (N < 0 || B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "bad N or B");
   if (N == 0) return NLC_OK;
   if (!obs || !window || !ts || !out || !ws) return fail(c, NLC_ERR_BAD_ARG, "NULL device pointer");
@@ -1018,6 +1017,56 @@ extern "C" int nlc_model_forward(nlc_ctx* c, const double* obs, const double* wi
     a.out = pa;
     ProfScope ps(c, "gru_encode_kernel");
     NLC_HIP(c, launch_gru_encode(a, c->g, c->stream, gru_use_coop(c, a.N)));
+  }
+  if (c->md.ilt.algo == NLC_ILT_FIXED_TALBOT || c->md.ilt.algo == NLC_ILT_STEHFEST) {
+    // staged (round 3): per-row query points s_k = node_k / t on the algorithm's own contour -> sphere inputs, the
+    // representation kernel on explicit sphere inputs -> (theta, phi) rows, the Fourier kernel's stream with the algorithm's
+    // per-term phase and weight
+    const int S = c->S, dd = c->md.d;
+    double* sph = pa + (N * 2 + 63) / 64 * 64;
+    double* th = sph + (N * 2 * S + 63) / 64 * 64;
+    double* ph = th + N * dd * S;
+    const double* tab = nullptr;
+    if (int r = linear_tables(c, &c->md.ilt, &tab)) return r;
+    {
+      RepInArgs ra{ts, ts, sph, N, 1, 0, S, 1, c->md.ilt.alpha, std::log(c->md.ilt.tol), c->md.ilt.scale, tab, tab + S, c->md.time_div};
+      ProfScope ps(c, "rep_inputs_kernel");
+      NLC_HIP(c, launch_rep_inputs(ra, c->stream));
+    }
+    RepFuncArgs rf{};
+    rf.net = c->net;
+    rf.N = N;
+    rf.obs = obs;
+    rf.obs_stride = dd;
+    rf.obs_per_sample = 1;
+    rf.Kep = 1;
+    rf.pa = pa;
+    rf.pa_stride = 2;
+    rf.general_t = 1;
+    rf.slot = c->slot_dev;
+    rf.fre = th;
+    rf.fim = ph;
+    rf.sph = sph;
+    rf.sph_stride = 2 * S;
+    rf.write_angles = 1;
+    {
+      ProfScope ps(c, "nl_repfunc_kernel");
+      NLC_HIP(c, launch_nl_repfunc(rf, c->stream));
+    }
+    IltArgs ia{th, ph, ts, out, N, dd, S, c->md.ilt.alpha, std::log(c->md.ilt.tol), c->md.ilt.scale, nullptr, nullptr, c->md.time_div, 1, 0, 0, 0};
+    ia.lin_wr = tab + 2 * S;
+    ia.lin_wi = tab + 3 * S;
+    hipError_t le;
+    {
+      ProfScope ps(c, "ilt_linear_stream_kernel");
+      le = launch_ilt_fourier(ia, c->stream);
+    }
+    if (le == hipErrorInvalidValue) {
+      (void)hipGetLastError();
+      return fail(c, NLC_ERR_UNSUPPORTED, "nlc_model_forward: this term count does not fit the stream kernel's tiling");
+    }
+    NLC_HIP(c, le);
+    return NLC_OK;
   }
   if (c->md.ilt.algo == NLC_ILT_DEHOOG) {
     // staged: representation function -> F_k (re, im) in HBM -> de Hoog kernel (nonlinear in F: not an MFMA epilogue)

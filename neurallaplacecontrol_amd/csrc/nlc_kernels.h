@@ -60,6 +60,7 @@ struct RepInArgs {
   // linear algorithms: query points s_k = (node_re[k] + i node_im[k]) / t from device tables (NULL: Fourier / de Hoog)
   const double* node_re;
   const double* node_im;
+  double t_div;  // t is divided by this before use (model time normalisation); 0 is read as 1
 };
 hipError_t launch_rep_inputs(const RepInArgs& a, hipStream_t s);
 

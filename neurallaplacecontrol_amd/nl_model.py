@@ -198,8 +198,8 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
         d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)
         desc = _lib.ModelDesc()
         desc.d, desc.nin, desc.h = d, nin, self.hidden_units
-        # fourier / dehoog: fused forward and planner kernels; fixed_tablot / stehfest: GRU encoder, representation kernel
-        # and the staged planner path (their model.forward runs staged in _forward below)
+        # fourier: fused forward and planner kernels; dehoog / fixed_tablot / stehfest: staged all-HIP forward (representation
+        # kernel -> ILT kernel) and staged planner path
         desc.ilt = _lib.ilt_desc(self.ilt_algorithm, self.s_recon_terms, self.ilt_options)
         f64 = lambda t: t.detach().to("cpu", torch.float64).reshape(-1)  # noqa: E731
         if self.normalize:
@@ -359,7 +359,7 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
                                                             _lib.ptr(out), _lib.ptr(ws)))
             return torch.squeeze(out.view(N, 1, d)).to(out_device)
         ts = torch.as_tensor(ts_pred).detach().to(dev, torch.float64)
-        fused = self.ilt_algorithm in ("fourier", "dehoog") and ts.numel() == N
+        fused = ts.numel() == N  # one query time per row: all-HIP forward for every implemented algorithm
         if fused:
             out = torch.empty((N, d), dtype=torch.float64, device=dev)
             ws = torch.empty(ctx.lib.nlc_model_workspace_bytes(ctx.h, N) // 8, dtype=torch.float64, device=dev)

@@ -1446,6 +1446,28 @@ def test_dehoog_autograd_path(nlc, monkeypatch, S, N, d):
         np.testing.assert_allclose((got_ / sc).numpy(), (ref_ / sc).numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_dehoog_backward_owns_its_scratch_across_streams(nlc):
+    """The QD tape of ilt_dehoog_bwd_kernel is stream-ordered scratch of each call (no ctx state): backward calls issued
+    back to back on two streams give the bits of a lone call."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    N, d, S = 700, 5, 33
+    theta = ((torch.rand(N, d, S, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * 3.0).requires_grad_()
+    phi = ((torch.rand(N, d, S, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * 1.2).requires_grad_()
+    t = torch.full((N,), 0.125, dtype=torch.float64, device="cuda")
+    gx = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    ref = torch.autograd.grad(nlc.ilt_reconstruct(theta, phi, t, "dehoog"), (theta, phi), gx)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(10):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(torch.autograd.grad(nlc.ilt_reconstruct(theta, phi, t, "dehoog"), (theta, phi), gx))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1])
+
+
 def test_error_paths_raise(nlc):
     from neurallaplacecontrol_amd import _lib
 
