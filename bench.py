@@ -248,6 +248,30 @@ def self_launch(n, argv, result_fd):
     return proc.returncode
 
 
+def preheat(one_step, ms, group=None, device="cpu", chunk=16):
+    """Untimed commands for about `ms` milliseconds, the SAME number on every rank: a sharded command() contains a
+    collective, so ranks that stopped on their own clocks after different counts would leave unmatched collectives behind
+    (and merge partials of different commands meanwhile).  Every `chunk` steps the ranks agree (MAX) on whether anyone
+    still wants more.  Returns the number of steps taken."""
+    import torch.distributed as dist
+
+    n = 0
+    if ms <= 0:
+        return n
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(chunk):
+            one_step()
+        n += chunk
+        more = (time.perf_counter() - t0) * 1e3 < ms
+        if group is not None:
+            flag = torch.tensor([1.0 if more else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            more = bool(flag.item() > 0.0)
+        if not more:
+            return n
+
+
 def git_commit():
     try:
         return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
@@ -348,9 +372,13 @@ def main():
     # set-up, before the W warm-up steps and outside every timed region: planner construction above, and `--preheat-ms` of
     # untimed commands so that a short run (the driver's K = 20) does not time the GPU's clock ramp from idle (at one
     # 8-GPU shard, 0.7 ms per step, 50 cold steps measured 0.74 ms per step where a 200-step loop measures 0.71)
-    t_heat = time.perf_counter()
-    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
-        abuf = step(abuf)
+    holder = [abuf]
+
+    def one_step():
+        holder[0] = step(holder[0])
+
+    preheat(one_step, args.preheat_ms, pg, f"cuda:{local}")
+    abuf = holder[0]
     for _ in range(args.warmup):
         abuf = step(abuf)
     fence()
@@ -461,9 +489,16 @@ def main():
                                traffic=tr3, traffic_source=tr3_src)
         del theta, phi, gx
 
-    if rank != 0:
+    def teardown():
+        # orderly end: rank 0 arrives late (stand-alone ILT section); nobody tears a communicator down under a peer
         if pg is not None:
+            fence()
+            if planner.native_collective:
+                planner.ctx.comm_destroy()
             dist.destroy_process_group()
+
+    if rank != 0:
+        teardown()
         return
 
     kernels = {k: dict(avg_ms=v["total_ms"] / max(v["launches"], 1), launches=v["launches"]) for k, v in prof.items()}
@@ -529,8 +564,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if pg is not None:
-        dist.destroy_process_group()
+    teardown()
 
 
 if __name__ == "__main__":

@@ -189,6 +189,44 @@ def test_multi_rank_gloo_sharded_command(tmp_path, world):
     np.testing.assert_allclose(float(r0["eta"]), float(full["eta"]), rtol=1e-12)
 
 
+PREHEAT_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+calls = []
+def one_step():
+    # every step holds a collective, as a sharded command() does; rank 1 is the slower host
+    t = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(t)
+    calls.append(float(t))
+    time.sleep(0.0005 * (1 + 3 * rank))
+n = bench.preheat(one_step, 60.0, dist.group.WORLD, "cpu", chunk=4)
+assert n == len(calls) and n >= 4 and n % 4 == 0
+assert bench.preheat(one_step, 0.0, dist.group.WORLD, "cpu") == 0
+counts = [None] * dist.get_world_size()
+dist.all_gather_object(counts, n)
+assert len(set(counts)) == 1, counts     # the same number of steps (= collectives) on every rank
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_bench_preheat_takes_the_same_number_of_steps_on_every_rank(tmp_path):
+    """bench.py's untimed pre-heat is bounded by wall time, and a sharded command() contains a collective: ranks stopping on
+    their own clocks would leave unmatched collectives behind.  Two gloo ranks with different step durations must agree on
+    the count."""
+    script = tmp_path / "preheat_worker.py"
+    script.write_text(PREHEAT_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29561", str(script), REPO],
+        env=env, timeout=600,
+    )
+
+
 def test_shard_range():
     from neurallaplacecontrol_amd.sharding import shard_range
 
