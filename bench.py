@@ -297,6 +297,10 @@ def main():
                     help="untimed commands for this long during set-up (clock ramp from idle), before the W warm-up steps")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch rehearsal: start the ranks, report the environment each one sees, touch no GPU")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="launch rehearsal WITH the GPU work (tests): every rank plans its shard on cuda:0 and the ranks talk "
+                         "over gloo (RCCL refuses two ranks per device) -- the whole N > 1 flow of this file on a 1-GPU box; "
+                         "its numbers mean nothing")
     ap.add_argument("--samples", type=int, default=K_SAMPLES,
                     help="override K (experiments only; the headline metric is quoted at the default 16384)")
     args = ap.parse_args()
@@ -335,10 +339,16 @@ def main():
     import neurallaplacecontrol_amd as nlc
 
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
+    coll_dev = "cpu" if args.rehearse_on_one_gpu else f"cuda:{local}"  # where the bench's own small collectives live
     pg = None
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run even a 1-rank job goes through RCCL
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = dist.group.WORLD
     K_total = args.samples
 
@@ -377,7 +387,7 @@ def main():
     def one_step():
         holder[0] = step(holder[0])
 
-    preheat(one_step, args.preheat_ms, pg, f"cuda:{local}")
+    preheat(one_step, args.preheat_ms, pg, coll_dev)
     abuf = holder[0]
     for _ in range(args.warmup):
         abuf = step(abuf)
@@ -388,7 +398,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if pg is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # second, untimed pass: the same steps with hipEvent pairs around every launch (on the launch stream)
@@ -536,6 +546,8 @@ def main():
     workload = (f"oderl-cartpole (nx=5, nu=1), K={K_total} MPPI samples sharded over the ranks, H={HORIZON}, "
                 f"action_buffer_size={ABUF}, NL dynamics h={HIDDEN} S={S_TERMS} fourier ILT")
     workload += " (BASELINE configs[1])" if K_total == K_SAMPLES else " -- EXPERIMENT: not the headline population of 16384"
+    if args.rehearse_on_one_gpu:
+        workload += " -- REHEARSAL: every rank on cuda:0 over gloo, not a measurement"
     out = dict(
         metric=f"MPPI planning steps/sec ({K_total} samples, H={HORIZON})",
         value=args.steps / elapsed,
@@ -553,7 +565,7 @@ def main():
                     commit=git_commit(), preheat_ms=args.preheat_ms,
                     collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
                                                         if planner.native_collective else
-                                                        "rccl all-gather via torch.distributed between the two phases")),
+                                                        f"{dist.get_backend(pg)} all-gather via torch.distributed between the two phases")),
         roofline=roofline,
         roofline_ilt=ilt,
         cpu_baseline=cpu,

@@ -2887,3 +2887,27 @@ def test_baseline_planners_edge_shapes_vs_oracle(nlc, kind, K, Tt, B):
     np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), **TOL)
     np.testing.assert_allclose(p.cost_total.numpy(), ref["cost_total"].numpy(), **TOL)
     np.testing.assert_allclose(p.states.numpy(), ref["states"].numpy(), **TOL)
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """The whole N > 1 flow of bench.py on the 1-GPU box: `python bench.py --gpus 2` starts its own two ranks, each plans
+    its K / 2 shard on cuda:0 (the ranks talk over gloo: RCCL refuses two ranks per device), rank-consistent pre-heat, timed
+    steps between barriers, MAX over ranks, ONE JSON line from rank 0, orderly teardown.  The numbers mean nothing; the run
+    must end with exit code 0 and a well-formed line."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "12",
+                          "--warmup", "2", "--preheat-ms", "40", "--no-ilt", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 12 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["config"]["samples_per_gpu"] == 8192 and "gloo" in rec["config"]["collective"]
+    assert "nl_rollout_kernel" in rec["kernels_avg_ms"] or "nl_plan_fused_kernel" in rec["kernels_avg_ms"]
+
