@@ -2,6 +2,8 @@
 finished after a few seconds, dumps the kernel's sync block (tickets, progress counters, census, flags) through a side
 stream and exits hard, so a hand-off bug never holds the GPU box.  The progress counters and the timeline need a library
 built with -DNLC_FUSED_TRACE=1 (make EXTRA_kernels_fused=-DNLC_FUSED_TRACE=1; NLC_LIB_PATH selects it).
+    (round 3: the merge kernel now zeroes the sync block after every command, so the dump shows the state of a HUNG launch
+    only; the timeline of a finished command needs the zeroing switched off in the trace build)
     python tools/fused_debug.py [K] [roll_cap] [<chain_first_tiles>x<partner_tiles>]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
