@@ -117,6 +117,8 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        is then two launches (this one + the merge after the shard all-gather) instead of five; 0 = separate
  *                        launches.  Same bits either way.
  *   "fused_spin_limit"   polls (~2 us each) before a waiting wave of the fused body gives up (default 2^18, ~0.5 s)
+ *   "fused_keep_sync"    tools only: the merge kernel does not zero the fused body's sync block (tools/fused_debug.py reads
+ *                        the launch's progress counters / timeline from it); the next command pays a memset instead
  *   "fused_test_drop_tile"  tests only: the encoder tile with this ticket is never published (-1 = none): forces the
  *                        hand-off timeout and the re-run on the two-launch body
  *   "fused_chain_first_tiles"  encoder tiles every such workgroup encodes before its chain starts (-1 = auto: 1)

@@ -131,6 +131,7 @@ struct nlc_ctx {
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
   int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
   int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
+  int opt_fused_keep_sync = 0;          // tools only: the merge kernel leaves the sync block as the launch left it (timeline dumps)
   const void* sync_clean_ws = nullptr;  // workspace whose fused sync block the last merge kernel left zeroed
   bool sync_dirty = false;              // a fused launch has used the sync block since
   // the last command's inputs, kept for a re-run on the two-launch body (nlc_mppi_finish, after a fused timeout)
@@ -527,6 +528,8 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "fused_spin_limit") {
     if (value < 1 || value > 4.0e9) return fail(c, NLC_ERR_BAD_ARG, "fused_spin_limit must be in 1 .. 4e9");
     c->opt_fused_spin_limit = (int64_t)value;
+  } else if (n == "fused_keep_sync") {
+    c->opt_fused_keep_sync = value != 0.0;
   } else if (n == "fused_test_drop_tile") {
     if (value < -1) return fail(c, NLC_ERR_BAD_ARG, "fused_test_drop_tile must be >= -1");
     c->opt_fused_test_drop_tile = (int)value;
@@ -2313,7 +2316,7 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
       m.seq_pinned = seq_word;
       m.seq = ++c->host_seq;
     }
-    if (c->sync_dirty && buf->workspace) {
+    if (c->sync_dirty && buf->workspace && !c->opt_fused_keep_sync) {
       // last launch of the command: leave the fused body's tickets / flags zeroed for the next one
       m.zero_words = reinterpret_cast<unsigned*>((double*)buf->workspace + ws_layout(c).sync);
       m.n_zero_words = (int64_t)fused_sync_words(d.T, d.K * d.E);

@@ -2,8 +2,7 @@
 finished after a few seconds, dumps the kernel's sync block (tickets, progress counters, census, flags) through a side
 stream and exits hard, so a hand-off bug never holds the GPU box.  The progress counters and the timeline need a library
 built with -DNLC_FUSED_TRACE=1 (make EXTRA_kernels_fused=-DNLC_FUSED_TRACE=1; NLC_LIB_PATH selects it).
-    (round 3: the merge kernel now zeroes the sync block after every command, so the dump shows the state of a HUNG launch
-    only; the timeline of a finished command needs the zeroing switched off in the trace build)
+    (the planner option fused_keep_sync = 1 set below keeps the merge kernel from zeroing the sync block after the command)
     python tools/fused_debug.py [K] [roll_cap] [<chain_first_tiles>x<partner_tiles>]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +20,7 @@ sched = sys.argv[3] if len(sys.argv) > 3 else None
 
 T, d, nu = bench.HORIZON, 5, 1
 model = bench.synthetic_state_dict(d, nu, bench.S_TERMS).to("cuda:0")
-opts = {"rollout_variant": 3}
+opts = {"rollout_variant": 3, "fused_keep_sync": 1}
 if cap:
     opts["fused_roll_cap"] = cap
 if sched is not None:
