@@ -10,6 +10,8 @@
 // in exactly the accumulator layout of the last layer's output tile (row 4r + q), so an Euler sub-step is
 // y_r += h * o_r with no lane movement, and y_r is directly the layer-1 B fragment of the next sub-step.
 //
+// Hidden activations: the short tanh pair of nlc_math.h (tanh_pair_fast: absolute error <= 1.5e-13, one reciprocal per
+// pair; round 3: 6.39 -> 6.31 ms per K = 16384, T = 40 rollout, every test at its tolerance).
 // Roofline: FP64 MFMA.  Per 16 samples and Euler sub-step: 3 HT + 4 HT^2 + 4 HT MFMAs (HT = ceil(H/16) = 17 for
 // H = 270: 1275 MFMAs of 2048 flop); three sub-steps per horizon step at the harness's dt.
 #include "nlc_device.h"
@@ -32,7 +34,7 @@ __device__ __forceinline__ v4d node_eval(const NodeNetArgs& n, int lane, int q, 
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
       double ta, tb;
-      m::tanh_pair_d(h1[j][r], h1[j][r + 1], &ta, &tb);
+      m::tanh_pair_fast(h1[j][r], h1[j][r + 1], &ta, &tb);
       h1[j][r] = ta;
       h1[j][r + 1] = tb;
     }
@@ -45,7 +47,7 @@ __device__ __forceinline__ v4d node_eval(const NodeNetArgs& n, int lane, int q, 
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
       double ta, tb;
-      m::tanh_pair_d(h2[j][r], h2[j][r + 1], &ta, &tb);
+      m::tanh_pair_fast(h2[j][r], h2[j][r + 1], &ta, &tb);
       h2[j][r] = ta;
       h2[j][r + 1] = tb;
     }
