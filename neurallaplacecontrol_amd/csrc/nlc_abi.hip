@@ -1533,14 +1533,14 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.abuf = take((size_t)d.E * d.B * d.nu);
   w.xcarry = take(d.dynamics == NLC_DYN_NL ? KE * d.d : 0);
   w.ccarry = take(d.dynamics == NLC_DYN_NL ? KE * 2 : 0);
-  const bool dh = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER;  // staged: de Hoog and the linear algorithms
-  w.fre = take(dh ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
-  w.fim = take(dh ? KE * 8 * (size_t)c->net.nt3 : 0);
-  w.dx = take(dh ? KE * d.d : 0);
-  w.tconst = take(dh ? 8 : 0);
+  const bool staged = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER;  // staged: de Hoog and the linear algorithms
+  w.fre = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
+  w.fim = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);
+  w.dx = take(staged ? KE * d.d : 0);
+  w.tconst = take(staged ? 8 : 0);
   w.rq = take(d.dynamics == NLC_DYN_DTRNN ? KE * d.T * d.d : 0);  // hidden part of linear_out, (T, K, d)
   // fused one-launch planner body: tickets, per-CU census, one flag word per encoder tile (unsigned words)
-  w.sync = take(d.dynamics == NLC_DYN_NL && !dh ? (fused_sync_words(d.T, (int64_t)KE) + 1) / 2 : 0);
+  w.sync = take(d.dynamics == NLC_DYN_NL && !staged ? (fused_sync_words(d.T, (int64_t)KE) + 1) / 2 : 0);
   w.total = off;
   return w;
 }
