@@ -96,7 +96,8 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        measured 4.224 vs 4.270 ms at 3 chunks (K = 16384) -- the two kernels leave each other little to fill
  *                        (95 % / 85 % of the issue slots busy), and per-launch times of overlapped kernels say nothing about
  *                        either, so the default and the reported roofline stay with the two plain launches.
- *   "dehoog_streams"     staged de Hoog planner (NLC_ILT_DEHOOG models): the population is cut into this many contiguous parts
+ *   "dehoog_streams"     staged planner (NLC_ILT_DEHOOG models; fixed Talbot / Stehfest models take the same path and the
+ *                        same options): the population is cut into this many contiguous parts
  *                        whose per-step launches run on streams of their own -- one part's FP64-VALU-bound QD pass beside
  *                        another part's MFMA-bound representation launch; 0 = auto (2 from 8192 samples), 1 = one stream.
  *                        Same bits for every value.
