@@ -1085,6 +1085,16 @@ def test_full_size_cfg5_dehoog(nlc):
     _subset_check(nlc, "oderl-cartpole", 16384, 40, 4, S=33, algo="dehoog", tol=1e-5, tame="dehoog")
 
 
+@pytest.mark.parametrize("algo,S", [("fixed_tablot", 17), ("stehfest", 16)])
+def test_full_size_linear_ilt_models(nlc, algo, S):
+    """The other closed-form values of nl_ilt_algorithm at configs[1]'s size (cartpole, K = 16384, T = 40) on the staged
+    all-HIP path (representation kernel -> slot-major linear reconstruction -> state / cost tail per horizon step): 64
+    strided samples through the oracle after 40 sequential steps at the north-star bar, softmax weights / U / action over
+    the whole population.  (Both algorithms sum terms with large alternating weights, so last-bit differences of F_k come
+    back amplified: the sweep's short-horizon cases hold 2e-5 / 1e-6.)"""
+    _subset_check(nlc, "oderl-cartpole", 16384, 40, 4, S=S, algo=algo, tol=1e-5)
+
+
 def test_cfg5_dehoog_planner_staged_hip_path(nlc):
     """BASELINE configs[4] ablation: a de Hoog (33 terms) model plans through the staged all-HIP path
     (rep-func kernel -> de Hoog kernel -> state/cost kernel per horizon step)."""
