@@ -3,9 +3,10 @@ import sys, time, numpy as np, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neurallaplacecontrol_amd as nlc
-S=33
+S=int(os.environ.get("CFG5_S", "33"))
+ALGO=os.environ.get("CFG5_ALGO", "dehoog")  # tools: the same breakdown for a fixed_tablot / stehfest model (staged path)
 torch.manual_seed(0)
-model = nlc.NeuralLaplaceModel(5, 1, 5, hidden_units=128, s_recon_terms=S, ilt_algorithm="dehoog", state_mean=np.zeros(5),
+model = nlc.NeuralLaplaceModel(5, 1, 5, hidden_units=128, s_recon_terms=S, ilt_algorithm=ALGO, state_mean=np.zeros(5),
     state_std=np.array([2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048]), action_mean=np.array([0]), action_std=np.array([1.5]), normalize=True, normalize_time=True).double()
 with torch.no_grad(): model.laplace_rep_func.linear_tanh_stack[4].bias[5*S:] += -3.0
 model = model.to("cuda")

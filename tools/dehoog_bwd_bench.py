@@ -54,7 +54,8 @@ def timed(fn, reps):
 out = []
 S, d = 33, 5
 desc = _lib.ilt_desc("dehoog", S)
-for N, with_torch in ((1024, True), (16384, True), (655360, False)):
+SIZES = [(int(a), False) for a in sys.argv[1:]] or [(1024, True), (16384, True), (655360, False)]  # argv: sizes, HIP only
+for N, with_torch in SIZES:
     g = torch.Generator(device="cuda").manual_seed(N)
     theta = ((torch.rand(N, d, S, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * 3.0).requires_grad_()
     phi = ((torch.rand(N, d, S, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * 1.2).requires_grad_()
