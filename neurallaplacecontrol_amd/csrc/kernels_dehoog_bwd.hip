@@ -6,7 +6,9 @@
 // The forward keeps ONE diagonal of the table in registers; reverse mode needs every entry again -- M (M + 1) q's and M^2
 // e's, 8.4 KB per row at M = 16 -- so this kernel rebuilds the table column by column into a TAPE in HBM scratch (the
 // mpmath column sweep: same rhombus rules, same operands per entry as the forward's diagonal sweep), then walks the
-// columns back with the adjoints in a second region of the same scratch.  The scratch belongs to the launch: the grid is
+// columns back with the adjoints in a second region of the same scratch -- each adjoint stored once, assembled from rolling
+// registers as the sweep walks up a column (a first version zeroed the adjoints and read-modify-wrote them: 93 KB of HBM
+// traffic per row against ~55 KB now).  The scratch belongs to the launch: the grid is
 // persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries are [entry][lane] so every access is one
 // 1-KB line per wavefront.  A training batch (some thousand rows) keeps its slabs in L2 / MALL; the kernel is a
 // latency-bound chain of complex divisions either way.
@@ -30,7 +32,8 @@ struct DhLayout {
   __host__ __device__ int A(int i) const { return M * (M + 1) + M * M + (2 * M + 1) + (i + 1); }          // i = -1..2M-1
   __host__ __device__ int B(int i) const { return M * (M + 1) + M * M + 2 * (2 * M + 1) + (i + 1); }      // i = -1..2M-1
   __host__ __device__ int n_values() const { return M * (M + 1) + M * M + 3 * (2 * M + 1); }
-  // adjoints: same q / e / a indices, offset by n_values()
+  // adjoints, offset by n_values(): qbar at q's index, parked ebar at e's index, the seeds dbar_i (i = 0..2M) behind them
+  __host__ __device__ int dbar(int i) const { return M * (M + 1) + M * M + i; }
   __host__ __device__ int n_adjoints() const { return M * (M + 1) + M * M + (2 * M + 1); }
   __host__ __device__ int entries() const { return n_values() + n_adjoints(); }
 };
@@ -43,11 +46,6 @@ struct Tape {
     return {v.x, v.y};
   }
   __device__ __forceinline__ void st(int e, cplx v) const { base[(size_t)e * 64 + lane] = make_double2(v.re, v.im); }
-  __device__ __forceinline__ void add(int e, cplx v) const {
-    double2* p = base + (size_t)e * 64 + lane;
-    const double2 o = *p;
-    *p = make_double2(o.x + v.re, o.y + v.im);
-  }
 };
 
 }  // namespace
@@ -138,7 +136,8 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
     const cplx res = cdiv(An, Bn);
 
     // ---------------------------------------------------------------- backward
-    for (int e = 0; e < L.n_adjoints(); ++e) tp.st(nv + e, zero);
+    // Every adjoint is STORED ONCE (no zeroing, no read-modify-write): the seeds d_i-bar go to slots of their own, and
+    // a column's adjoints are assembled on the fly from rolling registers as the sweep walks up the column.
     const double G = a.gx[row] * (exp(gamma * t) / Tt);  // x = e^{gamma t} / T Re(res)
     const cplx g_res = {G, 0.0};
     // res = An / Bn
@@ -157,10 +156,9 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
     cplx g_dend = cmul(g_u, cconj(z));
     // brem = (1 + (d_last - d_end) z) / 2
     const cplx g_diff = cscale(cmul(g_brem, cconj(z)), 0.5);
-    cplx g_dlast = g_diff;
+    const cplx g_dlast = g_diff;
     g_dend = csub(g_dend, g_diff);
-    // d_(2M) = -e_M^(0)
-    tp.add(nv + L.e(M, 0), cneg(g_dend));
+    tp.st(nv + L.dbar(2 * M), g_dend);
     // recurrence, i = 2M-1 .. 1
     for (int i = 2 * M - 1; i >= 1; --i) {
       const cplx di = dcoef(i);
@@ -175,45 +173,67 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
       gA0 = gAm2;
       gB1 = gB0;
       gB0 = gBm2;
-      // d_i = -q_r^(0) (i = 2r-1) or -e_r^(0) (i = 2r)
-      tp.add(nv + ((i & 1) ? L.q((i + 1) / 2, 0) : L.e(i / 2, 0)), cneg(g_di));
+      tp.st(nv + L.dbar(i), g_di);
     }
-    // A_0 = d_0 = a_0 (A_(-1), B_0, B_(-1) are constants)
-    tp.add(nv + L.a(0), gA1);
-    // table, columns r = M .. 1
+    // A_0 = d_0 = a_0 (A_(-1), B_0, B_(-1) are constants): d_0-bar = A_0-bar
+    const cplx g_a0_seed = gA1;
+    // table, columns r = M .. 1.  With wbar_j = qbar_(r+1)^(j) (zero for r = M):
+    //   ebar_r^(i) = [i = 0] (-dbar_2r) + ebar_(r+1)^(i-1)                                    (e_(r+1)^(i-1) = ... + e_r^(i))
+    //               + wbar_(i-1) conj(q_r^(i) / e_r^(i-1)) - wbar_i conj(q_(r+1)^(i) / e_r^(i))   (q_(r+1) = q e_hi / e_lo)
+    //   qbar_r^(i) = [i = 0] (-dbar_(2r-1)) + ebar_r^(i-1) - ebar_r^(i) + wbar_(i-1) conj(e_r^(i) / e_r^(i-1))
+    // ebar_(r+1)^(i-1) was parked in the slot of ebar_r^(i) by the sweep of column r + 1.
     for (int r = M; r >= 1; --r) {
       const int mr = 2 * (M - r) + 1;
-      if (r != M) {
-        for (int i = 0; i < mr - 1; ++i) {
-          const cplx gw = tp.ld(nv + L.q(r + 1, i));
-          const cplx qv = tp.ld(L.q(r, i + 1)), ehi = tp.ld(L.e(r, i + 1)), elo = tp.ld(L.e(r, i));
-          const double inv = m::rcp_refined(elo.re * elo.re + elo.im * elo.im);
-          const cplx ielo = {elo.re * inv, -elo.im * inv};  // 1 / e_r^(i)
-          const cplx ratio = cmul(ehi, ielo);
-          const cplx qi = cmul(qv, ielo);
-          tp.add(nv + L.q(r, i + 1), cmul(gw, cconj(ratio)));
-          tp.add(nv + L.e(r, i + 1), cmul(gw, cconj(qi)));
-          tp.add(nv + L.e(r, i), cneg(cmul(gw, cconj(cmul(qi, ratio)))));
+      const bool inner = r != M;
+      cplx g_prev = zero, wbar_im1 = zero, e_im1 = one;
+      cplx e_i = tp.ld(L.e(r, 0)), q_i = tp.ld(L.q(r, 0));
+      for (int i = 0; i <= mr; ++i) {
+        const bool has_e = i <= mr - 1;
+        const bool has_w = inner && i <= mr - 2;  // q_(r+1)^(i) exists
+        const cplx q_nxt = i + 1 <= mr ? tp.ld(L.q(r, i + 1)) : zero;
+        const cplx e_nxt = i + 1 <= mr - 1 ? tp.ld(L.e(r, i + 1)) : one;
+        const cplx wbar_i = has_w ? tp.ld(nv + L.q(r + 1, i)) : zero;
+        cplx g = zero;
+        cplx c_term = zero;  // wbar_(i-1) conj(e_r^(i) / e_r^(i-1))
+        if (has_e) {
+          const double inv_i = m::rcp_refined(e_i.re * e_i.re + e_i.im * e_i.im);
+          const cplx ie_i = {e_i.re * inv_i, -e_i.im * inv_i};  // 1 / e_r^(i)
+          if (i == 0) g = cneg(tp.ld(nv + L.dbar(2 * r)));
+          if (inner && i >= 1 && i <= mr - 2) g = cadd(g, tp.ld(nv + L.e(r, i)));  // parked ebar_(r+1)^(i-1)
+          if (inner && i >= 1) {
+            const double inv_m = m::rcp_refined(e_im1.re * e_im1.re + e_im1.im * e_im1.im);
+            const cplx ie_m = {e_im1.re * inv_m, -e_im1.im * inv_m};  // 1 / e_r^(i-1)
+            g = cadd(g, cmul(wbar_im1, cconj(cmul(q_i, ie_m))));
+            c_term = cmul(wbar_im1, cconj(cmul(e_i, ie_m)));
+          }
+          if (has_w) {
+            // q_(r+1)^(i) / e_r^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)^2
+            const cplx ratio = cmul(e_nxt, ie_i);
+            g = csub(g, cmul(wbar_i, cconj(cmul(cmul(q_nxt, ie_i), ratio))));
+          }
         }
-      }
-      for (int i = 0; i < mr; ++i) {
-        const cplx g = tp.ld(nv + L.e(r, i));
-        tp.add(nv + L.q(r, i + 1), g);
-        tp.add(nv + L.q(r, i), cneg(g));
-        if (r > 1) tp.add(nv + L.e(r - 1, i + 1), g);
+        cplx qb = csub(cadd(g_prev, c_term), g);
+        if (i == 0) qb = csub(qb, tp.ld(nv + L.dbar(2 * r - 1)));
+        tp.st(nv + L.q(r, i), qb);
+        if (has_e && r > 1) tp.st(nv + L.e(r - 1, i + 1), g);
+        g_prev = g;
+        wbar_im1 = wbar_i;
+        e_im1 = e_i;
+        e_i = e_nxt;
+        q_i = q_nxt;
       }
     }
-    // column 1: q_1^(i) = a_(i+1) / a_i
-    for (int i = 0; i < 2 * M; ++i) {
-      const cplx g = tp.ld(nv + L.q(1, i));
-      const cplx ai = tp.ld(L.a(i)), q1 = tp.ld(L.q(1, i));
-      const cplx ga_hi = cdiv(g, cconj(ai));
-      tp.add(nv + L.a(i + 1), ga_hi);
-      tp.add(nv + L.a(i), cneg(cmul(ga_hi, cconj(q1))));
-    }
-    // F_k = R (cos theta + i sin theta), R = tan(phi/2 + pi/4), dR/dphi = (1 + R^2) / 2;  a_0 = F_0 / 2
+    // column 1 (q_1^(i) = a_(i+1) / a_i) and the sphere map, per term k:
+    //   abar_k = [k = 0] dbar_0 + h_(k-1) - h_k conj(q_1^(k)),  h_k = qbar_1^(k) / conj(a_k)  (k <= 2M-1)
+    //   F_k = R (cos theta + i sin theta), R = tan(phi/2 + pi/4), dR/dphi = (1 + R^2) / 2;  a_0 = F_0 / 2
+    cplx h_prev = zero;
     for (int k = 0; k <= 2 * M; ++k) {
-      cplx gF = tp.ld(nv + L.a(k));
+      cplx gF = k == 0 ? g_a0_seed : h_prev;
+      if (k <= 2 * M - 1) {
+        const cplx h = cdiv(tp.ld(nv + L.q(1, k)), cconj(tp.ld(L.a(k))));
+        gF = csub(gF, cmul(h, cconj(tp.ld(L.q(1, k)))));
+        h_prev = h;
+      }
       if (k == 0) gF = cscale(gF, 0.5);
       const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
       double sn, cs;
