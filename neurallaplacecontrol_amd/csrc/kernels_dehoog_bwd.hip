@@ -87,22 +87,18 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
     }
     for (int r = 1; r <= M; ++r) {
       const int mr = 2 * (M - r) + 1;
-      // e_r^(i) = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)
-      cplx qlo = tp.ld(L.q(r, 0));
+      // one pass up the column, the previous entries in registers:
+      //   e_r^(i)       = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)
+      //   q_(r+1)^(i-1) = q_r^(i) e_r^(i) / e_r^(i-1)                      (r < M, i >= 1)
+      cplx qlo = tp.ld(L.q(r, 0)), elo = zero;
       for (int i = 0; i < mr; ++i) {
         const cplx qhi = tp.ld(L.q(r, i + 1));
         const cplx eprev = r > 1 ? tp.ld(L.e(r - 1, i + 1)) : zero;
-        tp.st(L.e(r, i), cadd(csub(qhi, qlo), eprev));
+        const cplx ei = cadd(csub(qhi, qlo), eprev);
+        tp.st(L.e(r, i), ei);
+        if (r != M && i >= 1) tp.st(L.q(r + 1, i - 1), cdiv(cmul(qlo, ei), elo));
         qlo = qhi;
-      }
-      if (r != M) {
-        // q_(r+1)^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)
-        cplx elo = tp.ld(L.e(r, 0));
-        for (int i = 0; i < mr - 1; ++i) {
-          const cplx ehi = tp.ld(L.e(r, i + 1));
-          tp.st(L.q(r + 1, i), cdiv(cmul(tp.ld(L.q(r, i + 1)), ehi), elo));
-          elo = ehi;
-        }
+        elo = ei;
       }
     }
     // continued fraction: d_0 = a_0, d_(2r-1) = -q_r^(0), d_(2r) = -e_r^(0);  A_i = A_(i-1) + d_i z A_(i-2)
