@@ -8,10 +8,10 @@
 // mpmath column sweep: same rhombus rules, same operands per entry as the forward's diagonal sweep), then walks the
 // columns back with the adjoints in a second region of the same scratch -- each adjoint stored once, assembled from rolling
 // registers as the sweep walks up a column (a first version zeroed the adjoints and read-modify-wrote them: 93 KB of HBM
-// traffic per row against ~55 KB now).  The scratch belongs to the launch: the grid is
-// persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries are [entry][lane] so every access is one
-// 1-KB line per wavefront.  A training batch (some thousand rows) keeps its slabs in L2 / MALL; the kernel is a
-// latency-bound chain of complex divisions either way.
+// traffic per row against 61.5 KB measured for this form, profiles/r3_pmc_new_ilt.json).  The scratch belongs to the launch: the
+// grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries are [entry][lane] so every access is
+// one 1-KB line per wavefront.  Bound: HBM traffic of the tape from a few ten thousand rows on (VALU-active 0.08), launch
+// latency of one long dependent chain below that.
 //
 // Adjoint convention: for a real loss L and a complex intermediate w, wbar = dL/dRe(w) + i dL/dIm(w); then for
 // holomorphic w = f(u): ubar += wbar conj(f'(u)).
