@@ -112,18 +112,23 @@ int main(void) {
     hipMemcpy(ph_d, ph, sizeof(ph), hipMemcpyHostToDevice);
     hipMemcpy(t_d, tt, sizeof(tt), hipMemcpyHostToDevice);
     hipMemcpy(gx_d, gx, sizeof(gx), hipMemcpyHostToDevice);
-    nlc_ilt_desc il;
-    il.algo = NLC_ILT_FOURIER; il.terms = S; il.alpha = 1e-3; il.tol = 1e-2; il.scale = 2.0;
-    CHECK(nlc_ilt_reconstruct(ctx, &il, th_d, ph_d, t_d, N, D, x_d));
-    CHECK(nlc_ilt_reconstruct_backward(ctx, &il, th_d, ph_d, t_d, gx_d, N, D, gth_d, gph_d));
-    CHECK(nlc_synchronize(ctx));
-    hipMemcpy(x, x_d, sizeof(x), hipMemcpyDeviceToHost);
-    hipMemcpy(gth, gth_d, sizeof(gth), hipMemcpyDeviceToHost);
-    hipMemcpy(gph, gph_d, sizeof(gph), hipMemcpyDeviceToHost);
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < N * D * S; ++i) { s1 += gth[i] * (1 + i % 3); s2 += gph[i] * (1 + i % 5); }
-    for (int i = 0; i < N * D; ++i) printf("%.17g ", x[i]);
-    printf("%.17g %.17g\n", s1, s2);
+    /* one line per algorithm: fourier, dehoog, fixed_tablot (17 terms each; defaults of the Python mirror's ilt_desc) */
+    const int algos[3] = {NLC_ILT_FOURIER, NLC_ILT_DEHOOG, NLC_ILT_FIXED_TALBOT};
+    const double alphas[3] = {1e-3, 1e-10, 1.0}, tols[3] = {1e-2, 1e-9, 10.0}, scales[3] = {2.0, 2.0, 1.0};
+    for (int m = 0; m < 3; ++m) {
+      nlc_ilt_desc il;
+      il.algo = algos[m]; il.terms = S; il.alpha = alphas[m]; il.tol = tols[m]; il.scale = scales[m];
+      CHECK(nlc_ilt_reconstruct(ctx, &il, th_d, ph_d, t_d, N, D, x_d));
+      CHECK(nlc_ilt_reconstruct_backward(ctx, &il, th_d, ph_d, t_d, gx_d, N, D, gth_d, gph_d));
+      CHECK(nlc_synchronize(ctx));
+      hipMemcpy(x, x_d, sizeof(x), hipMemcpyDeviceToHost);
+      hipMemcpy(gth, gth_d, sizeof(gth), hipMemcpyDeviceToHost);
+      hipMemcpy(gph, gph_d, sizeof(gph), hipMemcpyDeviceToHost);
+      double s1 = 0.0, s2 = 0.0;
+      for (int i = 0; i < N * D * S; ++i) { s1 += gth[i] * (1 + i % 3); s2 += gph[i] * (1 + i % 5); }
+      for (int i = 0; i < N * D; ++i) printf("%.17g ", x[i]);
+      printf("%.17g %.17g\n", s1, s2);
+    }
   }
   nlc_destroy(ctx);
   return 0;

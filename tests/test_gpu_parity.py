@@ -2460,19 +2460,21 @@ def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
     obs, rew = e.step(torch.tensor([[2.0], [-1.0]], dtype=torch.float64))
     assert obs.cpu().reshape(-1).tolist() + rew.cpu().tolist() == c_env
     # ILT forward / backward through the C client == through the Python mirror's autograd
-    c_ilt = [float(x) for x in lines[5].split()]
+    # (one line per algorithm: forward kernels AND backward kernels of fourier, dehoog, fixed_tablot)
     N, D, S = 3, 2, 17
     i = torch.arange(N * D * S, dtype=torch.float64)
-    th = (3.0 * ((i * 37) % 101) / 101.0 - 1.5).view(N, D, S).cuda().requires_grad_()
-    ph = (1.2 * ((i * 53) % 97) / 97.0 - 0.6).view(N, D, S).cuda().requires_grad_()
-    x = nlc.ilt_reconstruct(th, ph, torch.tensor([0.1, 0.125, 0.3], dtype=torch.float64).cuda())
-    gx = (1.0 + 0.5 * torch.arange(N * D, dtype=torch.float64)).view(N, D).cuda()
-    gt, gp = torch.autograd.grad(x, (th, ph), gx)
     w1 = (1 + torch.arange(N * D * S) % 3).double().cuda()
     w2 = (1 + torch.arange(N * D * S) % 5).double().cuda()
-    np.testing.assert_allclose(x.detach().cpu().reshape(-1).numpy(), c_ilt[: N * D], rtol=0, atol=0)
-    np.testing.assert_allclose([float((gt.reshape(-1) * w1).sum()), float((gp.reshape(-1) * w2).sum())], c_ilt[N * D:],
-                               rtol=1e-13)
+    gx = (1.0 + 0.5 * torch.arange(N * D, dtype=torch.float64)).view(N, D).cuda()
+    for m, algo in enumerate(("fourier", "dehoog", "fixed_tablot")):
+        c_ilt = [float(x) for x in lines[5 + m].split()]
+        th = (3.0 * ((i * 37) % 101) / 101.0 - 1.5).view(N, D, S).cuda().requires_grad_()
+        ph = (1.2 * ((i * 53) % 97) / 97.0 - 0.6).view(N, D, S).cuda().requires_grad_()
+        x = nlc.ilt_reconstruct(th, ph, torch.tensor([0.1, 0.125, 0.3], dtype=torch.float64).cuda(), algo)
+        gt, gp = torch.autograd.grad(x, (th, ph), gx)
+        np.testing.assert_allclose(x.detach().cpu().reshape(-1).numpy(), c_ilt[: N * D], rtol=0, atol=0, err_msg=algo)
+        np.testing.assert_allclose([float((gt.reshape(-1) * w1).sum()), float((gp.reshape(-1) * w2).sum())], c_ilt[N * D:],
+                                   rtol=1e-13, err_msg=algo)
 
 
 # --------------------------------------------------------------------------- Delta-t RNN baseline
