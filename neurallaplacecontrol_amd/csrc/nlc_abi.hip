@@ -131,6 +131,10 @@ struct nlc_ctx {
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
   int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
   int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
+  int opt_linear_fused = 1;             // fixed Talbot / Stehfest models of hidden width 128: LIN instances of the rollout kernels
+                                        // (0: the staged path, as for the other widths)
+  double* cp_lin = nullptr;             // [2][2 nt3][64] device: w_re / t and -w_im / t coefficient fragments (configure time)
+  std::vector<std::pair<int, int>> slot_elems;  // (dim, term) of every layer-3 slot (nlc_pack.h), kept from nlc_set_model
   int opt_fused_keep_sync = 0;          // tools only: the merge kernel leaves the sync block as the launch left it (timeline dumps)
   const void* sync_clean_ws = nullptr;  // workspace whose fused sync block the last merge kernel left zeroed
   bool sync_dirty = false;              // a fused launch has used the sync block since
@@ -471,6 +475,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   for (int i = 0; i < 2; ++i)
     if (c->U[i]) hipFree(c->U[i]);
   if (c->b1fold) hipFree(c->b1fold);
+  if (c->cp_lin) hipFree(c->cp_lin);
   if (c->b1fold_fwd) hipFree(c->b1fold_fwd);
   if (c->small) hipFree(c->small);
   if (c->pinned) hipHostFree(c->pinned);
@@ -528,6 +533,8 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "fused_spin_limit") {
     if (value < 1 || value > 4.0e9) return fail(c, NLC_ERR_BAD_ARG, "fused_spin_limit must be in 1 .. 4e9");
     c->opt_fused_spin_limit = (int64_t)value;
+  } else if (n == "linear_fused") {
+    c->opt_linear_fused = value != 0.0;
   } else if (n == "fused_keep_sync") {
     c->opt_fused_keep_sync = value != 0.0;
   } else if (n == "fused_test_drop_tile") {
@@ -821,6 +828,7 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   const int nt3 = nl_pick_nt3(ilt_tiles_needed(dd, S));
   if (nt3 < 0) return fail(c, NLC_ERR_UNSUPPORTED, "2*d*S too large for the fused kernel (max 25 output tiles)");
   const IltSlots slots = make_ilt_slots(dd, S, nt3);
+  c->slot_elems = slots.elems;
   const int n_even_groups = slots.n_even_groups;
   std::vector<double> b3p((size_t)nt3 * 16, 0.0);
   for (size_t i = 0; i < slots.rowmap3.size(); ++i)
@@ -1503,6 +1511,24 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     c->b1fold = nullptr;
     NLC_HIP(c, hipMalloc((void**)&c->b1fold, h * sizeof(double)));
     NLC_HIP(c, hipMemcpy(c->b1fold, bf.data(), h * sizeof(double), hipMemcpyHostToDevice));
+    if (c->md.ilt.algo == NLC_ILT_FIXED_TALBOT || c->md.ilt.algo == NLC_ILT_STEHFEST) {
+      // coefficient fragments of the LIN rollout instances: lane -> (dim = lane & 15, slot 4 g + (lane >> 4)), as Cp
+      std::vector<double> tab;
+      linear_tables_host(c->md.ilt.algo, S, tab);
+      const int ng = 2 * c->net.nt3;
+      std::vector<double> cp((size_t)2 * ng * 64, 0.0);
+      for (int g = 0; g < ng; ++g)
+        for (int lane = 0; lane < 64; ++lane) {
+          const auto el = c->slot_elems[(size_t)4 * g + (lane >> 4)];
+          if (el.first != (lane & 15)) continue;
+          cp[(size_t)g * 64 + lane] = tab[2 * S + el.second] / c->tn;
+          cp[(size_t)(ng + g) * 64 + lane] = -tab[3 * S + el.second] / c->tn;
+        }
+      if (c->cp_lin) hipFree(c->cp_lin);
+      c->cp_lin = nullptr;
+      NLC_HIP(c, hipMalloc((void**)&c->cp_lin, cp.size() * sizeof(double)));
+      NLC_HIP(c, hipMemcpy(c->cp_lin, cp.data(), cp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   c->has_mppi = true;
   c->sync_clean_ws = nullptr;
@@ -1513,6 +1539,13 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 }
 
 namespace {
+// fixed Talbot / Stehfest models whose rollout runs on the LIN instances of the rollout kernels (kernels_nl_lin.hip: hidden
+// width 128) instead of the staged path
+bool linear_on_rollout_kernels(const nlc_ctx* c) {
+  return c->has_model && (c->md.ilt.algo == NLC_ILT_FIXED_TALBOT || c->md.ilt.algo == NLC_ILT_STEHFEST) && c->md.h == 128 &&
+         c->opt_linear_fused != 0;
+}
+
 struct WsLayout {
   size_t tile_part, chunk_part, pa, state0, abuf, xcarry, ccarry, fre, fim, dx, tconst, rq, sync, total;
 };
@@ -1533,7 +1566,7 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.abuf = take((size_t)d.E * d.B * d.nu);
   w.xcarry = take(d.dynamics == NLC_DYN_NL ? KE * d.d : 0);
   w.ccarry = take(d.dynamics == NLC_DYN_NL ? KE * 2 : 0);
-  const bool staged = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER;  // staged: de Hoog and the linear algorithms
+  const bool staged = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER && !linear_on_rollout_kernels(c);
   w.fre = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
   w.fim = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);
   w.dx = take(staged ? KE * d.d : 0);
@@ -1732,7 +1765,8 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     NLC_HIP(c, launch_perturb(p, c->stream));
     return NLC_OK;
   };
-  const bool nl_fourier = d.dynamics == NLC_DYN_NL && c->md.ilt.algo == NLC_ILT_FOURIER;
+  const bool lin_direct = d.dynamics == NLC_DYN_NL && linear_on_rollout_kernels(c);
+  const bool nl_fourier = d.dynamics == NLC_DYN_NL && (c->md.ilt.algo == NLC_ILT_FOURIER || lin_direct);  // one rollout kernel
   if (!nl_fourier)
     if (int rc = launch_shift_perturb()) return rc;
   if (external) return NLC_OK;  // the caller runs the horizon loop, then nlc_mppi_weights
@@ -1772,7 +1806,14 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     r.cost_total = buf->cost_total;
     r.xcarry = ws + w.xcarry;
     r.ccarry = ws + w.ccarry;
-    if (c->md.ilt.algo != NLC_ILT_FOURIER) {
+    if (lin_direct) {
+      if (!c->cp_lin) return fail(c, NLC_ERR_STATE, "linear-algorithm coefficient tables missing (nlc_mppi_configure)");
+      const size_t ng = (size_t)2 * c->net.nt3 * 64;
+      r.net.Cp = c->cp_lin;
+      r.net.Cp2 = c->cp_lin + ng;
+      r.net.lin = 1;
+    }
+    if (c->md.ilt.algo != NLC_ILT_FOURIER && !lin_direct) {
       // staged de Hoog planner path (BASELINE configs[4]): hoisted GRU, then per horizon step three launches --
       // representation function -> F_k, de Hoog ILT -> dx, state/cost tail.  Everything stays on the device.
       // fixed_tablot / stehfest models (round 3) take the same path with the slot-major linear ILT in de Hoog's place.
@@ -1973,7 +2014,7 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     int variant = c->opt_rollout_variant;
     const int h_ = c->md.h;
     const bool fused_ok = (h_ == 64 || h_ == 128 || h_ == 256) && 2 * c->g == h_ && c->net.nt3 <= 21 &&
-                          KE * d.T * 16 < (int64_t)1 << 31;
+                          KE * d.T * 16 < (int64_t)1 << 31 && !lin_direct;  // (no LIN instance of the one-launch body)
     if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
     // instances per width: 3 and 4 workgroups per CU at hidden_units 64 / 128, 2 at 256 (68 KB of LDS per workgroup)
     const int bpc_hi = h_ == 256 ? 2 : 4, bpc_lo = h_ == 256 ? 2 : 3;

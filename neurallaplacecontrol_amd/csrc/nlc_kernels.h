@@ -222,6 +222,11 @@ struct NlNetArgs {
   const double* W3p;     // [h/4][nt3][64]     rows permuted into the slot layout
   const double* b3p;     // (16*nt3)           same permutation
   const double* Cp;      // [2*nt3][64]        ILT coefficient matrix fragments (rows = dims)
+  // fixed Talbot / Stehfest models on the fused rollout (round 3, LIN instances of the rollout kernels): the reconstruction
+  // x = sum_k (w_re,k / t) Re F_k - (w_im,k / t) Im F_k is TWO epilogue MFMAs per slot group -- Cp holds w_re / t against
+  // R cos(theta), Cp2 holds -w_im / t against R sin(theta) (both folded for the planner's constant t); lin = 1 selects them
+  const double* Cp2;
+  int lin;
   double state_mean[NLC_MAX_D], state_std[NLC_MAX_D];
   double alpha, log_tol, scale, time_div;
 };

@@ -11,7 +11,8 @@
 namespace nlc {
 
 // ------------------------------------------------------------------ T-step rollout (planner)
-template <int HT, int NT3>
+// LIN: fixed Talbot / Stehfest models (NlNetArgs::lin): two epilogue MFMAs per slot group, no Fourier prefactor
+template <int HT, int NT3, bool LIN = false>
 __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
   const NlNetArgs& n = a.net;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
   // ILT prefactor e^{gamma t}/T: constant over the rollout (ts_pred is constant)
   const double Tt = n.scale * a.tn;
   const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
-  const double factor = exp(gamma * a.tn) / Tt;
+  const double factor = LIN ? 1.0 : exp(gamma * a.tn) / Tt;
 
   double cost = 0.0, pcost = 0.0;
   if (!first_chunk) {
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
     const double* pa = a.pa + (kc * a.T + t) * 2;
     const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
     const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
-    const v4d ax = nl_eval<HT, NT3, false>(n, lane, q, p0, p1, a.tn);
+    const v4d ax = nl_eval<HT, NT3, false, false, LIN>(n, lane, q, p0, p1, a.tn);
     // state + model(state, window, ts_pred)   (mppi_with_model.py:120-121)
     if (i0 < d) x0 = x0 + factor * ax[0];
     if (i1 < d) x1 = x1 + factor * ax[1];
@@ -97,12 +98,12 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
 
 // ------------------------------------------------------------------ latency-split rollout (small K per GPU)
 // one workgroup per 16-sample tile: rollout_split_tile (nlc_rollout.h), GRU latents from the (K, T, 2) tensor
-template <int HT, int NT3>
+template <int HT, int NT3, bool LIN = false>
 __global__ __launch_bounds__(256) void nl_rollout_split_kernel(const RolloutArgs a) {
   constexpr int KS = HT * 4;
   __shared__ double H1[KS * 64], H2[KS * 64], AX[4 * 2 * 64];
   PaDirect src{a.pa, a.T, 0.0, 0.0, 0.0, 0.0};
-  rollout_split_tile<HT, NT3>(a, (int64_t)blockIdx.x, src, H1, H2, AX);
+  rollout_split_tile<HT, NT3, PaDirect, LIN>(a, (int64_t)blockIdx.x, src, H1, H2, AX);
 }
 
 // ------------------------------------------------------------------ single model forward, per-sample t

@@ -39,6 +39,17 @@ __device__ __forceinline__ double sphere_term(double theta, double phi, bool odd
   return (num * trig) * m::rcp_refined(den);
 }
 
+// LIN instances (fixed Talbot / Stehfest): both components of F = R e^{i theta}
+__device__ __forceinline__ void sphere_terms_lin(double theta, double phi, double* rc, double* rs) {
+  const m::IltTrigK K = m::ilt_trig_k();
+  double num, den, sn, cs;
+  m::tan_parts_short(K, phi / 2.0 + kPi / 4.0, &num, &den);
+  m::sincos_plus_mpio2(K, theta, 0.0, 0.0, &sn, &cs);
+  const double rad = num * m::rcp_refined(den);
+  *rc = rad * cs;
+  *rs = rad * sn;
+}
+
 // GENERAL_T: sphere coordinates of the per-sample query points enter layer 1 through W1s.
 // FOUT != nullptr-mode (WRITE_F): instead of the Fourier sum, F_k = |F| e^{i theta} of every Laplace term is
 // written to (N, d, S) arrays for the de Hoog kernel (nonlinear in F, cannot be an MFMA).
@@ -54,7 +65,7 @@ struct FOut {
 };
 // sph_row (GENERAL_T only): when non-NULL, this lane's sample has EXPLICIT sphere inputs [theta_s | phi_s] (2S doubles)
 // -- LaplaceRepresentationFunc.forward on an arbitrary input row (w_nl.py:55-63) -- instead of the ones of s_k(tn).
-template <int HT, int NT3, bool GENERAL_T, bool WRITE_F = false>
+template <int HT, int NT3, bool GENERAL_T, bool WRITE_F = false, bool LIN = false>
 __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn,
                                        const FOut* fo = nullptr, const double* sph_row = nullptr) {
   constexpr int KS = HT * 4;  // h / 4
@@ -152,7 +163,14 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
         } else {
           (void)num;
           (void)den;
-          ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
+          if constexpr (LIN) {
+            double rc, rs;
+            sphere_terms_lin(theta, phi, &rc, &rs);
+            ax[0] = mfma(cp[g * 64 + lane], rc, ax[0]);
+            ax[0] = mfma(opaque(n.Cp2)[g * 64 + lane], rs, ax[0]);
+          } else {
+            ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
+          }
         }
       }
     }
@@ -226,7 +244,7 @@ struct PaDirect {
 };
 
 // Returns the sample's total cost (meaningful in wave 0 when the launch runs the last horizon chunk).
-template <int HT, int NT3, class PA>
+template <int HT, int NT3, class PA, bool LIN = false>
 __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64_t tile, PA& src, double* __restrict__ H1,
                                                      double* __restrict__ H2, double* __restrict__ AX) {
   constexpr int KS = HT * 4;           // k-steps over the hidden dimension
@@ -258,7 +276,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
   }
   const double Tt = n.scale * a.tn;
   const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
-  const double factor = exp(gamma * a.tn) / Tt;
+  const double factor = LIN ? 1.0 : exp(gamma * a.tn) / Tt;  // (LIN: 1 / t rides in the coefficient tables)
   // this wave's layer-3 tiles (clamped: a wave with fewer tiles recomputes the last one and drops it)
   int j3[NTW];
 #pragma unroll
@@ -368,7 +386,14 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
             const int g = 2 * j3[i] + r;
             const double theta = m::tanh_d(o[i][r]) * kPi;
             const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
-            ax = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax);
+            if constexpr (LIN) {
+              double rc, rs;
+              sphere_terms_lin(theta, phi, &rc, &rs);
+              ax = mfma(cp[g * 64 + lane], rc, ax);
+              ax = mfma(opaque(n.Cp2)[g * 64 + lane], rs, ax);
+            } else {
+              ax = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax);
+            }
           }
         }
       }

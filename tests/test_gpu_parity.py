@@ -1095,6 +1095,48 @@ def test_full_size_linear_ilt_models(nlc, algo, S):
     _subset_check(nlc, "oderl-cartpole", 16384, 40, 4, S=S, algo=algo, tol=1e-5)
 
 
+@pytest.mark.parametrize("algo,S,K", [("fixed_tablot", 17, 2500), ("stehfest", 12, 700), ("fixed_tablot", 9, 16500)])
+def test_linear_ilt_models_on_rollout_kernels_vs_staged_path(nlc, algo, S, K):
+    """fixed_tablot / stehfest models of hidden width 128 plan on the LIN instances of the rollout kernels (the reconstruction
+    as two MFMAs per slot group in the epilogue; K <= 8192 the latency-split kernel, above it the wave-per-tile one) -- against
+    the staged path (option linear_fused = 0: representation kernel -> slot-major linear ILT -> tail per step), whose sum runs
+    in another order, and over two commands."""
+    from oracle import nl_model as onl
+
+    env, A = "oderl-cartpole", 3.0
+    st = onl.ENV_STATS[env]
+    d, nu = st["d"], st["nu"]
+    sd = onl.make_synthetic_state_dict(7, d, nu, 128, S, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd, S=S, algo=algo)
+    T = 9
+    g = torch.Generator().manual_seed(4)
+    raws = [torch.randn(K, T, nu, dtype=torch.float64, generator=g) for _ in range(2)]
+    U0 = torch.randn(T, nu, dtype=torch.float64, generator=g) * 0.2
+    state, ab = nlc.initial_state(env), torch.randn(4, nu, dtype=torch.float64, generator=g)
+    outs = {}
+    for key, opts in (("kernels", {}), ("staged", {"linear_fused": 0})):
+        m = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(), planner_options=opts)
+        assert m.fused
+        m.noise_dist = _Replay(*[r.clone() for r in raws])
+        with torch.no_grad():
+            acts = [m.command(state, ab).clone() for _ in range(2)]
+        m.ctx.profile(True)
+        with torch.no_grad():
+            m.noise_dist = _Replay(raws[0].clone())
+            m.command(state, ab)
+        names = set(m.ctx.profile_read())
+        m.ctx.profile(False)
+        assert ("ilt_linear_slot_kernel" in names) == (key == "staged") and ("nl_rollout_kernel" in names) == (key == "kernels")
+        outs[key] = (acts, m.states.clone(), m.cost_total.clone(), m.U.clone())
+    # (both algorithms sum terms with large alternating weights, and these random weights let some rollouts run away: the two
+    # summation orders are compared on the scale of the largest entry, at the north-star bar.
+    # U and the action are a softmax over ABSOLUTE cost differences -- of run-away costs of 1e10 here -- and say nothing.)
+    for a_, b_ in zip(outs["kernels"][1:3], outs["staged"][1:3]):  # rollout states, total costs (second command)
+        sc = float(b_.abs().max()) + 1e-300
+        np.testing.assert_allclose(a_.numpy() / sc, b_.numpy() / sc, rtol=0, atol=1e-5)
+
+
 def test_cfg5_dehoog_planner_staged_hip_path(nlc):
     """BASELINE configs[4] ablation: a de Hoog (33 terms) model plans through the staged all-HIP path
     (rep-func kernel -> de Hoog kernel -> state/cost kernel per horizon step)."""

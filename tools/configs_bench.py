@@ -21,15 +21,16 @@ CONFIGS = [  # (label, env, delay -> action_buffer rows, K, T, gpus, ilt, S)
 ]
 
 
-# the other closed-form values of the reference's nl_ilt_algorithm knob (config.py:36) at configs[1]'s shape: the staged
-# all-HIP planner path (round 3) beside the generic path (model.forward as the dynamics callable) it replaces
+# the other closed-form values of the reference's nl_ilt_algorithm knob (config.py:36) at configs[1]'s shape: the LIN instances of
+# the rollout kernels (round 3, default at hidden width 128), the staged all-HIP path (other widths; option linear_fused = 0)
+# and the generic path (model.forward as the dynamics callable)
 EXTRA = [
     ("cartpole K=16384 H=40 fixed_tablot S=17", "oderl-cartpole", 4, 16384, 40, "fixed_tablot", 17),
     ("cartpole K=16384 H=40 stehfest S=16", "oderl-cartpole", 4, 16384, 40, "stehfest", 16),
 ]
 
 
-def rate(env, B, K, T, algo, S, steps, generic=False):
+def rate(env, B, K, T, algo, S, steps, generic=False, opts=None):
     d, nu, A, std = STATS[env]
     torch.manual_seed(0)
     model = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=S, ilt_algorithm=algo, state_mean=np.zeros(d),
@@ -42,7 +43,7 @@ def rate(env, B, K, T, algo, S, steps, generic=False):
     mppi = nlc.MPPIDelay((lambda s_, w_: dyn(s_, w_)) if generic else dyn, nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
                          U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False,
-                         planner_options={"recognise_closures": 0})
+                         planner_options=dict({"recognise_closures": 0}, **(opts or {})))
     assert mppi.fused != generic
     st, ab = nlc.initial_state(env, torch.Generator().manual_seed(0)), torch.zeros(B, nu, dtype=torch.float64)
     with torch.no_grad():
@@ -67,7 +68,9 @@ for label, env, B, K, T, G, algo, S in ([] if only_extra else CONFIGS):
     out.append(row)
     print(row, file=sys.stderr, flush=True)
 for label, env, B, K, T, algo, S in EXTRA:
-    row = dict(config=label, staged_hip_path=rate(env, B, K, T, algo, S, 20), generic_path=rate(env, B, K, T, algo, S, 5, generic=True))
+    row = dict(config=label, rollout_kernels_lin_instances=rate(env, B, K, T, algo, S, 20),
+               staged_hip_path=rate(env, B, K, T, algo, S, 20, opts={"linear_fused": 0}),
+               generic_path=rate(env, B, K, T, algo, S, 5, generic=True))
     out.append(row)
     print(row, file=sys.stderr, flush=True)
 print(json.dumps(dict(metric="MPPI planning steps/s per BASELINE config, one MI355X, f64", results=out)))
