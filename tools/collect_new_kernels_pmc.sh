@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes (separate runs per counter group, --kernel-trace only) for the kernels added in round 3:
-# ilt_linear_stream (Fourier kernel's LIN instance), ilt_dehoog_bwd, ilt_linear_slot (+ the representation launch beside it).
+# ilt_linear_stream (Fourier kernel's LIN instance), ilt_dehoog_bwd, ilt_linear_slot (+ the representation launch beside it:
+# the staged planner path of a fixed_tablot model, which hidden width 128 only takes with linear_fused = 0).
 #   NLC_COMMIT=$(git rev-parse --short HEAD) gpurun --timeout 900 -- "NLC_COMMIT=$NLC_COMMIT tools/collect_new_kernels_pmc.sh r3"
 set -o pipefail
 TAG=${1:-r3}
@@ -16,14 +17,14 @@ run() {  # name, counters, program args...
 for C in FETCH_SIZE WRITE_SIZE; do
   run lin_$C $C tools/ilt_only.py 655360 fixed_tablot
   run dhb_$C $C tools/dehoog_bwd_bench.py 16384
-  CFG5_ALGO=fixed_tablot CFG5_S=17 run slot_$C $C tools/cfg5_breakdown.py
+  CFG5_ALGO=fixed_tablot CFG5_S=17 CFG5_OPTS=linear_fused=0 run slot_$C $C tools/cfg5_breakdown.py
 done
 run lin_mfma "$PMC_MFMA" tools/ilt_only.py 655360 fixed_tablot
 run dhb_mfma "$PMC_MFMA" tools/dehoog_bwd_bench.py 16384
-CFG5_ALGO=fixed_tablot CFG5_S=17 run slot_mfma "$PMC_MFMA" tools/cfg5_breakdown.py
+CFG5_ALGO=fixed_tablot CFG5_S=17 CFG5_OPTS=linear_fused=0 run slot_mfma "$PMC_MFMA" tools/cfg5_breakdown.py
 python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_lin_* $OUT/${TAG}_new_dhb_* > $OUT/${TAG}_pmc_new_ilt.json
 python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_slot_* > $OUT/${TAG}_pmc_linear_planner.json
-CFG5_ALGO=fixed_tablot CFG5_S=17 timeout -k 10 120 python tools/cfg5_breakdown.py > $OUT/${TAG}_linear_planner_breakdown.txt 2>/dev/null
+CFG5_ALGO=fixed_tablot CFG5_S=17 CFG5_OPTS=linear_fused=0 timeout -k 10 120 python tools/cfg5_breakdown.py > $OUT/${TAG}_linear_planner_breakdown.txt 2>/dev/null
 cat $OUT/${TAG}_linear_planner_breakdown.txt
 python - <<PY
 import json
