@@ -118,9 +118,9 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        is then two launches (this one + the merge after the shard all-gather) instead of five; 0 = separate
  *                        launches.  Same bits either way.
  *   "fused_spin_limit"   polls (~2 us each) before a waiting wave of the fused body gives up (default 2^18, ~0.5 s)
- *   "linear_fused"       NLC_ILT_FIXED_TALBOT / NLC_ILT_STEHFEST models of hidden width 128: 1 (default) = the rollout runs on LIN
- *                        instances of the rollout kernels (two epilogue MFMAs per slot group, coefficient fragments folded for
- *                        the constant prediction time at nlc_mppi_configure); 0 = the staged path the other widths take
+ *   "linear_fused"       NLC_ILT_FIXED_TALBOT / NLC_ILT_STEHFEST models: 1 (default) = the rollout runs on LIN instances of the
+ *                        rollout kernels (two epilogue MFMAs per slot group, coefficient fragments folded for the constant
+ *                        prediction time at nlc_mppi_configure); 0 = the staged path de Hoog models take
  *   "fused_keep_sync"    tools only: the merge kernel does not zero the fused body's sync block (tools/fused_debug.py reads
  *                        the launch's progress counters / timeline from it); the next command pays a memset instead
  *   "fused_test_drop_tile"  tests only: the encoder tile with this ticket is never published (-1 = none): forces the

@@ -120,13 +120,22 @@ hipError_t launch_nl_forward_h256(const ForwardArgs& a, hipStream_t s);
 hipError_t launch_nl_repfunc_h64(const RepFuncArgs& a, hipStream_t s);
 hipError_t launch_nl_repfunc_h256(const RepFuncArgs& a, hipStream_t s);
 
+hipError_t launch_nl_rollout_lin_h64(const RolloutArgs& a, hipStream_t s, bool split);
 hipError_t launch_nl_rollout_lin_h128(const RolloutArgs& a, hipStream_t s, bool split);
+hipError_t launch_nl_rollout_lin_h256(const RolloutArgs& a, hipStream_t s, bool split);
 hipError_t launch_nl_rollout(const RolloutArgs& a, hipStream_t s, int force_variant) {
   if (a.K <= 0) return hipSuccess;
   // one wave per 16-sample tile fills the 1024 SIMDs only for K >= 16384; below that, split the tile over
   // the 4 waves of a workgroup (force_variant: 0 auto, 1 wave-per-tile, 2 split)
   const bool split = force_variant == 2 || (force_variant == 0 && a.K <= 8192);
-  if (a.net.lin) return a.net.h == 128 ? launch_nl_rollout_lin_h128(a, s, split) : hipErrorInvalidValue;
+  if (a.net.lin) {
+    switch (a.net.h) {
+      case 64: return launch_nl_rollout_lin_h64(a, s, split);
+      case 128: return launch_nl_rollout_lin_h128(a, s, split);
+      case 256: return launch_nl_rollout_lin_h256(a, s, split);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (a.net.h) {
     case 64: return launch_nl_rollout_h64(a, s, split);
     case 128: return launch_nl_rollout_h128(a, s, split);

@@ -131,8 +131,8 @@ struct nlc_ctx {
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
   int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
   int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
-  int opt_linear_fused = 1;             // fixed Talbot / Stehfest models of hidden width 128: LIN instances of the rollout kernels
-                                        // (0: the staged path, as for the other widths)
+  int opt_linear_fused = 1;             // fixed Talbot / Stehfest models: LIN instances of the rollout kernels
+                                        // (0: the staged path)
   double* cp_lin = nullptr;             // [2][2 nt3][64] device: w_re / t and -w_im / t coefficient fragments (configure time)
   std::vector<std::pair<int, int>> slot_elems;  // (dim, term) of every layer-3 slot (nlc_pack.h), kept from nlc_set_model
   int opt_fused_keep_sync = 0;          // tools only: the merge kernel leaves the sync block as the launch left it (timeline dumps)
@@ -1539,11 +1539,11 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
 }
 
 namespace {
-// fixed Talbot / Stehfest models whose rollout runs on the LIN instances of the rollout kernels (kernels_nl_lin.hip: hidden
-// width 128) instead of the staged path
+// fixed Talbot / Stehfest models whose rollout runs on the LIN instances of the rollout kernels (kernels_nl_lin*.hip) instead of
+// the staged path
 bool linear_on_rollout_kernels(const nlc_ctx* c) {
-  return c->has_model && (c->md.ilt.algo == NLC_ILT_FIXED_TALBOT || c->md.ilt.algo == NLC_ILT_STEHFEST) && c->md.h == 128 &&
-         c->opt_linear_fused != 0;
+  return c->has_model && (c->md.ilt.algo == NLC_ILT_FIXED_TALBOT || c->md.ilt.algo == NLC_ILT_STEHFEST) &&
+         (c->md.h == 64 || c->md.h == 128 || c->md.h == 256) && c->opt_linear_fused != 0;
 }
 
 struct WsLayout {

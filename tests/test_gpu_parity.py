@@ -1095,9 +1095,10 @@ def test_full_size_linear_ilt_models(nlc, algo, S):
     _subset_check(nlc, "oderl-cartpole", 16384, 40, 4, S=S, algo=algo, tol=1e-5)
 
 
-@pytest.mark.parametrize("algo,S,K", [("fixed_tablot", 17, 2500), ("stehfest", 12, 700), ("fixed_tablot", 9, 16500)])
-def test_linear_ilt_models_on_rollout_kernels_vs_staged_path(nlc, algo, S, K):
-    """fixed_tablot / stehfest models of hidden width 128 plan on the LIN instances of the rollout kernels (the reconstruction
+@pytest.mark.parametrize("algo,S,K,h", [("fixed_tablot", 17, 2500, 128), ("stehfest", 12, 700, 128), ("fixed_tablot", 9, 16500, 128),
+                                        ("fixed_tablot", 11, 900, 64), ("stehfest", 8, 16400, 64), ("fixed_tablot", 13, 300, 256)])
+def test_linear_ilt_models_on_rollout_kernels_vs_staged_path(nlc, algo, S, K, h):
+    """fixed_tablot / stehfest models (hidden width 64 / 128 / 256) plan on the LIN instances of the rollout kernels (the reconstruction
     as two MFMAs per slot group in the epilogue; K <= 8192 the latency-split kernel, above it the wave-per-tile one) -- against
     the staged path (option linear_fused = 0: representation kernel -> slot-major linear ILT -> tail per step), whose sum runs
     in another order, and over two commands."""
@@ -1106,7 +1107,7 @@ def test_linear_ilt_models_on_rollout_kernels_vs_staged_path(nlc, algo, S, K):
     env, A = "oderl-cartpole", 3.0
     st = onl.ENV_STATS[env]
     d, nu = st["d"], st["nu"]
-    sd = onl.make_synthetic_state_dict(7, d, nu, 128, S, st["state_std"], [A / 2], tame=True)
+    sd = onl.make_synthetic_state_dict(7, d, nu, h, S, st["state_std"], [A / 2], tame=True)
     model = build_model(nlc, sd, S=S, algo=algo)
     T = 9
     g = torch.Generator().manual_seed(4)
