@@ -1566,7 +1566,9 @@ WsLayout ws_layout(const nlc_ctx* c) {
   w.abuf = take((size_t)d.E * d.B * d.nu);
   w.xcarry = take(d.dynamics == NLC_DYN_NL ? KE * d.d : 0);
   w.ccarry = take(d.dynamics == NLC_DYN_NL ? KE * 2 : 0);
-  const bool staged = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER && !linear_on_rollout_kernels(c);
+  // (the staged buffers are laid out for every non-Fourier model, also when a linear-algorithm model runs on the LIN rollout
+  // instances: the layout must not depend on an option that can change after the caller sized its workspace)
+  const bool staged = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER;
   w.fre = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
   w.fim = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);
   w.dx = take(staged ? KE * d.d : 0);
