@@ -22,6 +22,12 @@ done
 run lin_mfma "$PMC_MFMA" tools/ilt_only.py 655360 fixed_tablot
 run dhb_mfma "$PMC_MFMA" tools/dehoog_bwd_bench.py 16384
 CFG5_ALGO=fixed_tablot CFG5_S=17 CFG5_OPTS=linear_fused=0 run slot_mfma "$PMC_MFMA" tools/cfg5_breakdown.py
+# the LIN instances of the rollout kernels (a fixed_tablot model at the headline shape, default path)
+for C in FETCH_SIZE WRITE_SIZE; do
+  CFG5_ALGO=fixed_tablot CFG5_S=17 run linroll_$C $C tools/cfg5_breakdown.py
+done
+CFG5_ALGO=fixed_tablot CFG5_S=17 run linroll_mfma "$PMC_MFMA" tools/cfg5_breakdown.py
+python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_linroll_* > $OUT/${TAG}_pmc_lin_rollout.json
 python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_lin_* $OUT/${TAG}_new_dhb_* > $OUT/${TAG}_pmc_new_ilt.json
 python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_slot_* > $OUT/${TAG}_pmc_linear_planner.json
 CFG5_ALGO=fixed_tablot CFG5_S=17 CFG5_OPTS=linear_fused=0 timeout -k 10 120 python tools/cfg5_breakdown.py > $OUT/${TAG}_linear_planner_breakdown.txt 2>/dev/null
