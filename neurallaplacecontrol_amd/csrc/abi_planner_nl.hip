@@ -1,0 +1,470 @@
+// Host side of libnlc_hip.so, planner unit, Neural-Laplace dynamics: phase 1 of a command after the sampling arguments are
+// set (abi_planner.hip) -- the hoisted GRU encode and one of three rollout forms: the staged step chain (de Hoog and, as an
+// option, fixed Talbot / Stehfest models), the one-launch fused body of a small shard, or GRU launch + rollout launch.
+#include "nlc_host.h"
+
+using namespace nlc;
+using namespace nlc::host;
+
+namespace {
+
+// staged planner path (BASELINE configs[4]): hoisted GRU, then per horizon step two launches -- [tail of the previous step +]
+// representation function -> F_k, then de Hoog ILT -> dx; fixed_tablot / stehfest models (option linear_fused = 0) take the
+// same path with the slot-major linear ILT in de Hoog's place.  Everything stays on the device.
+int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r, double* pa) {
+  const nlc_mppi_desc& d = c->pd;
+  const nlc_mppi_buffers* buf = call.buf;
+  const WsLayout& w = call.w;
+  double* ws = call.ws;
+  double* state_dev = call.state_dev;
+  const int64_t KE = call.KE;
+  const int state_per_sample = call.state_per_sample;
+  // staged de Hoog planner path (BASELINE configs[4]): hoisted GRU, then per horizon step three launches --
+  // representation function -> F_k, de Hoog ILT -> dx, state/cost tail.  Everything stays on the device.
+  // fixed_tablot / stehfest models (round 3) take the same path with the slot-major linear ILT in de Hoog's place.
+  const bool dehoog = c->md.ilt.algo == NLC_ILT_DEHOOG;
+  const double* lin_tab = nullptr;
+  if (!dehoog)
+    if (int rc = linear_tables(c, &c->md.ilt, &lin_tab)) return rc;
+  // GRU encode: one launch up front, or (round 3, option "dehoog_gru_chunks" C > 1) C horizon chunks on a stream of
+  // their own that run BESIDE the step chain -- the chain's launches wait for the chunk that holds their horizon step.
+  // The chunks use the cooperative kernel at reduced occupancy (lds_pad) so that the chain's workgroups find room.
+  int C = d.E == 1 ? c->opt_dehoog_gru_chunks : 1;
+  if (C == 0) C = 1;  // auto: off
+  if (C > d.T) C = d.T;
+  if (C > 8) C = 8;
+  const int Tc = (d.T + C - 1) / C;
+  if (C == 1) {
+    g.t0 = 0;
+    g.Tc = d.T;
+    g.N = KE * d.T;
+    ProfScope ps(c, "gru_encode_kernel");
+    NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
+  }
+  double* tconst = ws + w.tconst;
+  NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (C > 1) {
+    if (!c->gru_stream) NLC_HIP(c, hipStreamCreateWithFlags(&c->gru_stream, hipStreamNonBlocking));
+    if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    while ((int)c->ev_gru.size() < C) {
+      hipEvent_t e2 = nullptr;
+      NLC_HIP(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      c->ev_gru.push_back(e2);
+    }
+    NLC_HIP(c, hipEventRecord(c->ev_fork, c->stream));  // behind the perturb kernel and the staged inputs
+    NLC_HIP(c, hipStreamWaitEvent(c->gru_stream, c->ev_fork, 0));
+    for (int ch = 0; ch < C; ++ch) {
+      g.t0 = ch * Tc;
+      g.Tc = (g.t0 + Tc <= d.T) ? Tc : d.T - g.t0;
+      if (g.Tc <= 0) break;
+      g.N = KE * g.Tc;
+      {
+        ProfScope ps(c, "gru_encode_kernel", c->gru_stream, true);
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->gru_stream, true, (unsigned)c->opt_dehoog_gru_lds_pad));
+      }
+      NLC_HIP(c, hipEventRecord(c->ev_gru[ch], c->gru_stream));
+    }
+  }
+  RepFuncArgs rf{};
+  rf.net = r.net;
+  rf.N = KE;
+  rf.obs_stride = d.d;
+  rf.Kep = d.K;
+  rf.pa_stride = (int64_t)d.T * 2;
+  rf.tn = c->tn;
+  rf.general_t = 0;
+  rf.slot = c->slot_dev;
+  rf.fre = ws + w.fre;
+  rf.fim = ws + w.fim;
+  // F travels slot-major between the two kernels of a step: four 128-B runs per store instruction of the MFMA
+  // epilogue, one full line per de Hoog load (kernels_ilt.hip, FMODE 2)
+  rf.slot_major = 1;
+  rf.split = c->md.h == 128 && c->opt_repfunc_split != 0;
+  IltArgs ia{nullptr, nullptr, tconst, ws + w.dx, KE, d.d, c->S, c->md.ilt.alpha, std::log(c->md.ilt.tol),
+             c->md.ilt.scale, rf.fre, rf.fim, 1.0, 0, 0, 0, 0, c->eidx_dev};
+  StepTailArgs st{};
+  st.K = KE;
+  st.Kep = d.K;
+  st.T = d.T;
+  st.nu = d.nu;
+  st.d = d.d;
+  st.env = d.cost_external ? -1 : d.env;
+  st.state_per_sample = state_per_sample;
+  st.state0 = state_dev;
+  st.x = r.xcarry;
+  st.dx = ws + w.dx;
+  st.ccarry = r.ccarry;
+  st.perturbed = buf->perturbed;
+  st.noise = buf->noise;
+  st.U = r.U;
+  for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) st.sigma_inv[i] = d.noise_sigma_inv[i];
+  st.lambda_ = d.lambda_;
+  st.u_scale = d.u_scale;
+  st.noise_abs_cost = d.noise_abs_cost;
+  st.states = buf->states;
+  st.cost_total = buf->cost_total;
+  // two launches per horizon step: [tail of step t-1 +] representation function -> F, then de Hoog -> dx; the tail
+  // of the LAST step is a launch of its own.
+  // Round 3: the population is cut into P contiguous parts (multiples of 64 samples) whose 2 T + 1 launches run on P
+  // streams.  A sample's chain never leaves its part, so the parts need no ordering among themselves, and the two
+  // kernels of a step bound different pipes -- the representation launch the FP64 MFMA (util 0.42: dependent layers),
+  // the QD launch the FP64 VALU at 1.25 wavefronts per SIMD (active 0.39) -- so while one part's QD pass runs, another
+  // part's representation launch fills the matrix pipe (option "dehoog_streams": 1 = one stream, as before).
+  int P = d.E == 1 ? c->opt_dehoog_streams : 1;
+  if (P == 0) P = KE >= 8192 ? 2 : 1;  // auto
+  if (P > 4) P = 4;
+  while (P > 1 && KE / P < 1024) --P;
+  if (P > 1) {
+    while ((int)c->aux_streams.size() < P - 1) {
+      hipStream_t s2 = nullptr;
+      NLC_HIP(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      c->aux_streams.push_back(s2);
+    }
+    if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    while ((int)c->ev_join.size() < P - 1) {
+      hipEvent_t e2 = nullptr;
+      NLC_HIP(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      c->ev_join.push_back(e2);
+    }
+    NLC_HIP(c, hipEventRecord(c->ev_fork, c->stream));  // behind the GRU encode and the staged inputs
+    for (int h = 1; h < P; ++h) NLC_HIP(c, hipStreamWaitEvent(c->aux_streams[h - 1], c->ev_fork, 0));
+  }
+  // part h: samples [off_h, off_h + n_h)
+  int64_t off_h[4], n_h[4];
+  {
+    const int64_t per = ((KE / P) + 63) / 64 * 64;
+    for (int h = 0; h < P; ++h) {
+      off_h[h] = (int64_t)h * per < KE ? (int64_t)h * per : KE;
+      n_h[h] = (h == P - 1) ? KE - off_h[h] : (off_h[h] + per <= KE ? per : KE - off_h[h]);
+    }
+  }
+  const size_t f_per_sample = 8 * (size_t)c->net.nt3;
+  auto part = [&](int h, RepFuncArgs& rfp, IltArgs& iap, StepTailArgs& stp) {
+    const int64_t o = off_h[h], n = n_h[h];
+    stp = st;
+    stp.K = n;
+    stp.Kep = P > 1 ? n : d.K;
+    stp.state0 = state_dev + (state_per_sample ? o * d.d : 0);
+    stp.x = st.x + o * d.d;
+    stp.dx = st.dx + o * d.d;
+    stp.ccarry = st.ccarry + o * 2;
+    stp.perturbed = st.perturbed + o * d.T * d.nu;
+    stp.noise = st.noise + o * d.T * d.nu;
+    stp.states = st.states ? st.states + o * d.T * d.d : nullptr;
+    stp.cost_total = st.cost_total + o;
+    rfp = rf;
+    rfp.N = n;
+    rfp.Kep = stp.Kep;
+    rfp.fre = rf.fre + (size_t)o * f_per_sample;  // slot-major (8 nt3, n) block of the part
+    rfp.fim = rf.fim + (size_t)o * f_per_sample;
+    iap = ia;
+    iap.N = n;
+    iap.x = ia.x + o * d.d;
+    iap.fre = rfp.fre;
+    iap.fim = rfp.fim;
+  };
+  RepFuncArgs rfs[4];
+  IltArgs ias[4];
+  StepTailArgs sts[4];
+  for (int h = 0; h < P; ++h) part(h, rfs[h], ias[h], sts[h]);
+  for (int t = 0; t < d.T; ++t) {
+    for (int h = 0; h < P; ++h) {
+      if (n_h[h] <= 0) continue;
+      hipStream_t sh = h == 0 ? c->stream : c->aux_streams[h - 1];
+      if (C > 1 && t % Tc == 0) NLC_HIP(c, hipStreamWaitEvent(sh, c->ev_gru[t / Tc], 0));  // latents of this chunk
+      RepFuncArgs& rp = rfs[h];
+      rp.obs = sts[h].state0;
+      rp.obs_per_sample = (t == 0) ? state_per_sample : 1;
+      rp.pa = pa + ((size_t)off_h[h] * d.T + (size_t)t) * 2;
+      rp.tail_prev = t > 0;
+      if (t > 0) {
+        rp.tail = sts[h];
+        rp.tail.t = t - 1;
+        rp.tail.first = t - 1 == 0;
+        rp.tail.last = 0;
+      }
+      {
+        ProfScope ps(c, "nl_repfunc_kernel", sh, true);
+        NLC_HIP(c, launch_nl_repfunc(rp, sh));
+      }
+      if (dehoog) {
+        ProfScope ps(c, "ilt_dehoog_kernel", sh, true);
+        NLC_HIP(c, launch_ilt_dehoog(ias[h], sh));
+      } else {
+        const IltArgs& ih = ias[h];
+        const IltLinSlotArgs il{ih.fre, ih.fim, ih.eidx, ih.t, ih.x, ih.N, ih.d, ih.S, lin_tab + 2 * ih.S, lin_tab + 3 * ih.S};
+        ProfScope ps(c, "ilt_linear_slot_kernel", sh, true);
+        NLC_HIP(c, launch_ilt_linear_slot(il, sh));
+      }
+    }
+  }
+  for (int h = 0; h < P; ++h) {
+    if (n_h[h] <= 0) continue;
+    hipStream_t sh = h == 0 ? c->stream : c->aux_streams[h - 1];
+    sts[h].t = d.T - 1;
+    sts[h].first = d.T == 1;
+    sts[h].last = 1;
+    {
+      ProfScope ps(c, "step_tail_kernel", sh, true);
+      NLC_HIP(c, launch_step_tail(sts[h], sh));
+    }
+    if (h > 0) {
+      NLC_HIP(c, hipEventRecord(c->ev_join[h - 1], sh));
+      NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
+    }
+  }
+  return d.cost_external ? NLC_OK : run_weights(c, buf);
+}
+
+// one persistent launch for a small shard (kernels_fused.hip): GRU encode and split rollout as roles of one grid, with the
+// sampling and the weight fold inside when the command allows.  Returns through *weights_done whether the launch folded the
+// importance weights itself.
+int rollout_nl_fused(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r, int bpc_hi, int bpc_lo, bool* weights_done) {
+  const nlc_mppi_desc& d = c->pd;
+  const nlc_mppi_buffers* buf = call.buf;
+  const WsLayout& w = call.w;
+  double* ws = call.ws;
+  const int64_t KE = call.KE;
+  const int rng = call.rng;
+  const bool inline_inputs = call.inline_inputs;
+  PerturbArgs& p = call.p;
+  const int h_ = c->md.h;
+  auto launch_shift_perturb = [&]() -> int { return nlc::host::launch_shift_perturb(c, call); };
+  const int ncu = c->prop.multiProcessorCount;
+  const int ntk_all = (int)((KE + 15) / 16);
+  // instance: three workgroups per CU (168 VGPRs) while chains sit on at most half of the CUs, else four (128 VGPRs)
+  int built = c->opt_fused_blocks_per_cu ? c->opt_fused_blocks_per_cu : (2 * ntk_all <= ncu ? 3 : 4);
+  if (built == 3 && c->fused_blocks_per_cu3 < 3) built = 4;
+  if (h_ == 256) built = 2;
+  const int bpc = built == bpc_lo ? (c->fused_blocks_per_cu3 < bpc_lo ? c->fused_blocks_per_cu3 : bpc_lo)
+                                  : (c->fused_blocks_per_cu < bpc_hi ? c->fused_blocks_per_cu : bpc_hi);
+  FusedArgs f{};
+  f.r = r;
+  f.r.t_begin = 0;
+  f.r.t_end = d.T;
+  f.g = g;
+  f.g.t0 = 0;
+  f.g.Tc = d.T;
+  f.g.N = KE * d.T;
+  FusedCtl& fc = f.ctl;
+  fc.sync = reinterpret_cast<unsigned*>(ws + w.sync);
+  fc.timeout_host = reinterpret_cast<unsigned*>(fused_timeout_word(c));
+  fc.ntk = (int)((KE + 15) / 16);
+  fc.n_enc = fc.ntk * d.T;
+  // rollout workgroups start one per CU on the first CUs to arrive; by default on half the CUs at most
+  // chains start on distinct CUs, one per 16-sample tile (the tiles beyond the CU count drain after the encoders)
+  fc.roll_cap = c->opt_fused_roll_cap > 0 ? c->opt_fused_roll_cap : ncu;
+  if (fc.roll_cap > fc.ntk) fc.roll_cap = fc.ntk;
+  // Schedule (profiles/r2_fused_small_shard.md).  Every workgroup -- the chains' too -- encodes one tile first.  A
+  // chain's CU partners then encode M - 1 more tiles each and sleep until the chain is done: with few chains the CUs
+  // WITHOUT one feed them alone (M = 1); the more CUs walk a chain, the longer their partners have to help.  M is an
+  // empirical fit to the best schedule measured on the MI355X at T = 40 (chains on 25 / 37.5 / 43.75 / 50 % of the
+  // CUs, K = 1024 / 1536 / 1792 / 2048: M = 1 / 2 / 3 / 4; e.g. 0.672 ms at K = 2048 against 0.723 without any of
+  // this and 0.846 with M = 1), scaled with the horizon.
+  const double f_chain = (double)fc.roll_cap / (double)ncu;
+  const double extra = (16.0 * f_chain - 4.5) * (double)d.T / 40.0;
+  int auto_partner = 1 + (extra > 0 ? (int)extra : 0);
+  if (built <= 3) {
+    // two partners per chain CU instead of three: measured best M = 1 / 1 / 2 / 6 at chains on 12.5 / 25 / 37.5 / 50 %
+    // of the CUs (K = 512 / 1024 / 1536 / 2048, T = 40; 0.521 / 0.527 / 0.563 / 0.674 ms per launch)
+    // (K = 1280 / 1792, 31 / 44 %: M = 1 / 4; linear in between)
+    const double m3 = f_chain <= 0.3125 ? 1.0 : 1.0 + 26.7 * (f_chain - 0.3125);
+    auto_partner = (int)(1.0 + (m3 - 1.0) * (double)d.T / 40.0);
+  }
+  // experiment (round 3, option "fused_tile_step_ratio" > 0): partners sleep unless the chain-free CUs alone would
+  // finish the remaining encoder tiles later than the chain finishes its remaining steps (the kernel's feedback
+  // rule).  Measured SLOWER than the static schedule at every K (K = 2048: 0.83 vs 0.67 ms): the rule balances the
+  // finishing times but not the ORDER -- the chains consume a horizon step per 11.5 us, the chain-free CUs produce one
+  // per 15 us, so the chains starve behind the encoder front while their partners sleep; default off.
+  const bool adaptive = c->opt_fused_partner_tiles == -2 && c->opt_fused_tile_step_ratio > 0.0;
+  fc.adaptive_q8 = adaptive ? (int)(256.0 * c->opt_fused_tile_step_ratio) : 0;
+  fc.pool_wgs = (ncu - fc.roll_cap) * bpc;
+  if (adaptive) auto_partner = 1;  // every partner encodes one tile first, then the rule decides
+  fc.chain_first_tiles = c->opt_fused_chain_first_tiles >= 0 ? c->opt_fused_chain_first_tiles : 1;
+  const int partner = c->opt_fused_partner_tiles >= -1 ? c->opt_fused_partner_tiles : auto_partner;
+  // (sleepers need CUs without a chain to produce the latents the chains wait for)
+  fc.partner_tiles = (adaptive || fc.roll_cap <= ncu / 2) ? partner : -1;
+  fc.spin_limit = (unsigned)c->opt_fused_spin_limit;
+  fc.test_drop_tile = c->opt_fused_test_drop_tile;
+  // Single planner: the weight reduction runs inside the launch, and with device noise and the command's inputs in
+  // the kernel arguments so does the sampling -- command() is then this launch + merge_kernel.
+  fc.inline_weights = (c->opt_fused_inline & 1) && d.E == 1 && !d.cost_external;
+  fc.inline_perturb = (c->opt_fused_inline & 2) && d.E == 1 && inline_inputs && rng == 1 && d.B <= kFusedMaxInlineB;
+  unsigned* sync_words = reinterpret_cast<unsigned*>(ws + w.sync);
+  const size_t n_sync = fused_sync_words(d.T, KE);
+  if (fc.inline_perturb) {
+    // tickets / flags start at zero: the previous command's merge kernel left them so (else: one memset)
+    if (c->sync_clean_ws != buf->workspace) NLC_HIP(c, hipMemsetAsync(sync_words, 0, n_sync * sizeof(unsigned), c->stream));
+  } else {
+    p.zero_words = sync_words;
+    p.n_zero_words = (int64_t)n_sync;
+    if (int rc = launch_shift_perturb()) return rc;
+  }
+  c->sync_clean_ws = nullptr;
+  c->sync_dirty = true;
+  c->last.fused = true;
+  f.p = p;
+  if (fc.inline_weights) f.w = make_weight_args(c, buf);
+  // every workgroup must be resident at once: a rollout workgroup waits for encoder workgroups of the same launch
+  const unsigned grid = (unsigned)(ncu * bpc);
+  {
+    ProfScope ps(c, "nl_plan_fused_kernel");
+    NLC_HIP(c, launch_nl_plan_fused(f, c->g, grid, built, c->stream));
+  }
+  *weights_done = fc.inline_weights != 0;
+  return NLC_OK;
+}
+
+// GRU launch + rollout launch (wave-per-tile or latency-split body), optionally in horizon chunks on two streams
+int rollout_nl_two_launch(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r, int variant) {
+  const nlc_mppi_desc& d = c->pd;
+  const int64_t KE = call.KE;
+  if (int rc2 = nlc::host::launch_shift_perturb(c, call)) return rc2;
+  // Horizon chunks (round 3, option "horizon_chunks"): the encoder input does not depend on the state, so the GRU
+  // encode of horizon steps [c Tc, (c + 1) Tc) can run on a stream of its own while the rollout walks the chunk before
+  // it.  The two kernels bound different things -- the encoder the FP64 MFMA pipe (95 % busy, two waves per SIMD), the
+  // wave-per-tile rollout the latency of ONE wave per SIMD (85 % busy) -- and since round 3 one wave of each fits a
+  // SIMD's registers (216 + 288 <= 512), so the encoder fills the rollout's issue bubbles.  State and cost sums travel
+  // between the rollout's chunk launches in xcarry / ccarry: same bits as the single launch.
+  int C = (variant != 2 && KE > 8192 && d.E == 1) ? c->opt_horizon_chunks : 1;
+  if (C < 1) C = 1;
+  if (C > d.T) C = d.T;
+  if (C > 8) C = 8;
+  if (C == 1) {
+    g.t0 = 0;
+    g.Tc = d.T;
+    g.N = KE * d.T;
+    {
+      ProfScope ps(c, "gru_encode_kernel");
+      NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
+    }
+    r.t_begin = 0;
+    r.t_end = d.T;
+    ProfScope ps(c, "nl_rollout_kernel");
+    NLC_HIP(c, launch_nl_rollout(r, c->stream, variant));
+  } else {
+    const int Tc = (d.T + C - 1) / C;
+    if (!c->gru_stream) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = lowest priority: the rollout's workgroups go first
+      NLC_HIP(c, hipStreamCreateWithPriority(&c->gru_stream, hipStreamNonBlocking, lo));
+    }
+    if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    while ((int)c->ev_gru.size() < C) {
+      hipEvent_t e2 = nullptr;
+      NLC_HIP(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      c->ev_gru.push_back(e2);
+    }
+    NLC_HIP(c, hipEventRecord(c->ev_fork, c->stream));  // behind the perturb kernel and the staged inputs
+    NLC_HIP(c, hipStreamWaitEvent(c->gru_stream, c->ev_fork, 0));
+    for (int ch = 0; ch < C; ++ch) {
+      g.t0 = ch * Tc;
+      g.Tc = (g.t0 + Tc <= d.T) ? Tc : d.T - g.t0;
+      if (g.Tc <= 0) break;
+      g.N = KE * g.Tc;
+      {
+        ProfScope ps(c, "gru_encode_kernel", c->gru_stream, true);
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->gru_stream, false));
+      }
+      NLC_HIP(c, hipEventRecord(c->ev_gru[ch], c->gru_stream));
+    }
+    for (int ch = 0; ch < C; ++ch) {
+      r.t_begin = ch * Tc;
+      r.t_end = (r.t_begin + Tc <= d.T) ? r.t_begin + Tc : d.T;
+      if (r.t_begin >= r.t_end) break;
+      NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_gru[ch], 0));
+      ProfScope ps(c, "nl_rollout_kernel");
+      NLC_HIP(c, launch_nl_rollout(r, c->stream, 1));
+    }
+  }
+  return NLC_OK;
+}
+
+}  // namespace
+
+int nlc::host::rollout_nl(nlc_ctx* c, RolloutCall& call) {
+  const nlc_mppi_desc& d = c->pd;
+  const nlc_mppi_buffers* buf = call.buf;
+  const WsLayout& w = call.w;
+  double* ws = call.ws;
+  double* state_dev = call.state_dev;
+  double* abuf_dev = call.abuf_dev;
+  const int64_t KE = call.KE;
+  const int state_per_sample = call.state_per_sample;
+  const bool replay = call.replay;
+  const bool lin_direct = linear_on_rollout_kernels(c);
+  double* pa = ws + w.pa;
+  GruArgs g = c->gru;
+  g.mode = 1;
+  g.perturbed = buf->perturbed;
+  g.abuf = abuf_dev;
+  g.u_scale = d.u_scale;
+  g.T = d.T;
+  g.B = d.B;
+  g.Kep = d.K;
+  g.nact = d.nu;
+  g.out = pa;
+  RolloutArgs r{};
+  r.net = c->net;
+  r.net.b1 = c->b1fold;
+  r.K = KE;
+  r.Kep = d.K;
+  r.T = d.T;
+  r.nu = d.nu;
+  r.B = d.B;
+  r.env = d.cost_external ? -1 : d.env;  // only the running cost reads it in the NL rollout
+  r.state_per_sample = state_per_sample;
+  r.state0 = state_dev;
+  r.pa = pa;
+  r.perturbed = buf->perturbed;
+  r.noise = buf->noise;
+  r.U = c->U[c->ucur];
+  for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) r.sigma_inv[i] = d.noise_sigma_inv[i];
+  r.lambda_ = d.lambda_;
+  r.u_scale = d.u_scale;
+  r.noise_abs_cost = d.noise_abs_cost;
+  r.tn = c->tn;
+  r.states = buf->states;
+  r.cost_total = buf->cost_total;
+  r.xcarry = ws + w.xcarry;
+  r.ccarry = ws + w.ccarry;
+  if (lin_direct) {
+    if (!c->cp_lin) return fail(c, NLC_ERR_STATE, "linear-algorithm coefficient tables missing (nlc_mppi_configure)");
+    const size_t ng = (size_t)2 * c->net.nt3 * 64;
+    r.net.Cp = c->cp_lin;
+    r.net.Cp2 = c->cp_lin + ng;
+    r.net.lin = 1;
+  }
+  if (c->md.ilt.algo != NLC_ILT_FOURIER && !lin_direct) return rollout_nl_staged(c, call, g, r, pa);
+  // rollout_variant (nlc_set_option): 0 auto, 1 wave-per-tile, 2 latency-split, 3 fused one-launch body
+  int variant = c->opt_rollout_variant;
+  const int h_ = c->md.h;
+  const bool fused_ok = (h_ == 64 || h_ == 128 || h_ == 256) && 2 * c->g == h_ && c->net.nt3 <= 21 &&
+                        KE * d.T * 16 < (int64_t)1 << 31 && !lin_direct;  // (no LIN instance of the one-launch body)
+  if (variant == 3 && !fused_ok) return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: model shape not instantiated");
+  // instances per width: 3 and 4 workgroups per CU at hidden_units 64 / 128, 2 at 256 (68 KB of LDS per workgroup)
+  const int bpc_hi = h_ == 256 ? 2 : 4, bpc_lo = h_ == 256 ? 2 : 3;
+  if (fused_ok && (c->fused_blocks_per_cu < 0 || c->fused_occ_h != h_)) {
+    int bpc = 0;
+    NLC_HIP(c, fused_max_resident_blocks(h_, bpc_hi, &bpc));
+    c->fused_blocks_per_cu = bpc;
+    NLC_HIP(c, fused_max_resident_blocks(h_, bpc_lo, &bpc));
+    c->fused_blocks_per_cu3 = bpc;
+    c->fused_occ_h = h_;
+  }
+  // The fused body's rollout workgroups wait for encoder workgroups of the SAME launch, so every workgroup must be
+  // resident and there must be workgroups left to encode beside one chain per CU: at least two per CU.  It
+  // also assumes the device to itself (include/nlc.h): after one hand-off timeout the ctx stays on the two-launch body.
+  if (variant == 3 && c->fused_blocks_per_cu < 2)
+    return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: fewer than two workgroups of the kernel fit a CU");
+  if (variant == 0 && fused_ok && c->fused_blocks_per_cu >= 2 && KE <= c->opt_fused_max_samples) variant = 3;
+  if (variant == 3 && (replay || c->fused_lost)) variant = 2;
+  if (variant == 3) {
+    bool weights_done = false;
+    if (int rc2 = rollout_nl_fused(c, call, g, r, bpc_hi, bpc_lo, &weights_done)) return rc2;
+    if (weights_done) return NLC_OK;
+  } else {
+    if (int rc2 = rollout_nl_two_launch(c, call, g, r, variant)) return rc2;
+  }
+  return d.cost_external ? NLC_OK : run_weights(c, buf);
+}

@@ -1,4 +1,4 @@
-// Host-side weight re-packing for the MFMA kernels: pure C++ (no HIP), shared by nlc_abi.hip and the CPU
+// Host-side weight re-packing for the MFMA kernels: pure C++ (no HIP), shared by abi_model.hip and the CPU
 // emulation test (tests/helpers/pack_host.cpp), which replays the kernels' dataflow lane by lane.
 #pragma once
 #include <cstddef>

@@ -129,7 +129,7 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 
   // Layer 3 in two halves of its output tiles (round 3): half the accumulators and prefetch registers live at a time --
   // the wave-per-tile rollout kernel drops under 256 VGPRs, so one of its waves fits a SIMD beside a GRU-encoder wave
-  // (horizon chunks of the two kernels running side by side, nlc_abi.hip).  Same MFMA sequence per tile, same ILT sum
+  // (horizon chunks of the two kernels running side by side, abi_planner_nl.hip).  Same MFMA sequence per tile, same ILT sum
   // order: same bits.
   v4d ax[1];
   ax[0] = splat(0.0);

@@ -18,6 +18,8 @@ CONFIGS = [  # (label, env, delay -> action_buffer rows, K, T, gpus, ilt, S)
     ("configs[2] pendulum d=4 K=65536 H=40 (2 GPUs)", "oderl-pendulum", 5, 65536, 40, 2, "fourier", 17),
     ("configs[3] acrobot d=2 K=262144 H=60 (8 GPUs)", "oderl-acrobot", 4, 262144, 60, 8, "fourier", 17),
     ("configs[4] cartpole K=16384 H=40 de Hoog S=33", "oderl-cartpole", 4, 16384, 40, 1, "dehoog", 33),
+    # the other leg of configs[4]'s "de Hoog (33 terms) vs FKT ablation": the Fourier series at the same 33 terms, same shape
+    ("configs[4] ablation leg: cartpole K=16384 H=40 fourier S=33", "oderl-cartpole", 4, 16384, 40, 1, "fourier", 33),
 ]
 
 
