@@ -8,7 +8,7 @@ as E separate :class:`~neurallaplacecontrol_amd.planners.mppi_delay.MPPIDelay` o
 launch covers all E*K samples (``nlc_mppi_desc.E``; per-episode softmax weights through ``blockIdx.y``).
 
 Episode e of a batched command is bit-identical to a single ``MPPIDelay.command()`` fed the same noise
-(``tests/test_gpu_parity.py::test_batched_planner_*``).
+(``tests/test_gpu_batched_sharded.py::test_batched_planner_*``).
 """
 
 import ctypes as C

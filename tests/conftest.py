@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def nlc():
+    """The product package, on a GPU box (the -m gpu tests): a missing device is a failure, not a skip."""
+    import torch
+
+    import neurallaplacecontrol_amd as n
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return n

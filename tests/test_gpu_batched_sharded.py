@@ -1,0 +1,446 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X), through the C ABI of libnlc_hip.so via the drop-in Python mirror:
+batched episodes (f2), K-sharding over ranks (e): shard merge, two processes on one GPU, the library RCCL communicator, the bench rehearsal.  Helpers and tolerances: tests/gpu_common.py.
+"""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import *  # noqa: F401,F403
+from gpu_common import GOLD, TOL, T64, load_sd, build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mppi_two_shards_merge_equals_single(nlc):
+    """SURVEY §8e on one GPU: two K/2 planners' partials merged through nlc_mppi_finish == one K planner."""
+    import ctypes as C
+
+    from neurallaplacecontrol_amd import _lib
+
+    env, K, T, A = "oderl-cartpole", 256, 7, 3.0
+    sig = nlc.noise_sigma(1)
+    torch.manual_seed(0)
+    raw = torch.randn(K, T, 1, dtype=torch.float64)
+    U0 = torch.randn(T, 1, dtype=torch.float64) * 0.2
+    st, ab = nlc.initial_state(env), torch.randn(4, 1, dtype=torch.float64)
+
+    def planner(**kw):
+        return nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 5, sig, K, T, "cpu", lambda_=1.0,
+                             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(), **kw)
+
+    full = planner()
+    full.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+    a_full = full.command(st, ab)
+    shards = []
+    for r in range(2):
+        p = planner()
+        p.K_local, p.k_offset = K // 2, r * (K // 2)
+        p.G, p.rank = 1, 0  # run phase 1 stand-alone; merge by hand below
+        p.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+        p.command(st, ab)  # fills partials (and applies a local-only update we overwrite next)
+        shards.append(p)
+    gathered = torch.stack([s._partials for s in shards]).contiguous()
+    for r, p in enumerate(shards):
+        p.U = torch.roll(U0, -1, 0).index_fill(0, torch.tensor([T - 1]), 0.0)  # U after the shift, before update
+        act = torch.empty(1, dtype=torch.float64)
+        p.ctx.check(p.ctx.lib.nlc_mppi_finish(p.ctx.h, _lib.ptr(gathered), 2, r, C.byref(p._buf), _lib.ptr(act)))
+        np.testing.assert_allclose(act.numpy(), a_full.numpy(), **TOL)
+        np.testing.assert_allclose(p.U.numpy(), full.U.numpy(), **TOL)
+        np.testing.assert_allclose(p.omega.numpy(), full.omega[r * (K // 2) : (r + 1) * (K // 2)].numpy(), **TOL)
+
+
+def _spawn_worker(q):
+    import torch as _t
+
+    import neurallaplacecontrol_amd as n
+
+    m = n.MPPIDelay(n.OracleDynamics("oderl-pendulum", 0.05, 0), n.EnvCost("oderl-pendulum"), 3, n.noise_sigma(1), 128, 5,
+                    "cpu", u_scale=2.0, U_init=_t.zeros(5, 1, dtype=_t.float64), noise_rng="philox", seed=3)
+    q.put(m.command(n.initial_state("oderl-pendulum"), _t.zeros(4, 1, dtype=_t.float64)).tolist())
+
+
+def test_spawned_worker_creates_its_own_ctx(nlc):
+    """The harness fans out with multiprocessing 'spawn' (run_exp_multi.py:145,207): HIP is initialised lazily in
+    the worker, and the Philox stream makes the result identical to the parent's."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_spawn_worker, args=(q,))
+    p.start()
+    child = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    m = nlc.MPPIDelay(nlc.OracleDynamics("oderl-pendulum", 0.05, 0), nlc.EnvCost("oderl-pendulum"), 3, nlc.noise_sigma(1),
+                      128, 5, "cpu", u_scale=2.0, U_init=torch.zeros(5, 1, dtype=torch.float64), noise_rng="philox", seed=3)
+    mine = m.command(nlc.initial_state("oderl-pendulum"), torch.zeros(4, 1, dtype=torch.float64)).tolist()
+    assert child == mine
+
+
+@pytest.mark.parametrize("env,delay", [("oderl-cartpole", 2), ("oderl-pendulum", 0), ("oderl-acrobot", 3)])
+def test_batched_planner_oracle_dynamics_equals_single_planners(nlc, env, delay):
+    """Collector shape (K = 1000 is ragged against every block size): bit-identical to E single planners."""
+    bat = _batched_vs_singles(nlc, lambda: nlc.OracleDynamics(env, 0.05, delay), env, E=5, K=1000, T=12)
+    assert bat.U.shape[0] == 5 and bat.noise.shape[:2] == (5, 1000)
+
+
+def test_batched_planner_oracle_options_and_per_sample_state(nlc):
+    _batched_vs_singles(nlc, lambda: nlc.OracleDynamics("oderl-acrobot", 0.05, 1), "oderl-acrobot", E=3, K=70, T=5,
+                        per_sample=True, sample_null_action=True, noise_abs_cost=True)
+
+
+@pytest.mark.parametrize("algo,S,K", [("fourier", 17, 100), ("fourier", 17, 8200), ("dehoog", 17, 72), ("fixed_tablot", 17, 72),
+                                      ("stehfest", 8, 100)])
+def test_batched_planner_nl_dynamics_equals_single_planners(nlc, algo, S, K):
+    """NL dynamics: K = 100 makes the 16-sample MFMA tiles straddle episodes; 8200 takes the wave-per-tile kernel."""
+    from oracle import nl_model as onl
+
+    env, d, nu, A = "oderl-cartpole", 5, 1, 3.0
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(4, d, nu, 128, S, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd, S=S, algo=algo)
+    E = 3 if K < 1000 else 2
+    _batched_vs_singles(nlc, lambda: nlc.NLDynamics(model, 0.05), env, E=E, K=K, T=6, n_cmd=2)
+
+
+def test_batched_planner_philox_streams_and_device_inputs(nlc):
+    """Device RNG: episode 0 continues the single planner's stream, other episodes draw different noise; states and
+    action buffers handed over as device tensors give the same result as host tensors; reset(env_ids) is per episode."""
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    env, E, K, T, A = "oderl-cartpole", 4, 512, 10, 3.0
+    sig = nlc.noise_sigma(1)
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=11)
+    U0 = torch.zeros(E, T, 1, dtype=torch.float64)
+    states = torch.stack([_state(nlc, env, e) for e in range(E)])
+    ab = torch.zeros(E, 4, 1, dtype=torch.float64)
+    mk = lambda dev: BatchedMPPIDelay(nlc.OracleDynamics(env, 0.05, 2), nlc.EnvCost(env), 5, sig, E, K, T, dev,  # noqa: E731
+                                      U_init=U0.clone(), **kw)
+    host, devp = mk("cpu"), mk("cuda")
+    a_h = host.command(states, ab)
+    a_d = devp.command(states.cuda(), ab.cuda())
+    assert a_d.is_cuda and torch.equal(a_h, a_d.cpu())
+    single = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 2), nlc.EnvCost(env), 5, sig, K, T, "cpu", U_init=U0[0].clone(), **kw)
+    a_s = single.command(states[0], ab[0])
+    assert torch.equal(a_s, a_h[0]) and torch.equal(single.noise, host.noise[0])
+    n = host.noise
+    assert not torch.equal(n[0], n[1]) and not torch.equal(n[1], n[2])
+    # U = 0 and bounds +-1 in normalised units: the bounded noise is N(0,1) clipped to [-1, 1] (std 0.718)
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 0.718) < 0.02 and float(n.abs().max()) <= 1.0
+    U_before = host.U.clone()
+    torch.manual_seed(5)
+    host.reset([1, 3])
+    U_after = host.U
+    assert torch.equal(U_after[0], U_before[0]) and torch.equal(U_after[2], U_before[2])
+    assert not torch.equal(U_after[1], U_before[1]) and not torch.equal(U_after[3], U_before[3])
+    host.reset()
+    assert host.U.shape == (E, T, 1)
+
+
+def test_batched_planner_rejects_unsupported(nlc):
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    sig = nlc.noise_sigma(1)
+    with pytest.raises(NotImplementedError):
+        BatchedMPPIDelay(lambda s, a: s, lambda s, a: s.sum(1), 5, sig, 4, 64, 5, "cpu")
+    b = BatchedMPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 0), nlc.EnvCost("oderl-cartpole"), 5, sig, 4, 64, 5, "cpu")
+    with pytest.raises(ValueError):
+        b.command(torch.zeros(5, dtype=torch.float64), torch.zeros(4, 4, 1, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        b.command(torch.zeros(4, 5, dtype=torch.float64), torch.zeros(4, 1, dtype=torch.float64))
+
+
+def test_planners_sharing_a_model_are_independent_and_track_weight_updates(nlc):
+    """Each planner owns its ctx (U, folded bias): interleaving two planners over ONE model changes nothing, and a
+    planner picks up new weights (load_state_dict) on its next command, carrying its U over."""
+    from oracle import nl_model as onl
+
+    env, d, nu, A, K, T = "oderl-cartpole", 5, 1, 3.0, 64, 5
+    st = onl.ENV_STATS[env]
+    sd1 = onl.make_synthetic_state_dict(5, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    sd2 = onl.make_synthetic_state_dict(6, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    g = torch.Generator().manual_seed(9)
+    raws = [torch.randn(K, T, nu, dtype=torch.float64, generator=g) for _ in range(3)]
+    Ua, Ub = torch.randn(T, nu, dtype=torch.float64, generator=g) * 0.2, torch.randn(T, nu, dtype=torch.float64, generator=g)
+    state, ab = _state(nlc, env, 1), torch.zeros(4, nu, dtype=torch.float64)
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A)
+
+    def planner(model, U0, draws):
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                          U_init=U0.clone(), **kw)
+        p.noise_dist = _Replay(*[r.clone() for r in draws])
+        return p
+
+    with torch.no_grad():
+        alone = planner(build_model(nlc, sd1), Ua, raws)
+        a1, a2 = alone.command(state, ab).clone(), alone.command(state, ab).clone()
+        U_after2 = alone.U.clone()
+        shared = build_model(nlc, sd1)
+        pa, pb = planner(shared, Ua, raws), planner(shared, Ub, raws)
+        assert pa.ctx is not pb.ctx
+        b1 = pa.command(state, ab)
+        pb.command(state, ab)
+        b2 = pa.command(state, ab)
+        assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(pa.U, U_after2)
+        shared.load_state_dict(sd2)  # new weights, same module
+        b3 = pa.command(state, ab)
+        fresh = planner(build_model(nlc, sd2), U_after2, raws[2:])
+        assert torch.equal(b3, fresh.command(state, ab))
+        assert not torch.equal(b3, alone.command(state, ab))
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import neurallaplacecontrol_amd as n
+dist.init_process_group("gloo")            # both ranks share cuda:0 here; bench.py uses "nccl" (= RCCL), one GPU per rank
+rank = dist.get_rank()
+sd = torch.load(os.path.join(sys.argv[2], "sd.pt"))
+d, nu, A, K, T = 5, 1, 3.0, 1024, 8
+import numpy as np
+model = n.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", state_mean=np.zeros(d),
+                             state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]),
+                             normalize=True, normalize_time=True).double()
+model.load_state_dict(sd)
+model = model.cuda()
+kw = dict(state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]),
+          normalize=True, normalize_time=True)
+rnn = n.DeltaTRNN(d, nu, hidden_units=64, **kw).double()
+rnn.load_state_dict(torch.load(os.path.join(sys.argv[2], "sd_rnn.pt")))
+node = n.NODE(d, nu, d, hidden_units=64, augment_dim=1, **kw).double()
+node.load_state_dict(torch.load(os.path.join(sys.argv[2], "sd_node.pt")))
+out = {}
+for name, dyn in (("nl", n.NLDynamics(model, 0.05)), ("oracle", n.OracleDynamics("oderl-cartpole", 0.05, 2)),
+                  ("dtrnn", n.NLDynamics(rnn.cuda(), 0.05)), ("node", n.NLDynamics(node.cuda(), 0.05))):
+    p = n.MPPIDelay(dyn, n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+                    u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                    noise_rng="philox", seed=21, process_group=dist.group.WORLD)
+    assert p.K_local == K // 2 and p.k_offset == rank * (K // 2)
+    state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
+    with torch.no_grad():
+        acts = [p.command(state, ab).cpu() for _ in range(3)]
+    out[name] = dict(acts=torch.stack(acts), U=p.U.cpu(), noise=p.noise.cpu(), omega=p.omega.cpu())
+# rollout_samples > 1 under the group: the variance term is a statistic of the WHOLE population (two small all-reduces)
+p = n.MPPIDelay(n.OracleDynamics("oderl-cartpole", 0.05, 1), n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda",
+                lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                noise_rng="philox", seed=22, process_group=dist.group.WORLD, rollout_samples=3, rollout_var_cost=0.7,
+                rollout_var_discount=0.9)
+with torch.no_grad():
+    a = p.command(state, ab).cpu()
+out["varcost"] = dict(acts=a, cost=p.cost_total.cpu())
+torch.save(out, os.path.join(sys.argv[2], f"r{rank}.pt"))
+dist.destroy_process_group()
+"""
+
+
+_NATIVE_COLLECTIVE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import neurallaplacecontrol_amd as n
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))   # RCCL, one rank (one GPU on this box)
+sd = torch.load(os.path.join(sys.argv[2], "sd.pt"))
+d, nu, A, K, T = 5, 1, 3.0, 2048, 12
+import numpy as np
+model = n.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", state_mean=np.zeros(d),
+                             state_std=np.ones(d), action_mean=np.array([0]), action_std=np.array([1.0]),
+                             normalize=True, normalize_time=True).double()
+model.load_state_dict(sd)
+model = model.cuda()
+def planner(pg, native):
+    return n.MPPIDelay(n.NLDynamics(model, 0.05), n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cuda", lambda_=1.0,
+                       u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                       noise_rng="philox", seed=5, process_group=pg, planner_options={"native_collective": native})
+ps = [planner(None, 0), planner(dist.group.WORLD, 0), planner(dist.group.WORLD, 1)]
+assert ps[2].native_collective and not ps[1].native_collective and not ps[0].native_collective
+state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
+with torch.no_grad():
+    for step in range(4):
+        acts = [p.command(state, ab) for p in ps]
+        assert torch.equal(acts[0], acts[1]) and torch.equal(acts[0], acts[2]), (step, acts)
+        assert torch.equal(ps[0].U, ps[2].U) and torch.equal(ps[0].omega, ps[2].omega)
+        ab = torch.roll(ab, -1, 0); ab[-1] = acts[0].cpu()
+    ps[2].ctx.profile(True)
+    ps[2].command(state, ab); torch.cuda.synchronize()
+    ps[2].ctx.profile(False)
+    assert "rccl_all_gather" in ps[2].ctx.profile_read()
+# a second communicator on a fresh ctx, and the error paths of the C ABI
+import ctypes as C
+c = n._lib.Ctx(0)
+try:
+    c.check(c.lib.nlc_comm_init(c.h, 3, 2, C.c_char_p(b"x" * 128)))
+    raise SystemExit("bad rank accepted")
+except n._lib.NlcError as e:
+    assert e.code == -1
+c.comm_init(0, 1, c.comm_unique_id())
+c.check(c.lib.nlc_comm_destroy(c.h))
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], "ok"), "w").write("ok")
+"""
+
+
+def test_native_collective_one_rank_rccl(nlc, tmp_path):
+    """include/nlc.h's own communicator (nlc_comm_unique_id / nlc_comm_init; nlc_mppi_finish with gathered_dev == NULL
+    runs ncclAllGather on the command's stream): a one-rank RCCL group on this box's one GPU.  The planner with the
+    native collective, the one with torch.distributed's and the one without a group return bit-identical actions, U and
+    omega over consecutive commands."""
+    import subprocess
+    import sys
+
+    from oracle import nl_model as onl
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    st = onl.ENV_STATS["oderl-cartpole"]
+    torch.save(onl.make_synthetic_state_dict(8, 5, 1, 128, 17, st["state_std"], [1.5], tame=True), tmp_path / "sd.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_NATIVE_COLLECTIVE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+         "--master-port", "29547", str(script), repo, str(tmp_path)], env=env, timeout=600)
+    assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
+    """`MPPIDelay(process_group=...)` through torch.distributed.run with world_size 2 (both ranks on this one GPU,
+    gloo collective): every rank returns the same action, and it equals the unsharded planner's (Philox counters are
+    global sample indices, so the draw does not depend on the sharding)."""
+    import subprocess
+    import sys
+
+    from oracle import nl_model as onl
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    d, nu, A, K, T = 5, 1, 3.0, 1024, 8
+    st = onl.ENV_STATS["oderl-cartpole"]
+    sd = onl.make_synthetic_state_dict(8, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    torch.save(sd, tmp_path / "sd.pt")
+    from oracle import node_model as onode
+    from oracle import rnn_model as ornn
+
+    sd_rnn = ornn.make_synthetic_state_dict(8, d, nu, 64, st["state_std"], [A / 2])
+    sd_node = onode.make_synthetic_state_dict(8, d, nu, 64, 1, st["state_std"], [A / 2])
+    torch.save(sd_rnn, tmp_path / "sd_rnn.pt")
+    torch.save(sd_node, tmp_path / "sd_node.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29541", str(script), repo, str(tmp_path)], env=env, timeout=600)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    model = build_model(nlc, sd)
+    state, ab = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64), torch.zeros(4, nu, dtype=torch.float64)
+    for name, dyn in (("nl", nlc.NLDynamics(model, 0.05)), ("oracle", nlc.OracleDynamics("oderl-cartpole", 0.05, 2)),
+                      ("dtrnn", nlc.NLDynamics(build_rnn(nlc, sd_rnn, 64), 0.05)),
+                      ("node", nlc.NLDynamics(build_node(nlc, sd_node, 64, 1), 0.05))):
+        assert torch.equal(r0[name]["acts"], r1[name]["acts"]) and torch.equal(r0[name]["U"], r1[name]["U"])
+        p = nlc.MPPIDelay(dyn, nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                          U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=21)
+        with torch.no_grad():
+            acts = torch.stack([p.command(state, ab) for _ in range(3)])
+        np.testing.assert_allclose(r0[name]["acts"].numpy(), acts.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r0[name]["U"].numpy(), p.U.numpy(), rtol=1e-10, atol=1e-12)
+        # the shards hold the two halves of the unsharded planner's last draw and weights
+        both = torch.cat((r0[name]["noise"], r1[name]["noise"]))
+        np.testing.assert_allclose(both.numpy(), p.noise.numpy(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(torch.cat((r0[name]["omega"], r1[name]["omega"])).numpy(), p.omega.numpy(),
+                                   rtol=1e-9, atol=1e-15)
+    # rollout_samples = 3 with a variance cost: sharded == unsharded (the reference's statistic over all K samples)
+    p = nlc.MPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 1), nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K,
+                      T, "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                      U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=22, rollout_samples=3,
+                      rollout_var_cost=0.7, rollout_var_discount=0.9)
+    a = p.command(state, ab)
+    np.testing.assert_allclose(r0["varcost"]["acts"].numpy(), a.numpy(), rtol=1e-10, atol=1e-12)
+    both = torch.cat((r0["varcost"]["cost"], r1["varcost"]["cost"]))
+    np.testing.assert_allclose(both.numpy(), p.cost_total.numpy(), rtol=1e-11, atol=1e-11)
+    plain = nlc.MPPIDelay(nlc.OracleDynamics("oderl-cartpole", 0.05, 1), nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K,
+                          T, "cpu", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                          U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=22)
+    plain.command(state, ab)
+    shift = p.cost_total - plain.cost_total
+    assert float(shift.min()) > 1e-6 and float(shift.max() - shift.min()) < 1e-9  # one constant, as in the reference
+
+
+def test_batched_planner_rollout_samples_per_episode_variance(nlc):
+    """rollout_samples > 1 in BatchedMPPIDelay: episode e gets ITS population's variance term, exactly what a single
+    MPPIDelay with the same options computes for it (reference mppi_delay.py:291-292, 310)."""
+    env, K, T, E, A = "oderl-pendulum", 200, 7, 3, 2.0
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, rollout_samples=2, rollout_var_cost=0.5,
+              rollout_var_discount=0.8)
+    torch.manual_seed(9)
+    raw = torch.randn(E, K, T, 1, dtype=torch.float64)
+    U0 = torch.randn(E, T, 1, dtype=torch.float64) * 0.3
+    states = torch.stack([nlc.initial_state(env) + 0.05 * e for e in range(E)])
+    abs_ = torch.randn(E, 4, 1, dtype=torch.float64)
+    b = nlc.BatchedMPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 3, nlc.noise_sigma(1), E, K, T, "cpu",
+                             U_init=U0.clone(), **kw)
+    b.noise_dist = type("R", (), {"sample": staticmethod(lambda shape: raw)})()
+    acts = b.command(states, abs_)
+    for e in range(E):
+        p = nlc.MPPIDelay(nlc.OracleDynamics(env, 0.05, 1), nlc.EnvCost(env), 3, nlc.noise_sigma(1), K, T, "cpu",
+                          U_init=U0[e].clone(), **kw)
+        p.noise_dist = type("R", (), {"sample": staticmethod(lambda shape, e=e: raw[e])})()
+        a = p.command(states[e], abs_[e])
+        assert torch.equal(a, acts[e])
+        np.testing.assert_allclose(b.cost_total[e].numpy(), p.cost_total.numpy(), rtol=1e-13, atol=1e-13)
+
+
+def test_batched_planner_acrobot_nl_u_per_command(nlc):
+    """nu = 2 NL dynamics, two actions per command, K ragged against the 16-sample tiles."""
+    from oracle import nl_model as onl
+
+    env, d, nu, A = "oderl-acrobot", 6, 2, 5.0
+    st = onl.ENV_STATS[env]
+    sd = onl.make_synthetic_state_dict(14, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    from neurallaplacecontrol_amd.planners.mppi_batch import BatchedMPPIDelay
+
+    E, K, T = 3, 50, 5
+    g = torch.Generator().manual_seed(77)
+    U0 = torch.randn(E, T, nu, dtype=torch.float64, generator=g) * 0.3
+    raw = torch.randn(E, K, T, nu, dtype=torch.float64, generator=g)
+    states = torch.stack([_state(nlc, env, e) for e in range(E)])
+    ab = torch.randn(E, 4, nu, dtype=torch.float64, generator=g)
+    kw = dict(lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, u_per_command=2)
+    bat = BatchedMPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), E, K, T, "cpu",
+                           U_init=U0.clone(), **kw)
+    bat.noise_dist = _Replay(raw.clone())
+    with torch.no_grad():
+        act = bat.command(states, ab)
+        assert act.shape == (E, 2, nu)
+        for e in range(E):
+            m = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu",
+                              U_init=U0[e].clone(), **kw)
+            m.noise_dist = _Replay(raw[e].clone())
+            assert torch.equal(m.command(states[e], ab[e]), act[e])
+            assert torch.equal(m.U, bat.U[e])
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """The whole N > 1 flow of bench.py on the 1-GPU box: `python bench.py --gpus 2` starts its own two ranks, each plans
+    its K / 2 shard on cuda:0 (the ranks talk over gloo: RCCL refuses two ranks per device), rank-consistent pre-heat, timed
+    steps between barriers, MAX over ranks, ONE JSON line from rank 0, orderly teardown.  The numbers mean nothing; the run
+    must end with exit code 0 and a well-formed line."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "12",
+                          "--warmup", "2", "--preheat-ms", "40", "--no-ilt", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 12 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["config"]["samples_per_gpu"] == 8192 and "gloo" in rec["config"]["collective"]
+    assert "nl_rollout_kernel" in rec["kernels_avg_ms"] or "nl_plan_fused_kernel" in rec["kernels_avg_ms"]

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neurallaplacecontrol_amd as nlc
 from oracle import ilt as oilt, nl_model as onl, envs as oenvs, mppi as omppi
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from test_gpu_parity import build_model, load_sd, T64, GOLD
+from gpu_common import build_model, load_sd, T64, GOLD
 torch.set_printoptions(precision=6, linewidth=200)
 
 def err(a, b):
