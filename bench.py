@@ -39,7 +39,7 @@ ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
 # newest committed PMC summary (separate rocprofv3 --pmc passes: tools/collect_profiles.sh + tools/pmc_summarize.py)
-PMC_CANDIDATES = ("r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
+PMC_CANDIDATES = ("r4_pmc_kernels.json", "r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
 # library kernel (nlc_profile_read name) -> key of the PMC summary; the summary's "_meta.kernel_names" must list a
 # rocprof kernel name containing the library name, or the traffic figure belongs to some other build
 PMC_KEYS = {"gru_encode_kernel": "gru_encode", "nl_rollout_kernel": "nl_rollout", "ilt_fourier_kernel": "ilt_fourier",
@@ -214,9 +214,12 @@ def cpu_baseline(sd, d, nu, budget_s=30.0):
                 f"{[(n, round(e, 3)) for n, e in sweep]} (threads, s)"),
         cpu_model=info["model"], physical_cores=info["physical_cores"], logical_cpus=info["logical_cpus"],
         usable_cpus=info["usable_cpus"],
-        one_thread=dict(value=1.0 / one, seconds_per_command=one, note=f"extrapolated x8 from K={K8}"),
-        all_physical_cores=(dict(value=1.0 / allc, seconds_per_command=allc, threads=info["physical_cores"],
-                                 note=f"extrapolated x8 from K={K8}") if allc else None),
+        # NOT measurements at the quoted size: one command at K / 8, scaled by 8 (context for the measured figure above only)
+        one_thread_extrapolated_x8=dict(value_extrapolated=1.0 / one, seconds_per_command_extrapolated=one, measured_at_K=K8,
+                                        note=f"EXTRAPOLATED: one command at K={K8}, time x 8"),
+        all_physical_cores_extrapolated_x8=(dict(value_extrapolated=1.0 / allc, seconds_per_command_extrapolated=allc,
+                                                 threads=info["physical_cores"], measured_at_K=K8,
+                                                 note=f"EXTRAPOLATED: one command at K={K8}, time x 8") if allc else None),
         torch=torch.__version__, oracle="oracle/ (torch-CPU float64, aten::gru encoder as in the reference)",
     )
 
@@ -539,6 +542,12 @@ def main():
     else:
         roofline = mfma_entry("gru_encode_kernel", gru_need, gru_iss, (8 * nu + 16) * windows)
         roofline["also"] = mfma_entry("nl_rollout_kernel", roll_need, roll_iss, (16 + 8 * (2 * nu + d)) * windows)
+    # whole step against the same roof: every algorithmic flop of one command() (GRU encode + rollout, all ranks) over the
+    # measured wall time per step -- the sampling / weighting / merge kernels add time but no matrix flops
+    step_flops = (gru_need + roll_need) * world
+    roofline["step"] = dict(flops=step_flops, achieved=step_flops / (elapsed / args.steps) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS * world,
+                            unit="TFLOP/s", frac=step_flops / (elapsed / args.steps) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+                            note="algorithmic flops of one command() (GRU encode + rollout; SURVEY 8d) / ms_per_step / FP64-MFMA peak")
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_cpu, d, nu, args.cpu_budget)

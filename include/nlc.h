@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 7
+#define NLC_ABI_VERSION 8
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -37,6 +37,9 @@ extern "C" {
 #define NLC_ERR_UNSUPPORTED (-4)
 #define NLC_ERR_STATE (-5)
 #define NLC_ERR_COMM (-6) /* RCCL reported an error (message in nlc_last_error) */
+/* nlc_mppi_finish only, caller-owned collective (gathered_dev != NULL, G > 1): the command was re-run on the two-launch body on
+ * every rank; buf->partials hold the new rows -- all-gather them again and call nlc_mppi_finish again.  Not an error. */
+#define NLC_AGAIN 1
 
 #define NLC_MAX_NU 2   /* action dims (cartpole/pendulum 1, acrobot 2) */
 #define NLC_MAX_NIN 3  /* GRU input dims = nu + encode_obs_time */
@@ -55,6 +58,10 @@ extern "C" {
 #define NLC_ENV_CARTPOLE 0
 #define NLC_ENV_PENDULUM 1
 #define NLC_ENV_ACROBOT 2
+/* cartpole WITHOUT the trig observation: CTCartpole(obs_trans=False), nx = 4, state [x, xdot, theta, thetadot]
+ * (ctcartpole.py:60; reward branch :297-300; oracle dynamics branch oracle.py:38-44, 80-86) -- BASELINE's literal
+ * "state_dim=4".  Planner only (running cost, oracle dynamics, NL dynamics); nlc_env_step keeps the three harness envs. */
+#define NLC_ENV_CARTPOLE_NOTRIG 3
 
 /* rollout dynamics */
 #define NLC_DYN_NL 0     /* state + NeuralLaplaceModel(state, window, ts_pred)  (mppi_with_model.py:103-122) */
@@ -106,9 +113,13 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        one launch up front -- measured no faster (the chip is busy either way).
  *   "host_spin"          nlc_mppi_finish with action_host (single planner): 1 (default) = the merge kernel stores a sequence
  *                        number behind the action in pinned host memory and the host spins on that word (sub-microsecond
- *                        hand-over, one busy core for the length of a command) instead of sleeping in hipStreamSynchronize
- *                        (an interrupt wake-up: 10-20 us per command); 0 = hipStreamSynchronize.  After the call the action is
- *                        valid; the stream may still be finishing omega / cost_nz (stream-ordered for every later call).
+ *                        hand-over, one busy core for the length of a command); 2 = the host first sleeps through most of the
+ *                        wait -- the shortest of its last eight waits predicts this one, it wakes "host_spin_margin_us"
+ *                        (default 150; at least 15 % of the prediction) early -- and spins only for the rest, leaving the core
+ *                        to the harness's other workers (run_exp_multi.py:145 fans out a Pool(12) on one GPU);
+ *                        0 = hipStreamSynchronize (measured: the runtime busy-waits as well, and wakes 5-9 us later).
+ *                        After the call ONLY the action is valid; the stream may still be finishing omega / cost_nz (they are
+ *                        stream-ordered for every later call; nlc_synchronize before reading them from the host).
  *   "fused_blocks_per_cu"  fused body: the instance compiled for 3 (168 VGPRs) or 4 (128 VGPRs) workgroups per CU; 0 = auto
  *                        (3 while rollout chains sit on at most half of the CUs, else 4)
  *   "fused_inline"       fused body, single planner (E <= 1), bit mask: 1 = the importance-weight reduction (:210-216) runs
@@ -131,9 +142,12 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        -2 = auto (1 .. 4 with the share of CUs that walk a chain: fit to MI355X measurements)
  * The fused body assumes the device to itself: its rollout workgroups wait for encoder workgroups of the SAME launch, so
  * all of its workgroups must be resident at once (auto picks it only when at least two fit a CU).  Every wait is bounded: on
- * a time-out the command is re-run on the two-launch body inside nlc_mppi_finish (single rank, library-side costs, host
- * action pointer given) or reported as NLC_ERR_HIP, and the ctx keeps to the two-launch body from then on (setting
- * "rollout_variant" again re-arms it).
+ * a time-out the launch marks its shard's partial row invalid (eta_r = -1), which travels through the shard all-gather, so
+ * merge_kernel on EVERY rank skips the update and tells its host: every rank re-runs the command on the two-launch body inside
+ * nlc_mppi_finish (library-side costs, host action pointer given; with a caller-owned collective the call returns NLC_AGAIN
+ * for the second all-gather) -- no rank is left waiting in a collective.  Otherwise (device-resident action, cost callables)
+ * the loss is reported as NLC_ERR_HIP by this or the next call, on every rank.  The ctx that timed out keeps to the
+ * two-launch body from then on (setting "rollout_variant" again re-arms it).
  * Unknown names / out-of-range values: NLC_ERR_BAD_ARG. */
 int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
 /* device properties the bench reports next to its roofline numbers */
@@ -341,8 +355,10 @@ int nlc_mppi_weights(nlc_ctx* ctx, const nlc_mppi_buffers* buf);
 /* Phase 2: merge G shard partials (gathered_dev: (G, E, 2+T*nu); pass buf->partials and G=1 on one GPU; NULL: gather
  * them with the ctx's own communicator, see the multi-GPU note below),
  * omega, U[t] += sum_k omega_k noise[k,t] (:210-216) and return action = U[:u_per_command]*u_scale
- * (:217-224) into action_host (E*u_per_command*nu) -- synchronises the stream -- and/or into buf->action on
- * the device.  With action_host == NULL nothing is copied back and the call does not synchronise. */
+ * (:217-224) into action_host (E*u_per_command*nu) -- the call waits until the ACTION is in host memory (see "host_spin":
+ * cost_nz / omega may still be in flight on the stream; nlc_synchronize before reading them from the host) -- and/or into
+ * buf->action on the device.  With action_host == NULL nothing is copied back and the call does not synchronise.
+ * Returns NLC_AGAIN (> 0, not an error) when a sharded command had to be re-run and the caller owns the collective. */
 int nlc_mppi_finish(nlc_ctx* ctx, const double* gathered_dev, int G, int rank, const nlc_mppi_buffers* buf,
                     double* action_host);
 /* Multi-GPU: the one exchange of a K-sharded command is the all-gather of buf->partials ((2+T*nu) doubles per rank and

@@ -16,11 +16,13 @@ NLC_MAX_NIN = 3
 NLC_MAX_D = 8
 
 ILT_ALGOS = {"fourier": 0, "dehoog": 1, "fixed_tablot": 2, "stehfest": 3}
-ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
+# "oderl-cartpole-notrig": CTCartpole(obs_trans=False), the 4-dim state [x, xdot, theta, thetadot] (ctcartpole.py:60, 297-300)
+ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2, "oderl-cartpole-notrig": 3}
 DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN, DYN_NODE = 0, 1, 2, 3, 4
 
 ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE", -6: "COMM"}
 COMM_ID_BYTES = 128
+NLC_AGAIN = 1  # include/nlc.h: nlc_mppi_finish re-ran the command on every rank; gather the partials again and call again
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnlc_hip.so")
 

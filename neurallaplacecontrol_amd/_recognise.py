@@ -12,6 +12,18 @@ A closure is opaque to a HIP kernel, but its free variables are not: this module
 that WOULD compute the same thing.  A proposal is only a candidate: ``MPPIDelay`` verifies it at its first ``command()``
 by running one short command both ways on the command's own state and action buffer and switches to the fused path only
 if rollout states and costs agree (``probe_equivalence``); otherwise it stays on the generic path, silently correct.
+A probe alone cannot establish equivalence (one state, a short horizon: a clamp, a termination branch or any
+state-dependent logic outside the probed region would go unseen -- ADVICE r3), so a closure is only ever a candidate if it
+also has the harness closures' STRUCTURE: its code object may reference nothing but the names those closures reference
+(``_DYN_NAMES`` / ``_COST_NAMES``: the torch calls that append the time channel; the env's two reward methods), close over
+nothing but their free variables, and carry no constants of its own beyond None / booleans / small integers / the strings
+they use -- a closure with a ``clamp``, a ``where``, a threshold constant or a helper call fails this and stays on the
+generic path.  ``planner_options={"recognise_closures": 0}`` switches recognition off altogether.
+
+A twin built from a reference model instance (``NeuralLaplaceModel.from_reference``) is a weight SNAPSHOT; the dynamics
+object keeps the source module and re-copies its weights whenever their ``(data_ptr, _version)`` key has moved since the last
+command (``refresh_twin``), so a ``load_state_dict`` / optimizer step on the closed-over model is seen by the fused path as
+it is by the literal closure.
 Nothing here executes or imports reference code: only attribute and type inspection of objects the caller passed in.
 """
 
@@ -28,6 +40,69 @@ _ORACLE_FUNCS = {
     "acrobot_dynamics_dt_delay": "oderl-acrobot",
 }
 _ENV_CLASS_HINTS = (("cartpole", "oderl-cartpole"), ("pendulum", "oderl-pendulum"), ("acrobot", "oderl-acrobot"))
+
+
+# What the harness's closures reference (mppi_with_model.py:103-122 and :145-171): global / attribute names, free variables,
+# argument names.  A structural fingerprint -- names only, no code.
+_DYN_NAMES = frozenset({"torch", "cat", "flip", "arange", "view", "repeat", "shape"})
+_DYN_FREE = frozenset({"model", "ts_pred", "device"})
+_DYN_ARGS = ("state", "perturbed_action")
+_DYN_STRS = frozenset({"nl", "device", "dim"})  # the model name it compares with, keyword names of its torch calls
+_COST_NAMES = frozenset({"diff_obs_reward_", "diff_ac_reward_", "change_goal_flipped"})
+_COST_FREE = frozenset({"env", "state_constraint", "change_goal"})
+_COST_STRS = frozenset({"exp_reward", "state_constraint", "change_goal", "change_goal_flipped"})
+
+
+def _consts_ok(consts, strings, doc):
+    for c in consts:
+        if c is None or isinstance(c, bool):
+            continue
+        if isinstance(c, int) and -4 <= c <= 4:
+            continue
+        if isinstance(c, str) and (c in strings or c == doc):
+            continue  # a keyword / model name the harness closure uses, or the function's own docstring
+        if isinstance(c, tuple) and all((isinstance(e, str) and e in strings) or (type(e) is int and -4 <= e <= 4) for e in c):
+            continue  # keyword-name tuple of a call / a small index tuple
+        return False
+    return True
+
+
+def has_harness_structure(fn, kind):
+    """True iff the function `fn` references nothing the harness's `kind` closure ("dynamics" / "cost") does not: names, free
+    variables, leading argument names and constants (see the module docstring)."""
+    if not inspect.isfunction(fn):
+        return False
+    code = fn.__code__
+    names, free, strs = (_DYN_NAMES, _DYN_FREE, _DYN_STRS) if kind == "dynamics" else (_COST_NAMES, _COST_FREE, _COST_STRS)
+    if not set(code.co_names) <= names or not set(code.co_freevars) <= free:
+        return False
+    if kind == "dynamics" and tuple(code.co_varnames[:2]) != _DYN_ARGS:
+        return False
+    if kind == "cost" and code.co_argcount != 2:
+        return False
+    if any(inspect.iscode(c) for c in code.co_consts):  # nested functions / comprehensions: not the harness's closure
+        return False
+    return _consts_ok(code.co_consts, strs, fn.__doc__)
+
+
+def _module_key(mod):
+    return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
+
+
+def refresh_twin(twin):
+    """Re-copy the weights of a twin built by ``_model_twin`` from a foreign (reference) module if that module's tensors
+    have been written or replaced since the last look.  No-op for the package's own models."""
+    src = twin.__dict__.get("_twin_source")
+    if src is None:
+        return
+    key = _module_key(src)
+    if key != twin.__dict__["_twin_source_key"]:
+        with torch.no_grad():
+            for name in ("state_mean", "state_std", "action_mean", "action_std", "dt"):
+                if hasattr(src, name):
+                    getattr(twin, name).copy_(getattr(src, name).detach().to(getattr(twin, name).device))
+            twin.load_state_dict({k: v.detach() for k, v in src.state_dict().items()})
+        twin.__dict__["_twin_source_key"] = key
 
 
 def _free_variables(fn):
@@ -70,9 +145,13 @@ def _model_twin(obj):
         return obj
     if isinstance(obj, torch.nn.Module) and type(obj).__name__ == "NeuralLaplaceModel" and hasattr(obj, "laplace_rep_func"):
         try:
-            return NeuralLaplaceModel.from_reference(obj)
+            twin = NeuralLaplaceModel.from_reference(obj)
         except Exception:
             return None
+        # a snapshot: remember where it came from, so that later weight updates of `obj` reach the fused path (refresh_twin)
+        # (through __dict__: a plain attribute assignment would register `obj` as a sub-module of the twin)
+        twin.__dict__["_twin_source"], twin.__dict__["_twin_source_key"] = obj, _module_key(obj)
+        return twin
     return None
 
 
@@ -91,6 +170,8 @@ def candidate_dynamics(fn):
         if ts is None or not isinstance(delay, int) or kw:
             return None
         return OracleDynamics(env, ts=ts, delay=delay, friction=friction)
+    if not has_harness_structure(fn, "dynamics"):
+        return None
     free = _free_variables(fn)
     if not free:
         return None
@@ -115,6 +196,8 @@ def candidate_cost(fn):
     """An ``EnvCost`` that `fn` appears to compute (the harness closure's default branch), or None."""
     if isinstance(fn, EnvCost):
         return fn
+    if not has_harness_structure(fn, "cost"):
+        return None
     free = _free_variables(fn)
     if not free:
         return None

@@ -148,6 +148,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "dehoog_gru_lds_pad") {
     if (value < 0 || value > 120000) return fail(c, NLC_ERR_BAD_ARG, "dehoog_gru_lds_pad must be in 0 .. 120000 bytes");
     c->opt_dehoog_gru_lds_pad = (int)value;
+  } else if (n == "dehoog_chain") {
+    if (value != -1 && value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "dehoog_chain must be -1 (auto), 0 or 1");
+    c->opt_dehoog_chain = (int)value;
   } else if (n == "dehoog_streams") {
     if (value < 0 || value > 4 || value != (int)value) return fail(c, NLC_ERR_BAD_ARG, "dehoog_streams must be 0 (auto), 1, 2, 3 or 4");
     c->opt_dehoog_streams = (int)value;
@@ -155,8 +158,13 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 64) return fail(c, NLC_ERR_BAD_ARG, "fused_tile_step_ratio must be in 0 .. 64 (0 = static schedule)");
     c->opt_fused_tile_step_ratio = value;
   } else if (n == "host_spin") {
-    if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "host_spin must be 0 or 1");
+    if (value != 0 && value != 1 && value != 2) return fail(c, NLC_ERR_BAD_ARG, "host_spin must be 0, 1 or 2");
     c->opt_host_spin = (int)value;
+    c->wait_hist_n = c->wait_hist_at = 0;
+    c->nap_margin_us = 0.0;
+  } else if (n == "host_spin_margin_us") {
+    if (value < 0 || value > 1.0e6) return fail(c, NLC_ERR_BAD_ARG, "host_spin_margin_us must be in 0 .. 1e6");
+    c->opt_host_spin_margin_us = value;
   } else if (n == "fused_blocks_per_cu") {
     if (value != 0 && value != 3 && value != 4) return fail(c, NLC_ERR_BAD_ARG, "fused_blocks_per_cu must be 0 (auto), 3 or 4");
     c->opt_fused_blocks_per_cu = (int)value;

@@ -25,10 +25,10 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   const bool env_free = d->cost_external &&
                         (d->dynamics == NLC_DYN_NL || d->dynamics == NLC_DYN_DTRNN || d->dynamics == NLC_DYN_NODE) &&
                         d->env == -1;
-  if (!env_free && (d->env < 0 || d->env > 2)) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
-  static const int env_d[3] = {5, 3, 6}, env_nu[3] = {1, 1, 2};
+  if (!env_free && (d->env < 0 || d->env > NLC_ENV_CARTPOLE_NOTRIG)) return fail(c, NLC_ERR_UNSUPPORTED, "unknown env id");
+  static const int env_d[4] = {5, 3, 6, 4}, env_nu[4] = {1, 1, 2, 1};
   if (!env_free && d->dynamics != NLC_DYN_EXTERNAL && (d->d != env_d[d->env] || d->nu != env_nu[d->env]))
-    return fail(c, NLC_ERR_BAD_SHAPE, "nx / nu do not match the env's trig observation");
+    return fail(c, NLC_ERR_BAD_SHAPE, "nx / nu do not match the env's observation");
   if (d->cost_external && d->dynamics == NLC_DYN_EXTERNAL)
     return fail(c, NLC_ERR_BAD_ARG, "cost_external needs fused dynamics (NLC_DYN_NL / NLC_DYN_ORACLE / NLC_DYN_DTRNN)");
   if (d->dynamics == NLC_DYN_EXTERNAL) {
@@ -155,8 +155,10 @@ WsLayout ws_layout(const nlc_ctx* c) {
   // (the staged buffers are laid out for every non-Fourier model, also when a linear-algorithm model runs on the LIN rollout
   // instances: the layout must not depend on an option that can change after the caller sized its workspace)
   const bool staged = d.dynamics == NLC_DYN_NL && c->md.ilt.algo != NLC_ILT_FOURIER;
-  w.fre = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);  // slot-major (8*nt3, KE), >= KE*d*S
-  w.fim = take(staged ? KE * 8 * (size_t)c->net.nt3 : 0);
+  // slot-major (8*nt3, KE), >= KE*d*S; the persistent step chain cuts it into private (8*nt3) x 64 blocks, one per 64 samples
+  const size_t KE64 = (KE + 63) / 64 * 64;
+  w.fre = take(staged ? KE64 * 8 * (size_t)c->net.nt3 : 0);
+  w.fim = take(staged ? KE64 * 8 * (size_t)c->net.nt3 : 0);
   w.dx = take(staged ? KE * d.d : 0);
   w.tconst = take(staged ? 8 : 0);
   w.rq = take(d.dynamics == NLC_DYN_DTRNN ? KE * d.T * d.d : 0);  // hidden part of linear_out, (T, K, d)
@@ -174,6 +176,14 @@ double* fused_timeout_word(nlc_ctx* c) {
 bool fused_gave_up(nlc_ctx* c) {
   unsigned* w = reinterpret_cast<unsigned*>(fused_timeout_word(c));
   if (*w == 0u) return false;
+  *w = 0u;
+  return true;
+}
+// pinned word merge_kernel sets when a gathered partial row is marked invalid (kPartialInvalidEta): read and cleared here
+unsigned* merge_status_word(nlc_ctx* c) { return reinterpret_cast<unsigned*>(fused_timeout_word(c) + 2); }
+bool merge_reported_invalid(nlc_ctx* c) {
+  unsigned* w = merge_status_word(c);
+  if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == 0u) return false;
   *w = 0u;
   return true;
 }
@@ -260,10 +270,12 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
   if (d.cost_external && !buf->states) return fail(c, NLC_ERR_BAD_ARG, "cost_external needs buf->states");
   NLC_HIP(c, hipSetDevice(c->device));
-  if (!replay && fused_gave_up(c)) {  // (a device-resident caller never synchronised inside nlc_mppi_finish)
-    c->fused_lost = true;  // from here on the two-launch body
-    return fail(c, NLC_ERR_HIP, "fused planner body: the PREVIOUS command timed out waiting inside the launch (its action "
-                                "was not valid); later commands run the two-launch body");
+  if (!replay) {  // (a device-resident caller never synchronised inside nlc_mppi_finish)
+    const bool lost_here = fused_gave_up(c), marked = merge_reported_invalid(c);
+    if (lost_here) c->fused_lost = true;  // from here on the two-launch body
+    if (lost_here || marked)  // `marked` is set on every rank of a sharded planner: they all fail here, none waits in a collective
+      return fail(c, NLC_ERR_HIP, "fused planner body: the PREVIOUS command timed out waiting inside the launch (on this or "
+                                  "another rank; its action was NaN and U was left alone); later commands run the two-launch body");
   }
   RolloutCall call{};
   call.buf = buf;
@@ -481,6 +493,81 @@ extern "C" int nlc_mppi_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
   NLC_GUARD_END(c)
 }
 
+namespace {
+
+// the library's own collective: one all-gather of this rank's partial rows on the command's stream
+int native_all_gather(nlc_ctx* c, const nlc_mppi_buffers* buf, int G, int rank, const double** gathered) {
+  const nlc_mppi_desc& d = c->pd;
+  if (!c->comm) return fail(c, NLC_ERR_BAD_ARG, "gathered_dev is NULL and no communicator (nlc_comm_init)");
+  if (G != c->comm_world || rank != c->comm_rank) return fail(c, NLC_ERR_BAD_ARG, "G / rank differ from the communicator's");
+  if (!buf->partials) return fail(c, NLC_ERR_BAD_ARG, "NULL buf->partials");
+  const size_t per_rank = (size_t)d.E * (size_t)(2 + d.T * d.nu);
+  if (c->comm_gather_n < per_rank * (size_t)G) {
+    if (c->comm_gather) NLC_HIP(c, hipFree(c->comm_gather));
+    c->comm_gather = nullptr;
+    NLC_HIP(c, hipMalloc((void**)&c->comm_gather, per_rank * (size_t)G * sizeof(double)));
+    c->comm_gather_n = per_rank * (size_t)G;
+  }
+  ProfScope ps(c, "rccl_all_gather");
+  const int rc = rccl()->AllGather(buf->partials, c->comm_gather, per_rank, kNcclFloat64, c->comm, c->stream);
+  if (rc != 0) return fail(c, NLC_ERR_COMM, std::string("ncclAllGather: ") + rccl()->GetErrorString(rc));
+  *gathered = c->comm_gather;
+  return NLC_OK;
+}
+
+inline double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
+// Host wait for the action of a single planner.  host_spin 1: spin on the pinned sequence word the merge kernel stores
+// behind the action.  host_spin 2: sleep through most of the command first -- the shortest of the last eight waits predicts
+// this one -- and spin only for the rest: the core is free for the harness's other workers (run_exp_multi.py:145 fans out a
+// Pool(12) over one GPU) at the price of a timer wake-up when the prediction is off.  host_spin 0 / batched planners /
+// profiling: hipStreamSynchronize (which, measured, busy-waits as well: profiles/r4_host_spin_contention.json).
+int wait_for_action(nlc_ctx* c, bool spin, const unsigned long long* seq_word) {
+  if (spin) {
+    const unsigned long long want = c->host_seq;
+    const double t0 = now_us();
+    if (c->opt_host_spin == 2 && c->wait_hist_n >= 2) {
+      double pred = c->wait_hist_us[0];
+      for (int i = 1; i < c->wait_hist_n; ++i) pred = pred < c->wait_hist_us[i] ? pred : c->wait_hist_us[i];
+      double margin = pred * 0.15 > c->opt_host_spin_margin_us ? pred * 0.15 : c->opt_host_spin_margin_us;
+      if (c->nap_margin_us > margin) margin = c->nap_margin_us;  // grown by earlier oversleeps (below)
+      const double nap = pred - margin;
+      if (nap >= 50.0 && __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) != want) {
+        timespec req;
+        req.tv_sec = (time_t)(nap * 1e-6);
+        req.tv_nsec = (long)((nap - (double)req.tv_sec * 1e6) * 1e3);
+        nanosleep(&req, nullptr);
+        // the timer's wake-up latency is the host's, not ours to know: if the action was already there when we woke, the nap
+        // was too long -- wake earlier from now on; while it is not, drift back towards the configured margin
+        if (__atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == want)
+          c->nap_margin_us = margin * 1.5 + 20.0;
+        else
+          c->nap_margin_us = margin * 0.995;
+      }
+    }
+    for (unsigned long long it = 0; it < 400000000ull; ++it) {  // ~ seconds: then fall back to the runtime's wait
+      // acquire: the action words the kernel stored BEFORE the sequence number are read after it
+      if (__atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == want) {
+        c->wait_hist_us[c->wait_hist_at] = now_us() - t0;
+        c->wait_hist_at = (c->wait_hist_at + 1) % 8;
+        if (c->wait_hist_n < 8) c->wait_hist_n += 1;
+        return NLC_OK;
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  NLC_HIP(c, hipStreamSynchronize(c->stream));
+  return NLC_OK;
+}
+
+}  // namespace
+
 extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int rank, const nlc_mppi_buffers* buf,
                                double* action_host) {
   if (!c) return NLC_ERR_BAD_ARG;
@@ -491,24 +578,9 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   if (G < 1 || rank < 0 || rank >= G) return fail(c, NLC_ERR_BAD_ARG, "bad G / rank");
   const nlc_mppi_desc& d = c->pd;
   NLC_HIP(c, hipSetDevice(c->device));
-  if (!gathered) {
-    // the library's own collective: one all-gather of this rank's partials on the command's stream
-    if (!c->comm) return fail(c, NLC_ERR_BAD_ARG, "gathered_dev is NULL and no communicator (nlc_comm_init)");
-    if (G != c->comm_world || rank != c->comm_rank)
-      return fail(c, NLC_ERR_BAD_ARG, "G / rank differ from the communicator's");
-    if (!buf->partials) return fail(c, NLC_ERR_BAD_ARG, "NULL buf->partials");
-    const size_t per_rank = (size_t)d.E * (size_t)(2 + d.T * d.nu);
-    if (c->comm_gather_n < per_rank * (size_t)G) {
-      if (c->comm_gather) NLC_HIP(c, hipFree(c->comm_gather));
-      c->comm_gather = nullptr;
-      NLC_HIP(c, hipMalloc((void**)&c->comm_gather, per_rank * (size_t)G * sizeof(double)));
-      c->comm_gather_n = per_rank * (size_t)G;
-    }
-    ProfScope ps(c, "rccl_all_gather");
-    const int rc = rccl()->AllGather(buf->partials, c->comm_gather, per_rank, kNcclFloat64, c->comm, c->stream);
-    if (rc != 0) return fail(c, NLC_ERR_COMM, std::string("ncclAllGather: ") + rccl()->GetErrorString(rc));
-    gathered = c->comm_gather;
-  }
+  const bool native = gathered == nullptr;
+  if (native)
+    if (int rc = native_all_gather(c, buf, G, rank, &gathered)) return rc;
   MergeArgs m{};
   m.Kep = d.K;
   m.E = d.E;
@@ -528,26 +600,12 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   if (!buf->cost_total) return fail(c, NLC_ERR_BAD_ARG, "NULL buf->cost_total");
   m.cost = buf->cost_total;
   // the returned action is stored by the kernel straight into pinned (host-coherent) memory: the only thing left
-  // on the host's critical path is the stream synchronisation
+  // on the host's critical path is the wait for it
   double* pin_act = c->pinned + (size_t)d.E * d.d + (size_t)d.E * d.B * d.nu;
   m.action_pinned = action_host ? pin_act : nullptr;
-  // host wait: spin on a pinned sequence word (single planner) or hipStreamSynchronize
+  m.status_pinned = merge_status_word(c);
   unsigned long long* seq_word = reinterpret_cast<unsigned long long*>(fused_timeout_word(c) + 1);
   const bool spin = action_host && c->opt_host_spin && d.E == 1 && !c->profiling;
-  auto wait_for_action = [&]() -> int {
-    if (spin) {
-      const unsigned long long want = c->host_seq;
-      const volatile unsigned long long* w = seq_word;
-      for (unsigned long long it = 0; it < 400000000ull; ++it) {  // ~ seconds: then fall back to the runtime's wait
-        if (*w == want) return NLC_OK;
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-      }
-    }
-    NLC_HIP(c, hipStreamSynchronize(c->stream));
-    return NLC_OK;
-  };
   auto launch_merge_now = [&]() -> int {
     if (spin) {
       m.seq_pinned = seq_word;
@@ -567,28 +625,46 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
     return NLC_OK;
   };
   if (int rc = launch_merge_now()) return rc;
-  if (action_host) {
-    const size_t na = (size_t)d.E * d.u_per_command * d.nu;
-    if (int rc = wait_for_action()) return rc;
-    if (fused_gave_up(c)) {
-      // A wave of the fused body gave up waiting for another workgroup of its launch (the device was not this planner's
-      // alone, or fewer workgroups were resident than the host assumed): the command's result is not valid.  This ctx
-      // runs the two-launch body from now on; a single-rank command with library-side costs is re-run on it right here.
-      c->fused_lost = true;
-      if (G != 1 || d.cost_external || !c->last.valid || !c->last.fused || !buf->workspace || !buf->partials)
-        return fail(c, NLC_ERR_HIP, "fused planner body: a workgroup timed out waiting inside the launch; command lost "
-                                    "(later commands run the two-launch body)");
-      c->fused_fallbacks += 1;
-      c->ucur ^= 1;  // back to the control sequence before this command's shift (the ping-pong partner is untouched)
-      const nlc_ctx::LastCommand L = c->last;
-      if (int rc = mppi_rollout_impl(c, L.state_in, L.state_per_sample, L.abuf_in, buf, L.rng, L.seed, L.counter, true)) return rc;
-      m.U = c->U[c->ucur];
-      if (gathered == nullptr || G == 1) m.gathered = buf->partials;
-      if (int rc = launch_merge_now()) return rc;
-      if (int rc = wait_for_action()) return rc;
+  if (!action_host) return NLC_OK;  // device-resident caller: no wait; a lost command surfaces at the next nlc_mppi_rollout
+  const size_t na = (size_t)d.E * d.u_per_command * d.nu;
+  if (int rc = wait_for_action(c, spin, seq_word)) return rc;
+  // A wave of the fused body gave up waiting for another workgroup of its launch (the device was not this planner's alone,
+  // or fewer workgroups were resident than the host assumed): that launch's results are not valid.
+  //   * here: the pinned give-up word is set; this ctx runs the two-launch body from now on;
+  //   * on ANY rank of a sharded planner: the shard's partial row is marked (kPartialInvalidEta) and travels through the
+  //     all-gather, so merge_kernel on EVERY rank has skipped the update and set the merge-status word.
+  // Every rank therefore takes the same decision: re-run the command on the two-launch body from the inputs the ctx keeps
+  // (the control sequence's ping-pong partner is untouched), gather again, merge again.
+  const bool lost_here = fused_gave_up(c);
+  const bool marked = merge_reported_invalid(c);
+  if (lost_here) c->fused_lost = true;
+  if (lost_here || marked) {
+    if (G > 1 && !marked)  // (a sharded command whose weights were folded outside the launch: the peers cannot know)
+      return fail(c, NLC_ERR_HIP, "fused planner body: a workgroup timed out waiting inside the launch and the shard's partials "
+                                  "were not marked; command lost (later commands run the two-launch body)");
+    if (d.cost_external || !c->last.valid || !buf->workspace || !buf->partials)
+      return fail(c, NLC_ERR_HIP, "fused planner body: a workgroup timed out waiting inside the launch; command lost "
+                                  "(later commands run the two-launch body)");
+    c->fused_fallbacks += 1;
+    c->ucur ^= 1;  // back to the control sequence before this command's shift
+    const nlc_ctx::LastCommand L = c->last;
+    if (int rc = mppi_rollout_impl(c, L.state_in, L.state_per_sample, L.abuf_in, buf, L.rng, L.seed, L.counter, true)) return rc;
+    m.U = c->U[c->ucur];
+    if (G == 1) {
+      m.gathered = buf->partials;
+    } else if (native) {
+      if (int rc = native_all_gather(c, buf, G, rank, &gathered)) return rc;
+      m.gathered = gathered;
+    } else {
+      // the caller owns the collective: buf->partials hold the re-run's values -- gather them again, call again
+      c->err = "the command was re-run on the two-launch body: all-gather buf->partials again and call nlc_mppi_finish again";
+      return NLC_AGAIN;
     }
-    std::memcpy(action_host, pin_act, na * sizeof(double));
+    if (int rc = launch_merge_now()) return rc;
+    if (int rc = wait_for_action(c, spin, seq_word)) return rc;
+    if (merge_reported_invalid(c)) return fail(c, NLC_ERR_STATE, "partials still marked invalid after the re-run");
   }
+  std::memcpy(action_host, pin_act, na * sizeof(double));
   return NLC_OK;
   NLC_GUARD_END(c)
 }

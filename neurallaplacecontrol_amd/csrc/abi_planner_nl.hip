@@ -29,7 +29,13 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
   // GRU encode: one launch up front, or (round 3, option "dehoog_gru_chunks" C > 1) C horizon chunks on a stream of
   // their own that run BESIDE the step chain -- the chain's launches wait for the chunk that holds their horizon step.
   // The chunks use the cooperative kernel at reduced occupancy (lds_pad) so that the chain's workgroups find room.
-  int C = d.E == 1 ? c->opt_dehoog_gru_chunks : 1;
+  // Round 4: the whole step chain as ONE persistent launch (kernels_dehoog_chain.hip; option "dehoog_chain": -1 auto, 0 the
+  // staged launches below, 1 required) -- a workgroup owns 64 samples for all T steps, F stays with the CU that wrote it.
+  const bool chain_ok = dehoog && d.E == 1 && nl_dehoog_chain_available(c->md.h, c->net.nt3, c->S);
+  if (c->opt_dehoog_chain == 1 && !chain_ok)
+    return fail(c, NLC_ERR_UNSUPPORTED, "dehoog_chain: single planner, hidden_units 128 and 17 or 33 de Hoog terms only");
+  const bool chain = chain_ok && c->opt_dehoog_chain != 0;
+  int C = d.E == 1 && !chain ? c->opt_dehoog_gru_chunks : 1;
   if (C == 0) C = 1;  // auto: off
   if (C > d.T) C = d.T;
   if (C > 8) C = 8;
@@ -40,6 +46,37 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
     g.N = KE * d.T;
     ProfScope ps(c, "gru_encode_kernel");
     NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
+  }
+  if (chain) {
+    DehoogChainArgs ca{};
+    ca.net = r.net;
+    ca.K = KE;
+    ca.T = d.T;
+    ca.nu = d.nu;
+    ca.env = d.cost_external ? -1 : d.env;
+    ca.state_per_sample = state_per_sample;
+    ca.state0 = state_dev;
+    ca.pa = pa;
+    ca.perturbed = buf->perturbed;
+    ca.noise = buf->noise;
+    ca.U = r.U;
+    for (int i = 0; i < NLC_MAX_NU * NLC_MAX_NU; ++i) ca.sigma_inv[i] = d.noise_sigma_inv[i];
+    ca.lambda_ = d.lambda_;
+    ca.u_scale = d.u_scale;
+    ca.noise_abs_cost = d.noise_abs_cost;
+    ca.tn = c->tn;
+    ca.slot = c->slot_dev;
+    ca.eidx = c->eidx_dev;
+    ca.fre = ws + w.fre;  // one private (8 nt3) x 64 block per 64 samples
+    ca.fim = ws + w.fim;
+    ca.states = buf->states;
+    ca.cost_total = buf->cost_total;
+    const int64_t nblk = (KE + 63) / 64;
+    {
+      ProfScope ps(c, "nl_dehoog_chain_kernel");
+      NLC_HIP(c, launch_nl_dehoog_chain(ca, (unsigned)(nblk < (1 << 20) ? nblk : (1 << 20)), c->stream));
+    }
+    return d.cost_external ? NLC_OK : run_weights(c, buf);
   }
   double* tconst = ws + w.tconst;
   NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -457,7 +494,11 @@ int nlc::host::rollout_nl(nlc_ctx* c, RolloutCall& call) {
   // also assumes the device to itself (include/nlc.h): after one hand-off timeout the ctx stays on the two-launch body.
   if (variant == 3 && c->fused_blocks_per_cu < 2)
     return fail(c, NLC_ERR_UNSUPPORTED, "fused planner body: fewer than two workgroups of the kernel fit a CU");
-  if (variant == 0 && fused_ok && c->fused_blocks_per_cu >= 2 && KE <= c->opt_fused_max_samples) variant = 3;
+  // A K-sharded planner takes the fused body by itself only when the weight fold runs inside the launch: a give-up then marks
+  // the shard's partial row, which every rank sees after the all-gather (nlc_mppi_finish re-runs the command everywhere).
+  const bool sharded = d.K_global > d.K;
+  const bool fold_inside = (c->opt_fused_inline & 1) && d.E == 1 && !d.cost_external;
+  if (variant == 0 && fused_ok && c->fused_blocks_per_cu >= 2 && KE <= c->opt_fused_max_samples && (!sharded || fold_inside)) variant = 3;
   if (variant == 3 && (replay || c->fused_lost)) variant = 2;
   if (variant == 3) {
     bool weights_done = false;

@@ -3,6 +3,7 @@
 // calculus/inverselaplace.py:476-531 (parity unpinned vs upstream, see oracle/ilt.py).  Any odd number of terms
 // S = 2M + 1 <= 33.  A translation unit of its own: 16 term counts x 3 input layouts of a fully unrolled kernel.
 #include "nlc_cplx.h"
+#include "nlc_dehoog_row.h"
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
@@ -39,6 +40,44 @@ namespace nlc {
 // paper (at most 2M complex together), but not in the allocator's hands, and a full LDS image (34 KB per wavefront) means
 // one wave per SIMD, i.e. the FP64 VALU -- the kernel's actual bound -- at half rate.  The chunked form stays; the planner
 // path (FMODE 2) reads exactly its bytes.
+// Term source of the row-major modes: the block's 64 rows are staged through LDS in chunks of CH terms, coalesced over
+// (row, term) pairs; FDIRECT: F (re, im) rows, else (theta, phi) rows with the sphere -> complex conversion here.
+template <int CH, bool FDIRECT>
+struct DehoogLdsTerms {
+  static constexpr int CP = CH | 1, ROWS = 64;
+  const IltArgs& a;
+  double* fr;
+  double* fi;
+  int lane, rows_here;
+  int64_t row0;
+  template <int S>
+  __device__ __forceinline__ void stage(int n) {
+    const int nt = (S - n < CH) ? (S - n) : CH;
+    if (n != 0) __syncthreads();
+#pragma nounroll
+    for (int e = lane; e < ROWS * nt; e += ROWS) {
+      const int r = e / nt, k = e - r * nt;
+      if (r < rows_here) {
+        const int64_t gi = (row0 + r) * S + n + k;
+        if constexpr (FDIRECT) {  // F_k supplied directly (staged planner / model path)
+          fr[r * CP + k] = a.fre[gi];
+          fi[r * CP + k] = a.fim[gi];
+        } else {
+          const double theta = a.theta[gi];
+          const double phi = a.phi[gi];
+          const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
+          double sn, cs;
+          m::sincos_bounded(theta, &sn, &cs);
+          fr[r * CP + k] = rad * cs;
+          fi[r * CP + k] = rad * sn;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ cplx term(int n) const { return {fr[lane * CP + n % CH], fi[lane * CP + n % CH]}; }
+};
+
 template <int M, int CH, int W, int FMODE>
 __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
   constexpr int S = 2 * M + 1;
@@ -62,111 +101,20 @@ __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
     const bool valid = lane < rows_here;
     const int64_t nsmp = n0 + (valid ? lane : 0);                     // SLOT: this lane's sample
     const int64_t row = SLOT ? nsmp * a.d + cdim : row0 + (valid ? lane : 0);
-    const int* ei = SLOT ? a.eidx + cdim * S : nullptr;               // wave-uniform slot of every term
-    cplx abuf[SLOT ? CH : 1];
     const double t = (a.t_stride ? a.t[row / a.d] : a.t[0]) / a.t_div;
     const double Tt = a.scale * t;
     const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
     const double ang = kPi * (t / Tt);
     const cplx z = {cos(ang), sin(ang)};
-
-    cplx D[2 * M];
-    cplx a_prev = {0.0, 0.0}, d0 = {0.0, 0.0};
-    // A/B continued-fraction recurrence, fed with d_1, d_2, ... as the diagonals produce them
-    cplx A_prev = {0.0, 0.0}, A_cur = {0.0, 0.0}, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
-    cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
-#pragma clang loop unroll(full)
-    for (int n = 0; n <= 2 * M; ++n) {
-      if (SLOT && n % CH == 0) {
-        // terms [n, n + nt) of this lane's row: one coalesced line per term and array
-        const int nt = (S - n < CH) ? (S - n) : CH;
-#pragma clang loop unroll(full)
-        for (int k = 0; k < CH; ++k)
-          if (k < nt) {
-            const int64_t at = (int64_t)ei[n + k] * a.N + nsmp;
-            abuf[k] = {a.fre[at], a.fim[at]};
-          }
-      } else if (n % CH == 0) {
-        // stage terms [n, n + nt) of the block's rows: coalesced over (row, term) pairs
-        const int nt = (S - n < CH) ? (S - n) : CH;
-        if (n != 0) __syncthreads();
-#pragma nounroll
-        for (int e = lane; e < ROWS * nt; e += ROWS) {
-          const int r = e / nt, k = e - r * nt;
-          if (r < rows_here) {
-            const int64_t gi = (row0 + r) * S + n + k;
-            if constexpr (FDIRECT) {  // F_k supplied directly (staged planner / model path)
-              fr[r * CP + k] = a.fre[gi];
-              fi[r * CP + k] = a.fim[gi];
-            } else {
-              const double theta = a.theta[gi];
-              const double phi = a.phi[gi];
-              const double rad = m::tan_0_halfpi(phi / 2.0 + kPi / 4.0);
-              double sn, cs;
-              m::sincos_bounded(theta, &sn, &cs);
-              fr[r * CP + k] = rad * cs;
-              fi[r * CP + k] = rad * sn;
-            }
-          }
-        }
-        __syncthreads();
-      }
-      cplx an;
-      if constexpr (SLOT) {
-        an = abuf[n % CH];
-      } else {
-        an = {fr[lane * CP + n % CH], fi[lane * CP + n % CH]};
-      }
-      if (n == 0) {
-        d0 = {0.5 * an.re, 0.5 * an.im};  // a_0 enters halved
-        a_prev = d0;
-        A_cur = d0;
-        continue;
-      }
-      cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
-      a_prev = an;
-      cplx old1 = D[0];              // previous diagonal, column c-1
-      cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
-      D[0] = newv;
-#pragma unroll
-      for (int c = 2; c <= n; ++c) {
-        const cplx oldc = D[c - 1];
-        const cplx val = (c & 1) ? cdiv(cmul(old2, newv), old1) : cadd(csub(newv, old1), old2);
-        D[c - 1] = val;
-        old2 = old1;
-        old1 = oldc;
-        newv = val;
-      }
-      // d_n = -(entry at i = 0); d_2M only enters the remainder
-      d_last = d_cur;
-      d_cur = {-newv.re, -newv.im};
-      if (n != 2 * M) {
-        const cplx dz = cmul(d_cur, z);
-        const cplx An = cadd(A_cur, cmul(dz, A_prev));
-        const cplx Bn = cadd(B_cur, cmul(dz, B_prev));
-        A_prev = A_cur;
-        A_cur = An;
-        B_prev = B_cur;
-        B_cur = Bn;
-      }
-      // keep the diagonals apart: hoisting the next terms' LDS reads / interleaving diagonals only costs registers
-      // (the asm ties this diagonal's results -- including BOTH continued-fraction recurrences, which the compiler
-      // otherwise defers to the end of the kernel, spilling every d_n z to scratch: 1 GB of HBM writes per launch --
-      // to a memory barrier, so the arithmetic cannot sink below the following reads either)
-      asm volatile(""
-                   : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
-      __builtin_amdgcn_sched_barrier(0);
+    cplx res;
+    if constexpr (SLOT) {
+      // wave-uniform slot of every term; one coalesced line per term and array
+      DehoogSlotTerms<CH> src{a.fre, a.fim, a.eidx + cdim * S, a.N, nsmp, {}};
+      res = dehoog_row<M, CH>(src, z);
+    } else {
+      DehoogLdsTerms<CH, FDIRECT> src{a, fr, fi, lane, rows_here, row0};
+      res = dehoog_row<M, CH>(src, z);
     }
-    // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
-    const cplx diff = csub(d_last, d_cur);
-    const cplx one = {1.0, 0.0};
-    cplx brem = cadd(one, cmul(diff, z));
-    brem = {0.5 * brem.re, 0.5 * brem.im};
-    const cplx inner = cadd(one, cdiv(cmul(d_cur, z), brem));
-    const cplx rem = cmul(brem, csub(csqrt_(inner), one));
-    const cplx An = cadd(A_cur, cmul(rem, A_prev));
-    const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
-    const cplx res = cdiv(An, Bn);
     if (valid) a.x[row] = exp(gamma * t) / Tt * res.re;
     if (!SLOT) __syncthreads();
   }

@@ -1,0 +1,131 @@
+// The step chain of the de Hoog planner (BASELINE configs[4]: NeuralLaplaceModel.forward with ilt_algorithm = "dehoog",
+// w_nl.py:137-144, inside the T sequential rollout steps of planners/mppi_delay.py:271-296) as ONE persistent launch.
+//
+// The staged path (abi_planner_nl.hip: rollout_nl_staged) runs 2 T + 1 launches per command -- representation function -> F_k
+// slot-major in HBM, de Hoog ILT -> dx, with the state / cost tail folded into the next representation launch -- on two streams.
+// Here a workgroup of eight wavefronts OWNS 64 consecutive samples (four 16-sample MFMA tiles) for the whole horizon and walks
+// their chain alone: no inter-workgroup dependency exists (samples are independent; the GRU latents come from the hoisted
+// encode launch), so the only synchronisation is the workgroup barrier.  Per horizon step:
+//   phase A   the representation MLP of the four tiles, two at a time (waves 0-3 and 4-7 each split one tile: repfunc_split_tile,
+//             the staged path's own code), F_k written slot-major into the workgroup's private (8 nt3) x 64 block;
+//   phase B   the QD table: wave p < d owns dim p of the 64 samples (dehoog_row, the staged path's own code; every load one
+//             full 512-B line of the block, which this CU wrote a few microseconds ago), dx added to the state in LDS;
+//   tail      wave 0, one lane per sample: state store, running cost and perturbation cost of the step (StepTailArgs semantics).
+// Same arithmetic, in the same order, as the staged path: bit-identical states, costs and actions (tests).
+// F never leaves the chip's caches as far as the kernel can tell: 169 KB per workgroup and step, written and re-read by the
+// same CU (the staged path moves the same 43 MB per step through two launches).  It cannot live in LDS: 64 samples x 165 terms
+// x 16 B = 169 KB, and a 16-sample tile's QD is 80 rows -- 1.25 wavefronts -- so a tile-local chain would run the FP64-VALU-bound
+// half at a third of the lanes.
+#include "nlc_dehoog_row.h"
+#include "nlc_nl_kernels.h"
+
+namespace nlc {
+
+template <int NT3, int M>
+__global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogChainArgs a) {
+  constexpr int HT = 8, KS = HT * 4, S = 2 * M + 1;
+  constexpr int CH = M > 8 ? M + 1 : 9;  // terms fetched at a time (as ilt_dehoog_kernel)
+  __shared__ double H1[2][KS * 64], H2[2][KS * 64];
+  __shared__ double XS[64 * NLC_MAX_D];  // the block's states, [sample][dim]
+  const NlNetArgs& n = a.net;
+  const int d = n.d;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wv = wave & 3;
+  const int64_t nblk = (a.K + 63) / 64;
+  const double t = a.tn;
+  const double Tt = n.scale * t;
+  const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
+  const double ang = kPi * (t / Tt);
+  const cplx z = {cos(ang), sin(ang)};
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t k0 = blk * 64;
+    const int rows_here = (int)((a.K - k0 < 64) ? (a.K - k0) : 64);
+    double* fre = a.fre + (size_t)blk * 64 * 8 * NT3;
+    double* fim = a.fim + (size_t)blk * 64 * 8 * NT3;
+    // start state of every sample of the block
+    for (int i = threadIdx.x; i < 64 * NLC_MAX_D; i += 512) {
+      const int sm = i / NLC_MAX_D, dim = i % NLC_MAX_D;
+      const int64_t k = k0 + (sm < rows_here ? sm : rows_here - 1);
+      XS[i] = dim < d ? a.state0[(a.state_per_sample ? k : 0) * d + dim] : 0.0;
+    }
+    double cost = 0.0, pcost = 0.0;  // wave 0: lane = sample
+    __syncthreads();
+    for (int t_h = 0; t_h < a.T; ++t_h) {
+      // ---- phase A: representation function of tiles grp and grp + 2 of the block
+      const int q = lane >> 4, c = lane & 15, i0 = q, i1 = 4 + q;
+#pragma unroll 1
+      for (int round = 0; round < 2; ++round) {
+        const int kb = (2 * round + grp) * 16 + c;           // sample within the block
+        const bool valid = kb < rows_here;
+        const int kc = valid ? kb : rows_here - 1;
+        const double* pa = a.pa + ((size_t)(k0 + kc) * a.T + t_h) * 2;
+        const double* xr = XS + kc * NLC_MAX_D;
+        const double x0 = (i0 < d) ? xr[i0] : 0.0, x1 = (i1 < d) ? xr[i1] : 0.0;
+        const double p0 = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0]
+                                   : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+        const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
+                                   : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+        repfunc_split_mlp<HT, NT3>(n, p0, p1, valid, (int64_t)kb, (int64_t)64, a.slot, fre, fim, H1[grp], H2[grp], wv, lane, []() {});
+        __syncthreads();  // (the group's LDS images are free again; after the second round: F is complete)
+      }
+      // ---- phase B: one wavefront per state dim, one lane per sample
+      if (wave < d) {
+        DehoogSlotTerms<CH> src{fre, fim, a.eidx + wave * S, (int64_t)64, (int64_t)(lane < rows_here ? lane : 0), {}};
+        const cplx res = dehoog_row<M, CH>(src, z);
+        const double dx = exp(gamma * t) / Tt * res.re;
+        XS[lane * NLC_MAX_D + wave] = XS[lane * NLC_MAX_D + wave] + dx;  // mppi_with_model.py:120-121
+      }
+      __syncthreads();
+      // ---- tail of the step (wave 0; the other waves go on to the next step's phase A, which only reads XS)
+      if (wave == 0 && lane < rows_here) {
+        const int64_t k = k0 + lane;
+        double x[NLC_MAX_D];
+#pragma unroll
+        for (int i = 0; i < NLC_MAX_D; ++i) x[i] = XS[lane * NLC_MAX_D + i];
+        if (a.states != nullptr)
+          for (int i = 0; i < d; ++i) a.states[(k * a.T + t_h) * d + i] = x[i];
+        double u[NLC_MAX_NU] = {0.0, 0.0};
+        for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(k * a.T + t_h) * a.nu + j];
+        double pc = 0.0;
+        for (int j = 0; j < a.nu; ++j) {
+          double acj = 0.0;
+          for (int ii = 0; ii < a.nu; ++ii) {
+            double ev = a.noise[(k * a.T + t_h) * a.nu + ii];
+            if (a.noise_abs_cost) ev = fabs(ev);
+            acj += (a.lambda_ * ev) * a.sigma_inv[ii * a.nu + j];
+          }
+          pc += a.U[t_h * a.nu + j] * acj;
+        }
+        cost = cost + running_cost(a.env, x, u, a.nu);
+        pcost = pcost + pc;
+      }
+    }
+    if (wave == 0 && lane < rows_here) a.cost_total[k0 + lane] = cost + pcost;
+    __syncthreads();  // XS is rewritten for the next block
+  }
+}
+
+hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, unsigned grid, hipStream_t s) {
+  if (a.K <= 0) return hipSuccess;
+  if (a.net.h != 128) return hipErrorInvalidValue;
+#define NLC_CHAIN(N, MM)                                                                               \
+  if (a.net.nt3 == N && a.net.S == 2 * MM + 1) {                                                       \
+    hipLaunchKernelGGL((nl_dehoog_chain_kernel<N, MM>), dim3(grid), dim3(512), 0, s, a);               \
+    return hipGetLastError();                                                                          \
+  }
+  // 33 terms (BASELINE configs[4]) and 17 terms (the reference's default count), every state dim 3 .. 6
+  NLC_CHAIN(13, 16) NLC_CHAIN(17, 16) NLC_CHAIN(21, 16) NLC_CHAIN(25, 16)
+  NLC_CHAIN(7, 8) NLC_CHAIN(9, 8) NLC_CHAIN(11, 8) NLC_CHAIN(13, 8)
+#undef NLC_CHAIN
+  return hipErrorInvalidValue;
+}
+
+bool nl_dehoog_chain_available(int h, int nt3, int S) {
+  if (h != 128) return false;
+  if (S == 33) return nt3 == 13 || nt3 == 17 || nt3 == 21 || nt3 == 25;
+  if (S == 17) return nt3 == 7 || nt3 == 9 || nt3 == 11 || nt3 == 13;
+  return false;
+}
+
+}  // namespace nlc

@@ -159,6 +159,27 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
     a.zero_words[i] = 0u;
   const double* gat = a.gathered + e * W;       // rank g's row of this episode: gat + g * E * W
   const int64_t gs = (int64_t)a.E * W;
+  // a shard whose fused launch gave up marks its row (kPartialInvalidEta): identical on every rank after the all-gather, so
+  // every rank skips the update, reports it to its host and the command is re-run everywhere (nlc_mppi_finish)
+  bool invalid = false;
+  for (int g = 0; g < a.G; ++g) invalid = invalid || gat[g * gs + 1] < 0.0;
+  if (invalid) {
+    if (blockIdx.x == 0) {
+      const double nan = __builtin_nan("");
+      for (int i = threadIdx.x; i < a.u_per_command * a.nu; i += 256) {
+        a.action[e * a.u_per_command * a.nu + i] = nan;
+        if (a.action_pinned != nullptr) a.action_pinned[e * a.u_per_command * a.nu + i] = nan;
+      }
+      if (a.status_pinned != nullptr && threadIdx.x == 0)
+        __hip_atomic_store(a.status_pinned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.seq_pinned != nullptr) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.seq_pinned, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
   double beta = INFINITY;
   for (int g = 0; g < a.G; ++g) beta = fmin(beta, gat[g * gs]);
   double eta = 0.0;
@@ -228,6 +249,12 @@ __device__ __forceinline__ double running_cost_o(int env, const double* x, const
     const double sr = -(e0 * e0 + e1 * e1);
     const double vr = -(x[1] * x[1]) - x[4] * x[4];
     return -((sr + 0.01 * vr) + (-0.01 * uu));
+  } else if (env == NLC_ENV_CARTPOLE_NOTRIG) {  // ctcartpole.py:297-300: explicit angle
+    const double cl = 1.0 * cos(x[2]), sl = 1.0 * sin(x[2]);
+    const double e0 = x[0] + sl - 0.0, e1 = cl - 1.0;
+    const double sr = -(e0 * e0 + e1 * e1);
+    const double vr = -(x[1] * x[1]) - x[3] * x[3];
+    return -((sr + 0.01 * vr) + (-0.01 * uu));
   } else if (env == NLC_ENV_PENDULUM) {
     const double om = 1.0 - x[0];
     const double sr = -(om * om + x[1] * x[1]);
@@ -246,13 +273,24 @@ __device__ __forceinline__ double running_cost_o(int env, const double* x, const
 
 // One Euler step of the closed-form dynamics on the trig observation (oracle.py:11-86, 89-174, 177-224)
 __device__ __forceinline__ void oracle_step(int env, double* x, const double* uraw, double ts, int friction) {
-  if (env == NLC_ENV_CARTPOLE) {
+  if (env == NLC_ENV_CARTPOLE || env == NLC_ENV_CARTPOLE_NOTRIG) {
+    const bool trig = env == NLC_ENV_CARTPOLE;  // oracle.py:29-37 (5-D observation) / :38-44 (4-D state: explicit angle)
     const double u = clampd(uraw[0], -3.0, 3.0);
-    double xx = x[0], xd = x[1], c = x[2], s = x[3], thd = x[4];
-    const double C = c * c + s * s;
-    c = c / C;
-    s = s / C;
-    const double th = atan2(s / C, c / C);
+    double xx = x[0], xd = x[1], c, s, thd, th;
+    if (trig) {
+      c = x[2];
+      s = x[3];
+      thd = x[4];
+      const double C = c * c + s * s;
+      c = c / C;
+      s = s / C;
+      th = atan2(s / C, c / C);
+    } else {
+      th = x[2];
+      thd = x[3];
+      c = cos(th);
+      s = sin(th);
+    }
     const double g = 9.8, fmag = 3.0, mc = 1.0, mp = 0.1, len = 1.0;
     const double mt = mp + mc, pml = mp * len;
     const double force = u * fmag;
@@ -270,9 +308,14 @@ __device__ __forceinline__ void oracle_step(int env, double* x, const double* ur
     const double nxd = xd + xacc * ts, nx = xx + xd * ts;
     x[0] = nx;
     x[1] = nxd;
-    x[2] = cos(nth);
-    x[3] = sin(nth);
-    x[4] = nthd;
+    if (trig) {
+      x[2] = cos(nth);
+      x[3] = sin(nth);
+      x[4] = nthd;
+    } else {  // oracle.py:80-86
+      x[2] = nth;
+      x[3] = nthd;
+    }
   } else if (env == NLC_ENV_PENDULUM) {
     const double u = clampd(uraw[0], -2.0, 2.0);
     const double c = x[0], s = x[1], thd = x[2];

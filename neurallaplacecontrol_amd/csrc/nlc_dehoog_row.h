@@ -1,0 +1,100 @@
+// One row of the de Hoog, Knight & Stokes accelerated inverse Laplace transform: the quotient-difference table of the 2M + 1
+// terms a_0 .. a_2M of one (point, dim) row, its continued-fraction coefficients and the A / B recurrence with the improved
+// remainder -- restated from mpmath 1.3.0 calculus/inverselaplace.py:476-531 (see kernels_dehoog.hip for the formulation and
+// its measurements).  Shared by the stand-alone kernel (kernels_dehoog.hip, three input layouts) and the persistent step
+// chain of the de Hoog planner (kernels_dehoog_chain.hip): ONE implementation, so every path produces the same bits.
+#pragma once
+#include "nlc_cplx.h"
+#include "nlc_device.h"
+
+namespace nlc {
+
+// Term source over SLOT-major F: term k of this lane's row is fre / fim[slot_of_term[k] * stride + col] -- the lanes of a
+// wavefront read consecutive columns, so every load is one full line.  CH terms are fetched at a time into registers.
+template <int CH>
+struct DehoogSlotTerms {
+  const double* fre;
+  const double* fim;
+  const int* slot_of_term;  // wave-uniform: (S) slots of this row's dim
+  int64_t stride, col;
+  cplx buf[CH];
+  template <int S>
+  __device__ __forceinline__ void stage(int n) {
+    const int nt = (S - n < CH) ? (S - n) : CH;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < CH; ++k)
+      if (k < nt) {
+        const int64_t at = (int64_t)slot_of_term[n + k] * stride + col;
+        buf[k] = {fre[at], fim[at]};
+      }
+  }
+  __device__ __forceinline__ cplx term(int n) const { return buf[n % CH]; }
+};
+
+// SRC: stage<S>(n) is called before term n whenever n % CH == 0 (it makes terms [n, n + CH) available), term(n) returns a_n.
+// Returns A_2M / B_2M, the continued fraction with the improved remainder; the caller scales Re by e^{gamma t} / T.
+template <int M, int CH, class SRC>
+__device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
+  constexpr int S = 2 * M + 1;
+  cplx D[2 * M];
+  cplx a_prev = {0.0, 0.0}, d0 = {0.0, 0.0};
+  // A/B continued-fraction recurrence, fed with d_1, d_2, ... as the diagonals produce them
+  cplx A_prev = {0.0, 0.0}, A_cur = {0.0, 0.0}, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
+  cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
+#pragma clang loop unroll(full)
+  for (int n = 0; n <= 2 * M; ++n) {
+    if (n % CH == 0) src.template stage<S>(n);
+    const cplx an = src.term(n);
+    if (n == 0) {
+      d0 = {0.5 * an.re, 0.5 * an.im};  // a_0 enters halved
+      a_prev = d0;
+      A_cur = d0;
+      continue;
+    }
+    cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
+    a_prev = an;
+    cplx old1 = D[0];              // previous diagonal, column c-1
+    cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
+    D[0] = newv;
+#pragma unroll
+    for (int c = 2; c <= n; ++c) {
+      const cplx oldc = D[c - 1];
+      const cplx val = (c & 1) ? cdiv(cmul(old2, newv), old1) : cadd(csub(newv, old1), old2);
+      D[c - 1] = val;
+      old2 = old1;
+      old1 = oldc;
+      newv = val;
+    }
+    // d_n = -(entry at i = 0); d_2M only enters the remainder
+    d_last = d_cur;
+    d_cur = {-newv.re, -newv.im};
+    if (n != 2 * M) {
+      const cplx dz = cmul(d_cur, z);
+      const cplx An = cadd(A_cur, cmul(dz, A_prev));
+      const cplx Bn = cadd(B_cur, cmul(dz, B_prev));
+      A_prev = A_cur;
+      A_cur = An;
+      B_prev = B_cur;
+      B_cur = Bn;
+    }
+    // keep the diagonals apart: hoisting the next terms' reads / interleaving diagonals only costs registers
+    // (the asm ties this diagonal's results -- including BOTH continued-fraction recurrences, which the compiler
+    // otherwise defers to the end of the kernel, spilling every d_n z to scratch: 1 GB of HBM writes per launch --
+    // to a memory barrier, so the arithmetic cannot sink below the following reads either)
+    asm volatile(""
+                 : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
+  const cplx diff = csub(d_last, d_cur);
+  const cplx one = {1.0, 0.0};
+  cplx brem = cadd(one, cmul(diff, z));
+  brem = {0.5 * brem.re, 0.5 * brem.im};
+  const cplx inner = cadd(one, cdiv(cmul(d_cur, z), brem));
+  const cplx rem = cmul(brem, csub(csqrt_(inner), one));
+  const cplx An = cadd(A_cur, cmul(rem, A_prev));
+  const cplx Bn = cadd(B_cur, cmul(rem, B_prev));
+  return cdiv(An, Bn);
+}
+
+}  // namespace nlc

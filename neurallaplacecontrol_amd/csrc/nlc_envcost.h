@@ -27,6 +27,13 @@ __device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MA
     const double state_reward = -(e0 * e0 + e1 * e1);
     const double vel_reward = -(x[1] * x[1]) - x[4] * x[4];
     return -((state_reward + 0.01 * vel_reward) + (-0.01 * uu));
+  } else if (env == NLC_ENV_CARTPOLE_NOTRIG) {
+    // ctcartpole.py:297-300 (s.shape[-1] == 4: explicit angle), then :303-339 as above
+    const double cl = 1.0 * cos(x[2]), sl = 1.0 * sin(x[2]);
+    const double e0 = x[0] + sl - 0.0, e1 = cl - 1.0;
+    const double state_reward = -(e0 * e0 + e1 * e1);
+    const double vel_reward = -(x[1] * x[1]) - x[3] * x[3];
+    return -((state_reward + 0.01 * vel_reward) + (-0.01 * uu));
   } else if (env == NLC_ENV_PENDULUM) {
     // ctpendulum.py:139-155
     const double om = 1.0 - x[0];

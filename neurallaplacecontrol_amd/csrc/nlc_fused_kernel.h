@@ -133,6 +133,9 @@ struct PaHandoff {
       if (spins > spin_limit) {
         __hip_atomic_store(sync + kFusedTimeout, 1u + (unsigned)t_first, NLC_RLX_AGENT);
         __hip_atomic_store(timeout_host, 1u + (unsigned)t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the give-up word has reached the L2 before this workgroup can count its tile done (the barrier after the poll, then
+        // wave 0's ticket): the workgroup that folds the shard's partials reads it and marks them invalid (fused_weight_rank)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ready_upto = t_end;  // stop polling: the command is lost, the grid must still drain
         return;
       }
@@ -175,13 +178,6 @@ struct PaHandoff {
     nc1 = nn1;
   }
 };
-
-// give-up of any bounded wait of this launch: the command is lost (the host re-runs it on the two-launch body)
-__device__ __forceinline__ void report_timeout(unsigned* sync, unsigned* timeout_host, unsigned code) {
-  // (every lane stores the same word: no lane-divergent branch inside a polling loop)
-  __hip_atomic_store(sync + kFusedTimeout, code, NLC_RLX_AGENT);
-  __hip_atomic_store(timeout_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 // the kernel-argument segment as ordinary (global) memory: per-lane indexed reads of the small arrays that ride in it
 __device__ __forceinline__ const FusedArgs* args_in_memory() {
@@ -273,7 +269,13 @@ __device__ __forceinline__ fused_args_cptr role_args() {
 static __device__ __attribute__((noinline)) void fused_weight_tile(const WeightArgs w, int tile, int lane, double cost, bool valid) {
   weight_tile<MemSc1>(w, 0, (int64_t)tile, lane, cost, valid);
 }
-static __device__ __attribute__((noinline)) void fused_weight_rank(const WeightArgs w, double* lds) { weight_rank<MemSc1>(w, 0, lds); }
+// A shard whose launch gave up somewhere (bounded waits) must not be merged: its partial row is marked with eta = -1 (a sum of
+// exponentials is never negative), which travels through the shard all-gather, so that merge_kernel on EVERY rank sees it,
+// leaves U alone and reports it -- every rank then re-runs the command on the two-launch body (nlc_mppi_finish).
+static __device__ __attribute__((noinline)) void fused_weight_rank(const WeightArgs w, double* lds, const unsigned* gave_up) {
+  weight_rank<MemSc1>(w, 0, lds);
+  if (threadIdx.x == 0 && __hip_atomic_load(gave_up, NLC_RLX_AGENT) != 0u) w.partials[1] = kPartialInvalidEta;  // (thread 0 stored eta)
+}
 
 template <int HT, int NT3>
 __device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* cu_state = nullptr) {
@@ -321,7 +323,7 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* 
     __syncthreads();
     const bool last = __builtin_amdgcn_readfirstlane(s_last[0]) == a.ctl.ntk - 1;
     __syncthreads();
-    if (last) fused_weight_rank(a.w, smem + 8);
+    if (last) fused_weight_rank(a.w, smem + 8, a.ctl.sync + kFusedTimeout);
     __syncthreads();
   }
   if (wv == 0) {

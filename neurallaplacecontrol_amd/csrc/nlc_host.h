@@ -12,6 +12,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <time.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -125,14 +127,19 @@ struct nlc_ctx {
   int opt_dehoog_gru_lds_pad = 49152;   // unused dynamic LDS of those chunk launches (bytes): 32 KB + 48 KB -> two workgroups per CU
   hipStream_t gru_stream = nullptr;
   std::vector<hipEvent_t> ev_gru;
+  int opt_dehoog_chain = -1;            // de Hoog planner: the step chain as one persistent launch (kernels_dehoog_chain.hip): -1 auto, 0 / 1
   int opt_dehoog_streams = 0;           // staged de Hoog planner: parts of the population on streams of their own (0 auto)
   std::vector<hipStream_t> aux_streams;
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_join;
   double opt_fused_tile_step_ratio = 0.0;  // > 0: the adaptive partner rule (measured slower: profiles/r3_fused_small_shard.md); 0 = static schedule
-  int opt_host_spin = 1;                // nlc_mppi_finish with a host action pointer: spin on a pinned word the merge kernel
-                                        // stores (1) instead of hipStreamSynchronize (0)
+  int opt_host_spin = 1;                // nlc_mppi_finish with a host action pointer: 1 spin on a pinned word the merge kernel
+                                        // stores, 2 sleep through the predicted wait first, 0 hipStreamSynchronize
   unsigned long long host_seq = 0;      // sequence number of the last command handed to the spin protocol
+  double opt_host_spin_margin_us = 150.0;  // host_spin 2: the host wakes this long (or 15 % of the predicted wait) before the predicted end
+  double wait_hist_us[8] = {0};         // host_spin: the last waits for the action (their minimum predicts the next one)
+  int wait_hist_n = 0, wait_hist_at = 0;
+  double nap_margin_us = 0.0;           // host_spin 2: the margin in use (grows when a nap overshoots the action's arrival)
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
   int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
   int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
@@ -271,6 +278,8 @@ struct WsLayout {
 WsLayout ws_layout(const nlc_ctx* c);
 double* fused_timeout_word(nlc_ctx* c);
 bool fused_gave_up(nlc_ctx* c);
+unsigned* merge_status_word(nlc_ctx* c);
+bool merge_reported_invalid(nlc_ctx* c);
 WeightArgs make_weight_args(nlc_ctx* c, const nlc_mppi_buffers* buf);
 int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf);
 

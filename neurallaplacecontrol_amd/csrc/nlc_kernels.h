@@ -320,6 +320,32 @@ struct RepFuncArgs {
 hipError_t launch_nl_repfunc(const RepFuncArgs& a, hipStream_t s);
 
 
+// the whole step chain of the de Hoog planner as one persistent launch (kernels_dehoog_chain.hip): a workgroup owns 64
+// consecutive samples for all T horizon steps.  Single planner (E == 1), hidden_units 128, 17 or 33 terms.
+struct DehoogChainArgs {
+  NlNetArgs net;            // net.b1: the bias with the constant sphere inputs folded in
+  int64_t K;
+  int T, nu, env;
+  int state_per_sample;
+  const double* state0;     // (d) or (K, d)
+  const double* pa;         // (K, T, 2) GRU latents of the hoisted encode
+  const double* perturbed;  // (K, T, nu)
+  const double* noise;
+  const double* U;          // (T, nu)
+  double sigma_inv[NLC_MAX_NU * NLC_MAX_NU];
+  double lambda_, u_scale;
+  int noise_abs_cost;
+  double tn;                // normalised prediction time
+  const int* slot;          // (8 nt3) layer-3 slot -> c*S + k, -1 = padding
+  const int* eidx;          // (d*S)   term k of dim c -> slot
+  double* fre;              // ceil(K / 64) private blocks of (8 nt3) x 64 doubles each
+  double* fim;
+  double* states;           // (K, T, d) or NULL
+  double* cost_total;       // (K)
+};
+hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, unsigned grid, hipStream_t s);
+bool nl_dehoog_chain_available(int h, int nt3, int S);
+
 // ------------------------------------------------------------------ oracle-dynamics rollout (§8f-1)
 struct OracleRolloutArgs {
   int64_t K, Kep;
@@ -433,6 +459,9 @@ struct WeightArgs {
   double* partials;     // (E, 2 + T*nu)
   int nblk;             // weight tiles per episode
 };
+// partial rows are (beta_r, eta_r, S_r[T*nu]); eta_r = kPartialInvalidEta marks a shard whose rollout launch gave up (the
+// fused planner body's bounded waits): merge_kernel on every rank then leaves U alone and reports it (MergeArgs::status_pinned)
+constexpr double kPartialInvalidEta = -1.0;
 constexpr int kWeightTile = 16;  // = the rollout kernels' MFMA tile: a tile's samples become final together
 inline int weight_tiles(int64_t Kep) { return (int)((Kep + kWeightTile - 1) / kWeightTile); }
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s);
@@ -455,6 +484,9 @@ struct MergeArgs {
   // spins on this word instead of sleeping in hipStreamSynchronize (an interrupt wake-up costs 10-20 us per command)
   unsigned long long* seq_pinned;
   unsigned long long seq;
+  // pinned word the kernel sets to 1 -- before seq -- when some rank's partial row is marked invalid (kPartialInvalidEta): U, the
+  // action (NaN), cost_nz and omega are then NOT produced; the host clears the word when it has seen it.  May be NULL.
+  unsigned* status_pinned;
 };
 hipError_t launch_merge(const MergeArgs& a, hipStream_t s);
 

@@ -454,12 +454,140 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
 // horizon step: a wave-sized tile (nl_repfunc_kernel) does the whole MLP of 16 samples serially, one wave per SIMD, and
 // is latency-bound for the 75 us the launch lasts; four waves per tile at up to four workgroups per CU overlap.
 // Planner form only (constant query time folded into b1, slot-major F, optional tail of the previous step).
-template <int HT, int NT3>
-__device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t tile, double* __restrict__ H1,
-                                                   double* __restrict__ H2) {
+//
+// The MLP of repfunc_split_tile from the layer-1 B fragments on: p0 / p1 = this lane's latent entries q and 4 + q of sample c
+// (normalised state dims, then the two GRU latents), `k` the sample's column in the slot-major F arrays of `n_cols` columns.
+// after_l1() runs behind the first barrier (the staged kernel stores the carried state there).  `wv`: the wave's index within
+// the FOUR waves that share the tile -- a workgroup of eight waves may run two tiles side by side, each group with LDS images
+// of its own and the same barrier sequence (kernels_dehoog_chain.hip).  The weights must be reachable through kernel-argument
+// (wave-uniform) pointers: `n` is a reference into the kernel's argument block, never a local copy.
+template <int HT, int NT3, class AfterL1>
+__device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const double p0, const double p1, const bool valid,
+                                                  const int64_t k, const int64_t n_cols, const int* __restrict__ slot,
+                                                  double* __restrict__ fre, double* __restrict__ fim, double* __restrict__ H1,
+                                                  double* __restrict__ H2, const int wv, const int lane, AfterL1 after_l1) {
   constexpr int KS = HT * 4;
   constexpr int TW = HT / 4;
   constexpr int NTW = (NT3 + 3) / 4;
+  const int q = lane >> 4;
+  // (the bias tiles are loaded through laundered pointers: inside a persistent horizon loop the compiler would otherwise hoist
+  // these loop-invariant loads and keep ~80 VGPRs live across the QD phase of kernels_dehoog_chain.hip)
+  int j3[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) j3[i] = (wv + 4 * i < NT3) ? wv + 4 * i : NT3 - 1;
+  // ---- layer 1: output tiles TW*wv .. TW*wv+TW-1
+  {
+    v4d acc[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile((const double*)opaque(n.b1), TW * wv + i, q);
+    gptr p = opaque(n.W1p + (size_t)TW * wv * 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const double b = ks == 0 ? p0 : p1;
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = mfma(p[(ks * HT + i) * 64 + lane], b, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
+        H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+        H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+      }
+  }
+  __syncthreads();
+  after_l1();
+  // ---- layer 2
+  {
+    v4d acc[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile((const double*)opaque(n.b2), TW * wv + i, q);
+    gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
+    double a_cur[TW], a_nxt[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
+    double b_cur = H1[lane], b_nxt = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + HT * 64);
+#pragma unroll
+        for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
+        b_nxt = H1[(ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
+#pragma unroll
+      for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
+      b_cur = b_nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
+        H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
+        H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
+      }
+  }
+  __syncthreads();
+  // ---- layer 3 (own tiles) + sphere -> complex, F_k stored slot-major
+  {
+    v4d o[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile((const double*)opaque(n.b3p), j3[i], q);
+    gptr p = opaque(n.W3p);
+    double a_cur[NTW], a_nxt[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
+    double b_cur = H2[lane], b_nxt = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + NT3 * 64);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
+        b_nxt = H2[(ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
+      b_cur = b_nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (wv + 4 * i < NT3) {  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int g = 2 * j3[i] + r;
+          // (same arithmetic as nl_eval's WRITE_F branch)
+          const double theta = m::tanh_d(o[i][r]) * kPi;
+          const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
+          double num, den;
+          m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+          const int idx = slot[4 * g + q];
+          if (valid && idx >= 0) {
+            double sn, cs;
+            m::sincos_bounded(theta, &sn, &cs);
+            const double rad = num * m::rcp_refined(den);
+            const int64_t at = (int64_t)(4 * g + q) * n_cols + k;
+            fre[at] = rad * cs;
+            fim[at] = rad * sn;
+          }
+        }
+      }
+    }
+  }
+}
+
+// the staged planner's per-step launch: observation (or the tail of the previous step) -> layer-1 fragments -> the MLP above
+template <int HT, int NT3>
+__device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t tile, double* __restrict__ H1,
+                                                   double* __restrict__ H2) {
   const NlNetArgs& n = a.net;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -512,119 +640,12 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
                              : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
   const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
                              : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
-  int j3[NTW];
-#pragma unroll
-  for (int i = 0; i < NTW; ++i) j3[i] = (wv + 4 * i < NT3) ? wv + 4 * i : NT3 - 1;
-  // ---- layer 1: output tiles TW*wv .. TW*wv+TW-1
-  {
-    v4d acc[TW];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b1, TW * wv + i, q);
-    gptr p = opaque(n.W1p + (size_t)TW * wv * 64);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const double b = ks == 0 ? p0 : p1;
-#pragma unroll
-      for (int i = 0; i < TW; ++i) acc[i] = mfma(p[(ks * HT + i) * 64 + lane], b, acc[i]);
+  repfunc_split_mlp<HT, NT3>(n, p0, p1, valid, k, a.N, a.slot, a.fre, a.fim, H1, H2, wv, lane, [&]() {
+    if (a.tail_prev && wv == 0 && valid) {  // every wave has read the previous state: now it may be replaced
+      if (i0 < d) a.tail.x[k * d + i0] = x0;
+      if (i1 < d) a.tail.x[k * d + i1] = x1;
     }
-#pragma unroll
-    for (int i = 0; i < TW; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        double ta, tb;
-        NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
-        H1[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
-        H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
-      }
-  }
-  __syncthreads();
-  if (a.tail_prev && wv == 0 && valid) {  // every wave has read the previous state: now it may be replaced
-    if (i0 < d) a.tail.x[k * d + i0] = x0;
-    if (i1 < d) a.tail.x[k * d + i1] = x1;
-  }
-  // ---- layer 2
-  {
-    v4d acc[TW];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b2, TW * wv + i, q);
-    gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
-    double a_cur[TW], a_nxt[TW];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
-    double b_cur = H1[lane], b_nxt = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        p = opaque(p + HT * 64);
-#pragma unroll
-        for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
-        b_nxt = H1[(ks + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
-      b_cur = b_nxt;
-    }
-#pragma unroll
-    for (int i = 0; i < TW; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        double ta, tb;
-        NLC_HIDDEN_TANH_PAIR(acc[i][r], acc[i][r + 1], &ta, &tb);
-        H2[(4 * (TW * wv + i) + r) * 64 + lane] = ta;
-        H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
-      }
-  }
-  __syncthreads();
-  // ---- layer 3 (own tiles) + sphere -> complex, F_k stored slot-major
-  {
-    v4d o[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile(n.b3p, j3[i], q);
-    gptr p = opaque(n.W3p);
-    double a_cur[NTW], a_nxt[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
-    double b_cur = H2[lane], b_nxt = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        p = opaque(p + NT3 * 64);
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
-        b_nxt = H2[(ks + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
-      b_cur = b_nxt;
-    }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-      if (wv + 4 * i < NT3) {  // wave-uniform
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int g = 2 * j3[i] + r;
-          // (same arithmetic as nl_eval's WRITE_F branch)
-          const double theta = m::tanh_d(o[i][r]) * kPi;
-          const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
-          double num, den;
-          m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
-          const int idx = a.slot[4 * g + q];
-          if (valid && idx >= 0) {
-            double sn, cs;
-            m::sincos_bounded(theta, &sn, &cs);
-            const double rad = num * m::rcp_refined(den);
-            const int64_t at = (int64_t)(4 * g + q) * a.N + k;
-            a.fre[at] = rad * cs;
-            a.fim[at] = rad * sn;
-          }
-        }
-      }
-    }
-  }
+  });
 }
 
 }  // namespace nlc

@@ -16,7 +16,8 @@ import torch
 
 from . import _lib
 
-ENV_DIMS = {"oderl-cartpole": (5, 1, 3.0), "oderl-pendulum": (3, 1, 2.0), "oderl-acrobot": (6, 2, 5.0)}
+ENV_DIMS = {"oderl-cartpole": (5, 1, 3.0), "oderl-pendulum": (3, 1, 2.0), "oderl-acrobot": (6, 2, 5.0),
+            "oderl-cartpole-notrig": (4, 1, 3.0)}
 
 
 def _check_env(env_name):
@@ -76,7 +77,8 @@ def _trig2angle(c, s):
 
 
 class EnvCost:
-    """Running cost of the three reference envs on the trig observation (same formulas as the HIP kernels)."""
+    """Running cost of the three reference envs on the trig observation, and of cartpole on its raw 4-dim state
+    (``obs_trans=False``); same formulas as the HIP kernels."""
 
     def __init__(self, env_name):
         self.env_name = _check_env(env_name)
@@ -87,6 +89,12 @@ class EnvCost:
             e0, e1 = state[..., 0] + state[..., 3] - 0.0, state[..., 2] - 1.0
             sr = -(e0 * e0 + e1 * e1)
             vr = -(state[..., 1] ** 2) - state[..., 4] ** 2
+            return -((sr + 0.01 * vr) + (-0.01 * uu))
+        if self.env_name == "oderl-cartpole-notrig":  # ctcartpole.py:297-300: explicit angle
+            cl, sl = 1.0 * torch.cos(state[..., 2]), 1.0 * torch.sin(state[..., 2])
+            e0, e1 = state[..., 0] + sl - 0.0, cl - 1.0
+            sr = -(e0 * e0 + e1 * e1)
+            vr = -(state[..., 1] ** 2) - state[..., 3] ** 2
             return -((sr + 0.01 * vr) + (-0.01 * uu))
         if self.env_name == "oderl-pendulum":
             sr = -((1.0 - state[..., 0]) ** 2 + state[..., 1] ** 2)
@@ -115,6 +123,9 @@ def initial_state(env_name, generator=None):
         st = (torch.rand(4, generator=generator, dtype=torch.float64) - 0.5) * 0.1
         th = st[2] + math.pi
         return torch.stack((st[0], st[1], torch.cos(th), torch.sin(th), st[3]))
+    if env_name == "oderl-cartpole-notrig":
+        st = (torch.rand(4, generator=generator, dtype=torch.float64) - 0.5) * 0.1
+        return torch.stack((st[0], st[1], st[2] + math.pi, st[3]))
     if env_name == "oderl-pendulum":
         return torch.tensor([math.cos(math.pi), math.sin(math.pi), 1.0], dtype=torch.float64)
     st = (torch.rand(4, generator=generator, dtype=torch.float64) - 0.5) * 0.2

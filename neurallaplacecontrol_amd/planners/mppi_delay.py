@@ -208,10 +208,16 @@ class MPPIDelay:
                     self.ctx.comm_init(self.rank, self.G, uid)
                     self.ctx.comm_self_test()  # one all-gather of the rank numbers, checked on the host
             except _lib.NlcError as err:
-                if planner_options and planner_options.get("native_collective"):
-                    raise  # asked for explicitly
                 ok, self._native_error = 0, str(err)
-            if not all_ranks_agree(ok, self.pg, self.cd):
+            # the ranks agree FIRST (a rank that raised on its own would leave its peers waiting in this all-reduce), then an
+            # explicit request that could not be met fails on every rank together
+            agreed = all_ranks_agree(ok, self.pg, self.cd)
+            if not agreed and planner_options and planner_options.get("native_collective"):
+                with torch.cuda.device(self.cd):
+                    self.ctx.comm_destroy()
+                raise RuntimeError("native_collective was requested, but the library-owned RCCL communicator could not be "
+                                   f"brought up on every rank ({getattr(self, '_native_error', 'failed on another rank')})")
+            if not agreed:
                 # the default is a preference: if any rank could not bring the communicator up, every rank uses the
                 # collective of the group the caller gave us
                 import warnings
@@ -370,6 +376,7 @@ class MPPIDelay:
         stale = self._buf is None or B != self._B
         if self.fused_dynamics and isinstance(self.F, NLDynamics):
             model = self.F.model
+            _recognise.refresh_twin(model)  # a twin of a reference model instance follows that instance's weight updates
             if model._weights_key() != self._model_key:
                 if self._buf is not None:  # nlc_set_model drops the planner configuration: carry U over
                     self._pending_U, self._buf, self._B = self.U, None, None
@@ -484,9 +491,13 @@ class MPPIDelay:
                 act = self._action.clone()
             else:
                 act = torch.empty(self.u_per_command * self.nu, dtype=torch.float64)
-                ctx.check(
-                    lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act))
-                )
+                rc = lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act))
+                if rc == _lib.NLC_AGAIN:
+                    # a rank's fused launch gave up: EVERY rank saw the marked partial row after the all-gather and has
+                    # re-run the command on the two-launch body (include/nlc.h); the collective is ours, so gather again
+                    gathered = gather_partials(self._partials, self._gathered, self.pg)
+                    rc = lib.nlc_mppi_finish(ctx.h, _lib.ptr(gathered), self.G, self.rank, C.byref(self._buf), _lib.ptr(act))
+                ctx.check(rc)
             if self.M > 1 and self.rollout_var_cost != 0 and self.fused_dynamics:
                 self._add_rollout_var_cost()
         action = act.view(self.u_per_command, self.nu)

@@ -16,10 +16,11 @@ import math
 import numpy as np
 import torch
 
-ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2}
-ACTION_HIGH = {"oderl-cartpole": 3.0, "oderl-pendulum": 2.0, "oderl-acrobot": 5.0}
-OBS_DIM = {"oderl-cartpole": 5, "oderl-pendulum": 3, "oderl-acrobot": 6}
-ACT_DIM = {"oderl-cartpole": 1, "oderl-pendulum": 1, "oderl-acrobot": 2}
+# "oderl-cartpole-notrig": the same env built with obs_trans=False (ctcartpole.py:60): 4-dim state [x, xdot, theta, thetadot]
+ENV_IDS = {"oderl-cartpole": 0, "oderl-pendulum": 1, "oderl-acrobot": 2, "oderl-cartpole-notrig": 3}
+ACTION_HIGH = {"oderl-cartpole": 3.0, "oderl-pendulum": 2.0, "oderl-acrobot": 5.0, "oderl-cartpole-notrig": 3.0}
+OBS_DIM = {"oderl-cartpole": 5, "oderl-pendulum": 3, "oderl-acrobot": 6, "oderl-cartpole-notrig": 4}
+ACT_DIM = {"oderl-cartpole": 1, "oderl-pendulum": 1, "oderl-acrobot": 2, "oderl-cartpole-notrig": 1}
 
 
 def trig2angle(c, s):
@@ -31,6 +32,18 @@ def trig2angle(c, s):
 
 def cartpole_cost(state, u):
     x, xd, cl, sl, thd = (state[..., i] for i in range(5))
+    e0 = x + sl - 0.0
+    e1 = cl - 1.0
+    state_reward = -(e0 * e0 + e1 * e1)
+    vel_reward = -(xd * xd) - thd * thd
+    ac_reward = -0.01 * (u * u).sum(-1)
+    return -((state_reward + 0.01 * vel_reward) + ac_reward)
+
+
+def cartpole_notrig_cost(state, u):
+    """ctcartpole.py:297-300 (s.shape[-1] == 4: cos / sin of the explicit angle), then the swing-up reward :303-339."""
+    x, xd, th, thd = (state[..., i] for i in range(4))
+    cl, sl = 1.0 * torch.cos(th), 1.0 * torch.sin(th)
     e0 = x + sl - 0.0
     e1 = cl - 1.0
     state_reward = -(e0 * e0 + e1 * e1)
@@ -79,7 +92,8 @@ def acrobot_cost(state, u):
     return -((state_reward + 1e-1 * vel_reward) + ac_reward)
 
 
-RUNNING_COST = {"oderl-cartpole": cartpole_cost, "oderl-pendulum": pendulum_cost, "oderl-acrobot": acrobot_cost}
+RUNNING_COST = {"oderl-cartpole": cartpole_cost, "oderl-pendulum": pendulum_cost, "oderl-acrobot": acrobot_cost,
+                "oderl-cartpole-notrig": cartpole_notrig_cost}
 
 
 def cartpole_dynamics(state, window, ts, delay, friction=False):
@@ -104,6 +118,25 @@ def cartpole_dynamics(state, window, ts, delay, friction=False):
     nxd = xd + xacc * ts
     nx = x + xd * ts
     return torch.cat((nx, nxd, torch.cos(nth), torch.sin(nth), nthd), dim=1)
+
+
+def cartpole_notrig_dynamics(state, window, ts, delay, friction=False):
+    """oracle.py:11-86 on the 4-dim state (the `else` branches :38-44 and :80-86: explicit angle in, explicit angle out)."""
+    u = window[:, -(delay + 1), :1].clamp(-3.0, 3.0)
+    ts = ts.view(-1, 1)
+    x, xd, th, thd = (state[:, i : i + 1] for i in range(4))
+    c, s = torch.cos(th), torch.sin(th)
+    g, fmag, mc, mp, length = 9.8, 3.0, 1.0, 0.1, 1.0
+    mt, pml = mp + mc, mp * length
+    force = u * fmag
+    if friction:
+        temp = (force + pml * thd * thd * s - 5e-4 * torch.sign(xd)) / mt
+        thacc = (g * s - c * temp - 2e-6 * thd / pml) / (length * (4.0 / 3.0 - mp * c * c / mt))
+    else:
+        temp = (force + pml * thd * thd * s) / mt
+        thacc = (g * s - c * temp) / (length * (4.0 / 3.0 - mp * c * c / mt))
+    xacc = temp - pml * thacc * c / mt
+    return torch.cat((x + xd * ts, xd + xacc * ts, th + thd * ts, thd + thacc * ts), dim=1)
 
 
 def pendulum_dynamics(state, window, ts, delay, friction=False):
@@ -149,6 +182,7 @@ ORACLE_DYNAMICS = {
     "oderl-cartpole": cartpole_dynamics,
     "oderl-pendulum": pendulum_dynamics,
     "oderl-acrobot": acrobot_dynamics,
+    "oderl-cartpole-notrig": cartpole_notrig_dynamics,
 }
 
 
@@ -159,6 +193,9 @@ def initial_state(env_name, seed=0):
         st = (torch.rand(4, generator=gen, dtype=torch.float64) - 0.5) * 0.1
         th = st[2] + math.pi
         return torch.stack((st[0], st[1], torch.cos(th), torch.sin(th), st[3]))
+    if env_name == "oderl-cartpole-notrig":  # the same start as a raw state
+        st = (torch.rand(4, generator=gen, dtype=torch.float64) - 0.5) * 0.1
+        return torch.stack((st[0], st[1], st[2] + math.pi, st[3]))
     if env_name == "oderl-pendulum":  # mppi_with_model.py:188-189  state = [pi, 1]
         return torch.tensor([math.cos(math.pi), math.sin(math.pi), 1.0], dtype=torch.float64)
     if env_name == "oderl-acrobot":  # ctacrobot.py:149  U(-0.1, 0.1)

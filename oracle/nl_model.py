@@ -28,6 +28,9 @@ ENV_STATS = {
         d=5, nu=1, act_high=3.0, state_std=[2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048]
     ),
     "oderl-pendulum": dict(d=3, nu=1, act_high=2.0, state_std=[0.70634571, 0.70784512, 2.89072771]),
+    # obs_trans=False (BASELINE's literal state_dim = 4): train_utils.py has no constants for it; position / velocity stds of the
+    # trig variant, the angle's std that of U(-pi, pi)
+    "oderl-cartpole-notrig": dict(d=4, nu=1, act_high=3.0, state_std=[2.88646771, 11.54556671, 1.81379936, 17.3199048]),
     "oderl-acrobot": dict(
         d=6, nu=2, act_high=5.0, state_std=[0.70711024, 0.70710328, 0.7072186, 0.7069949, 2.88642115, 2.88627309]
     ),

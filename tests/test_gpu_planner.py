@@ -106,24 +106,32 @@ def test_literal_oracle_partial_is_recognised_and_plans_fused_g1(nlc, path):
 
 
 def test_closure_that_differs_from_its_candidate_stays_generic(nlc):
-    """The probe is the decision: a closure over a model + constant ts_pred that ALSO does something else (here: clamps the
-    state) is recognised as a candidate, fails the probe and keeps the generic path with the closure's own semantics."""
+    """Two gates.  Structure: a closure over a model + constant ts_pred that ALSO clamps the state references a
+    name the harness closure does not (`clamp`) and carries constants of its own: it is never a candidate.  Probe: a closure
+    with the harness closure's structure that computes something else (here: state MINUS the model's prediction -- no name,
+    no constant gives it away) is a candidate, fails the probe and keeps the generic path with the closure's own semantics."""
     g = np.load(f"{GOLD}/g3_nl_cartpole.npz")
     model = build_model(nlc, load_sd(g))
     K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
     ts_pred = torch.full((K, 1), 0.05, dtype=torch.double, device="cuda")
 
-    def dynamics(state, perturbed_action):
+    def clamped(state, perturbed_action):
         return (state + model(state, perturbed_action, ts_pred)).clamp(-0.5, 0.5)
+
+    def minus(state, perturbed_action):
+        state_diff_pred = model(state, perturbed_action, ts_pred)
+        return state - state_diff_pred
 
     cost = nlc.EnvCost("oderl-cartpole")
     with torch.no_grad():
-        p = nlc.MPPIDelay(dynamics, cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A),
-                          u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64))
-        assert p._candidate is not None
-        p.command(g["s0_state"], T64(g["s0_action_buffer"]))
-    assert p.fused is False and p.recognised is False and p.F is dynamics
-    assert float(p.states.abs().max()) <= 0.5
+        for dynamics, is_candidate in ((clamped, False), (minus, True)):
+            p = nlc.MPPIDelay(dynamics, cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A),
+                              u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64))
+            assert (p._candidate is not None) == is_candidate, dynamics.__name__
+            p.command(g["s0_state"], T64(g["s0_action_buffer"]))
+            assert p.fused is False and p.recognised is False and p.F is dynamics, dynamics.__name__
+            if dynamics is clamped:
+                assert float(p.states.abs().max()) <= 0.5
 
 
 @pytest.mark.parametrize("env", ["cartpole", "acrobot"])
@@ -469,3 +477,41 @@ def test_plain_c_client_of_the_abi_matches_the_python_mirror(nlc, tmp_path):
         np.testing.assert_allclose(x.detach().cpu().reshape(-1).numpy(), c_ilt[: N * D], rtol=0, atol=0, err_msg=algo)
         np.testing.assert_allclose([float((gt.reshape(-1) * w1).sum()), float((gp.reshape(-1) * w2).sum())], c_ilt[N * D:],
                                    rtol=1e-13, err_msg=algo)
+
+
+class _Prefixed:
+    """View of the fixture keys that start with a prefix (G15 stores several cases in one file)."""
+
+    def __init__(self, g, prefix):
+        self.g, self.p = g, prefix
+
+    def __getitem__(self, k):
+        return self.g[self.p + k]
+
+
+@pytest.mark.parametrize("case", ["o0_", "o2_", "n_"])
+def test_state_dim_4_cartpole_without_trig_vs_reference_golden(nlc, case):
+    """BASELINE's literal state_dim = 4 on the FUSED planner: CTCartpole(obs_trans=False), state [x, xdot, theta, thetadot]
+    (env "oderl-cartpole-notrig": running cost ctcartpole.py:297-300, oracle dynamics oracle.py:38-44 / 80-86, NL dynamics at
+    d = 4) against G15 -- the reference's MPPIDelay driving its own oracle function / its own NeuralLaplaceModel(state_dim=4)
+    and the real env's reward methods."""
+    g = np.load(os.path.join(GOLD, "g15_notrig_cartpole.npz"))
+    env = "oderl-cartpole-notrig"
+    K, Tn, nx, nu, A, S = int(g["K"]), int(g["T"]), int(g["nx"]), int(g["nu"]), float(g["A"]), int(g["S"])
+    if case == "n_":
+        model = build_model(nlc, load_sd(g), S=S)
+        with torch.no_grad():
+            fwd = model(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda()).cpu()
+        np.testing.assert_allclose(fwd.numpy(), g["fwd_out"], **TOL)
+        dyn = nlc.NLDynamics(model, 0.05)
+    else:
+        dyn = nlc.OracleDynamics(env, 0.05, int(case[1]))
+
+    def make(U0):
+        p = nlc.MPPIDelay(dyn, nlc.EnvCost(env), nx, nlc.noise_sigma(nu), K, Tn, "cpu", lambda_=1.0, u_min=torch.tensor(-A),
+                          u_max=torch.tensor(A), u_scale=A, U_init=U0)
+        assert p.fused
+        return p
+
+    with torch.no_grad():
+        check_command_steps(nlc, _Prefixed(g, case), make)

@@ -283,13 +283,13 @@ def test_dehoog_planner_parts_on_streams_bit_identical(nlc):
     model = build_model(nlc, sd, S=S, algo="dehoog")
     planners = {P: nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
                                  u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=4,
-                                 U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"dehoog_streams": P})
+                                 U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"dehoog_streams": P, "dehoog_chain": 0})
                 for P in (1, 2, 3, 4)}
     # + the GRU encode in horizon chunks on a stream of its own, beside the chains (cooperative kernel: same bits)
     planners[5] = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
                                 u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=4,
                                 U_init=torch.zeros(T, nu, dtype=torch.float64),
-                                planner_options={"dehoog_streams": 2, "dehoog_gru_chunks": 4})
+                                planner_options={"dehoog_streams": 2, "dehoog_gru_chunks": 4, "dehoog_chain": 0})
     state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
     for step in range(3):
         acts = {P: p.command(state, ab) for P, p in planners.items()}
@@ -299,6 +299,52 @@ def test_dehoog_planner_parts_on_streams_bit_identical(nlc):
                 assert torch.equal(getattr(planners[1], attr), getattr(planners[P], attr)), (P, attr, step)
         ab = torch.roll(ab, -1, 0)
         ab[-1] = acts[1]
+
+
+@pytest.mark.parametrize("env,K,T,S,per_sample,ext_cost", [
+    ("oderl-cartpole", 16384, 40, 33, False, False),   # BASELINE configs[4] at its own size: 256 blocks of 64 samples
+    ("oderl-cartpole", 1000 + 37, 7, 33, False, False),  # ragged: the last block holds 13 samples
+    ("oderl-acrobot", 70, 5, 33, True, False),         # d = 6 (25 layer-3 tiles, six QD wavefronts), nu = 2, per-sample start states
+    ("oderl-pendulum", 200, 6, 17, False, True),       # d = 3, 17 terms, the running cost a caller's closure
+    ("oderl-cartpole", 5, 3, 17, False, False),        # fewer samples than one tile
+])
+def test_dehoog_step_chain_kernel_bit_identical_to_staged_path(nlc, env, K, T, S, per_sample, ext_cost):
+    """Round 4: the de Hoog planner's step chain as ONE persistent launch (kernels_dehoog_chain.hip: a workgroup owns 64
+    samples for all T steps; representation MLP, QD table and state / cost tail are the staged path's own device functions)
+    against the staged 2 T + 1 launches (`dehoog_chain` 1 / 0): states, costs, weights, U and actions must be the same BITS over
+    consecutive commands, and the chain planner must not launch the per-step kernels at all."""
+    from oracle import nl_model as onl
+
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(6, d, nu, 128, S, st["state_std"], [A / 2], tame="dehoog")
+    model = build_model(nlc, sd, S=S, algo="dehoog")
+    if ext_cost:
+        def cost(x, u):
+            return (x * x).sum(-1) * 0.3 + 0.01 * (u * u).sum(-1)
+    else:
+        cost = nlc.EnvCost(env)
+    planners = {ch: nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                                  u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=9,
+                                  U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"dehoog_chain": ch})
+                for ch in (0, 1)}
+    g = torch.Generator().manual_seed(3)
+    state = nlc.initial_state(env, g)
+    if per_sample:
+        state = state + 0.01 * torch.randn(K, d, dtype=torch.float64, generator=g)
+    ab = torch.zeros(4, nu, dtype=torch.float64)
+    planners[1].ctx.profile(True)
+    for step in range(2 if K > 10000 else 3):
+        with torch.no_grad():
+            acts = {ch: p.command(state, ab) for ch, p in planners.items()}
+        assert torch.equal(acts[0], acts[1]) and bool(torch.isfinite(acts[1]).all()), step
+        for attr in ("states", "cost_total", "omega", "U", "perturbed_action"):
+            assert torch.equal(getattr(planners[0], attr), getattr(planners[1], attr)), (attr, step)
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = acts[0].view(-1, nu)[0]
+    planners[1].ctx.profile(False)
+    prof = planners[1].ctx.profile_read()
+    assert "nl_dehoog_chain_kernel" in prof and "ilt_dehoog_kernel" not in prof and "nl_repfunc_kernel" not in prof, sorted(prof)
 
 
 def test_repfunc_split_kernel_agrees_with_wave_per_tile_planner(nlc):

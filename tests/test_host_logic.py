@@ -143,3 +143,72 @@ def test_recognise_literal_harness_closures_without_gpu():
         return state
 
     assert R.candidate_dynamics(functools.partial(some_other_name, ts=ts_pred, delay=0)) is None
+    # a probe cannot see logic outside the probed region, so a closure must also have the harness closure's
+    # STRUCTURE (names, free variables, constants).  Same free variables, but a clamp / a threshold / a helper call / extra
+    # state-dependent logic -> no candidate, whatever a probe would say.
+    env = CTCartpole()
+
+    def clamped(state, perturbed_action):
+        return torch.clamp(state + model(state, perturbed_action, ts_pred), -10.0, 10.0)
+
+    def thresholded(state, perturbed_action):
+        out = state + model(state, perturbed_action, ts_pred)
+        return out * (out.abs() < 1000.0)
+
+    def wrong_args(x, w):
+        return x + model(x, w, ts_pred)
+
+    def cost_plus_barrier(state, action):
+        return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action)) + torch.relu(state[:, 0] - 2.0)
+
+    def cost_scaled(state, action):
+        return -(env.diff_obs_reward_(state, exp_reward=False) + 0.5 * env.diff_ac_reward_(action))
+
+    for f in (clamped, thresholded, wrong_args):
+        assert not R.has_harness_structure(f, "dynamics") and R.candidate_dynamics(f) is None, f.__name__
+    for f in (cost_plus_barrier, cost_scaled):
+        assert not R.has_harness_structure(f, "cost") and R.candidate_cost(f) is None, f.__name__
+    assert R.has_harness_structure(dyn, "dynamics") and R.has_harness_structure(cost, "cost")
+
+
+def test_twin_of_a_foreign_model_follows_its_weight_updates():
+    """a closure over an instance of the REFERENCE's model class is planned through a converted twin (a weight
+    snapshot).  refresh_twin re-copies the weights whenever the source's (data_ptr, _version) key moved: load_state_dict, an
+    in-place optimizer-style write and a replaced buffer all reach the twin; an untouched source costs one key comparison."""
+    import numpy as np
+
+    import neurallaplacecontrol_amd as nlc
+    from neurallaplacecontrol_amd import _recognise as R
+
+    ours = nlc.NeuralLaplaceModel(3, 1, 3, hidden_units=64, s_recon_terms=9, ilt_algorithm="fourier", state_mean=np.zeros(3),
+                                  state_std=np.ones(3), action_mean=np.array([0]), action_std=np.array([1.0]), normalize=True,
+                                  normalize_time=True).double()
+
+    # a foreign class with the reference's name, sub-modules and attributes (w_nl.py:66-115): built from ours
+    NeuralLaplaceModel = type("NeuralLaplaceModel", (torch.nn.Module,), {})
+    src = NeuralLaplaceModel()
+    src.action_encoder, src.laplace_rep_func = ours.action_encoder, ours.laplace_rep_func
+    for name in ("state_mean", "state_std", "action_mean", "action_std", "dt"):
+        src.register_buffer(name, getattr(ours, name).clone())
+    for name in ("output_dim", "latent_dim", "s_recon_terms", "ilt_algorithm", "encode_obs_time", "normalize", "normalize_time"):
+        setattr(src, name, getattr(ours, name))
+    twin = R._model_twin(src)
+    assert isinstance(twin, nlc.NeuralLaplaceModel) and twin is not src and twin.__dict__["_twin_source"] is src
+    w_src = src.laplace_rep_func.linear_tanh_stack[0].weight
+    w_twin = twin.laplace_rep_func.linear_tanh_stack[0].weight
+    assert torch.equal(w_src, w_twin) and w_src.data_ptr() != w_twin.data_ptr()
+    key0 = twin._weights_key()
+    R.refresh_twin(twin)
+    assert twin._weights_key() == key0  # nothing moved: no copy
+    with torch.no_grad():
+        w_src.mul_(1.5)  # an optimizer step
+    assert not torch.equal(w_src, w_twin)
+    R.refresh_twin(twin)
+    assert torch.equal(w_src, w_twin) and twin._weights_key() != key0  # ... and the planner will re-upload
+    sd = {k: v * 0.5 for k, v in src.state_dict().items()}
+    src.load_state_dict(sd)
+    R.refresh_twin(twin)
+    assert torch.equal(w_src, w_twin)
+    src.state_std = torch.full((3,), 2.0, dtype=torch.float64)  # a replaced buffer
+    R.refresh_twin(twin)
+    assert torch.equal(twin.state_std, src.state_std)

@@ -472,3 +472,35 @@ def test_g14_other_hidden_widths_vs_reference(name, golden_dir):
     np.testing.assert_allclose(out.numpy(), g["fwd_out"], **TOL)
     ts = torch.full((K, 1), 0.05, dtype=torch.float64)
     run_steps(g, onl.nl_dynamics(sd, ts, S=S), oenvs.RUNNING_COST[env], d, nu, A)
+
+
+class _Sub:
+    """View of the fixture keys that start with a prefix (G15 stores several cases in one file)."""
+
+    def __init__(self, g, prefix):
+        self.g, self.p = g, prefix
+
+    def __getitem__(self, k):
+        return self.g[self.p + k]
+
+
+@pytest.mark.parametrize("case", ["o0_", "o2_", "n_"])
+def test_g15_state_dim_4_cartpole_without_trig_observation(case, golden_dir):
+    """BASELINE's literal state_dim = 4: CTCartpole(obs_trans=False) -- the 4-dim branches of the reference's oracle dynamics
+    (oracle.py:38-44, 80-86) and of the REAL env's reward (ctcartpole.py:297-300), and the reference's NeuralLaplaceModel at
+    state_dim 4 behind the harness closure, all through the reference's own MPPIDelay (tests/golden/make_golden_notrig.py)."""
+    g = np.load(f"{golden_dir}/g15_notrig_cartpole.npz")
+    env = "oderl-cartpole-notrig"
+    K, nx, nu, A, S = int(g["K"]), int(g["nx"]), int(g["nu"]), float(g["A"]), int(g["S"])
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    if case == "n_":
+        sd = load_sd(g)
+        with torch.no_grad():
+            fwd = onl.nl_forward(sd, T(g["fwd_obs"]), T(g["fwd_window"]), T(g["fwd_ts"]), S=S)
+        np.testing.assert_allclose(fwd.numpy(), g["fwd_out"], **TOL)
+        dyn = onl.nl_dynamics(sd, ts, S=S)
+    else:
+        delay = int(case[1])
+        dyn = lambda s, w: oenvs.ORACLE_DYNAMICS[env](s, w, ts, delay)  # noqa: E731
+    with torch.no_grad():
+        run_steps(_Sub(g, case), dyn, oenvs.RUNNING_COST[env], nx, nu, A)

@@ -11,6 +11,7 @@ STATS = {  # train_utils.py:187-200
     "oderl-cartpole": (5, 1, 3.0, [2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048]),
     "oderl-pendulum": (3, 1, 2.0, [0.70634571, 0.70784512, 2.89072771]),
     "oderl-acrobot": (6, 2, 5.0, [0.70711024, 0.70710328, 0.7072186, 0.7069949, 2.88642115, 2.88627309]),
+    "oderl-cartpole-notrig": (4, 1, 3.0, [2.88646771, 11.54556671, 1.81379936, 17.3199048]),  # obs_trans=False (ctcartpole.py:60)
 }
 CONFIGS = [  # (label, env, delay -> action_buffer rows, K, T, gpus, ilt, S)
     ("configs[0] cartpole d=0 K=1024 H=20", "oderl-cartpole", 4, 1024, 20, 1, "fourier", 17),
@@ -19,6 +20,8 @@ CONFIGS = [  # (label, env, delay -> action_buffer rows, K, T, gpus, ilt, S)
     ("configs[3] acrobot d=2 K=262144 H=60 (8 GPUs)", "oderl-acrobot", 4, 262144, 60, 8, "fourier", 17),
     ("configs[4] cartpole K=16384 H=40 de Hoog S=33", "oderl-cartpole", 4, 16384, 40, 1, "dehoog", 33),
     # the other leg of configs[4]'s "de Hoog (33 terms) vs FKT ablation": the Fourier series at the same 33 terms, same shape
+    # north_star's literal synthetic shape: state_dim = 4 -- the reference's cartpole without the trig observation
+    ("north_star literal: cartpole obs_trans=False (state_dim=4) K=16384 H=40", "oderl-cartpole-notrig", 4, 16384, 40, 1, "fourier", 17),
     ("configs[4] ablation leg: cartpole K=16384 H=40 fourier S=33", "oderl-cartpole", 4, 16384, 40, 1, "fourier", 33),
 ]
 
