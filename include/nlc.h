@@ -103,6 +103,13 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        measured 4.224 vs 4.270 ms at 3 chunks (K = 16384) -- the two kernels leave each other little to fill
  *                        (95 % / 85 % of the issue slots busy), and per-launch times of overlapped kernels say nothing about
  *                        either, so the default and the reported roofline stay with the two plain launches.
+ *   "dehoog_chain"       de Hoog planner (single planner, hidden_units 128, 17 or 33 terms): 1 = the whole step chain as ONE
+ *                        persistent launch (kernels_dehoog_chain.hip: a workgroup of eight waves owns 64 samples for all T
+ *                        steps -- representation MLP of its four tiles in one pass, QD table one wavefront per dim, state / cost
+ *                        tail; F_k stays with the CU that wrote it); 0 = the staged 2 T + 1 launches below; -1 (default) = auto,
+ *                        which is the staged path: measured 151.7 vs 158.9 planning steps/s at BASELINE configs[4]'s size
+ *                        (profiles/r4_dehoog_chain.md).  Same bits either way.  ("dehoog_chain_phases": tools only, 1 / 2 = only
+ *                        the representation / only the QD phase of that kernel runs -- a timing breakdown, meaningless results)
  *   "dehoog_streams"     staged planner (NLC_ILT_DEHOOG models; fixed Talbot / Stehfest models take the same path and the
  *                        same options): the population is cut into this many contiguous parts
  *                        whose per-step launches run on streams of their own -- one part's FP64-VALU-bound QD pass beside
@@ -134,6 +141,8 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        prediction time at nlc_mppi_configure); 0 = the staged path de Hoog models take
  *   "fused_keep_sync"    tools only: the merge kernel does not zero the fused body's sync block (tools/fused_debug.py reads
  *                        the launch's progress counters / timeline from it); the next command pays a memset instead
+ *   "test_lin_coeff_scale"  tests only: the largest coefficient of the LIN rollout instances' folded w_re / t fragment is
+ *                        scaled by this at the next nlc_mppi_configure (1 = off): the parity sweep's bound must catch 1 + 1e-6
  *   "fused_test_drop_tile"  tests only: the encoder tile with this ticket is never published (-1 = none): forces the
  *                        hand-off timeout and the re-run on the two-launch body
  *   "fused_chain_first_tiles"  encoder tiles every such workgroup encodes before its chain starts (-1 = auto: 1)

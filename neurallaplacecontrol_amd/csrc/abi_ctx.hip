@@ -151,6 +151,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "dehoog_chain") {
     if (value != -1 && value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "dehoog_chain must be -1 (auto), 0 or 1");
     c->opt_dehoog_chain = (int)value;
+  } else if (n == "dehoog_chain_phases") {
+    if (value != 1 && value != 2 && value != 3) return fail(c, NLC_ERR_BAD_ARG, "dehoog_chain_phases must be 1, 2 or 3");
+    c->opt_dehoog_chain_phases = (int)value;
   } else if (n == "dehoog_streams") {
     if (value < 0 || value > 4 || value != (int)value) return fail(c, NLC_ERR_BAD_ARG, "dehoog_streams must be 0 (auto), 1, 2, 3 or 4");
     c->opt_dehoog_streams = (int)value;
@@ -176,6 +179,9 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     c->opt_fused_spin_limit = (int64_t)value;
   } else if (n == "linear_fused") {
     c->opt_linear_fused = value != 0.0;
+  } else if (n == "test_lin_coeff_scale") {
+    c->opt_test_lin_coeff_scale = value;
+    c->has_mppi = false;  // folded at nlc_mppi_configure
   } else if (n == "fused_keep_sync") {
     c->opt_fused_keep_sync = value != 0.0;
   } else if (n == "fused_test_drop_tile") {

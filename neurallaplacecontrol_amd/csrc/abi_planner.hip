@@ -112,6 +112,12 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
           cp[(size_t)g * 64 + lane] = tab[2 * S + el.second] / c->tn;
           cp[(size_t)(ng + g) * 64 + lane] = -tab[3 * S + el.second] / c->tn;
         }
+      if (c->opt_test_lin_coeff_scale != 1.0) {  // tests only: the sweep's tolerance must catch this
+        size_t at = 0;
+        for (size_t i = 0; i < cp.size(); ++i)
+          if (std::fabs(cp[i]) > std::fabs(cp[at])) at = i;
+        cp[at] *= c->opt_test_lin_coeff_scale;  // (the largest weight: Stehfest's span many orders of magnitude)
+      }
       if (c->cp_lin) hipFree(c->cp_lin);
       c->cp_lin = nullptr;
       NLC_HIP(c, hipMalloc((void**)&c->cp_lin, cp.size() * sizeof(double)));

@@ -34,7 +34,9 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
   const bool chain_ok = dehoog && d.E == 1 && nl_dehoog_chain_available(c->md.h, c->net.nt3, c->S);
   if (c->opt_dehoog_chain == 1 && !chain_ok)
     return fail(c, NLC_ERR_UNSUPPORTED, "dehoog_chain: single planner, hidden_units 128 and 17 or 33 de Hoog terms only");
-  const bool chain = chain_ok && c->opt_dehoog_chain != 0;
+  // auto = the staged launches: measured on the MI355X at configs[4]'s size the persistent chain is 5 % slower than the staged
+  // path on two streams (profiles/r4_dehoog_chain.md)
+  const bool chain = chain_ok && c->opt_dehoog_chain == 1;
   int C = d.E == 1 && !chain ? c->opt_dehoog_gru_chunks : 1;
   if (C == 0) C = 1;  // auto: off
   if (C > d.T) C = d.T;
@@ -71,6 +73,7 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
     ca.fim = ws + w.fim;
     ca.states = buf->states;
     ca.cost_total = buf->cost_total;
+    ca.phases = c->opt_dehoog_chain_phases;
     const int64_t nblk = (KE + 63) / 64;
     {
       ProfScope ps(c, "nl_dehoog_chain_kernel");

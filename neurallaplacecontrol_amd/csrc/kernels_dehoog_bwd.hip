@@ -4,14 +4,19 @@
 // (kernels_dehoog.hip; mpmath 1.3.0 calculus/inverselaplace.py:476-531), one thread per (point, dim) row.
 //
 // The forward keeps ONE diagonal of the table in registers; reverse mode needs every entry again -- M (M + 1) q's and M^2
-// e's, 8.4 KB per row at M = 16 -- so this kernel rebuilds the table column by column into a TAPE in HBM scratch (the
-// mpmath column sweep: same rhombus rules, same operands per entry as the forward's diagonal sweep), then walks the
-// columns back with the adjoints in a second region of the same scratch -- each adjoint stored once, assembled from rolling
-// registers as the sweep walks up a column (a first version zeroed the adjoints and read-modify-wrote them: 93 KB of HBM
-// traffic per row against 61.5 KB measured for this form, profiles/r3_pmc_new_ilt.json).  The scratch belongs to the launch: the
-// grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries are [entry][lane] so every access is
-// one 1-KB line per wavefront.  Bound: HBM traffic of the tape from a few ten thousand rows on (VALU-active 0.08), launch
-// latency of one long dependent chain below that.
+// e's, 8.4 KB per row at M = 16 -- so this kernel rebuilds the table column by column (the mpmath column sweep: same rhombus
+// rules, same operands per entry as the forward's diagonal sweep) and writes every entry ONCE to a value TAPE in HBM scratch,
+// then walks the columns back, reading every value ONCE.  Round 4: the term count is a template parameter, every loop is
+// unrolled and every register array is statically indexed, so
+//   * the forward sweep keeps its two live columns (q_r and e_(r-1)) in registers and only STORES to the tape (round 3 read
+//     the previous column back from it),
+//   * the backward sweep keeps its two live ADJOINT columns (qbar_(r+1) -> qbar_r in place, the parked ebar's) in registers
+//     (round 3 kept them in a second 9 KB-per-row region of the scratch: 61.5 KB of HBM traffic per row for a 19 KB tape),
+//   * the continued-fraction adjoint recurrence runs lazily, two steps before each column, so its seeds dbar_i never leave
+//     registers either.
+// What travels per row: the value tape (10 KB written + 10 KB read at M = 16), theta / phi in, both gradients out.
+// The scratch belongs to the launch: the grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries
+// are [entry][lane] so every access is one 1-KB line per wavefront.
 //
 // Adjoint convention: for a real loss L and a complex intermediate w, wbar = dL/dRe(w) + i dL/dIm(w); then for
 // holomorphic w = f(u): ubar += wbar conj(f'(u)).
@@ -26,38 +31,50 @@ namespace {
 struct DhLayout {
   int M;
   // value tape
-  __host__ __device__ int q(int r, int i) const { return (r - 1) * (2 * M + 2 - r) + i; }                 // r = 1..M, i = 0..2(M-r)+1
-  __host__ __device__ int e(int r, int i) const { return M * (M + 1) + (r - 1) * (2 * M + 1 - r) + i; }   // r = 1..M, i = 0..2(M-r)
-  __host__ __device__ int a(int i) const { return M * (M + 1) + M * M + i; }                              // i = 0..2M
-  __host__ __device__ int A(int i) const { return M * (M + 1) + M * M + (2 * M + 1) + (i + 1); }          // i = -1..2M-1
-  __host__ __device__ int B(int i) const { return M * (M + 1) + M * M + 2 * (2 * M + 1) + (i + 1); }      // i = -1..2M-1
-  __host__ __device__ int n_values() const { return M * (M + 1) + M * M + 3 * (2 * M + 1); }
-  // adjoints, offset by n_values(): qbar at q's index, parked ebar at e's index, the seeds dbar_i (i = 0..2M) behind them
-  __host__ __device__ int dbar(int i) const { return M * (M + 1) + M * M + i; }
-  __host__ __device__ int n_adjoints() const { return M * (M + 1) + M * M + (2 * M + 1); }
-  __host__ __device__ int entries() const { return n_values() + n_adjoints(); }
+  __host__ __device__ constexpr int q(int r, int i) const { return (r - 1) * (2 * M + 2 - r) + i; }                 // r = 1..M, i = 0..2(M-r)+1
+  __host__ __device__ constexpr int e(int r, int i) const { return M * (M + 1) + (r - 1) * (2 * M + 1 - r) + i; }   // r = 1..M, i = 0..2(M-r)
+  __host__ __device__ constexpr int a(int i) const { return M * (M + 1) + M * M + i; }                              // i = 0..2M
+  __host__ __device__ constexpr int A(int i) const { return M * (M + 1) + M * M + (2 * M + 1) + (i + 1); }          // i = -1..2M-1
+  __host__ __device__ constexpr int B(int i) const { return M * (M + 1) + M * M + 2 * (2 * M + 1) + (i + 1); }      // i = -1..2M-1
+  __host__ __device__ constexpr int entries() const { return M * (M + 1) + M * M + 3 * (2 * M + 1); }
 };
 
+// Tape accesses go through a wave-uniform (SGPR) slab pointer that is laundered at every access: the entry offsets are
+// compile-time constants of the unrolled sweeps, and left alone the compiler hoists ~1300 per-lane 64-bit addresses out of the
+// persistent block loop and spills them (6.8 KB of scratch per lane at M = 16); behind the asm statement every access is
+// `global_load / store_dwordx4 v, v_lane_offset, s[base + const]`.
+// (a slab entry is (re, im) = 16 bytes per lane; the two scalar accesses below merge into one dwordx4)
+typedef __attribute__((address_space(1))) double* tape_ptr;
+constexpr int64_t kTapeElemBytes = 16;
 struct Tape {
-  double2* base;  // this wavefront's slab, [entry][lane]
+  tape_ptr base;  // this wavefront's slab, [entry][lane][2]; wave-uniform
   int lane;
-  __device__ __forceinline__ cplx ld(int e) const {
-    const double2 v = base[(size_t)e * 64 + lane];
-    return {v.x, v.y};
+  __device__ __forceinline__ tape_ptr at(int e) const {
+    tape_ptr p = base + (size_t)e * 128;
+    asm volatile("" : "+s"(p));
+    return p;
   }
-  __device__ __forceinline__ void st(int e, cplx v) const { base[(size_t)e * 64 + lane] = make_double2(v.re, v.im); }
+  __device__ __forceinline__ cplx ld(int e) const {
+    const tape_ptr p = at(e);
+    return {p[2 * lane], p[2 * lane + 1]};
+  }
+  __device__ __forceinline__ void st(int e, cplx v) const {
+    const tape_ptr p = at(e);
+    p[2 * lane] = v.re;
+    p[2 * lane + 1] = v.im;
+  }
 };
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdArgs a) {
+template <int M>
+__global__ __launch_bounds__(64, 1) void ilt_dehoog_bwd_kernel(const IltDehoogBwdArgs a) {
+  constexpr int S = 2 * M + 1;
+  constexpr DhLayout L{M};
   const int lane = threadIdx.x;
-  const int M = (a.S - 1) / 2;
-  const DhLayout L{M};
-  const int nv = L.n_values();
   const int64_t rows_total = a.N * a.d;
   const int64_t nblk = (rows_total + 63) / 64;
-  const Tape tp{reinterpret_cast<double2*>(a.scratch) + (size_t)blockIdx.x * L.entries() * 64, lane};
+  const Tape tp{(tape_ptr)(reinterpret_cast<double*>(a.scratch) + (size_t)blockIdx.x * L.entries() * 128), lane};
   const cplx one = {1.0, 0.0}, zero = {0.0, 0.0};
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int64_t row = blk * 64 + lane;
@@ -67,13 +84,15 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
     const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
     const double ang = kPi * (t / Tt);
     const cplx z = {cos(ang), sin(ang)};
-    const double* th = a.theta + row * a.S;
-    const double* ph = a.phi + row * a.S;
+    const double* th = a.theta + row * S;
+    const double* ph = a.phi + row * S;
 
     // ---------------------------------------------------------------- forward, taped
     // a_k = F_k = R e^{i theta}, R = tan(phi/2 + pi/4); a_0 enters halved.  Column 1: q_1^(i) = a_{i+1} / a_i
+    cplx Q[2 * M], E[2 * M];  // the live columns: Q[i] = q_r^(i), E[i] = e_(r-1)^(i)
     {
       cplx prev = zero;
+#pragma unroll
       for (int k = 0; k <= 2 * M; ++k) {
         const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
         double sn, cs;
@@ -81,47 +100,63 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
         cplx ak = {rad * cs, rad * sn};
         if (k == 0) ak = cscale(ak, 0.5);
         tp.st(L.a(k), ak);
-        if (k > 0) tp.st(L.q(1, k - 1), cdiv(ak, prev));
+        if (k > 0) {
+          Q[k - 1] = cdiv(ak, prev);
+          tp.st(L.q(1, k - 1), Q[k - 1]);
+        }
         prev = ak;
       }
     }
-    for (int r = 1; r <= M; ++r) {
-      const int mr = 2 * (M - r) + 1;
-      // one pass up the column, the previous entries in registers:
-      //   e_r^(i)       = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)
-      //   q_(r+1)^(i-1) = q_r^(i) e_r^(i) / e_r^(i-1)                      (r < M, i >= 1)
-      cplx qlo = tp.ld(L.q(r, 0)), elo = zero;
-      for (int i = 0; i < mr; ++i) {
-        const cplx qhi = tp.ld(L.q(r, i + 1));
-        const cplx eprev = r > 1 ? tp.ld(L.e(r - 1, i + 1)) : zero;
-        const cplx ei = cadd(csub(qhi, qlo), eprev);
-        tp.st(L.e(r, i), ei);
-        if (r != M && i >= 1) tp.st(L.q(r + 1, i - 1), cdiv(cmul(qlo, ei), elo));
-        qlo = qhi;
-        elo = ei;
-      }
-    }
-    // continued fraction: d_0 = a_0, d_(2r-1) = -q_r^(0), d_(2r) = -e_r^(0);  A_i = A_(i-1) + d_i z A_(i-2)
-    auto dcoef = [&](int i) -> cplx {
-      if (i == 0) return tp.ld(L.a(0));
-      return cneg((i & 1) ? tp.ld(L.q((i + 1) / 2, 0)) : tp.ld(L.e(i / 2, 0)));
-    };
-    cplx A_prev = zero, A_cur = dcoef(0), B_prev = one, B_cur = one;
+#pragma unroll
+    for (int i = 0; i < 2 * M; ++i) E[i] = zero;
+    // continued fraction: d_0 = a_0, d_(2r-1) = -q_r^(0), d_(2r) = -e_r^(0);  A_i = A_(i-1) + d_i z A_(i-2), fed as the columns
+    // produce the coefficients
+    cplx A_prev = zero, A_cur = tp.ld(L.a(0)), B_prev = one, B_cur = one;
     tp.st(L.A(-1), A_prev);
     tp.st(L.A(0), A_cur);
     tp.st(L.B(-1), B_prev);
     tp.st(L.B(0), B_cur);
-    for (int i = 1; i <= 2 * M - 1; ++i) {
-      const cplx dz = cmul(dcoef(i), z);
-      const cplx An = cadd(A_cur, cmul(dz, A_prev)), Bn = cadd(B_cur, cmul(dz, B_prev));
-      A_prev = A_cur;
-      A_cur = An;
-      B_prev = B_cur;
-      B_cur = Bn;
-      tp.st(L.A(i), A_cur);
-      tp.st(L.B(i), B_cur);
+    cplx d_last = zero, d_end = zero;
+    auto feed = [&](int i, cplx di) {  // i = 1 .. 2M
+      d_last = d_end;
+      d_end = di;
+      if (i <= 2 * M - 1) {
+        const cplx dz = cmul(di, z);
+        const cplx An = cadd(A_cur, cmul(dz, A_prev)), Bn = cadd(B_cur, cmul(dz, B_prev));
+        A_prev = A_cur;
+        A_cur = An;
+        B_prev = B_cur;
+        B_cur = Bn;
+        tp.st(L.A(i), A_cur);
+        tp.st(L.B(i), B_cur);
+      }
+    };
+#pragma unroll
+    for (int r = 1; r <= M; ++r) {
+      const int mr = 2 * (M - r) + 1;
+      feed(2 * r - 1, cneg(Q[0]));
+      // one pass up the column, both live columns updated in place:
+      //   e_r^(i)       = q_r^(i+1) - q_r^(i) + e_(r-1)^(i+1)
+      //   q_(r+1)^(i-1) = q_r^(i) e_r^(i) / e_r^(i-1)                      (r < M, i >= 1)
+      cplx qlo = Q[0], elo = zero;
+#pragma unroll
+      for (int i = 0; i < mr; ++i) {
+        const cplx qhi = Q[i + 1];
+        const cplx ei = cadd(csub(qhi, qlo), E[i + 1]);
+        tp.st(L.e(r, i), ei);
+        if (r != M && i >= 1) {
+          Q[i - 1] = cdiv(cmul(qlo, ei), elo);
+          tp.st(L.q(r + 1, i - 1), Q[i - 1]);
+        }
+        E[i] = ei;
+        qlo = qhi;
+        elo = ei;
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      feed(2 * r, cneg(E[0]));
+      // (keeps the columns apart: the compiler otherwise interleaves them and the live ranges explode)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const cplx d_last = dcoef(2 * M - 1), d_end = dcoef(2 * M);
     const cplx brem = cscale(cadd(one, cmul(csub(d_last, d_end), z)), 0.5);
     const cplx uoverb = cdiv(cmul(d_end, z), brem);  // inner - 1
     const cplx sq = csqrt_(cadd(one, uoverb));
@@ -132,8 +167,6 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
     const cplx res = cdiv(An, Bn);
 
     // ---------------------------------------------------------------- backward
-    // Every adjoint is STORED ONCE (no zeroing, no read-modify-write): the seeds d_i-bar go to slots of their own, and
-    // a column's adjoints are assembled on the fly from rolling registers as the sweep walks up the column.
     const double G = a.gx[row] * (exp(gamma * t) / Tt);  // x = e^{gamma t} / T Re(res)
     const cplx g_res = {G, 0.0};
     // res = An / Bn
@@ -154,10 +187,9 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
     const cplx g_diff = cscale(cmul(g_brem, cconj(z)), 0.5);
     const cplx g_dlast = g_diff;
     g_dend = csub(g_dend, g_diff);
-    tp.st(nv + L.dbar(2 * M), g_dend);
-    // recurrence, i = 2M-1 .. 1
-    for (int i = 2 * M - 1; i >= 1; --i) {
-      const cplx di = dcoef(i);
+    // one step of the recurrence's adjoint, i = 2M-1 .. 1 (called in descending order): returns dbar_i
+    auto unfeed = [&](int i) -> cplx {
+      const cplx di = cneg((i & 1) ? tp.ld(L.q((i + 1) / 2, 0)) : tp.ld(L.e(i / 2, 0)));
       const cplx Am2 = tp.ld(L.A(i - 2)), Bm2 = tp.ld(L.B(i - 2));
       cplx g_di = cadd(cmul(gA1, cconj(cmul(z, Am2))), cmul(gB1, cconj(cmul(z, Bm2))));
       if (i == 2 * M - 1) g_di = cadd(g_di, g_dlast);
@@ -169,35 +201,46 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
       gA0 = gAm2;
       gB1 = gB0;
       gB0 = gBm2;
-      tp.st(nv + L.dbar(i), g_di);
-    }
-    // A_0 = d_0 = a_0 (A_(-1), B_0, B_(-1) are constants): d_0-bar = A_0-bar
-    const cplx g_a0_seed = gA1;
+      return g_di;
+    };
     // table, columns r = M .. 1.  With wbar_j = qbar_(r+1)^(j) (zero for r = M):
     //   ebar_r^(i) = [i = 0] (-dbar_2r) + ebar_(r+1)^(i-1)                                    (e_(r+1)^(i-1) = ... + e_r^(i))
     //               + wbar_(i-1) conj(q_r^(i) / e_r^(i-1)) - wbar_i conj(q_(r+1)^(i) / e_r^(i))   (q_(r+1) = q e_hi / e_lo)
     //   qbar_r^(i) = [i = 0] (-dbar_(2r-1)) + ebar_r^(i-1) - ebar_r^(i) + wbar_(i-1) conj(e_r^(i) / e_r^(i-1))
-    // ebar_(r+1)^(i-1) was parked in the slot of ebar_r^(i) by the sweep of column r + 1.
+    // W[i]: qbar_(r+1)^(i) on entry to column r, qbar_r^(i) on exit (in place).  P[i]: ebar_(r+1)^(i-1), parked by the sweep of
+    // column r + 1 in the slot of ebar_r^(i); the sweep of column r parks ebar_r^(i) in P[i + 1].
+    cplx W[2 * M], P[2 * M];
+#pragma unroll
+    for (int i = 0; i < 2 * M; ++i) {
+      W[i] = zero;
+      P[i] = zero;
+    }
+#pragma unroll
     for (int r = M; r >= 1; --r) {
       const int mr = 2 * (M - r) + 1;
       const bool inner = r != M;
+      const cplx dbar_even = r == M ? g_dend : unfeed(2 * r);  // dbar_(2r)
+      const cplx dbar_odd = unfeed(2 * r - 1);                 // dbar_(2r-1)
       cplx g_prev = zero, wbar_im1 = zero, e_im1 = one;
       cplx e_i = tp.ld(L.e(r, 0)), q_i = tp.ld(L.q(r, 0));
+      cplx park_in = zero;  // the old P[i] (read before the sweep overwrites it one iteration earlier)
+#pragma unroll
       for (int i = 0; i <= mr; ++i) {
         const bool has_e = i <= mr - 1;
         const bool has_w = inner && i <= mr - 2;  // q_(r+1)^(i) exists
         const cplx q_nxt = i + 1 <= mr ? tp.ld(L.q(r, i + 1)) : zero;
         const cplx e_nxt = i + 1 <= mr - 1 ? tp.ld(L.e(r, i + 1)) : one;
-        const cplx wbar_i = has_w ? tp.ld(nv + L.q(r + 1, i)) : zero;
+        const cplx wbar_i = has_w ? W[i] : zero;
+        const cplx park_nxt = (i + 1 < 2 * M) ? P[i + 1] : zero;  // old value, before this iteration parks into it
         cplx g = zero;
         cplx c_term = zero;  // wbar_(i-1) conj(e_r^(i) / e_r^(i-1))
         if (has_e) {
-          const double inv_i = m::rcp_refined(e_i.re * e_i.re + e_i.im * e_i.im);
+          const double inv_i = m::rcp_refined(fma(e_i.re, e_i.re, e_i.im * e_i.im));
           const cplx ie_i = {e_i.re * inv_i, -e_i.im * inv_i};  // 1 / e_r^(i)
-          if (i == 0) g = cneg(tp.ld(nv + L.dbar(2 * r)));
-          if (inner && i >= 1 && i <= mr - 2) g = cadd(g, tp.ld(nv + L.e(r, i)));  // parked ebar_(r+1)^(i-1)
+          if (i == 0) g = cneg(dbar_even);
+          if (inner && i >= 1 && i <= mr - 2) g = cadd(g, park_in);  // parked ebar_(r+1)^(i-1)
           if (inner && i >= 1) {
-            const double inv_m = m::rcp_refined(e_im1.re * e_im1.re + e_im1.im * e_im1.im);
+            const double inv_m = m::rcp_refined(fma(e_im1.re, e_im1.re, e_im1.im * e_im1.im));
             const cplx ie_m = {e_im1.re * inv_m, -e_im1.im * inv_m};  // 1 / e_r^(i-1)
             g = cadd(g, cmul(wbar_im1, cconj(cmul(q_i, ie_m))));
             c_term = cmul(wbar_im1, cconj(cmul(e_i, ie_m)));
@@ -209,24 +252,35 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
           }
         }
         cplx qb = csub(cadd(g_prev, c_term), g);
-        if (i == 0) qb = csub(qb, tp.ld(nv + L.dbar(2 * r - 1)));
-        tp.st(nv + L.q(r, i), qb);
-        if (has_e && r > 1) tp.st(nv + L.e(r - 1, i + 1), g);
+        if (i == 0) qb = csub(qb, dbar_odd);
+        W[i] = qb;
+        if (has_e && r > 1 && i + 1 < 2 * M) P[i + 1] = g;
+        park_in = park_nxt;
         g_prev = g;
         wbar_im1 = wbar_i;
         e_im1 = e_i;
         e_i = e_nxt;
         q_i = q_nxt;
+        // (the tape loads of at most eight iterations are in flight at a time: sixteen 1-KB lines per wavefront)
+        if ((i & 7) == 7) {
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // A_0 = d_0 = a_0 (A_(-1), B_0, B_(-1) are constants): d_0-bar = A_0-bar
+    const cplx g_a0_seed = gA1;
     // column 1 (q_1^(i) = a_(i+1) / a_i) and the sphere map, per term k:
     //   abar_k = [k = 0] dbar_0 + h_(k-1) - h_k conj(q_1^(k)),  h_k = qbar_1^(k) / conj(a_k)  (k <= 2M-1)
     //   F_k = R (cos theta + i sin theta), R = tan(phi/2 + pi/4), dR/dphi = (1 + R^2) / 2;  a_0 = F_0 / 2
     cplx h_prev = zero;
+#pragma unroll
     for (int k = 0; k <= 2 * M; ++k) {
       cplx gF = k == 0 ? g_a0_seed : h_prev;
       if (k <= 2 * M - 1) {
-        const cplx h = cdiv(tp.ld(nv + L.q(1, k)), cconj(tp.ld(L.a(k))));
+        const cplx h = cdiv(W[k], cconj(tp.ld(L.a(k))));
         gF = csub(gF, cmul(h, cconj(tp.ld(L.q(1, k)))));
         h_prev = h;
       }
@@ -234,18 +288,20 @@ __global__ __launch_bounds__(64) void ilt_dehoog_bwd_kernel(const IltDehoogBwdAr
       const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
       double sn, cs;
       m::sincos_bounded(th[k], &sn, &cs);
-      a.gtheta[row * a.S + k] = rad * (gF.im * cs - gF.re * sn);
-      a.gphi[row * a.S + k] = (gF.re * cs + gF.im * sn) * (0.5 * (1.0 + rad * rad));
+      a.gtheta[row * S + k] = rad * (gF.im * cs - gF.re * sn);
+      a.gphi[row * S + k] = (gF.re * cs + gF.im * sn) * (0.5 * (1.0 + rad * rad));
     }
   }
 }
 
+// One wavefront per SIMD (the two adjoint columns alone are 256 VGPRs at M = 16: launch bounds (64, 1), accumulation registers
+// as overflow), i.e. four workgroups per CU hold a slab: 1024 x 642 KB = 0.66 GB at 33 terms (round 3 took 2.5 GB).
 int64_t ilt_dehoog_bwd_scratch_bytes(int64_t N, int d, int S, unsigned* grid_out) {
   const int64_t nblk = (N * d + 63) / 64;
-  const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
+  const unsigned grid = (unsigned)(nblk < 1024 ? nblk : 1024);
   if (grid_out) *grid_out = grid;
   const DhLayout L{(S - 1) / 2};
-  return (int64_t)grid * L.entries() * 64 * (int64_t)sizeof(double2);
+  return (int64_t)grid * L.entries() * 64 * kTapeElemBytes;
 }
 
 hipError_t launch_ilt_dehoog_bwd(const IltDehoogBwdArgs& a, hipStream_t s) {
@@ -253,7 +309,17 @@ hipError_t launch_ilt_dehoog_bwd(const IltDehoogBwdArgs& a, hipStream_t s) {
   if (a.S < 3 || a.S > 33 || (a.S & 1) == 0 || !a.scratch) return hipErrorInvalidValue;
   unsigned grid = 0;
   ilt_dehoog_bwd_scratch_bytes(a.N, a.d, a.S, &grid);
-  hipLaunchKernelGGL(ilt_dehoog_bwd_kernel, dim3(grid), dim3(64), 0, s, a);
+  switch ((a.S - 1) / 2) {
+#define NLC_DHB(MM)                                                                              \
+  case MM:                                                                                       \
+    hipLaunchKernelGGL((ilt_dehoog_bwd_kernel<MM>), dim3(grid), dim3(64), 0, s, a);              \
+    break;
+    NLC_DHB(1) NLC_DHB(2) NLC_DHB(3) NLC_DHB(4) NLC_DHB(5) NLC_DHB(6) NLC_DHB(7) NLC_DHB(8)
+    NLC_DHB(9) NLC_DHB(10) NLC_DHB(11) NLC_DHB(12) NLC_DHB(13) NLC_DHB(14) NLC_DHB(15) NLC_DHB(16)
+#undef NLC_DHB
+    default:
+      return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -6,8 +6,10 @@
 // Here a workgroup of eight wavefronts OWNS 64 consecutive samples (four 16-sample MFMA tiles) for the whole horizon and walks
 // their chain alone: no inter-workgroup dependency exists (samples are independent; the GRU latents come from the hoisted
 // encode launch), so the only synchronisation is the workgroup barrier.  Per horizon step:
-//   phase A   the representation MLP of the four tiles, two at a time (waves 0-3 and 4-7 each split one tile: repfunc_split_tile,
-//             the staged path's own code), F_k written slot-major into the workgroup's private (8 nt3) x 64 block;
+//   phase A   the representation MLP of the four tiles in ONE pass (repfunc_block_mlp: wave w owns output tile w of the hidden
+//             layers and tiles w, w + 8, w + 16 of layer 3 for all four sample tiles, so a weight fragment fetched from L2 feeds
+//             four MFMAs; same MFMA sequence per tile and same activations as the staged path's repfunc_split_tile), F_k written
+//             slot-major into the workgroup's private (8 nt3) x 64 block;
 //   phase B   the QD table: wave p < d owns dim p of the 64 samples (dehoog_row, the staged path's own code; every load one
 //             full 512-B line of the block, which this CU wrote a few microseconds ago), dx added to the state in LDS;
 //   tail      wave 0, one lane per sample: state store, running cost and perturbation cost of the step (StepTailArgs semantics).
@@ -25,13 +27,12 @@ template <int NT3, int M>
 __global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogChainArgs a) {
   constexpr int HT = 8, KS = HT * 4, S = 2 * M + 1;
   constexpr int CH = M > 8 ? M + 1 : 9;  // terms fetched at a time (as ilt_dehoog_kernel)
-  __shared__ double H1[2][KS * 64], H2[2][KS * 64];
+  __shared__ double H1[4][KS * 64], H2[4][KS * 64];
   __shared__ double XS[64 * NLC_MAX_D];  // the block's states, [sample][dim]
   const NlNetArgs& n = a.net;
   const int d = n.d;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wave >> 2, wv = wave & 3;
   const int64_t nblk = (a.K + 63) / 64;
   const double t = a.tn;
   const double Tt = n.scale * t;
@@ -52,29 +53,34 @@ __global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogCha
     double cost = 0.0, pcost = 0.0;  // wave 0: lane = sample
     __syncthreads();
     for (int t_h = 0; t_h < a.T; ++t_h) {
-      // ---- phase A: representation function of tiles grp and grp + 2 of the block
-      const int q = lane >> 4, c = lane & 15, i0 = q, i1 = 4 + q;
-#pragma unroll 1
-      for (int round = 0; round < 2; ++round) {
-        const int kb = (2 * round + grp) * 16 + c;           // sample within the block
-        const bool valid = kb < rows_here;
-        const int kc = valid ? kb : rows_here - 1;
-        const double* pa = a.pa + ((size_t)(k0 + kc) * a.T + t_h) * 2;
-        const double* xr = XS + kc * NLC_MAX_D;
-        const double x0 = (i0 < d) ? xr[i0] : 0.0, x1 = (i1 < d) ? xr[i1] : 0.0;
-        const double p0 = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0]
-                                   : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
-        const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
-                                   : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
-        repfunc_split_mlp<HT, NT3>(n, p0, p1, valid, (int64_t)kb, (int64_t)64, a.slot, fre, fim, H1[grp], H2[grp], wv, lane, []() {});
-        __syncthreads();  // (the group's LDS images are free again; after the second round: F is complete)
+      // ---- phase A: representation function of the block's four tiles in one pass (every weight fragment feeds four MFMAs)
+      if (a.phases & 1) {
+        const int q = lane >> 4, c = lane & 15, i0 = q, i1 = 4 + q;
+        double p0[4], p1[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const int kb = 16 * s2 + c;  // sample within the block
+          const int kc = kb < rows_here ? kb : rows_here - 1;
+          const double* pa = a.pa + ((size_t)(k0 + kc) * a.T + t_h) * 2;
+          const double* xr = XS + kc * NLC_MAX_D;
+          const double x0 = (i0 < d) ? xr[i0] : 0.0, x1 = (i1 < d) ? xr[i1] : 0.0;
+          p0[s2] = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0] : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
+          p1[s2] = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1] : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+        }
+        repfunc_block_mlp<NT3>(n, p0, p1, rows_here, a.slot, fre, fim, &H1[0][0], &H2[0][0], wave, lane);
+        __syncthreads();  // F is complete
       }
       // ---- phase B: one wavefront per state dim, one lane per sample
-      if (wave < d) {
+      if (wave < d && (a.phases & 2)) {
         DehoogSlotTerms<CH> src{fre, fim, a.eidx + wave * S, (int64_t)64, (int64_t)(lane < rows_here ? lane : 0), {}};
         const cplx res = dehoog_row<M, CH>(src, z);
-        const double dx = exp(gamma * t) / Tt * res.re;
-        XS[lane * NLC_MAX_D + wave] = XS[lane * NLC_MAX_D + wave] + dx;  // mppi_with_model.py:120-121
+        {
+          // dx is a ROUNDED product, as the staged path's ilt_dehoog_kernel stores it, and the update a separate addition
+          // (left contractable, x + (e^{gamma t} / T) Re(res) becomes one fused multiply-add: states off by an ulp per step)
+#pragma clang fp contract(off)
+          const double dx = exp(gamma * t) / Tt * res.re;
+          XS[lane * NLC_MAX_D + wave] = XS[lane * NLC_MAX_D + wave] + dx;  // mppi_with_model.py:120-121
+        }
       }
       __syncthreads();
       // ---- tail of the step (wave 0; the other waves go on to the next step's phase A, which only reads XS)
@@ -87,16 +93,8 @@ __global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogCha
           for (int i = 0; i < d; ++i) a.states[(k * a.T + t_h) * d + i] = x[i];
         double u[NLC_MAX_NU] = {0.0, 0.0};
         for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(k * a.T + t_h) * a.nu + j];
-        double pc = 0.0;
-        for (int j = 0; j < a.nu; ++j) {
-          double acj = 0.0;
-          for (int ii = 0; ii < a.nu; ++ii) {
-            double ev = a.noise[(k * a.T + t_h) * a.nu + ii];
-            if (a.noise_abs_cost) ev = fabs(ev);
-            acj += (a.lambda_ * ev) * a.sigma_inv[ii * a.nu + j];
-          }
-          pc += a.U[t_h * a.nu + j] * acj;
-        }
+        const double pc = perturbation_cost_step(a.noise + (k * a.T + t_h) * a.nu, a.U + t_h * a.nu, a.sigma_inv, a.lambda_, a.nu,
+                                                 a.noise_abs_cost);
         cost = cost + running_cost(a.env, x, u, a.nu);
         pcost = pcost + pc;
       }

@@ -574,44 +574,4 @@ hipError_t launch_rnn_rollout(const RnnRolloutArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ per-step tail of the staged (de Hoog) planner path
-// x <- x + dx (mppi_with_model.py:120-121), store, running cost and perturbation cost of horizon step t.
-__global__ __launch_bounds__(256) void step_tail_kernel(const StepTailArgs a) {
-  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= a.K) return;
-  double x[NLC_MAX_D];
-  const int64_t e = k / a.Kep;
-  const double* src = a.first ? a.state0 + (a.state_per_sample ? k : e) * a.d : a.x + k * a.d;
-  for (int i = 0; i < a.d; ++i) {
-    x[i] = src[i] + a.dx[k * a.d + i];
-    a.x[k * a.d + i] = x[i];
-    if (a.states != nullptr) a.states[(k * a.T + a.t) * a.d + i] = x[i];
-  }
-  double u[NLC_MAX_NU];
-  for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(k * a.T + a.t) * a.nu + j];
-  double pc = 0.0;
-  for (int j = 0; j < a.nu; ++j) {
-    double acj = 0.0;
-    for (int ii = 0; ii < a.nu; ++ii) {
-      double e = a.noise[(k * a.T + a.t) * a.nu + ii];
-      if (a.noise_abs_cost) e = fabs(e);
-      acj += (a.lambda_ * e) * a.sigma_inv[ii * a.nu + j];
-    }
-    pc += a.U[(e * a.T + a.t) * a.nu + j] * acj;
-  }
-  const double cost = (a.first ? 0.0 : a.ccarry[k * 2]) + running_cost_o(a.env, x, u, a.nu);
-  const double pcost = (a.first ? 0.0 : a.ccarry[k * 2 + 1]) + pc;
-  if (a.last) {
-    a.cost_total[k] = cost + pcost;
-  } else {
-    a.ccarry[k * 2] = cost;
-    a.ccarry[k * 2 + 1] = pcost;
-  }
-}
-hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s) {
-  if (a.K <= 0) return hipSuccess;
-  hipLaunchKernelGGL(step_tail_kernel, dim3((unsigned)((a.K + 255) / 256)), dim3(256), 0, s, a);
-  return hipGetLastError();
-}
-
 }  // namespace nlc

@@ -104,6 +104,42 @@ hipError_t launch_nl_repfunc_h128(const RepFuncArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ per-step tail of the staged (de Hoog) planner path
+// x <- x + dx (mppi_with_model.py:120-121), store, running cost and perturbation cost of horizon step t.  The staged path runs
+// this launch for the LAST step only (the tails of the steps before ride in the next representation launch, nlc_rollout.h); it
+// lives in this translation unit -- not in kernels_mppi.hip, which is built without a*b+c contraction -- so that every step's
+// cost is the same arithmetic (round 4: the persistent step chain is tested bit for bit against this path).
+__global__ __launch_bounds__(256) void step_tail_kernel(const StepTailArgs a) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.K) return;
+  double x[NLC_MAX_D];
+  const int64_t e = k / a.Kep;
+  const double* src = a.first ? a.state0 + (a.state_per_sample ? k : e) * a.d : a.x + k * a.d;
+  for (int i = 0; i < a.d; ++i) {
+    x[i] = src[i] + a.dx[k * a.d + i];
+    a.x[k * a.d + i] = x[i];
+    if (a.states != nullptr) a.states[(k * a.T + a.t) * a.d + i] = x[i];
+  }
+  double u[NLC_MAX_NU] = {0.0, 0.0};
+  for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(k * a.T + a.t) * a.nu + j];
+  const double pc = perturbation_cost_step(a.noise + (k * a.T + a.t) * a.nu, a.U + (e * a.T + a.t) * a.nu, a.sigma_inv, a.lambda_,
+                                           a.nu, a.noise_abs_cost);
+  const double cost = (a.first ? 0.0 : a.ccarry[k * 2]) + running_cost(a.env, x, u, a.nu);
+  const double pcost = (a.first ? 0.0 : a.ccarry[k * 2 + 1]) + pc;
+  if (a.last) {
+    a.cost_total[k] = cost + pcost;
+  } else {
+    a.ccarry[k * 2] = cost;
+    a.ccarry[k * 2 + 1] = pcost;
+  }
+}
+hipError_t launch_step_tail(const StepTailArgs& a, hipStream_t s) {
+  if (a.K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(step_tail_kernel, dim3((unsigned)((a.K + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+
 int nl_pick_nt3(int need) {
 #define X(N) \
   if (need <= N) return N;

@@ -35,6 +35,7 @@ struct DehoogSlotTerms {
 // Returns A_2M / B_2M, the continued fraction with the improved remainder; the caller scales Re by e^{gamma t} / T.
 template <int M, int CH, class SRC>
 __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
+#pragma clang fp contract(off)
   constexpr int S = 2 * M + 1;
   cplx D[2 * M];
   cplx a_prev = {0.0, 0.0}, d0 = {0.0, 0.0};

@@ -18,6 +18,8 @@ __device__ __forceinline__ double trig2angle(double c, double s) {
 
 __device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MAX_D], const double (&u)[NLC_MAX_NU],
                                                int nu) {
+  // a*b+c is a multiply and an add here, as in the torch-CPU op order (and the same bits in every kernel that inlines this)
+#pragma clang fp contract(off)
   if (env < 0) return 0.0;  // cost_external: the caller evaluates its own running cost on the stored states
   double uu = 0.0;
   for (int j = 0; j < nu; ++j) uu += u[j] * u[j];
@@ -50,6 +52,24 @@ __device__ __forceinline__ double running_cost(int env, const double (&x)[NLC_MA
     const double state_reward = -(ex * ex) - p2y * p2y;
     return -((state_reward + 1e-1 * vel_reward) + (-1e-4 * uu));
   }
+}
+
+// perturbation cost of one horizon step: sum_j U[t,j] (lambda eps Sigma^-1)[j]   (planners/mppi_delay.py:335, 343).
+// eps / U: the step's nu entries.  Used by every tail of the de Hoog planner path (staged launches and the persistent chain).
+__device__ __forceinline__ double perturbation_cost_step(const double* eps, const double* U, const double* sigma_inv,
+                                                         double lambda_, int nu, int noise_abs_cost) {
+#pragma clang fp contract(off)
+  double pc = 0.0;
+  for (int j = 0; j < nu; ++j) {
+    double acj = 0.0;
+    for (int ii = 0; ii < nu; ++ii) {
+      double ev = eps[ii];
+      if (noise_abs_cost) ev = fabs(ev);
+      acj += (lambda_ * ev) * sigma_inv[ii * nu + j];
+    }
+    pc += U[j] * acj;
+  }
+  return pc;
 }
 
 }  // namespace nlc

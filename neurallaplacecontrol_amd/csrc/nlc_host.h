@@ -128,6 +128,7 @@ struct nlc_ctx {
   hipStream_t gru_stream = nullptr;
   std::vector<hipEvent_t> ev_gru;
   int opt_dehoog_chain = -1;            // de Hoog planner: the step chain as one persistent launch (kernels_dehoog_chain.hip): -1 auto, 0 / 1
+  int opt_dehoog_chain_phases = 3;      // tools only: 1 / 2 = only the representation / QD phase of the chain kernel runs (timing)
   int opt_dehoog_streams = 0;           // staged de Hoog planner: parts of the population on streams of their own (0 auto)
   std::vector<hipStream_t> aux_streams;
   hipEvent_t ev_fork = nullptr;
@@ -143,6 +144,7 @@ struct nlc_ctx {
   int opt_fused_inline = 3;             // fused body: sampling / bounding and the weight reduction inside the launch
   int64_t opt_fused_spin_limit = 1 << 18;  // polls (~2 us each) before a waiting wave of the fused body gives up (~0.5 s)
   int opt_fused_test_drop_tile = -1;    // tests only: this encoder tile is never published (forces the timeout path)
+  double opt_test_lin_coeff_scale = 1.0;  // tests only: the largest w_re / t coefficient of the LIN fragments is scaled by this
   int opt_linear_fused = 1;             // fixed Talbot / Stehfest models: LIN instances of the rollout kernels
                                         // (0: the staged path)
   double* cp_lin = nullptr;             // [2][2 nt3][64] device: w_re / t and -w_im / t coefficient fragments (configure time)

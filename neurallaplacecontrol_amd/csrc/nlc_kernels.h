@@ -342,6 +342,7 @@ struct DehoogChainArgs {
   double* fim;
   double* states;           // (K, T, d) or NULL
   double* cost_total;       // (K)
+  int phases;               // 3; tools only: 1 = the representation phase alone, 2 = the QD phase alone (timing breakdown)
 };
 hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, unsigned grid, hipStream_t s);
 bool nl_dehoog_chain_available(int h, int nt3, int S);

@@ -175,16 +175,8 @@ __global__ __launch_bounds__(256) void nl_repfunc_kernel(const RepFuncArgs a) {
       if (q == 0 && valid) {
         double u[NLC_MAX_NU] = {0.0, 0.0};
         for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
-        double pc = 0.0;
-        for (int j = 0; j < s.nu; ++j) {
-          double acj = 0.0;
-          for (int ii = 0; ii < s.nu; ++ii) {
-            double ev = s.noise[(k * s.T + s.t) * s.nu + ii];
-            if (s.noise_abs_cost) ev = fabs(ev);
-            acj += (s.lambda_ * ev) * s.sigma_inv[ii * s.nu + j];
-          }
-          pc += s.U[(e * s.T + s.t) * s.nu + j] * acj;
-        }
+        const double pc = perturbation_cost_step(s.noise + (k * s.T + s.t) * s.nu, s.U + (e * s.T + s.t) * s.nu, s.sigma_inv,
+                                                 s.lambda_, s.nu, s.noise_abs_cost);
         s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
         s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
       }

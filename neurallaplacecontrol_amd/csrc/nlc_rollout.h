@@ -39,6 +39,22 @@ __device__ __forceinline__ double sphere_term(double theta, double phi, bool odd
   return (num * trig) * m::rcp_refined(den);
 }
 
+// The module's two angles from the raw layer-3 outputs (w_nl.py:59-62) and the tangent's argument, with every product and sum a
+// separate operation (a saturated phi must be EXACTLY pi/2 to reproduce the reference's clamped |F|, and the de Hoog path's
+// kernels -- staged launches, persistent chain -- must agree to the bit whatever the compiler would fuse around them).
+__device__ __forceinline__ double sphere_theta(double y) {
+#pragma clang fp contract(off)
+  return m::tanh_d(y) * kPi;
+}
+__device__ __forceinline__ double sphere_phi(double y) {
+#pragma clang fp contract(off)
+  return m::tanh_d(y) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
+}
+__device__ __forceinline__ double sphere_tan_arg(double phi) {
+#pragma clang fp contract(off)
+  return phi / 2.0 + kPi / 4.0;
+}
+
 // LIN instances (fixed Talbot / Stehfest): both components of F = R e^{i theta}
 __device__ __forceinline__ void sphere_terms_lin(double theta, double phi, double* rc, double* rs) {
   const m::IltTrigK K = m::ilt_trig_k();
@@ -142,11 +158,11 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
       for (int r = 0; r < 2; ++r) {
         const int g = 2 * j + r;
         // (not paired: a saturated phi must be EXACTLY pi/2 to reproduce the reference's clamped |F|)
-        const double theta = m::tanh_d(o[jj][r]) * kPi;                               // w_nl.py:59
-        const double phi = m::tanh_d(o[jj][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;  // w_nl.py:60-62
+        const double theta = sphere_theta(o[jj][r]);    // w_nl.py:59
+        const double phi = sphere_phi(o[jj][r + 2]);    // w_nl.py:60-62
         // |F| (cos theta | sin theta) = num/den * cos(theta - [odd] pi/2); the division is folded into the product
         double num, den;
-        m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+        m::tan_parts_0_halfpi(sphere_tan_arg(phi), &num, &den);
         if constexpr (WRITE_F) {
           const int idx = fo->slot[4 * g + q];
           if (fo->row >= 0 && idx >= 0 && fo->angles) {
@@ -565,10 +581,10 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
         for (int r = 0; r < 2; ++r) {
           const int g = 2 * j3[i] + r;
           // (same arithmetic as nl_eval's WRITE_F branch)
-          const double theta = m::tanh_d(o[i][r]) * kPi;
-          const double phi = m::tanh_d(o[i][r + 2]) * kPi / 2.0 - kPi / 2.0 + kPi / 2.0;
+          const double theta = sphere_theta(o[i][r]);
+          const double phi = sphere_phi(o[i][r + 2]);
           double num, den;
-          m::tan_parts_0_halfpi(phi / 2.0 + kPi / 4.0, &num, &den);
+          m::tan_parts_0_halfpi(sphere_tan_arg(phi), &num, &den);
           const int idx = slot[4 * g + q];
           if (valid && idx >= 0) {
             double sn, cs;
@@ -579,6 +595,152 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
             fim[at] = rad * sn;
           }
         }
+      }
+    }
+  }
+}
+
+// The same MLP for FOUR 16-sample tiles at once by a workgroup of EIGHT waves (hidden_units 128: HT = 8), the form the persistent
+// de Hoog step chain uses (kernels_dehoog_chain.hip): wave w owns output tile w of layers 1 and 2 and output tiles w, w + 8,
+// w + 16 of layer 3 -- for all four sample tiles, so every weight fragment fetched from L2 feeds four MFMAs instead of one (the
+// 4-wave form streams the whole 466 KB weight set once per 16 samples).  Per output tile and sample tile the MFMA sequence over
+// k is the one of repfunc_split_mlp and the activations are the same functions: the F values are the same bits.
+// p0 / p1 [s]: layer-1 fragments of sample tile s for this lane's column; column of sample (s, c) in the F block: 16 s + c.
+// H1 / H2: [4][32 * 64] LDS images.  Two workgroup barriers.
+template <int NT3>
+__device__ __forceinline__ void repfunc_block_mlp(const NlNetArgs& n, const double (&p0)[4], const double (&p1)[4],
+                                                  const int rows_here, const int* __restrict__ slot, double* __restrict__ fre,
+                                                  double* __restrict__ fim, double* __restrict__ H1, double* __restrict__ H2,
+                                                  const int wave, const int lane) {
+  constexpr int HT = 8, KS = 32, NS = 4;
+  constexpr int NTW = (NT3 + 7) / 8;  // layer-3 output tiles per wave (tile j = wave + 8 i)
+  const int q = lane >> 4, c = lane & 15;
+  // ---- layer 1: output tile `wave`
+  {
+    v4d acc[NS];
+    const v4d bias = load_bias_tile((const double*)opaque(n.b1), wave, q);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) acc[s2] = bias;
+    gptr p = opaque(n.W1p + (size_t)wave * 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const double a = p[(ks * HT) * 64 + lane];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) acc[s2] = mfma(a, ks == 0 ? p0[s2] : p1[s2], acc[s2]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        NLC_HIDDEN_TANH_PAIR(acc[s2][r], acc[s2][r + 1], &ta, &tb);
+        H1[s2 * KS * 64 + (4 * wave + r) * 64 + lane] = ta;
+        H1[s2 * KS * 64 + (4 * wave + r + 1) * 64 + lane] = tb;
+      }
+  }
+  __syncthreads();
+  // ---- layer 2: output tile `wave`
+  {
+    v4d acc[NS];
+    const v4d bias = load_bias_tile((const double*)opaque(n.b2), wave, q);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) acc[s2] = bias;
+    gptr p = opaque(n.W2p + (size_t)wave * 64);
+    double a_cur = p[lane], a_nxt = 0.0;
+    double b_cur[NS], b_nxt[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      b_cur[s2] = H1[s2 * KS * 64 + lane];
+      b_nxt[s2] = 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + HT * 64);
+        a_nxt = p[lane];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) b_nxt[s2] = H1[s2 * KS * 64 + (ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) acc[s2] = mfma(a_cur, b_cur[s2], acc[s2]);
+      a_cur = a_nxt;
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) b_cur[s2] = b_nxt[s2];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        NLC_HIDDEN_TANH_PAIR(acc[s2][r], acc[s2][r + 1], &ta, &tb);
+        H2[s2 * KS * 64 + (4 * wave + r) * 64 + lane] = ta;
+        H2[s2 * KS * 64 + (4 * wave + r + 1) * 64 + lane] = tb;
+      }
+  }
+  __syncthreads();
+  // ---- layer 3 (own tiles, all four sample tiles) + sphere -> complex, F_k stored slot-major
+  {
+    int j3[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) j3[i] = (wave + 8 * i < NT3) ? wave + 8 * i : NT3 - 1;
+    v4d o[NTW][NS];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const v4d bias = load_bias_tile((const double*)opaque(n.b3p), j3[i], q);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) o[i][s2] = bias;
+    }
+    gptr p = opaque(n.W3p);
+    double a_cur[NTW], a_nxt[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
+    double b_cur[NS], b_nxt[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      b_cur[s2] = H2[s2 * KS * 64 + lane];
+      b_nxt[s2] = 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + NT3 * 64);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) b_nxt[s2] = H2[s2 * KS * 64 + (ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) o[i][s2] = mfma(a_cur[i], b_cur[s2], o[i][s2]);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) b_cur[s2] = b_nxt[s2];
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (wave + 8 * i < NT3) {  // wave-uniform
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int g = 2 * j3[i] + r;
+            // (same arithmetic as repfunc_split_mlp / nl_eval's WRITE_F branch)
+            const double theta = sphere_theta(o[i][s2][r]);
+            const double phi = sphere_phi(o[i][s2][r + 2]);
+            double num, den;
+            m::tan_parts_0_halfpi(sphere_tan_arg(phi), &num, &den);
+            const int idx = slot[4 * g + q];
+            if (16 * s2 + c < rows_here && idx >= 0) {
+              double sn, cs;
+              m::sincos_bounded(theta, &sn, &cs);
+              const double rad = num * m::rcp_refined(den);
+              const int64_t at = (int64_t)(4 * g + q) * 64 + 16 * s2 + c;
+              fre[at] = rad * cs;
+              fim[at] = rad * sn;
+            }
+          }
       }
     }
   }
@@ -621,16 +783,8 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
       if (q == 0 && valid) {
         double u[NLC_MAX_NU] = {0.0, 0.0};
         for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
-        double pc = 0.0;
-        for (int j = 0; j < s.nu; ++j) {
-          double acj = 0.0;
-          for (int ii = 0; ii < s.nu; ++ii) {
-            double ev = s.noise[(k * s.T + s.t) * s.nu + ii];
-            if (s.noise_abs_cost) ev = fabs(ev);
-            acj += (s.lambda_ * ev) * s.sigma_inv[ii * s.nu + j];
-          }
-          pc += s.U[(e * s.T + s.t) * s.nu + j] * acj;
-        }
+        const double pc = perturbation_cost_step(s.noise + (k * s.T + s.t) * s.nu, s.U + (e * s.T + s.t) * s.nu, s.sigma_inv,
+                                                 s.lambda_, s.nu, s.noise_abs_cost);
         s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
         s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
       }

@@ -337,9 +337,10 @@ def test_dehoog_step_chain_kernel_bit_identical_to_staged_path(nlc, env, K, T, S
     for step in range(2 if K > 10000 else 3):
         with torch.no_grad():
             acts = {ch: p.command(state, ab) for ch, p in planners.items()}
+        for attr in ("perturbed_action", "states", "cost_total", "omega", "U"):
+            x0, x1 = getattr(planners[0], attr), getattr(planners[1], attr)
+            assert torch.equal(x0, x1), (attr, step, float((x0 - x1).abs().max()))
         assert torch.equal(acts[0], acts[1]) and bool(torch.isfinite(acts[1]).all()), step
-        for attr in ("states", "cost_total", "omega", "U", "perturbed_action"):
-            assert torch.equal(getattr(planners[0], attr), getattr(planners[1], attr)), (attr, step)
         ab = torch.roll(ab, -1, 0)
         ab[-1] = acts[0].view(-1, nu)[0]
     planners[1].ctx.profile(False)

@@ -31,6 +31,12 @@ done
 timeout -k 10 200 rocprofv3 --pmc $PMC_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_cfg5_pmc_mfma -- python3 tools/cfg5_breakdown.py > /dev/null 2>&1 || echo "cfg5 mfma pass failed"
 timeout -k 10 200 rocprofv3 --pmc $PMC_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_k2048_pmc_mfma -- python3 tools/fused_pmc.py > /dev/null 2>&1 || echo "k2048 mfma pass failed"
 python tools/pmc_summarize.py --commit "$COMMIT" --device "$DEV" $OUT/${TAG}_cfg5_pmc_FETCH_SIZE $OUT/${TAG}_cfg5_pmc_WRITE_SIZE $OUT/${TAG}_cfg5_pmc_mfma > $OUT/${TAG}_pmc_cfg5.json
+# round 4: the same planner on the persistent step-chain kernel (option dehoog_chain = 1)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_chain_pmc_$C -- python3 tools/cfg5_chain_pmc.py > /dev/null 2>&1 || echo "chain pmc $C failed"
+done
+timeout -k 10 200 rocprofv3 --pmc $PMC_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_chain_pmc_mfma -- python3 tools/cfg5_chain_pmc.py > /dev/null 2>&1 || echo "chain mfma pass failed"
+python tools/pmc_summarize.py --commit "$COMMIT" --device "$DEV" $OUT/${TAG}_chain_pmc_FETCH_SIZE $OUT/${TAG}_chain_pmc_WRITE_SIZE $OUT/${TAG}_chain_pmc_mfma > $OUT/${TAG}_pmc_cfg5_chain.json
 python tools/pmc_summarize.py --commit "$COMMIT" --device "$DEV" $OUT/${TAG}_k2048_pmc_FETCH_SIZE $OUT/${TAG}_k2048_pmc_WRITE_SIZE $OUT/${TAG}_k2048_pmc_mfma > $OUT/${TAG}_pmc_k2048.json
 timeout -k 10 120 python tools/cfg5_breakdown.py > $OUT/${TAG}_cfg5_breakdown.txt 2>/dev/null
 timeout -k 10 200 python tools/fused_probe.py 2048 4096 > $OUT/${TAG}_fused_probe.jsonl 2>/dev/null

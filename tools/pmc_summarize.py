@@ -14,7 +14,7 @@ import glob
 import json
 import sys
 
-KEYS = ("gru_encode", "nl_plan_fused", "nl_rollout", "nl_repfunc", "ilt_fourier_bwd", "ilt_fourier", "ilt_dehoog_bwd", "ilt_dehoog",
+KEYS = ("gru_encode", "nl_plan_fused", "nl_rollout", "nl_repfunc", "nl_dehoog_chain", "ilt_fourier_bwd", "ilt_fourier", "ilt_dehoog_bwd", "ilt_dehoog",
         "ilt_linear_slot", "ilt_linear_bwd", "ilt_linear", "perturb",
         "weight_tile", "weight_rank", "weight_chunk", "weight_final", "oracle_rollout", "rnn_encode", "rnn_rollout", "merge", "step_tail")
 
