@@ -125,6 +125,8 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     }
   }
   c->has_mppi = true;
+  c->wait_hist_n = c->wait_hist_at = 0;  // host_spin 2: a new problem size, a new wait to predict
+  c->nap_margin_us = 0.0;
   c->sync_clean_ws = nullptr;
   c->sync_dirty = false;
   c->last.valid = false;

@@ -24,6 +24,12 @@
 #include "nlc_device.h"
 #include "nlc_kernels.h"
 
+// sweep iterations per prefetch chunk of the backward pass (two chunks of tape values are register-resident; measured on the
+// MI355X at 3.3 M rows, M = 16: 8 -> 23.5 ms with 197 spilled VGPRs, 4 -> 21.5 ms with 93, no prefetch 25.6 ms)
+#ifndef NLC_DHB_GROUP
+#define NLC_DHB_GROUP 4
+#endif
+
 namespace nlc {
 
 namespace {
@@ -67,8 +73,9 @@ struct Tape {
 
 }  // namespace
 
+// (M <= 8: 221 VGPRs, two wavefronts per SIMD; above: up to 360, one)
 template <int M>
-__global__ __launch_bounds__(64, 1) void ilt_dehoog_bwd_kernel(const IltDehoogBwdArgs a) {
+__global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(const IltDehoogBwdArgs a) {
   constexpr int S = 2 * M + 1;
   constexpr DhLayout L{M};
   const int lane = threadIdx.x;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64, 1) void ilt_dehoog_bwd_kernel(const IltDehoogBw
         E[i] = ei;
         qlo = qhi;
         elo = ei;
-        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        if ((i & (NLC_DHB_GROUP - 1)) == NLC_DHB_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
       }
       feed(2 * r, cneg(E[0]));
       // (keeps the columns apart: the compiler otherwise interleaves them and the live ranges explode)
@@ -187,11 +194,18 @@ __global__ __launch_bounds__(64, 1) void ilt_dehoog_bwd_kernel(const IltDehoogBw
     const cplx g_diff = cscale(cmul(g_brem, cconj(z)), 0.5);
     const cplx g_dlast = g_diff;
     g_dend = csub(g_dend, g_diff);
-    // one step of the recurrence's adjoint, i = 2M-1 .. 1 (called in descending order): returns dbar_i
-    auto unfeed = [&](int i) -> cplx {
-      const cplx di = cneg((i & 1) ? tp.ld(L.q((i + 1) / 2, 0)) : tp.ld(L.e(i / 2, 0)));
-      const cplx Am2 = tp.ld(L.A(i - 2)), Bm2 = tp.ld(L.B(i - 2));
-      cplx g_di = cadd(cmul(gA1, cconj(cmul(z, Am2))), cmul(gB1, cconj(cmul(z, Bm2))));
+    // one step of the recurrence's adjoint, i = 2M-1 .. 1 (called in descending order): returns dbar_i.  Its three tape operands
+    // (d_i's table entry, A_(i-2), B_(i-2)) are loaded a column AHEAD of their use (UnfeedOps), like every other tape value of
+    // the sweep: the kernel runs one wavefront per SIMD, so nothing else hides a load's latency.
+    struct UnfeedOps {
+      cplx entry, Am2, Bm2;
+    };
+    auto unfeed_load = [&](int i) -> UnfeedOps {
+      return {(i & 1) ? tp.ld(L.q((i + 1) / 2, 0)) : tp.ld(L.e(i / 2, 0)), tp.ld(L.A(i - 2)), tp.ld(L.B(i - 2))};
+    };
+    auto unfeed = [&](int i, const UnfeedOps& o) -> cplx {
+      const cplx di = cneg(o.entry);
+      cplx g_di = cadd(cmul(gA1, cconj(cmul(z, o.Am2))), cmul(gB1, cconj(cmul(z, o.Bm2))));
       if (i == 2 * M - 1) g_di = cadd(g_di, g_dlast);
       const cplx cdz = cconj(cmul(di, z));
       const cplx gAm2 = cmul(gA1, cdz), gBm2 = cmul(gB1, cdz);
@@ -215,60 +229,90 @@ __global__ __launch_bounds__(64, 1) void ilt_dehoog_bwd_kernel(const IltDehoogBw
       W[i] = zero;
       P[i] = zero;
     }
+    // Tape values are fetched in chunks of kChunk sweep iterations, one chunk AHEAD of the chunk being computed (two register
+    // buffers), and the next column's recurrence operands one column ahead.
+    constexpr int kChunk = NLC_DHB_GROUP;
+    UnfeedOps uo_even = unfeed_load(2 * M - 1), uo_odd = uo_even;  // column M: dbar_2M is g_dend, dbar_(2M-1) needs step 2M-1
 #pragma unroll
     for (int r = M; r >= 1; --r) {
       const int mr = 2 * (M - r) + 1;
       const bool inner = r != M;
-      const cplx dbar_even = r == M ? g_dend : unfeed(2 * r);  // dbar_(2r)
-      const cplx dbar_odd = unfeed(2 * r - 1);                 // dbar_(2r-1)
-      cplx g_prev = zero, wbar_im1 = zero, e_im1 = one;
+      const int nch = (mr + 1 + kChunk - 1) / kChunk;
+      cplx qn[2][kChunk], en[2][kChunk];  // qn[b][j] = q_r^(i+1), en[b][j] = e_r^(i+1) for sweep iteration i = c kChunk + j
+      // first chunk + the sweep's first entries
       cplx e_i = tp.ld(L.e(r, 0)), q_i = tp.ld(L.q(r, 0));
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const int i = j;
+        qn[0][j] = (i <= mr && i + 1 <= mr) ? tp.ld(L.q(r, i + 1)) : zero;
+        en[0][j] = (i <= mr && i + 1 <= mr - 1) ? tp.ld(L.e(r, i + 1)) : one;
+      }
+      // the recurrence steps of THIS column (operands loaded during the previous column), then the next column's operands
+      const cplx dbar_even = r == M ? g_dend : unfeed(2 * r, uo_even);  // dbar_(2r)
+      const cplx dbar_odd = unfeed(2 * r - 1, r == M ? uo_even : uo_odd);  // dbar_(2r-1)
+      if (r > 1) {
+        uo_even = unfeed_load(2 * (r - 1));
+        uo_odd = unfeed_load(2 * (r - 1) - 1);
+      }
+      cplx g_prev = zero, wbar_im1 = zero, e_im1 = one;
       cplx park_in = zero;  // the old P[i] (read before the sweep overwrites it one iteration earlier)
 #pragma unroll
-      for (int i = 0; i <= mr; ++i) {
-        const bool has_e = i <= mr - 1;
-        const bool has_w = inner && i <= mr - 2;  // q_(r+1)^(i) exists
-        const cplx q_nxt = i + 1 <= mr ? tp.ld(L.q(r, i + 1)) : zero;
-        const cplx e_nxt = i + 1 <= mr - 1 ? tp.ld(L.e(r, i + 1)) : one;
-        const cplx wbar_i = has_w ? W[i] : zero;
-        const cplx park_nxt = (i + 1 < 2 * M) ? P[i + 1] : zero;  // old value, before this iteration parks into it
-        cplx g = zero;
-        cplx c_term = zero;  // wbar_(i-1) conj(e_r^(i) / e_r^(i-1))
-        if (has_e) {
-          const double inv_i = m::rcp_refined(fma(e_i.re, e_i.re, e_i.im * e_i.im));
-          const cplx ie_i = {e_i.re * inv_i, -e_i.im * inv_i};  // 1 / e_r^(i)
-          if (i == 0) g = cneg(dbar_even);
-          if (inner && i >= 1 && i <= mr - 2) g = cadd(g, park_in);  // parked ebar_(r+1)^(i-1)
-          if (inner && i >= 1) {
-            const double inv_m = m::rcp_refined(fma(e_im1.re, e_im1.re, e_im1.im * e_im1.im));
-            const cplx ie_m = {e_im1.re * inv_m, -e_im1.im * inv_m};  // 1 / e_r^(i-1)
-            g = cadd(g, cmul(wbar_im1, cconj(cmul(q_i, ie_m))));
-            c_term = cmul(wbar_im1, cconj(cmul(e_i, ie_m)));
-          }
-          if (has_w) {
-            // q_(r+1)^(i) / e_r^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)^2
-            const cplx ratio = cmul(e_nxt, ie_i);
-            g = csub(g, cmul(wbar_i, cconj(cmul(cmul(q_nxt, ie_i), ratio))));
+      for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) {
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j) {
+            const int i = (c + 1) * kChunk + j;
+            qn[(c + 1) & 1][j] = (i <= mr && i + 1 <= mr) ? tp.ld(L.q(r, i + 1)) : zero;
+            en[(c + 1) & 1][j] = (i <= mr && i + 1 <= mr - 1) ? tp.ld(L.e(r, i + 1)) : one;
           }
         }
-        cplx qb = csub(cadd(g_prev, c_term), g);
-        if (i == 0) qb = csub(qb, dbar_odd);
-        W[i] = qb;
-        if (has_e && r > 1 && i + 1 < 2 * M) P[i + 1] = g;
-        park_in = park_nxt;
-        g_prev = g;
-        wbar_im1 = wbar_i;
-        e_im1 = e_i;
-        e_i = e_nxt;
-        q_i = q_nxt;
-        // (the tape loads of at most eight iterations are in flight at a time: sixteen 1-KB lines per wavefront)
-        if ((i & 7) == 7) {
-          asm volatile("" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
+        // (the next chunk's loads are issued before this chunk's arithmetic and cannot sink below it)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+          const int i = c * kChunk + j;
+          if (i <= mr) {
+            const bool has_e = i <= mr - 1;
+            const bool has_w = inner && i <= mr - 2;  // q_(r+1)^(i) exists
+            const cplx q_nxt = qn[c & 1][j];
+            const cplx e_nxt = en[c & 1][j];
+            const cplx wbar_i = has_w ? W[i] : zero;
+            const cplx park_nxt = (i + 1 < 2 * M) ? P[i + 1] : zero;  // old value, before this iteration parks into it
+            cplx g = zero;
+            cplx c_term = zero;  // wbar_(i-1) conj(e_r^(i) / e_r^(i-1))
+            if (has_e) {
+              const double inv_i = m::rcp_refined(fma(e_i.re, e_i.re, e_i.im * e_i.im));
+              const cplx ie_i = {e_i.re * inv_i, -e_i.im * inv_i};  // 1 / e_r^(i)
+              if (i == 0) g = cneg(dbar_even);
+              if (inner && i >= 1 && i <= mr - 2) g = cadd(g, park_in);  // parked ebar_(r+1)^(i-1)
+              if (inner && i >= 1) {
+                const double inv_m = m::rcp_refined(fma(e_im1.re, e_im1.re, e_im1.im * e_im1.im));
+                const cplx ie_m = {e_im1.re * inv_m, -e_im1.im * inv_m};  // 1 / e_r^(i-1)
+                g = cadd(g, cmul(wbar_im1, cconj(cmul(q_i, ie_m))));
+                c_term = cmul(wbar_im1, cconj(cmul(e_i, ie_m)));
+              }
+              if (has_w) {
+                // q_(r+1)^(i) / e_r^(i) = q_r^(i+1) e_r^(i+1) / e_r^(i)^2
+                const cplx ratio = cmul(e_nxt, ie_i);
+                g = csub(g, cmul(wbar_i, cconj(cmul(cmul(q_nxt, ie_i), ratio))));
+              }
+            }
+            cplx qb = csub(cadd(g_prev, c_term), g);
+            if (i == 0) qb = csub(qb, dbar_odd);
+            W[i] = qb;
+            if (has_e && r > 1 && i + 1 < 2 * M) P[i + 1] = g;
+            park_in = park_nxt;
+            g_prev = g;
+            wbar_im1 = wbar_i;
+            e_im1 = e_i;
+            e_i = e_nxt;
+            q_i = q_nxt;
+          }
         }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
     }
     // A_0 = d_0 = a_0 (A_(-1), B_0, B_(-1) are constants): d_0-bar = A_0-bar
     const cplx g_a0_seed = gA1;
@@ -294,11 +338,13 @@ __global__ __launch_bounds__(64, 1) void ilt_dehoog_bwd_kernel(const IltDehoogBw
   }
 }
 
-// One wavefront per SIMD (the two adjoint columns alone are 256 VGPRs at M = 16: launch bounds (64, 1), accumulation registers
-// as overflow), i.e. four workgroups per CU hold a slab: 1024 x 642 KB = 0.66 GB at 33 terms (round 3 took 2.5 GB).
+// The two adjoint columns alone are 256 VGPRs at M = 16: one wavefront per SIMD above M = 8 (accumulation registers as overflow),
+// two up to M = 8.  Every resident workgroup (= wavefront) holds a slab: at most 4 / 8 per CU, i.e. 1024 x 642 KB = 0.66 GB at 33
+// terms (round 3 took 2.5 GB from the stream-ordered pool: ADVICE r3).
 int64_t ilt_dehoog_bwd_scratch_bytes(int64_t N, int d, int S, unsigned* grid_out) {
   const int64_t nblk = (N * d + 63) / 64;
-  const unsigned grid = (unsigned)(nblk < 1024 ? nblk : 1024);
+  const int64_t cap = (S - 1) / 2 <= 8 ? 2048 : 1024;
+  const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
   if (grid_out) *grid_out = grid;
   const DhLayout L{(S - 1) / 2};
   return (int64_t)grid * L.entries() * 64 * kTapeElemBytes;

@@ -4,8 +4,10 @@ a training-size batch and the bench's N = K*T.  One JSON line on stdout."""
 import json, math, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import neurallaplacecontrol_amd as nlc
 from neurallaplacecontrol_amd import _lib
+if os.environ.get("NLC_LIB_PATH"):  # tools only: another build of the same library (A/B of kernel variants)
+    _lib.use_library(os.environ["NLC_LIB_PATH"])
+import neurallaplacecontrol_amd as nlc
 
 
 def torch_ops(theta, phi, t, desc):
