@@ -106,10 +106,16 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "dehoog_chain"       de Hoog planner (single planner, hidden_units 128, 17 or 33 terms): 1 = the whole step chain as ONE
  *                        persistent launch (kernels_dehoog_chain.hip: a workgroup of eight waves owns 64 samples for all T
  *                        steps -- representation MLP of its four tiles in one pass, QD table one wavefront per dim, state / cost
- *                        tail; F_k stays with the CU that wrote it); 0 = the staged 2 T + 1 launches below; -1 (default) = auto,
- *                        which is the staged path: measured 151.7 vs 158.9 planning steps/s at BASELINE configs[4]'s size
- *                        (profiles/r4_dehoog_chain.md).  Same bits either way.  ("dehoog_chain_phases": tools only, 1 / 2 = only
- *                        the representation / only the QD phase of that kernel runs -- a timing breakdown, meaningless results)
+ *                        tail; F_k stays with the CU that wrote it); 2 = the same with four waves per 32 samples, two workgroups
+ *                        per CU; 0 = the staged 2 T + 1 launches below; -1 (default) = auto.  Same bits for every value.
+ *                        AUTO (this knob and "dehoog_streams" both on auto, >= 8192 local samples): the planner MEASURES -- its
+ *                        first commands run the candidate forms (staged on two streams, staged on one, persistent kernel) in
+ *                        turns for at least four rounds and half a second, an event pair around the chain, and it keeps the
+ *                        fastest.  On most boxes that is the staged path on two streams (155-159 planning steps/s at BASELINE
+ *                        configs[4]'s size vs 151 on one stream and 150 for the persistent kernel); on a box whose streams do not
+ *                        overlap two streams measure 134 and auto settles on one (profiles/r4_dehoog_chain.md).
+ *                        ("dehoog_chain_phases": tools only, 1 / 2 = only the representation / only the QD phase of that kernel
+ *                        runs -- a timing breakdown, meaningless results)
  *   "dehoog_streams"     staged planner (NLC_ILT_DEHOOG models; fixed Talbot / Stehfest models take the same path and the
  *                        same options): the population is cut into this many contiguous parts
  *                        whose per-step launches run on streams of their own -- one part's FP64-VALU-bound QD pass beside

@@ -113,6 +113,8 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   if (c->small) hipFree(c->small);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->stage_ev) hipEventDestroy(c->stage_ev);
+  for (hipEvent_t e : c->dh_ev)
+    if (e) hipEventDestroy(e);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   for (hipEvent_t e : c->ev_join) hipEventDestroy(e);
   for (hipStream_t s2 : c->aux_streams) hipStreamDestroy(s2);
@@ -149,7 +151,7 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value < 0 || value > 120000) return fail(c, NLC_ERR_BAD_ARG, "dehoog_gru_lds_pad must be in 0 .. 120000 bytes");
     c->opt_dehoog_gru_lds_pad = (int)value;
   } else if (n == "dehoog_chain") {
-    if (value != -1 && value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "dehoog_chain must be -1 (auto), 0 or 1");
+    if (value != -1 && value != 0 && value != 1 && value != 2) return fail(c, NLC_ERR_BAD_ARG, "dehoog_chain must be -1 (auto), 0, 1 or 2");
     c->opt_dehoog_chain = (int)value;
   } else if (n == "dehoog_chain_phases") {
     if (value != 1 && value != 2 && value != 3) return fail(c, NLC_ERR_BAD_ARG, "dehoog_chain_phases must be 1, 2 or 3");

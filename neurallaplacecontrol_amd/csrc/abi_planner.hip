@@ -125,6 +125,9 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
     }
   }
   c->has_mppi = true;
+  c->dh_n = 0;  // de Hoog chain form: measured again for the new problem
+  c->dh_choice = c->dh_pending = -1;
+  for (auto& v : c->dh_ms) v[0] = v[1] = 1e30f;
   c->wait_hist_n = c->wait_hist_at = 0;  // host_spin 2: a new problem size, a new wait to predict
   c->nap_margin_us = 0.0;
   c->sync_clean_ws = nullptr;

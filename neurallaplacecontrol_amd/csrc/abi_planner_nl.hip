@@ -8,6 +8,12 @@ using namespace nlc::host;
 
 namespace {
 
+inline double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + (double)ts.tv_nsec * 1e-9;
+}
+
 // staged planner path (BASELINE configs[4]): hoisted GRU, then per horizon step two launches -- [tail of the previous step +]
 // representation function -> F_k, then de Hoog ILT -> dx; fixed_tablot / stehfest models (option linear_fused = 0) take the
 // same path with the slot-major linear ILT in de Hoog's place.  Everything stays on the device.
@@ -32,11 +38,54 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
   // Round 4: the whole step chain as ONE persistent launch (kernels_dehoog_chain.hip; option "dehoog_chain": -1 auto, 0 the
   // staged launches below, 1 required) -- a workgroup owns 64 samples for all T steps, F stays with the CU that wrote it.
   const bool chain_ok = dehoog && d.E == 1 && nl_dehoog_chain_available(c->md.h, c->net.nt3, c->S);
-  if (c->opt_dehoog_chain == 1 && !chain_ok)
+  if (c->opt_dehoog_chain >= 1 && !chain_ok)
     return fail(c, NLC_ERR_UNSUPPORTED, "dehoog_chain: single planner, hidden_units 128 and 17 or 33 de Hoog terms only");
-  // auto = the staged launches: measured on the MI355X at configs[4]'s size the persistent chain is 5 % slower than the staged
-  // path on two streams (profiles/r4_dehoog_chain.md)
-  const bool chain = chain_ok && c->opt_dehoog_chain == 1;
+  // Which form runs the chain is MEASURED when both knobs are on auto and the population is large enough for two streams to be
+  // considered (round 4): the staged launches on two streams are the fastest form on most boxes of the pool (158 planning
+  // steps/s at configs[4]'s size against 151 on one stream and 150 for the persistent kernel) but the slowest on others, where
+  // launches on two streams do not overlap (134, same kernels, same per-launch durations: profiles/r4_dehoog_chain.md).  The
+  // first commands of a planner therefore run the candidates in turns -- same bits whichever runs -- with an event pair around
+  // the chain (read back one command later, when the caller has long waited for that command's action: no synchronisation is
+  // added), and the planner keeps the fastest.
+  const bool calibrate = dehoog && d.E == 1 && c->opt_dehoog_chain < 0 && c->opt_dehoog_streams == 0 && KE >= 8192 && !c->profiling;
+  int calib_variant = -1;  // 0: two streams, 1: one stream, 2: persistent kernel
+  if (calibrate) {
+    const int ncand = chain_ok ? 3 : 2;
+    if (c->dh_pending >= 0 && c->dh_ev[0] && c->dh_ev[1]) {  // the previous command's measurement
+      float ms = 0.f;
+      if (hipEventSynchronize(c->dh_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->dh_ev[0], c->dh_ev[1]) == hipSuccess)
+        c->dh_ms[c->dh_pending][c->dh_pending_round & 1] = ms;
+      c->dh_pending = -1;
+    }
+    // the candidates take turns, round after round, until at least four rounds AND half a second have passed (the clocks of
+    // an idle GPU ramp for ~0.3 s: whoever is measured last in a cold start would win); the decision compares the LAST TWO rounds
+    const int round = c->dh_n / ncand;
+    if (c->dh_choice < 0 && c->dh_n % ncand == 0 && ((round >= 4 && now_s() - c->dh_t0 >= 0.5) || round >= 64)) {
+      c->dh_choice = 0;
+      float best = 1e30f;
+      for (int v = 0; v < ncand; ++v) {
+        const float mv = c->dh_ms[v][0] < c->dh_ms[v][1] ? c->dh_ms[v][0] : c->dh_ms[v][1];
+        if (mv < best) {
+          best = mv;
+          c->dh_choice = v;
+        }
+      }
+    }
+    if (c->dh_choice >= 0) {
+      calib_variant = c->dh_choice;
+    } else {
+      if (c->dh_n == 0) c->dh_t0 = now_s();
+      calib_variant = c->dh_n % ncand;
+      c->dh_pending = calib_variant;
+      c->dh_pending_round = round;
+      c->dh_n += 1;
+      for (int e = 0; e < 2; ++e)
+        if (!c->dh_ev[e]) NLC_HIP(c, hipEventCreate(&c->dh_ev[e]));
+      NLC_HIP(c, hipEventRecord(c->dh_ev[0], c->stream));
+    }
+  }
+  const bool timing = calibrate && c->dh_choice < 0;
+  const bool chain = chain_ok && (c->opt_dehoog_chain >= 1 || calib_variant == 2);
   int C = d.E == 1 && !chain ? c->opt_dehoog_gru_chunks : 1;
   if (C == 0) C = 1;  // auto: off
   if (C > d.T) C = d.T;
@@ -74,11 +123,11 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
     ca.states = buf->states;
     ca.cost_total = buf->cost_total;
     ca.phases = c->opt_dehoog_chain_phases;
-    const int64_t nblk = (KE + 63) / 64;
     {
       ProfScope ps(c, "nl_dehoog_chain_kernel");
-      NLC_HIP(c, launch_nl_dehoog_chain(ca, (unsigned)(nblk < (1 << 20) ? nblk : (1 << 20)), c->stream));
+      NLC_HIP(c, launch_nl_dehoog_chain(ca, c->opt_dehoog_chain == 2 ? 2 : 4, c->stream));
     }
+    if (timing) NLC_HIP(c, hipEventRecord(c->dh_ev[1], c->stream));
     return d.cost_external ? NLC_OK : run_weights(c, buf);
   }
   double* tconst = ws + w.tconst;
@@ -151,7 +200,9 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
   // the QD launch the FP64 VALU at 1.25 wavefronts per SIMD (active 0.39) -- so while one part's QD pass runs, another
   // part's representation launch fills the matrix pipe (option "dehoog_streams": 1 = one stream, as before).
   int P = d.E == 1 ? c->opt_dehoog_streams : 1;
-  if (P == 0) P = KE >= 8192 ? 2 : 1;  // auto
+  if (P == 0) P = KE >= 8192 ? 2 : 1;  // auto ...
+  if (calib_variant == 0) P = 2;       // ... or what the calibration above runs / chose
+  if (calib_variant == 1) P = 1;
   if (P > 4) P = 4;
   while (P > 1 && KE / P < 1024) --P;
   if (P > 1) {
@@ -253,6 +304,7 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
       NLC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join[h - 1], 0));
     }
   }
+  if (timing) NLC_HIP(c, hipEventRecord(c->dh_ev[1], c->stream));
   return d.cost_external ? NLC_OK : run_weights(c, buf);
 }
 

@@ -23,29 +23,33 @@
 
 namespace nlc {
 
-template <int NT3, int M>
-__global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogChainArgs a) {
-  constexpr int HT = 8, KS = HT * 4, S = 2 * M + 1;
+// NS = sample tiles per workgroup.  NS = 4: eight waves own 64 samples, one workgroup per CU (256 VGPRs x 8 waves), the QD phase is
+// one wavefront per dim.  NS = 2 (round 4, second form): four waves own 32 samples and TWO workgroups share a CU -- independent
+// chains that drift apart, so one's VALU-bound QD phase runs beside the other's MFMA-bound representation phase; a QD wavefront
+// then holds two dims' rows (lanes 0-31 / 32-63) and the idle fourth wave rotates over the SIMDs from step to step.
+template <int NT3, int M, int NS>
+__global__ __launch_bounds__(128 * NS, NS == 4 ? 1 : 2) void nl_dehoog_chain_kernel(const DehoogChainArgs a) {
+  constexpr int HT = 8, KS = HT * 4, S = 2 * M + 1, NW = 2 * NS, SPB = 16 * NS;  // SPB: samples per block
   constexpr int CH = M > 8 ? M + 1 : 9;  // terms fetched at a time (as ilt_dehoog_kernel)
-  __shared__ double H1[4][KS * 64], H2[4][KS * 64];
-  __shared__ double XS[64 * NLC_MAX_D];  // the block's states, [sample][dim]
+  __shared__ double H1[NS][KS * 64], H2[NS][KS * 64];
+  __shared__ double XS[SPB * NLC_MAX_D];  // the block's states, [sample][dim]
   const NlNetArgs& n = a.net;
   const int d = n.d;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nblk = (a.K + 63) / 64;
+  const int64_t nblk = (a.K + SPB - 1) / SPB;
   const double t = a.tn;
   const double Tt = n.scale * t;
   const double gamma = n.alpha - n.log_tol / (n.scale * Tt);
   const double ang = kPi * (t / Tt);
   const cplx z = {cos(ang), sin(ang)};
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t k0 = blk * 64;
-    const int rows_here = (int)((a.K - k0 < 64) ? (a.K - k0) : 64);
-    double* fre = a.fre + (size_t)blk * 64 * 8 * NT3;
-    double* fim = a.fim + (size_t)blk * 64 * 8 * NT3;
+    const int64_t k0 = blk * SPB;
+    const int rows_here = (int)((a.K - k0 < SPB) ? (a.K - k0) : SPB);
+    double* fre = a.fre + (size_t)blk * SPB * 8 * NT3;
+    double* fim = a.fim + (size_t)blk * SPB * 8 * NT3;
     // start state of every sample of the block
-    for (int i = threadIdx.x; i < 64 * NLC_MAX_D; i += 512) {
+    for (int i = threadIdx.x; i < SPB * NLC_MAX_D; i += 64 * NW) {
       const int sm = i / NLC_MAX_D, dim = i % NLC_MAX_D;
       const int64_t k = k0 + (sm < rows_here ? sm : rows_here - 1);
       XS[i] = dim < d ? a.state0[(a.state_per_sample ? k : 0) * d + dim] : 0.0;
@@ -53,12 +57,12 @@ __global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogCha
     double cost = 0.0, pcost = 0.0;  // wave 0: lane = sample
     __syncthreads();
     for (int t_h = 0; t_h < a.T; ++t_h) {
-      // ---- phase A: representation function of the block's four tiles in one pass (every weight fragment feeds four MFMAs)
+      // ---- phase A: representation function of the block's NS tiles in one pass (every weight fragment feeds NS MFMAs)
       if (a.phases & 1) {
         const int q = lane >> 4, c = lane & 15, i0 = q, i1 = 4 + q;
-        double p0[4], p1[4];
+        double p0[NS], p1[NS];
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
+        for (int s2 = 0; s2 < NS; ++s2) {
           const int kb = 16 * s2 + c;  // sample within the block
           const int kc = kb < rows_here ? kb : rows_here - 1;
           const double* pa = a.pa + ((size_t)(k0 + kc) * a.T + t_h) * 2;
@@ -67,19 +71,36 @@ __global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogCha
           p0[s2] = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0] : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
           p1[s2] = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1] : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
         }
-        repfunc_block_mlp<NT3>(n, p0, p1, rows_here, a.slot, fre, fim, &H1[0][0], &H2[0][0], wave, lane);
+        repfunc_block_mlp<NT3, NS>(n, p0, p1, rows_here, a.slot, fre, fim, &H1[0][0], &H2[0][0], wave, lane);
         __syncthreads();  // F is complete
       }
-      // ---- phase B: one wavefront per state dim, one lane per sample
-      if (wave < d && (a.phases & 2)) {
-        DehoogSlotTerms<CH> src{fre, fim, a.eidx + wave * S, (int64_t)64, (int64_t)(lane < rows_here ? lane : 0), {}};
-        const cplx res = dehoog_row<M, CH>(src, z);
-        {
-          // dx is a ROUNDED product, as the staged path's ilt_dehoog_kernel stores it, and the update a separate addition
-          // (left contractable, x + (e^{gamma t} / T) Re(res) becomes one fused multiply-add: states off by an ulp per step)
+      // ---- phase B: the QD table, one lane per (dim, sample) row: row rho = 64 slot + lane -> dim rho / SPB, sample rho % SPB.
+      // NS = 4: slot = wave = dim.  NS = 2: two dims per wavefront, and the slots rotate over the waves (SIMDs) with the step and
+      // the block so that the CU's two workgroups do not pile their QD passes on the same SIMDs.
+      {
+        const int rot = NS == 4 ? 0 : (int)((t_h + blk) & (NW - 1));
+        const int slot_w = (wave + NW - rot) & (NW - 1);
+        const int rho = 64 * slot_w + lane;
+        const int dim = rho / SPB, sm = rho % SPB;
+        if (64 * slot_w < d * SPB && (a.phases & 2)) {  // (wave-uniform: this wavefront holds rows)
+          const bool row_ok = dim < d;
+          const int dimc = row_ok ? dim : d - 1;
+          const int smc = sm < rows_here ? sm : 0;
+          cplx res;
+          if constexpr (NS == 4) {
+            DehoogSlotTerms<CH> src{fre, fim, a.eidx + slot_w * S, (int64_t)SPB, (int64_t)smc, {}};
+            res = dehoog_row<M, CH>(src, z);
+          } else {
+            DehoogSlotTermsLane<CH> src{fre, fim, a.eidx + dimc * S, (int64_t)SPB, (int64_t)smc, {}};
+            res = dehoog_row<M, CH>(src, z);
+          }
+          if (row_ok) {
+            // dx is a ROUNDED product, as the staged path's ilt_dehoog_kernel stores it, and the update a separate addition
+            // (left contractable, x + (e^{gamma t} / T) Re(res) becomes one fused multiply-add: states off by an ulp per step)
 #pragma clang fp contract(off)
-          const double dx = exp(gamma * t) / Tt * res.re;
-          XS[lane * NLC_MAX_D + wave] = XS[lane * NLC_MAX_D + wave] + dx;  // mppi_with_model.py:120-121
+            const double dx = exp(gamma * t) / Tt * res.re;
+            XS[sm * NLC_MAX_D + dim] = XS[sm * NLC_MAX_D + dim] + dx;  // mppi_with_model.py:120-121
+          }
         }
       }
       __syncthreads();
@@ -104,12 +125,19 @@ __global__ __launch_bounds__(512, 1) void nl_dehoog_chain_kernel(const DehoogCha
   }
 }
 
-hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, unsigned grid, hipStream_t s) {
+// block_tiles: 4 = eight waves per 64 samples (one workgroup per CU), 2 = four waves per 32 samples (two per CU)
+hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, int block_tiles, hipStream_t s) {
   if (a.K <= 0) return hipSuccess;
-  if (a.net.h != 128) return hipErrorInvalidValue;
+  if (a.net.h != 128 || (block_tiles != 2 && block_tiles != 4)) return hipErrorInvalidValue;
+  const int64_t spb = 16 * block_tiles, nblk = (a.K + spb - 1) / spb;
+  const unsigned grid = (unsigned)(nblk < (1 << 20) ? nblk : (1 << 20));
 #define NLC_CHAIN(N, MM)                                                                               \
   if (a.net.nt3 == N && a.net.S == 2 * MM + 1) {                                                       \
-    hipLaunchKernelGGL((nl_dehoog_chain_kernel<N, MM>), dim3(grid), dim3(512), 0, s, a);               \
+    if (block_tiles == 4) {                                                                            \
+      hipLaunchKernelGGL((nl_dehoog_chain_kernel<N, MM, 4>), dim3(grid), dim3(512), 0, s, a);          \
+    } else {                                                                                           \
+      hipLaunchKernelGGL((nl_dehoog_chain_kernel<N, MM, 2>), dim3(grid), dim3(256), 0, s, a);          \
+    }                                                                                                  \
     return hipGetLastError();                                                                          \
   }
   // 33 terms (BASELINE configs[4]) and 17 terms (the reference's default count), every state dim 3 .. 6

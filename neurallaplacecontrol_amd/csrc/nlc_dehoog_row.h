@@ -31,6 +31,28 @@ struct DehoogSlotTerms {
   __device__ __forceinline__ cplx term(int n) const { return buf[n % CH]; }
 };
 
+// The same over a per-LANE slot table (the lanes of one wavefront may belong to two dims: kernels_dehoog_chain.hip with 32-sample
+// blocks): slot_of_term is this lane's dim's (S) table, read with vector loads.
+template <int CH>
+struct DehoogSlotTermsLane {
+  const double* fre;
+  const double* fim;
+  const int* slot_of_term;  // per lane
+  int64_t stride, col;
+  cplx buf[CH];
+  template <int S>
+  __device__ __forceinline__ void stage(int n) {
+    const int nt = (S - n < CH) ? (S - n) : CH;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < CH; ++k)
+      if (k < nt) {
+        const int64_t at = (int64_t)slot_of_term[n + k] * stride + col;
+        buf[k] = {fre[at], fim[at]};
+      }
+  }
+  __device__ __forceinline__ cplx term(int n) const { return buf[n % CH]; }
+};
+
 // SRC: stage<S>(n) is called before term n whenever n % CH == 0 (it makes terms [n, n + CH) available), term(n) returns a_n.
 // Returns A_2M / B_2M, the continued fraction with the improved remainder; the caller scales Re by e^{gamma t} / T.
 template <int M, int CH, class SRC>

@@ -128,6 +128,11 @@ struct nlc_ctx {
   hipStream_t gru_stream = nullptr;
   std::vector<hipEvent_t> ev_gru;
   int opt_dehoog_chain = -1;            // de Hoog planner: the step chain as one persistent launch (kernels_dehoog_chain.hip): -1 auto, 0 / 1
+  // de Hoog planner, both knobs on auto: the chain's form is measured over the planner's first commands (abi_planner_nl.hip)
+  int dh_n = 0, dh_choice = -1, dh_pending = -1, dh_pending_round = 0;
+  double dh_t0 = 0.0;
+  float dh_ms[3][2] = {{1e30f, 1e30f}, {1e30f, 1e30f}, {1e30f, 1e30f}};  // [candidate][round & 1]: the last two rounds
+  hipEvent_t dh_ev[2] = {nullptr, nullptr};
   int opt_dehoog_chain_phases = 3;      // tools only: 1 / 2 = only the representation / QD phase of the chain kernel runs (timing)
   int opt_dehoog_streams = 0;           // staged de Hoog planner: parts of the population on streams of their own (0 auto)
   std::vector<hipStream_t> aux_streams;

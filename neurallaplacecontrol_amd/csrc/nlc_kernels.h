@@ -338,13 +338,13 @@ struct DehoogChainArgs {
   double tn;                // normalised prediction time
   const int* slot;          // (8 nt3) layer-3 slot -> c*S + k, -1 = padding
   const int* eidx;          // (d*S)   term k of dim c -> slot
-  double* fre;              // ceil(K / 64) private blocks of (8 nt3) x 64 doubles each
+  double* fre;              // one private (8 nt3) x (16 block_tiles) block per workgroup's samples: ceil(K / 64) * 64 * 8 nt3 doubles
   double* fim;
   double* states;           // (K, T, d) or NULL
   double* cost_total;       // (K)
   int phases;               // 3; tools only: 1 = the representation phase alone, 2 = the QD phase alone (timing breakdown)
 };
-hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, unsigned grid, hipStream_t s);
+hipError_t launch_nl_dehoog_chain(const DehoogChainArgs& a, int block_tiles, hipStream_t s);
 bool nl_dehoog_chain_available(int h, int nt3, int S);
 
 // ------------------------------------------------------------------ oracle-dynamics rollout (§8f-1)

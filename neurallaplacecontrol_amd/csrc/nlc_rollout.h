@@ -600,53 +600,71 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
   }
 }
 
-// The same MLP for FOUR 16-sample tiles at once by a workgroup of EIGHT waves (hidden_units 128: HT = 8), the form the persistent
-// de Hoog step chain uses (kernels_dehoog_chain.hip): wave w owns output tile w of layers 1 and 2 and output tiles w, w + 8,
-// w + 16 of layer 3 -- for all four sample tiles, so every weight fragment fetched from L2 feeds four MFMAs instead of one (the
-// 4-wave form streams the whole 466 KB weight set once per 16 samples).  Per output tile and sample tile the MFMA sequence over
-// k is the one of repfunc_split_mlp and the activations are the same functions: the F values are the same bits.
-// p0 / p1 [s]: layer-1 fragments of sample tile s for this lane's column; column of sample (s, c) in the F block: 16 s + c.
-// H1 / H2: [4][32 * 64] LDS images.  Two workgroup barriers.
-template <int NT3>
-__device__ __forceinline__ void repfunc_block_mlp(const NlNetArgs& n, const double (&p0)[4], const double (&p1)[4],
+// The same MLP for NS 16-sample tiles at once by a workgroup of NW = 2 NS waves (hidden_units 128: HT = 8), the form the
+// persistent de Hoog step chain uses (kernels_dehoog_chain.hip; NS = 4: eight waves, NS = 2: four): wave w owns output tiles
+// TW w .. TW w + TW - 1 (TW = 8 / NW) of layers 1 and 2 and output tiles w, w + NW, w + 2 NW, ... of layer 3 -- for ALL NS sample
+// tiles, so every weight fragment fetched from L2 feeds NS MFMAs instead of one (the 4-wave form streams the whole 466 KB weight
+// set once per 16 samples).  Per output tile and sample tile the MFMA sequence over k is the one of repfunc_split_mlp and the
+// activations are the same functions: the F values are the same bits.
+// p0 / p1 [s]: layer-1 fragments of sample tile s for this lane's column; column of sample (s, c) in the F block: 16 s + c of
+// 16 NS.  H1 / H2: [NS][32 * 64] LDS images.  Two workgroup barriers.
+template <int NT3, int NS>
+__device__ __forceinline__ void repfunc_block_mlp(const NlNetArgs& n, const double (&p0)[NS], const double (&p1)[NS],
                                                   const int rows_here, const int* __restrict__ slot, double* __restrict__ fre,
                                                   double* __restrict__ fim, double* __restrict__ H1, double* __restrict__ H2,
                                                   const int wave, const int lane) {
-  constexpr int HT = 8, KS = 32, NS = 4;
-  constexpr int NTW = (NT3 + 7) / 8;  // layer-3 output tiles per wave (tile j = wave + 8 i)
+  constexpr int HT = 8, KS = 32, NW = 2 * NS, TW = HT / NW;
+  constexpr int NTW = (NT3 + NW - 1) / NW;  // layer-3 output tiles per wave (tile j = wave + NW i)
+  static_assert(NS == 2 || NS == 4, "two or four sample tiles per workgroup");
   const int q = lane >> 4, c = lane & 15;
-  // ---- layer 1: output tile `wave`
+  // ---- layer 1: output tiles TW wave + i
   {
-    v4d acc[NS];
-    const v4d bias = load_bias_tile((const double*)opaque(n.b1), wave, q);
+    v4d acc[TW][NS];
 #pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) acc[s2] = bias;
-    gptr p = opaque(n.W1p + (size_t)wave * 64);
+    for (int i = 0; i < TW; ++i) {
+      const v4d bias = load_bias_tile((const double*)opaque(n.b1), TW * wave + i, q);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) acc[i][s2] = bias;
+    }
+    gptr p = opaque(n.W1p + (size_t)TW * wave * 64);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const double a = p[(ks * HT) * 64 + lane];
 #pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) acc[s2] = mfma(a, ks == 0 ? p0[s2] : p1[s2], acc[s2]);
+      for (int i = 0; i < TW; ++i) {
+        const double a = p[(ks * HT + i) * 64 + lane];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) acc[i][s2] = mfma(a, ks == 0 ? p0[s2] : p1[s2], acc[i][s2]);
+      }
     }
 #pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        double ta, tb;
-        NLC_HIDDEN_TANH_PAIR(acc[s2][r], acc[s2][r + 1], &ta, &tb);
-        H1[s2 * KS * 64 + (4 * wave + r) * 64 + lane] = ta;
-        H1[s2 * KS * 64 + (4 * wave + r + 1) * 64 + lane] = tb;
-      }
+      for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          double ta, tb;
+          NLC_HIDDEN_TANH_PAIR(acc[i][s2][r], acc[i][s2][r + 1], &ta, &tb);
+          H1[s2 * KS * 64 + (4 * (TW * wave + i) + r) * 64 + lane] = ta;
+          H1[s2 * KS * 64 + (4 * (TW * wave + i) + r + 1) * 64 + lane] = tb;
+        }
   }
   __syncthreads();
-  // ---- layer 2: output tile `wave`
+  // ---- layer 2: output tiles TW wave + i
   {
-    v4d acc[NS];
-    const v4d bias = load_bias_tile((const double*)opaque(n.b2), wave, q);
+    v4d acc[TW][NS];
 #pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2) acc[s2] = bias;
-    gptr p = opaque(n.W2p + (size_t)wave * 64);
-    double a_cur = p[lane], a_nxt = 0.0;
+    for (int i = 0; i < TW; ++i) {
+      const v4d bias = load_bias_tile((const double*)opaque(n.b2), TW * wave + i, q);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) acc[i][s2] = bias;
+    }
+    gptr p = opaque(n.W2p + (size_t)TW * wave * 64);
+    double a_cur[TW], a_nxt[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      a_cur[i] = p[i * 64 + lane];
+      a_nxt[i] = 0.0;
+    }
     double b_cur[NS], b_nxt[NS];
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
@@ -657,32 +675,38 @@ __device__ __forceinline__ void repfunc_block_mlp(const NlNetArgs& n, const doub
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + 1 < KS) {
         p = opaque(p + HT * 64);
-        a_nxt = p[lane];
+#pragma unroll
+        for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) b_nxt[s2] = H1[s2 * KS * 64 + (ks + 1) * 64 + lane];
       }
 #pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) acc[s2] = mfma(a_cur, b_cur[s2], acc[s2]);
-      a_cur = a_nxt;
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) acc[i][s2] = mfma(a_cur[i], b_cur[s2], acc[i][s2]);
+#pragma unroll
+      for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) b_cur[s2] = b_nxt[s2];
     }
 #pragma unroll
-    for (int s2 = 0; s2 < NS; ++s2)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        double ta, tb;
-        NLC_HIDDEN_TANH_PAIR(acc[s2][r], acc[s2][r + 1], &ta, &tb);
-        H2[s2 * KS * 64 + (4 * wave + r) * 64 + lane] = ta;
-        H2[s2 * KS * 64 + (4 * wave + r + 1) * 64 + lane] = tb;
-      }
+      for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          double ta, tb;
+          NLC_HIDDEN_TANH_PAIR(acc[i][s2][r], acc[i][s2][r + 1], &ta, &tb);
+          H2[s2 * KS * 64 + (4 * (TW * wave + i) + r) * 64 + lane] = ta;
+          H2[s2 * KS * 64 + (4 * (TW * wave + i) + r + 1) * 64 + lane] = tb;
+        }
   }
   __syncthreads();
-  // ---- layer 3 (own tiles, all four sample tiles) + sphere -> complex, F_k stored slot-major
+  // ---- layer 3 (own tiles, all NS sample tiles) + sphere -> complex, F_k stored slot-major
   {
     int j3[NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) j3[i] = (wave + 8 * i < NT3) ? wave + 8 * i : NT3 - 1;
+    for (int i = 0; i < NTW; ++i) j3[i] = (wave + NW * i < NT3) ? wave + NW * i : NT3 - 1;
     v4d o[NTW][NS];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -720,7 +744,7 @@ __device__ __forceinline__ void repfunc_block_mlp(const NlNetArgs& n, const doub
     }
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-      if (wave + 8 * i < NT3) {  // wave-uniform
+      if (wave + NW * i < NT3) {  // wave-uniform
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
@@ -736,7 +760,7 @@ __device__ __forceinline__ void repfunc_block_mlp(const NlNetArgs& n, const doub
               double sn, cs;
               m::sincos_bounded(theta, &sn, &cs);
               const double rad = num * m::rcp_refined(den);
-              const int64_t at = (int64_t)(4 * g + q) * 64 + 16 * s2 + c;
+              const int64_t at = (int64_t)(4 * g + q) * (16 * NS) + 16 * s2 + c;
               fre[at] = rad * cs;
               fim[at] = rad * sn;
             }

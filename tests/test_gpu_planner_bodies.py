@@ -308,11 +308,13 @@ def test_dehoog_planner_parts_on_streams_bit_identical(nlc):
     ("oderl-pendulum", 200, 6, 17, False, True),       # d = 3, 17 terms, the running cost a caller's closure
     ("oderl-cartpole", 5, 3, 17, False, False),        # fewer samples than one tile
 ])
-def test_dehoog_step_chain_kernel_bit_identical_to_staged_path(nlc, env, K, T, S, per_sample, ext_cost):
+@pytest.mark.parametrize("form", [1, 2])
+def test_dehoog_step_chain_kernel_bit_identical_to_staged_path(nlc, env, K, T, S, per_sample, ext_cost, form):
     """Round 4: the de Hoog planner's step chain as ONE persistent launch (kernels_dehoog_chain.hip: a workgroup owns 64
     samples for all T steps; representation MLP, QD table and state / cost tail are the staged path's own device functions)
     against the staged 2 T + 1 launches (`dehoog_chain` 1 / 0): states, costs, weights, U and actions must be the same BITS over
-    consecutive commands, and the chain planner must not launch the per-step kernels at all."""
+    consecutive commands, and the chain planner must not launch the per-step kernels at all.  `form` 1: eight waves own 64
+    samples; 2: four waves own 32 samples, two workgroups per CU, two dims' QD rows per wavefront."""
     from oracle import nl_model as onl
 
     st = onl.ENV_STATS[env]
@@ -326,7 +328,8 @@ def test_dehoog_step_chain_kernel_bit_identical_to_staged_path(nlc, env, K, T, S
         cost = nlc.EnvCost(env)
     planners = {ch: nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
                                   u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=9,
-                                  U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options={"dehoog_chain": ch})
+                                  U_init=torch.zeros(T, nu, dtype=torch.float64),
+                                  planner_options={"dehoog_chain": form if ch else 0})
                 for ch in (0, 1)}
     g = torch.Generator().manual_seed(3)
     state = nlc.initial_state(env, g)

@@ -16,7 +16,7 @@ model = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=S, ilt_
 with torch.no_grad():
     model.laplace_rep_func.linear_tanh_stack[4].bias[d * S:] += -3.0
 model = model.to("cuda")
-variants = {"chain": {"dehoog_chain": 1}, "staged_2_streams": {"dehoog_chain": 0, "dehoog_streams": 2},
+variants = {"auto_measured_choice": {}, "chain": {"dehoog_chain": 1}, "chain_32_samples_two_per_cu": {"dehoog_chain": 2}, "staged_2_streams": {"dehoog_chain": 0, "dehoog_streams": 2},
             "staged_1_stream": {"dehoog_chain": 0, "dehoog_streams": 1},
             # timing breakdown of the chain kernel (results meaningless): only its representation phase / only its QD phase
             "chain_phase_A_only": {"dehoog_chain": 1, "dehoog_chain_phases": 1},
@@ -29,7 +29,7 @@ st, ab = nlc.initial_state(env, torch.Generator().manual_seed(0)), torch.zeros(4
 out = {n: [] for n in planners}
 with torch.no_grad():
     for p in planners.values():
-        for _ in range(3):
+        for _ in range(130):  # (auto takes its candidate forms in turns for at least half a second before it settles)
             p.command(st, ab)
     for rep in range(3):
         for name, p in planners.items():
