@@ -47,7 +47,7 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
   // first commands of a planner therefore run the candidates in turns -- same bits whichever runs -- with an event pair around
   // the chain (read back one command later, when the caller has long waited for that command's action: no synchronisation is
   // added), and the planner keeps the fastest.
-  const bool calibrate = dehoog && d.E == 1 && c->opt_dehoog_chain < 0 && c->opt_dehoog_streams == 0 && KE >= 8192 && !c->profiling;
+  const bool calibrate = d.E == 1 && c->opt_dehoog_chain < 0 && c->opt_dehoog_streams == 0 && KE >= 8192 && !c->profiling;
   int calib_variant = -1;  // 0: two streams, 1: one stream, 2: persistent kernel
   if (calibrate) {
     const int ncand = chain_ok ? 3 : 2;
