@@ -20,6 +20,19 @@
 // Roofline: FP64 MFMA bound; per 16 samples and step (2 + h/4)*HT + (h/4)*nt3 + 2*nt3 MFMAs.
 #include "nlc_nl_kernels.h"
 
+#if NLC_PHASE_CLOCKS
+namespace nlc {
+__device__ unsigned long long nlc_phase_clk[16];
+}
+// tools/rollout_phase_clocks.py: reads (and clears) the phase sums of the launches since the last call
+extern "C" int nlc_debug_phase_clocks(unsigned long long* out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(nlc::nlc_phase_clk), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned long long zero[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(nlc::nlc_phase_clk), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace nlc {
 
 // launchers for hidden width 16 * 8

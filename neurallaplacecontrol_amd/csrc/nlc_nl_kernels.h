@@ -8,6 +8,16 @@
 #include "nlc_kernels.h"
 #include "nlc_rollout.h"
 
+// NLC_ROLLOUT_LDS_TABS: nl_rollout_kernel reads the network's small tables from a workgroup copy in LDS (NlTabsLds, nlc_rollout.h)
+#ifndef NLC_ROLLOUT_LDS_TABS
+#define NLC_ROLLOUT_LDS_TABS 1
+#endif
+// NLC_ROLLOUT_LDS_W2: layer 2's whole matrix in LDS as well (154 KB).  Measured (round 4, K = 16384): 1.105 -> 1.146 ms -- the
+// k loop's fragment reads are hidden behind its MFMAs either way, and the LDS reads of the other three waves are not free.  Off.
+#ifndef NLC_ROLLOUT_LDS_W2
+#define NLC_ROLLOUT_LDS_W2 0
+#endif
+
 namespace nlc {
 
 // ------------------------------------------------------------------ T-step rollout (planner)
@@ -49,11 +59,47 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
     cost = a.ccarry[kc * 2];
     pcost = a.ccarry[kc * 2 + 1];
   }
+  PhaseClk clk;
+  clk.start();
+  // One wave per SIMD has nobody to hide a load behind: everything a step reads that does not depend on the state -- the next
+  // step's GRU latents, this step's action, noise and nominal control, the next evaluation's layer-1 tiles -- is issued one phase
+  // or one step ahead (NLC_EVAL_PIPELINE, nlc_rollout.h).
+#if NLC_ROLLOUT_LDS_TABS
+  // (layer 2's matrix too where everything fits the CU's 160 KB)
+  constexpr bool kW2 = NLC_ROLLOUT_LDS_W2 && NlTabsLds<HT, NT3, true>::kDoubles * 8 <= 160 * 1024;
+  using Tabs = NlTabsLds<HT, NT3, kW2>;
+  __shared__ double tabs_sm[Tabs::kDoubles];
+  Tabs::fill(tabs_sm, n, threadIdx.x, 256);
+  __syncthreads();
+  const Tabs tabs{(lptr)tabs_sm};
+#else
+  const NlTabsGlobal tabs;
+#endif
+  // (hidden_units 256: layer 1 alone is 192 registers -- loaded where it is used)
+  using Pre = typename std::conditional<(HT <= 8), NlL1Pre<HT>, NlNoPre>::type;
+  Pre l1;
+  if constexpr (HT <= 8) l1.load(n, lane, q, tabs);
+  double pa0 = 0.0, pa1 = 0.0;
+  if (a.t_begin < a.t_end) {
+    const double* pa = a.pa + (kc * a.T + a.t_begin) * 2;
+    pa0 = pa[0];
+    pa1 = pa[1];
+  }
   for (int t = a.t_begin; t < a.t_end; ++t) {
-    const double* pa = a.pa + (kc * a.T + t) * 2;
-    const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
-    const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
-    const v4d ax = nl_eval<HT, NT3, false, false, LIN>(n, lane, q, p0, p1, a.tn);
+    double pert[NLC_MAX_NU] = {0.0, 0.0}, eps[NLC_MAX_NU] = {0.0, 0.0}, Ut[NLC_MAX_NU] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < NLC_MAX_NU; ++j)
+      if (j < a.nu) {
+        pert[j] = a.perturbed[(kc * a.T + t) * a.nu + j];
+        eps[j] = a.noise[(kc * a.T + t) * a.nu + j];
+        Ut[j] = a.U[uoff + t * a.nu + j];
+      }
+    const double* pan = a.pa + (kc * a.T + (t + 1 < a.t_end ? t + 1 : t)) * 2;
+    const double npa0 = pan[0], npa1 = pan[1];
+    __builtin_amdgcn_sched_barrier(0);
+    const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa0 : (i0 == d + 1 ? pa1 : 0.0));
+    const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa0 : (i1 == d + 1 ? pa1 : 0.0));
+    const v4d ax = nl_eval_impl<HT, NT3, false, false, LIN>(n, lane, q, p0, p1, a.tn, nullptr, nullptr, &clk, l1, tabs);
     // state + model(state, window, ts_pred)   (mppi_with_model.py:120-121)
     if (i0 < d) x0 = x0 + factor * ax[0];
     if (i1 < d) x1 = x1 + factor * ax[1];
@@ -68,20 +114,35 @@ __global__ __launch_bounds__(256) void nl_rollout_kernel(const RolloutArgs a) {
     for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
     double u[NLC_MAX_NU] = {0.0, 0.0};
     double pc = 0.0;
-    for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * a.perturbed[(kc * a.T + t) * a.nu + j];
+#pragma unroll
+    for (int j = 0; j < NLC_MAX_NU; ++j)
+      if (j < a.nu) u[j] = a.u_scale * pert[j];
     // perturbation cost sum_j U[t,j] * (lambda * eps @ Sigma^-1)[j]   (mppi_delay.py:335,343)
-    for (int j = 0; j < a.nu; ++j) {
-      double acj = 0.0;
-      for (int i = 0; i < a.nu; ++i) {
-        double e = a.noise[(kc * a.T + t) * a.nu + i];
-        if (a.noise_abs_cost) e = fabs(e);
-        acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+#pragma unroll
+    for (int j = 0; j < NLC_MAX_NU; ++j)
+      if (j < a.nu) {
+        double acj = 0.0;
+#pragma unroll
+        for (int i = 0; i < NLC_MAX_NU; ++i)
+          if (i < a.nu) {
+            double e = eps[i];
+            if (a.noise_abs_cost) e = fabs(e);
+            acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+          }
+        pc += Ut[j] * acj;
       }
-      pc += a.U[uoff + t * a.nu + j] * acj;
-    }
     cost += running_cost(a.env, xs, u, a.nu);
     pcost += pc;
+    pa0 = npa0;
+    pa1 = npa1;
+    clk.mark(PhaseClk::kTail);
   }
+#if NLC_PHASE_CLOCKS
+  if (lane == 0) {
+    for (int i = 0; i < PhaseClk::kN; ++i) atomicAdd(&nlc_phase_clk[i], (unsigned long long)clk.acc[i]);
+    atomicAdd(&nlc_phase_clk[PhaseClk::kN], 1ull);  // waves
+  }
+#endif
   if (valid) {
     if (last_chunk) {
       if (q == 0) a.cost_total[k] = cost + pcost;

@@ -23,7 +23,38 @@
 #define NLC_HIDDEN_TANH_PAIR m::tanh_pair_d
 #endif
 
+// -DNLC_PHASE_CLOCKS=1 (tools only: tools/rollout_phase_clocks.py, a separate build of the library): shader-clock stamps at the
+// phase boundaries of one model evaluation, summed per wave in SGPRs and added to nlc_phase_clk[] when the wave retires.  The
+// product build compiles none of it.
+#ifndef NLC_PHASE_CLOCKS
+#define NLC_PHASE_CLOCKS 0
+#endif
+
 namespace nlc {
+
+struct PhaseClk {
+  static constexpr int kN = 10;
+  enum { kL1 = 0, kTanh1, kL2, kTanh2, kL3a, kEpiA, kL3b, kEpiB, kTail, kOther };
+  uint64_t last;
+  uint64_t acc[kN];
+  __device__ __forceinline__ void start() {
+    if (!NLC_PHASE_CLOCKS) return;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) acc[i] = 0;
+    last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    if (!NLC_PHASE_CLOCKS) return;
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    acc[i] += now - last;
+    last = now;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+#if NLC_PHASE_CLOCKS
+extern __device__ unsigned long long nlc_phase_clk[16];  // kernels_nl.hip
+#endif
 
 // ------------------------------------------------------------------ one model evaluation
 // p0/p1: layer-1 latent B fragments (index 4s+q).  Returns acc_x: ILT sums, rows = dims (reg r -> dim q+4r).
@@ -81,13 +112,120 @@ struct FOut {
 };
 // sph_row (GENERAL_T only): when non-NULL, this lane's sample has EXPLICIT sphere inputs [theta_s | phi_s] (2S doubles)
 // -- LaplaceRepresentationFunc.forward on an arbitrary input row (w_nl.py:55-63) -- instead of the ones of s_k(tn).
-template <int HT, int NT3, bool GENERAL_T, bool WRITE_F = false, bool LIN = false>
-__device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn,
-                                       const FOut* fo = nullptr, const double* sph_row = nullptr) {
+// NLC_EVAL_PIPELINE (A/B switch, tools/bench_ab.sh): where the loads that are NOT a GEMM's own k-step fragments are issued --
+// bias tiles, each GEMM's first fragments, the ILT coefficient tiles, a horizon loop's next layer 1.
+//   0  at the head of the phase that consumes them (rounds 1-3)
+//   1  inside the k loop of the GEMM BEFORE that phase, a few per k-step, scheduled into the MFMA shadows together with the
+//      k-step's own fragments (gemm_acc_head's `extra`).  One wave per SIMD has nobody to hide behind, and a vector load costs
+//      its wave ~17 issue clocks wherever no MFMA is running (tools/rollout_phase_clocks.py: moving the loads in front of the
+//      activation phase made that phase longer by exactly their issue time).
+// Arithmetic, MFMA order per tile and ILT sum order are the same in both: same bits.
+// NLC_L3_SINGLE_PASS: 1 = layer 3 as one GEMM over its NT3 output tiles, 0 = two halves (round 3).
+#ifndef NLC_EVAL_PIPELINE
+#define NLC_EVAL_PIPELINE 1
+#endif
+#ifndef NLC_L3_SINGLE_PASS
+#define NLC_L3_SINGLE_PASS 0
+#endif
+// Where the SMALL tables of the network are read from (bias vectors, layer-1 fragments, ILT coefficient tiles: 23 KB at the
+// headline shape) -- every access returns a pointer the optimiser cannot see through, so nothing is hoisted out of a horizon loop.
+//   NlTabsGlobal  the packed arrays in HBM / L2 (NlNetArgs)
+//   NlTabsLds     a copy the workgroup made in LDS at kernel start (nl_rollout_kernel): an LDS read costs its wave a fraction
+//                 of a vector load's issue time and latency, and these loads sit at the HEAD of every phase, where one wave per
+//                 SIMD has nothing to hide them behind
+struct NlTabsGlobal {
+  __device__ __forceinline__ const double* b1(const NlNetArgs& n) const { return (const double*)opaque(n.b1); }
+  __device__ __forceinline__ const double* b2(const NlNetArgs& n) const { return (const double*)opaque(n.b2); }
+  __device__ __forceinline__ const double* b3p(const NlNetArgs& n) const { return (const double*)opaque(n.b3p); }
+  __device__ __forceinline__ gptr w1(const NlNetArgs& n) const { return opaque(n.W1p); }
+  __device__ __forceinline__ gptr cp(const NlNetArgs& n) const { return opaque(n.Cp); }
+  __device__ __forceinline__ const double* w2(const NlNetArgs& n) const { return n.W2p; }  // (laundered by the GEMM)
+};
+// W2: layer 2's whole fragment-packed matrix as well (h^2 doubles: 128 KB at hidden_units 128 -- with the small tables that is
+// 154 KB of the CU's 160 KB, one workgroup per CU, which the kernel's one wave per SIMD implies anyway)
+template <int HT, int NT3, bool W2 = false>
+struct NlTabsLds {
+  static constexpr int kB1 = 0, kB2 = 16 * HT, kB3 = 32 * HT, kW1 = kB3 + 16 * NT3, kCp = kW1 + 2 * HT * 64;
+  static constexpr int kW2 = kCp + 2 * NT3 * 64;
+  static constexpr int kDoubles = kW2 + (W2 ? HT * HT * 4 * 64 : 0);
+  lptr base;
+  __device__ __forceinline__ auto w2(const NlNetArgs& n) const {
+    if constexpr (W2)
+      return (lptr)(base + kW2);
+    else
+      return n.W2p;
+  }
+  __device__ __forceinline__ lptr b1(const NlNetArgs&) const { return opaque_lds(base + kB1); }
+  __device__ __forceinline__ lptr b2(const NlNetArgs&) const { return opaque_lds(base + kB2); }
+  __device__ __forceinline__ lptr b3p(const NlNetArgs&) const { return opaque_lds(base + kB3); }
+  __device__ __forceinline__ lptr w1(const NlNetArgs&) const { return opaque_lds(base + kW1); }
+  __device__ __forceinline__ lptr cp(const NlNetArgs&) const { return opaque_lds(base + kCp); }
+  // all threads of the workgroup, before its first barrier
+  __device__ __forceinline__ static void fill(double* sm, const NlNetArgs& n, int tid, int nthreads) {
+    for (int i = tid; i < 16 * HT; i += nthreads) {
+      sm[kB1 + i] = n.b1[i];
+      sm[kB2 + i] = n.b2[i];
+    }
+    for (int i = tid; i < 16 * NT3; i += nthreads) sm[kB3 + i] = n.b3p[i];
+    for (int i = tid; i < 2 * HT * 64; i += nthreads) sm[kW1 + i] = n.W1p[i];
+    for (int i = tid; i < 2 * NT3 * 64; i += nthreads) sm[kCp + i] = n.Cp[i];
+    if constexpr (W2) {
+      for (int i = tid; i < HT * HT * 4 * 64; i += nthreads) sm[kW2 + i] = n.W2p[i];
+    }
+  }
+};
+
+// Layer 1 of one model evaluation: bias tiles and both k-steps' weight fragments -- what a horizon loop loads one step ahead.
+template <int HT>
+struct NlL1Pre {
+  v4d bias[HT];
+  double w1[2 * HT];
+  static constexpr int kItems = 6 * HT;
+  // item I < 4 HT: register I & 3 of bias tile I >> 2; then the 2 HT fragments.  b1q = b1 + q, both pointers laundered.
+  template <int I, class BP, class WP>
+  __device__ __forceinline__ void item(BP b1q, WP w, int lane) {
+    if constexpr (I < 4 * HT)
+      bias[I >> 2][I & 3] = b1q[16 * (I >> 2) + 4 * (I & 3)];
+    else if constexpr (I < kItems)
+      w1[I - 4 * HT] = w[(I - 4 * HT) * 64 + lane];
+  }
+  template <class TABS = NlTabsGlobal>
+  __device__ __forceinline__ void load(const NlNetArgs& n, int lane, int q, const TABS& tabs = TABS{}) {
+    const auto b1q = tabs.b1(n) + q;
+    const auto w = tabs.w1(n);
+    static_for<kItems>([&](auto ic) { item<decltype(ic)::value>(b1q, w, lane); });
+  }
+};
+
+struct NlNoPre {};  // a single evaluation: layer 1 is loaded where it is used
+
+// PRE = NlL1Pre<HT>: `pre` holds this evaluation's layer 1 and receives the next one's; NlNoPre: neither.  (A type, not a
+// nullable pointer: a null test on the caller's register struct would pin it to scratch memory.)
+template <int HT, int NT3, bool GENERAL_T, bool WRITE_F, bool LIN, class PRE, class TABS = NlTabsGlobal>
+__device__ __forceinline__ v4d nl_eval_impl(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn, const FOut* fo,
+                                            const double* sph_row, PhaseClk* pc, PRE& pre, const TABS& tabs = TABS{}) {
   constexpr int KS = HT * 4;  // h / 4
+  // (wider output layers, hidden_units 256: the registers are needed elsewhere)
+  constexpr bool PIPE = NLC_EVAL_PIPELINE != 0 && NT3 <= 17 && HT <= 8;
+  constexpr bool HAS_PRE = !std::is_same<PRE, NlNoPre>::value;
+  auto phase = [&](int i) {
+    if (NLC_PHASE_CLOCKS && pc != nullptr) pc->mark(i);
+  };
   v4d h1[HT];
+  double w1[2 * HT];
+  if constexpr (HAS_PRE) {
 #pragma unroll
-  for (int j = 0; j < HT; ++j) h1[j] = load_bias_tile(n.b1, j, q);
+    for (int j = 0; j < HT; ++j) h1[j] = pre.bias[j];
+#pragma unroll
+    for (int i = 0; i < 2 * HT; ++i) w1[i] = pre.w1[i];
+  } else {
+    NlL1Pre<HT> now;
+    now.load(n, lane, q, tabs);
+#pragma unroll
+    for (int j = 0; j < HT; ++j) h1[j] = now.bias[j];
+#pragma unroll
+    for (int i = 0; i < 2 * HT; ++i) w1[i] = now.w1[i];
+  }
   if constexpr (GENERAL_T) {
     // s_k = gamma + i pi k / T,  T = scale*t,  gamma = alpha - ln(tol)/(scale*T); theta_s = atan2(Im, Re),
     // phi_s = asin((|s|^2-1)/(|s|^2+1)); input order [theta_s(0..S-1) | phi_s(0..S-1)]
@@ -115,24 +253,86 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
       p = opaque(p + HT * 64);
     }
   }
-  gemm_acc<HT, 2>(h1, n.W1p, lane, [&](int ks) { return ks == 0 ? p0 : p1; });
-  // Activations are applied as one batch of 32 independent tanh chains per layer.  (On gfx950 an FP64 MFMA
-  // holds the SIMD's VALU issue for its whole 64 cycles -- tools/ubench_f64.hip -- so interleaving the
-  // activation with the next layer's MFMAs buys nothing, while batching keeps the FP64 VALU latency hidden.)
-#pragma unroll
-  for (int j = 0; j < HT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; r += 2) {
-      double ta, tb;
-      NLC_HIDDEN_TANH_PAIR(h1[j][r], h1[j][r + 1], &ta, &tb);
-      h1[j][r] = ta;
-      h1[j][r + 1] = tb;
-    }
 
+  // ---- layer 1 (fragments already in registers); in its shadow: layer 2's bias tiles and first fragments
   v4d h2[HT];
+  double a2[HT];
+  {
+    const auto b2q = tabs.b2(n) + q;
+    const auto w2 = opaque(tabs.w2(n));
+    auto item2 = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < 4 * HT)
+        h2[i >> 2][i & 3] = b2q[16 * (i >> 2) + 4 * (i & 3)];
+      else if constexpr (i < 5 * HT)
+        a2[i - 4 * HT] = w2[(i - 4 * HT) * 64 + lane];
+    };
+    constexpr int IPM = 3;  // 5 HT items over 2 HT MFMAs
+    static_for<2 * HT>([&](auto mc) {
+      constexpr int km = decltype(mc)::value, ks = km / HT, m = km % HT;
+      h1[m] = mfma(w1[ks * HT + m], ks == 0 ? p0 : p1, h1[m]);
+      if (PIPE) {
+        static_for<IPM>([&](auto e) { item2(std::integral_constant<int, km * IPM + decltype(e)::value>{}); });
+#if NLC_GEMM_INTERLEAVE
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, IPM, 0);
+#endif
+      }
+    });
+    if (PIPE) __builtin_amdgcn_sched_barrier(0);
+    phase(PhaseClk::kL1);
+    // Activations are applied as one batch of 32 independent tanh chains per layer.  (On gfx950 an FP64 MFMA
+    // holds the SIMD's VALU issue for its whole 64 cycles -- tools/ubench_f64.hip -- so interleaving the
+    // activation with the next layer's MFMAs buys nothing, while batching keeps the FP64 VALU latency hidden.)
 #pragma unroll
-  for (int j = 0; j < HT; ++j) h2[j] = load_bias_tile(n.b2, j, q);
-  gemm_acc<HT, KS>(h2, n.W2p, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; });
+    for (int j = 0; j < HT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        double ta, tb;
+        NLC_HIDDEN_TANH_PAIR(h1[j][r], h1[j][r + 1], &ta, &tb);
+        h1[j][r] = ta;
+        h1[j][r + 1] = tb;
+      }
+    phase(PhaseClk::kTanh1);
+    if (!PIPE) static_for<5 * HT>(item2);
+  }
+
+  // ---- layer 2; in its shadow: the bias tiles, first fragments and ILT coefficient tiles of layer 3's first pass.
+  // Layer 3 runs in two passes over its output tiles (round 3): half the accumulators and prefetch registers live at a time.
+  constexpr int NA = NLC_L3_SINGLE_PASS ? NT3 : (NT3 + 1) / 2, NB = NT3 - NA, NB1 = NB > 0 ? NB : 1;
+  // coefficient tiles fetched ahead per output tile (not pipelined: read where they are used, as LIN's second table always is)
+  constexpr int NCP = (WRITE_F || !PIPE) ? 0 : 2;
+  v4d oa[NA], ob[NB1];
+  double a3a[NA], a3b[NB1], cpa[2 * NA], cpb[2 * NB1];
+  const auto b3q = tabs.b3p(n) + q;
+  gptr w3 = opaque(n.W3p);
+  const auto cp = tabs.cp(n);
+  auto item3a = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < 4 * NA)
+      oa[i >> 2][i & 3] = b3q[16 * (i >> 2) + 4 * (i & 3)];
+    else if constexpr (i < 5 * NA)
+      a3a[i - 4 * NA] = w3[(i - 4 * NA) * 64 + lane];
+    else if constexpr (i < (5 + NCP) * NA)
+      cpa[i - 5 * NA] = cp[(i - 5 * NA) * 64 + lane];
+  };
+  auto item3b = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (NB > 0) {
+      if constexpr (i < 4 * NB)
+        ob[i >> 2][i & 3] = b3q[16 * (NA + (i >> 2)) + 4 * (i & 3)];
+      else if constexpr (i < 5 * NB)
+        a3b[i - 4 * NB] = w3[(NA + i - 4 * NB) * 64 + lane];
+      else if constexpr (i < (5 + NCP) * NB)
+        cpb[i - 5 * NB] = cp[(2 * NA + i - 5 * NB) * 64 + lane];
+    }
+  };
+  constexpr int N3A = (5 + NCP) * NA, N3B = (5 + NCP) * NB;
+  constexpr int E2 = PIPE ? (N3A + KS - 1) / KS : 0;
+  gemm_acc_head<HT, HT, KS, E2>(h2, a2, tabs.w2(n), 0, lane, [&](int ks) { return h1[ks >> 2][ks & 3]; }, [&](auto kc) {
+    static_for<E2>([&](auto e) { item3a(std::integral_constant<int, decltype(kc)::value * E2 + decltype(e)::value>{}); });
+  });
+  phase(PhaseClk::kL2);
 #pragma unroll
   for (int j = 0; j < HT; ++j)
 #pragma unroll
@@ -142,15 +342,12 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
       h2[j][r] = ta;
       h2[j][r + 1] = tb;
     }
+  phase(PhaseClk::kTanh2);
+  if (!PIPE) static_for<N3A>(item3a);
 
-  // Layer 3 in two halves of its output tiles (round 3): half the accumulators and prefetch registers live at a time --
-  // the wave-per-tile rollout kernel drops under 256 VGPRs, so one of its waves fits a SIMD beside a GRU-encoder wave
-  // (horizon chunks of the two kernels running side by side, abi_planner_nl.hip).  Same MFMA sequence per tile, same ILT sum
-  // order: same bits.
   v4d ax[1];
   ax[0] = splat(0.0);
-  gptr cp = opaque(n.Cp);
-  auto epilogue = [&](auto& o, auto J0, auto NJ) {
+  auto epilogue = [&](auto& o, auto& cpv, auto J0, auto NJ) {
 #pragma unroll
     for (int jj = 0; jj < decltype(NJ)::value; ++jj) {
       const int j = decltype(J0)::value + jj;
@@ -182,31 +379,53 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
           if constexpr (LIN) {
             double rc, rs;
             sphere_terms_lin(theta, phi, &rc, &rs);
-            ax[0] = mfma(cp[g * 64 + lane], rc, ax[0]);
+            ax[0] = mfma(NCP ? cpv[2 * jj + r] : cp[g * 64 + lane], rc, ax[0]);
             ax[0] = mfma(opaque(n.Cp2)[g * 64 + lane], rs, ax[0]);
           } else {
-            ax[0] = mfma(cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
+            ax[0] = mfma(NCP ? cpv[2 * jj + r] : cp[g * 64 + lane], sphere_term(theta, phi, g >= n.n_even_groups), ax[0]);
           }
         }
       }
     }
   };
-  constexpr int NA = (NT3 + 1) / 2, NB = NT3 - NA;
-  {
-    v4d o[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) o[j] = load_bias_tile(n.b3p, j, q);
-    gemm_acc_part<NA, NT3, KS>(o, n.W3p, 0, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
-    epilogue(o, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+  // a horizon loop's next evaluation: its layer-1 tiles ride in the shadow of this one's last GEMM
+  const auto b1q = tabs.b1(n) + q;
+  const auto w1n = tabs.w1(n);
+  constexpr int NL1 = NlL1Pre<HT>::kItems;
+  constexpr int EL1 = PIPE ? (NL1 + KS - 1) / KS : 0;
+  auto next_l1 = [&](auto kc) {
+    if constexpr (HAS_PRE)
+      static_for<EL1>([&](auto e) { pre.template item<decltype(kc)::value * EL1 + decltype(e)::value>(b1q, w1n, lane); });
+  };
+  if constexpr (NB > 0) {
+    // ---- layer 3, first pass; in its shadow: the second pass's tiles
+    constexpr int E3A = PIPE ? (N3B + KS - 1) / KS : 0;
+    gemm_acc_head<NA, NT3, KS, E3A>(oa, a3a, n.W3p, 0, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; }, [&](auto kc) {
+      static_for<E3A>([&](auto e) { item3b(std::integral_constant<int, decltype(kc)::value * E3A + decltype(e)::value>{}); });
+    });
+    phase(PhaseClk::kL3a);
+    epilogue(oa, cpa, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+    phase(PhaseClk::kEpiA);
+    if (!PIPE) static_for<N3B>(item3b);
+    // ---- layer 3, second pass; in its shadow: the next evaluation's layer 1
+    gemm_acc_head<NB1, NT3, KS, EL1>(ob, a3b, n.W3p, NA, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; }, next_l1);
+    phase(PhaseClk::kL3b);
+    epilogue(ob, cpb, std::integral_constant<int, NA>{}, std::integral_constant<int, NB>{});
+    phase(PhaseClk::kEpiB);
+  } else {
+    gemm_acc_head<NA, NT3, KS, EL1>(oa, a3a, n.W3p, 0, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; }, next_l1);
+    phase(PhaseClk::kL3a);
+    epilogue(oa, cpa, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+    phase(PhaseClk::kEpiA);
   }
-  {
-    v4d o[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) o[j] = load_bias_tile(n.b3p, NA + j, q);
-    gemm_acc_part<NB, NT3, KS>(o, n.W3p, NA, lane, [&](int ks) { return h2[ks >> 2][ks & 3]; });
-    epilogue(o, std::integral_constant<int, NA>{}, std::integral_constant<int, NB>{});
-  }
+  if constexpr (!PIPE && HAS_PRE) pre.load(n, lane, q, tabs);
   return ax[0];
+}
+template <int HT, int NT3, bool GENERAL_T, bool WRITE_F = false, bool LIN = false>
+__device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, double p0, double p1, double tn,
+                                       const FOut* fo = nullptr, const double* sph_row = nullptr, PhaseClk* pc = nullptr) {
+  NlNoPre none;
+  return nl_eval_impl<HT, NT3, GENERAL_T, WRITE_F, LIN>(n, lane, q, p0, p1, tn, fo, sph_row, pc, none);
 }
 
 // ------------------------------------------------------------------ latency-split rollout of one 16-sample tile
