@@ -11,7 +11,9 @@ namespace nlc {
 // streaming 2.65 ms, gate transcendentals 0.8 ms; a two-k-step fragment prefetch changed nothing: loads are hidden.)
 // Gate GEMMs are processed in CHUNKS of one 16-feature tile per gate (r_j, z_j, n_j): only four accumulator
 // tiles are live at a time instead of sixteen, which keeps the kernel under 256 VGPRs -> two waves per SIMD,
-// so one wave's gate transcendentals (FP64 VALU) overlap the other wave's MFMAs.
+// so one wave's gate transcendentals (FP64 VALU) overlap the other wave's MFMAs.  (With two waves per SIMD the k-step's loads
+// stay in front of its MFMAs: the MFMA / load interleave that pays at one wave per SIMD -- gemm_kstep_order -- cost this kernel
+// 2.5 %, 2.967 -> 3.042 ms; round 4.)
 // Chunk-packed weights: Wc[((j*KS + ks)*3 + g)*64 + lane], g in {r, z, n}: row g*G + 16 j + (lane & 15).
 template <int KS>
 __device__ __forceinline__ void chunk_gemm(v4d& c0, v4d& c1, v4d& c2, const double* __restrict__ wc, int lane,
