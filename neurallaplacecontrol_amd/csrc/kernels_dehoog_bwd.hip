@@ -14,7 +14,10 @@
 //     (round 3 kept them in a second 9 KB-per-row region of the scratch: 61.5 KB of HBM traffic per row for a 19 KB tape),
 //   * the continued-fraction adjoint recurrence runs lazily, two steps before each column, so its seeds dbar_i never leave
 //     registers either.
-// What travels per row: the value tape (10 KB written + 10 KB read at M = 16), theta / phi in, both gradients out.
+// What travels per row: the value tape (10 KB written + 10 KB read at M = 16), theta / phi in, both gradients out -- 28.2 KB per
+// row at the memory counters, i.e. 92 GB for the bench's 3.3 M rows in 19.8-22.2 ms = 4.2-4.7 TB/s, which is what a read + write
+// stream attains on this chip (tools/ubench_hbm_copy.hip: 4.5-5.5): at 33 terms the kernel is bound by its own tape, and getting
+// under ~19 ms needs a smaller tape (checkpointed columns + recomputation: the forward sweep is 1.35 ms), not a better schedule.
 // The scratch belongs to the launch: the grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries
 // are [entry][lane] so every access is one 1-KB line per wavefront.
 //
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
 // terms (round 3 took 2.5 GB from the stream-ordered pool: ADVICE r3).
 int64_t ilt_dehoog_bwd_scratch_bytes(int64_t N, int d, int S, unsigned* grid_out) {
   const int64_t nblk = (N * d + 63) / 64;
+  // (slabs in flight, measured at 3.3 M rows, S = 33: 256 -> 36.3 ms, 512 -> 29.8, 768 -> 22.7, 1024 -> 19.8, 2048 (1024
+  // resident) -> 20.9: fewer slabs would fit the Infinity Cache but starve the latency hiding)
   const int64_t cap = (S - 1) / 2 <= 8 ? 2048 : 1024;
   const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
   if (grid_out) *grid_out = grid;
