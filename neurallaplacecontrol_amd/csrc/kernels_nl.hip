@@ -65,58 +65,6 @@ hipError_t launch_nl_rollout_h128(const RolloutArgs& a, hipStream_t s, bool spli
   return hipGetLastError();
 }
 
-hipError_t launch_nl_forward_h128(const ForwardArgs& a, hipStream_t s) {
-  const unsigned grid = (unsigned)((a.N + 63) / 64);
-  switch (a.net.nt3) {
-#define X(N)                                                                            \
-  case N:                                                                               \
-    if (a.const_t) {                                                                        \
-      hipLaunchKernelGGL((nl_forward_kernel<8, N, false>), dim3(grid), dim3(256), 0, s, a); \
-    } else {                                                                                \
-      hipLaunchKernelGGL((nl_forward_kernel<8, N, true>), dim3(grid), dim3(256), 0, s, a);  \
-    }                                                                                       \
-    break;
-    NLC_FOR_NT3(X)
-#undef X
-    default:
-      return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_nl_repfunc_h128(const RepFuncArgs& a, hipStream_t s) {
-  if (!a.general_t && a.slot_major && !a.write_angles && a.split) {
-    const unsigned g16 = (unsigned)((a.N + 15) / 16);
-    switch (a.net.nt3) {
-#define X(N)                                                                                  \
-  case N:                                                                                     \
-    hipLaunchKernelGGL((nl_repfunc_split_kernel<8, N>), dim3(g16), dim3(256), 0, s, a);   \
-    break;
-      NLC_FOR_NT3(X)
-#undef X
-      default:
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-  }
-  const unsigned grid = (unsigned)((a.N + 63) / 64);
-  switch (a.net.nt3) {
-#define X(N)                                                                                          \
-  case N:                                                                                             \
-    if (a.general_t) {                                                                                \
-      hipLaunchKernelGGL((nl_repfunc_kernel<8, N, true>), dim3(grid), dim3(256), 0, s, a);        \
-    } else {                                                                                          \
-      hipLaunchKernelGGL((nl_repfunc_kernel<8, N, false>), dim3(grid), dim3(256), 0, s, a);       \
-    }                                                                                                 \
-    break;
-    NLC_FOR_NT3(X)
-#undef X
-    default:
-      return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 // ------------------------------------------------------------------ per-step tail of the staged (de Hoog) planner path
 // x <- x + dx (mppi_with_model.py:120-121), store, running cost and perturbation cost of horizon step t.  The staged path runs
 // this launch for the LAST step only (the tails of the steps before ride in the next representation launch, nlc_rollout.h); it
@@ -161,7 +109,14 @@ int nl_pick_nt3(int need) {
   return -1;
 }
 
-// the other hidden widths: one translation unit each (kernels_nl_h64.hip, kernels_nl_h256.hip)
+// this width's forward / representation launchers: kernels_nl_fwd.hip, kernels_nl_fwdt.hip, kernels_nl_rep.hip
+hipError_t launch_nl_forward_h128_const(const ForwardArgs& a, hipStream_t s);    // kernels_nl_fwd.hip
+hipError_t launch_nl_forward_h128_general(const ForwardArgs& a, hipStream_t s);  // kernels_nl_fwdt.hip
+hipError_t launch_nl_forward_h128(const ForwardArgs& a, hipStream_t s) {
+  return a.const_t ? launch_nl_forward_h128_const(a, s) : launch_nl_forward_h128_general(a, s);
+}
+hipError_t launch_nl_repfunc_h128(const RepFuncArgs& a, hipStream_t s);
+// the other hidden widths: translation units of their own (kernels_nl_h64.hip, kernels_nl_h256*.hip)
 hipError_t launch_nl_rollout_h64(const RolloutArgs& a, hipStream_t s, bool split);
 hipError_t launch_nl_rollout_h256(const RolloutArgs& a, hipStream_t s, bool split);
 hipError_t launch_nl_forward_h64(const ForwardArgs& a, hipStream_t s);

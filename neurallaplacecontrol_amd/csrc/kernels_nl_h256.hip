@@ -33,42 +33,10 @@ hipError_t launch_nl_rollout_h256(const RolloutArgs& a, hipStream_t s, bool spli
   return hipGetLastError();
 }
 
+hipError_t launch_nl_forward_h256_const(const ForwardArgs& a, hipStream_t s);    // kernels_nl_h256_fwd.hip
+hipError_t launch_nl_forward_h256_general(const ForwardArgs& a, hipStream_t s);  // kernels_nl_h256_fwdt.hip
 hipError_t launch_nl_forward_h256(const ForwardArgs& a, hipStream_t s) {
-  const unsigned grid = (unsigned)((a.N + 63) / 64);
-  switch (a.net.nt3) {
-#define X(N)                                                                            \
-  case N:                                                                               \
-    if (a.const_t) {                                                                        \
-      hipLaunchKernelGGL((nl_forward_kernel<16, N, false>), dim3(grid), dim3(256), 0, s, a); \
-    } else {                                                                                \
-      hipLaunchKernelGGL((nl_forward_kernel<16, N, true>), dim3(grid), dim3(256), 0, s, a);  \
-    }                                                                                       \
-    break;
-    NLC_FOR_NT3(X)
-#undef X
-    default:
-      return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_nl_repfunc_h256(const RepFuncArgs& a, hipStream_t s) {
-  const unsigned grid = (unsigned)((a.N + 63) / 64);
-  switch (a.net.nt3) {
-#define X(N)                                                                                          \
-  case N:                                                                                             \
-    if (a.general_t) {                                                                                \
-      hipLaunchKernelGGL((nl_repfunc_kernel<16, N, true>), dim3(grid), dim3(256), 0, s, a);        \
-    } else {                                                                                          \
-      hipLaunchKernelGGL((nl_repfunc_kernel<16, N, false>), dim3(grid), dim3(256), 0, s, a);       \
-    }                                                                                                 \
-    break;
-    NLC_FOR_NT3(X)
-#undef X
-    default:
-      return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
+  return a.const_t ? launch_nl_forward_h256_const(a, s) : launch_nl_forward_h256_general(a, s);
 }
 
 }  // namespace nlc
