@@ -7,6 +7,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurallaplacecontrol_amd import _lib
 LIB = os.environ.get("NLC_LIB_PATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libnlc_phase.so"))
+if not os.path.exists(LIB):
+    sys.exit(f"{LIB} is missing: build it with `make -C neurallaplacecontrol_amd/csrc variant` (a tools-only build of the library)")
 _lib.use_library(LIB)
 import neurallaplacecontrol_amd as nlc
 
