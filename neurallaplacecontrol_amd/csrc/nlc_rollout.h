@@ -436,7 +436,9 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 // activation vector is exchanged through LDS ([k-step][lane] images, conflict-free ds_read_b64/ds_write_b64),
 // three barriers per horizon step.  Per-step latency drops ~4x; total MFMA work is unchanged.
 // (The k loops here are left to the compiler's schedule: forcing the MFMA / load interleave that pays in the wave-per-tile
-// kernel -- gemm_kstep_order -- cost this one 13 %, 0.428 -> 0.482 ms at K = 2048, and the fused body 7 %; round 4.)
+// kernel -- gemm_kstep_order -- cost this one 13 %, 0.428 -> 0.482 ms at K = 2048, and the fused body 7 %; handing wave 0's
+// layer-1 tiles to the other three waves, so that its state-and-cost tail overlaps their layer 1, gained 1.9 % here at K <= 4096
+// but lost 1.5 % at 8192 and 3 % in the fused body, where the SIMD time of the recomputed surplus tile is an encoder wave's; round 4.)
 //
 // Where the GRU latents of a step come from is a policy:
 //   PaDirect   the (K, T, 2) tensor an earlier launch wrote (nl_rollout_split_kernel)
