@@ -110,8 +110,6 @@ struct FOut {
   int64_t n_rows;   // > 0: slot-major (8*nt3, n_rows) arrays -- slot 4g+q of sample `row` at (4g+q)*n_rows + row, so one
                     // store instruction writes four 128-B runs (16 consecutive samples per lane group q)
 };
-// sph_row (GENERAL_T only): when non-NULL, this lane's sample has EXPLICIT sphere inputs [theta_s | phi_s] (2S doubles)
-// -- LaplaceRepresentationFunc.forward on an arbitrary input row (w_nl.py:55-63) -- instead of the ones of s_k(tn).
 // NLC_EVAL_PIPELINE (A/B switch, tools/bench_ab.sh): where the loads that are NOT a GEMM's own k-step fragments are issued --
 // bias tiles, each GEMM's first fragments, the ILT coefficient tiles, a horizon loop's next layer 1.
 //   0  at the head of the phase that consumes them (rounds 1-3)
@@ -199,6 +197,8 @@ struct NlL1Pre {
 
 struct NlNoPre {};  // a single evaluation: layer 1 is loaded where it is used
 
+// sph_row (GENERAL_T only): when non-NULL, this lane's sample has EXPLICIT sphere inputs [theta_s | phi_s] (2S doubles)
+// -- LaplaceRepresentationFunc.forward on an arbitrary input row (w_nl.py:55-63) -- instead of the ones of s_k(tn).
 // PRE = NlL1Pre<HT>: `pre` holds this evaluation's layer 1 and receives the next one's; NlNoPre: neither.  (A type, not a
 // nullable pointer: a null test on the caller's register struct would pin it to scratch memory.)
 template <int HT, int NT3, bool GENERAL_T, bool WRITE_F, bool LIN, class PRE, class TABS = NlTabsGlobal>
