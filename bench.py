@@ -1,16 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: MPPI planning steps/s on the Neural-Laplace-Control hot path (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: starts its own ranks as a child process
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {0,1,2,3,4,d4}]   # N > 1: starts its own ranks as a child process
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W    # N > 1, one rank per GPU (RCCL): the driver's form
 
-A "step" is one ``MPPIDelay.command()`` -- the region the reference times at mppi_with_model.py:257-259 --
+A "step" is one ``MPPIDelay.command()`` -- the region the reference times at mppi_with_model.py:257-259 -- by default
 on BASELINE configs[1]: oderl-cartpole (nx=5, nu=1), K=16384 samples, horizon T=40, action_buffer_size 4,
 Neural-Laplace dynamics h=128 / S=17 / Fourier ILT, float64, seeded synthetic weights (no checkpoints ship).
-Noise is drawn on the device (Philox) so every input of the timed region is HBM-resident.  With N > 1 the
-SAME K=16384 population is sharded over the ranks (strong scaling, as the metric is worded) and each
-command() does one RCCL all-gather of 2+T*nu doubles.
+``--config`` selects another BASELINE config (0, 2, 3, 4) or north_star's literal state_dim=4 shape (d4) at its full
+population; the default line is unchanged.  Noise is drawn on the device (Philox) so every input of the timed region is
+HBM-resident.  With N > 1 the SAME population is sharded over the ranks (strong scaling, as the metric is worded) and
+each command() does one RCCL all-gather of 2+T*nu doubles.
+
+N > 1 cannot hang the run that measures it.  Under a launcher every rank process is a SUPERVISOR that
+touches no GPU: it runs the measurement in a fresh child process under a progress watchdog, the supervisors agree on the
+outcome through the launcher's TCP store, and
+  * a child that fails or stops making progress with ``--collective auto`` (the library-owned RCCL communicator inside
+    nlc_mppi_finish) is killed on every rank and a second fresh child measures with ``--collective torch``; the line then
+    carries ``config.collective_fallback_reason``;
+  * when the first child succeeds with the library's collective, a second child measures torch.distributed's all-gather
+    too and the line carries it under ``also_collective`` -- one record, both modes;
+  * ``config.ranks_seen`` holds the group size torch.distributed and the library's communicator report, and per rank the
+    device, the rollout body, the kernel averages (``rccl_all_gather`` among them) and the collective's own timing.
 
 The K timed steps run WITHOUT the library's per-launch event profiling; a second, untimed pass of the same steps
 with profiling on gives the per-kernel averages the roofline uses (hipEvent pairs on the launch stream).
@@ -24,9 +36,11 @@ reference op sequence, timed on this host's cores; rank 0, N=1 only).
 import argparse
 import json
 import os
+import signal
 import statistics
 import subprocess
 import sys
+import tempfile
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -39,12 +53,32 @@ ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
 # newest committed PMC summary (separate rocprofv3 --pmc passes: tools/collect_profiles.sh + tools/pmc_summarize.py)
-PMC_CANDIDATES = ("r4_pmc_kernels.json", "r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
+PMC_CANDIDATES = ("r5_pmc_kernels.json", "r4_pmc_kernels.json", "r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
 # library kernel (nlc_profile_read name) -> key of the PMC summary; the summary's "_meta.kernel_names" must list a
 # rocprof kernel name containing the library name, or the traffic figure belongs to some other build
 PMC_KEYS = {"gru_encode_kernel": "gru_encode", "nl_rollout_kernel": "nl_rollout", "ilt_fourier_kernel": "ilt_fourier",
             "ilt_dehoog_kernel": "ilt_dehoog", "ilt_fourier_bwd_kernel": "ilt_fourier_bwd",
             "nl_plan_fused_kernel": "nl_plan_fused"}
+
+# env -> (nx, nu, action bound A, state_std of train_utils.py:187-200).  "oderl-cartpole-notrig": CTCartpole(obs_trans=False),
+# the reference's 4-dim cartpole state (ctcartpole.py:60) = north_star's literal "state_dim=4".
+ENV_SHAPES = {
+    "oderl-cartpole": (5, 1, 3.0, [2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048]),
+    "oderl-pendulum": (3, 1, 2.0, [0.70634571, 0.70784512, 2.89072771]),
+    "oderl-acrobot": (6, 2, 5.0, [0.70711024, 0.70710328, 0.7072186, 0.7069949, 2.88642115, 2.88627309]),
+    "oderl-cartpole-notrig": (4, 1, 3.0, [2.88646771, 11.54556671, 1.81379936, 17.3199048]),
+}
+# BASELINE.json configs[i] (+ "d4").  B = action_buffer rows: 4 (config.py:58), 5 for delay 4.  `gpus` = the
+# GPU count the config is worded for; `--config i --gpus 1` runs its WHOLE population on one GPU.
+CONFIGS = {
+    "0": dict(name="BASELINE configs[0]", env="oderl-cartpole", B=4, K=1024, T=20, algo="fourier", S=17, gpus=1, delay=0),
+    "1": dict(name="BASELINE configs[1]", env="oderl-cartpole", B=4, K=16384, T=40, algo="fourier", S=17, gpus=1, delay=2),
+    "2": dict(name="BASELINE configs[2]", env="oderl-pendulum", B=5, K=65536, T=40, algo="fourier", S=17, gpus=2, delay=4),
+    "3": dict(name="BASELINE configs[3]", env="oderl-acrobot", B=4, K=262144, T=60, algo="fourier", S=17, gpus=8, delay=2),
+    "4": dict(name="BASELINE configs[4]", env="oderl-cartpole", B=4, K=16384, T=40, algo="dehoog", S=33, gpus=1, delay=2),
+    "d4": dict(name="north_star literal state_dim=4 (CTCartpole(obs_trans=False))", env="oderl-cartpole-notrig", B=4, K=16384,
+               T=40, algo="fourier", S=17, gpus=1, delay=2),
+}
 
 
 def load_pmc():
@@ -55,9 +89,26 @@ def load_pmc():
     return None, None
 
 
+def build_info():
+    """What __graft_entry__.build() recorded next to the library it built (neurallaplacecontrol_amd/_build_info.py):
+    the commit of the tree and the content hash of the library's sources.  {} when the library was built some other way."""
+    try:
+        from neurallaplacecontrol_amd import _build_info as bi
+
+        return dict(commit=bi.COMMIT, csrc_commit=bi.CSRC_COMMIT, csrc_sha=bi.CSRC_SHA, dirty=bi.DIRTY, built=bi.BUILT)
+    except Exception:
+        return {}
+
+
+STRICT_PMC = False  # --strict-pmc: a stale PMC summary is an error instead of `traffic: null` with the reason
+
+
 def pmc_traffic(pmc_name, pj, lib_kernel):
     """HBM bytes per launch of `lib_kernel` from the committed PMC summary, with its provenance; (None, None) if the
-    summary has no such kernel.  A summary that names kernels this library does not have is a stale file: fail loudly."""
+    summary has no such kernel.  A summary that names kernels this library does not have is a stale file: fail loudly.
+    A summary collected from OTHER SOURCES than the library in use was built from (`_meta.csrc_sha` vs the hash
+    __graft_entry__.build() recorded) is not quoted: traffic is null and the reason takes its place
+    (an error under --strict-pmc)."""
     if pj is None:
         return None, None
     key = PMC_KEYS[lib_kernel]
@@ -69,28 +120,66 @@ def pmc_traffic(pmc_name, pj, lib_kernel):
         if not any(lib_kernel in n for n in names):
             raise RuntimeError(f"profiles/{pmc_name}: entry {key!r} was collected from kernels {names}, none of which is "
                                f"the library's {lib_kernel!r} -- stale PMC summary, re-run tools/collect_profiles.sh")
+        bi = build_info()
+        have, want = meta.get("csrc_sha"), bi.get("csrc_sha")
+        if want and have != want:
+            why = (f"STALE: profiles/{pmc_name} was collected at commit {meta.get('commit', '?')} from kernel sources "
+                   f"{have or '(hash not recorded)'}; this library was built from {want} (commit {bi.get('commit')}) -- "
+                   "re-run tools/collect_profiles.sh")
+            if STRICT_PMC:
+                raise RuntimeError(why)
+            sys.stderr.write("bench.py: " + why + "\n")
+            return None, why
         src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 "
-               f"correction; collected at commit {meta.get('commit', '?')} on {meta.get('device', '?')}, {meta.get('date', '?')})")
+               f"correction; collected at commit {meta.get('commit', '?')} on {meta.get('device', '?')}, {meta.get('date', '?')}; "
+               f"kernel sources {have or 'unrecorded'}{' = this build' if want else ''})")
     else:
         src = f"profiles/{pmc_name} (round-1 summary without provenance record; rocprofv3 --pmc, FETCH x2 gfx950 correction)"
     return pj[key].get("hbm_bytes_per_launch"), src
 
 
-def synthetic_state_dict(d, nu, S, seed=0):
-    """Reference-constructor init (seed 0) + the 'trained-like' phi-bias shift (see DESIGN.md §synthetic weights).
+def tame_dehoog_(model, d, S, t_norm=0.125, alpha=1e-10, tol=1e-9, scale=2.0, w3_scale=0.02):
+    """Product-side twin of oracle.nl_model.tame_dehoog_ (tests check they agree): the last layer's biases put F on a real
+    Laplace transform a_c / (s + b_c) sampled on the model's own contour, its weights are scaled by w3_scale."""
+    import math
 
-    Product-side twin of oracle.nl_model.make_synthetic_state_dict(tame=True); tests check they agree.
+    Tc = scale * t_norm
+    gamma = alpha - math.log(tol) / (scale * Tc)
+    k = torch.arange(S, dtype=torch.float64)
+    s_k = torch.complex(torch.full((S,), gamma, dtype=torch.float64), math.pi * k / Tc)
+    last = model.laplace_rep_func.linear_tanh_stack[4]
+    with torch.no_grad():
+        last.weight *= w3_scale
+        for c in range(d):
+            a_c, b_c = 0.03 * (c + 1) * (-1.0) ** c, 1.0 + 0.5 * c
+            F = a_c / (s_k + b_c)
+            theta = torch.atan2(F.imag, F.real)
+            r2 = F.real**2 + F.imag**2
+            phi = torch.asin((r2 - 1.0) / (r2 + 1.0))
+            last.bias[c * S : (c + 1) * S] = torch.atanh(torch.clamp(theta / math.pi, -1 + 1e-12, 1 - 1e-12))
+            last.bias[(d + c) * S : (d + c + 1) * S] = torch.atanh(torch.clamp(phi / (math.pi / 2), -1 + 1e-12, 1 - 1e-12))
+    return model
+
+
+def synthetic_state_dict(d, nu, S, seed=0, env=ENV, algo="fourier"):
+    """Reference-constructor init (seed 0) + the 'trained-like' taming (see DESIGN.md §synthetic weights): the phi-bias
+    shift for Fourier models, the Laplace-transform biases for de Hoog models.
+
+    Product-side twin of oracle.nl_model.make_synthetic_state_dict(tame=True / "dehoog"); tests check they agree.
     """
     import neurallaplacecontrol_amd as nlc
 
+    _, _, A, std = ENV_SHAPES[env]
     rng = torch.random.get_rng_state()
     torch.manual_seed(seed)
     model = nlc.NeuralLaplaceModel(
-        d, nu, d, hidden_units=HIDDEN, s_recon_terms=S, ilt_algorithm="fourier",
-        state_mean=np.zeros(d), state_std=np.array([2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048][:d]),
-        action_mean=np.array([0] * nu), action_std=np.array([A_HIGH / 2.0]), normalize=True, normalize_time=True,
+        d, nu, d, hidden_units=HIDDEN, s_recon_terms=S, ilt_algorithm=algo,
+        state_mean=np.zeros(d), state_std=np.array(std[:d]),
+        action_mean=np.array([0] * nu), action_std=np.array([A / 2.0]), normalize=True, normalize_time=True,
     ).double()
     torch.random.set_rng_state(rng)
+    if algo == "dehoog":
+        return tame_dehoog_(model, d, S)
     with torch.no_grad():
         model.laplace_rep_func.linear_tanh_stack[4].bias[d * S :] += -3.0
     return model
@@ -144,17 +233,20 @@ def host_cpu_info():
     return dict(model=model, physical_cores=len(cores) or logical, logical_cpus=logical, usable_cpus=usable)
 
 
-def cpu_baseline(sd, d, nu, budget_s=30.0):
+def cpu_baseline(sd, cfg, budget_s=30.0):
     """Oracle (torch-CPU float64, aten::gru like the reference) timed on this host over the same region as the GPU
-    step (mppi_with_model.py:257-259).  SURVEY §8d: warm-up, median of >= 3, 1 thread and all physical cores stated."""
+    step (mppi_with_model.py:257-259).  SURVEY §8d: warm-up, median of >= 3, 1 thread and all physical cores stated.
+    The headline config is measured at its full population; a config whose full-size command would not fit the budget
+    (configs[2], [3]) is measured at K / 8 and says so (`value` is then absent: `value_extrapolated` carries the x 8 figure)."""
     from oracle import envs as oenvs
     from oracle import mppi as omppi
     from oracle import nl_model as onl
 
-    T = HORIZON
+    env, T, B, K_full, algo, S = cfg["env"], cfg["T"], cfg["B"], cfg["K"], cfg["algo"], cfg["S"]
+    d, nu, A, _ = ENV_SHAPES[env]
     tg = onl.TorchGRUModel(sd, nu)
     sig = torch.ones((nu, nu), dtype=torch.double) * 0.5 + torch.eye(nu, dtype=torch.double) * 0.5
-    state, ab = oenvs.initial_state(ENV), torch.zeros(ABUF, nu, dtype=torch.float64)
+    state, ab = oenvs.initial_state(env), torch.zeros(B, nu, dtype=torch.float64)
     info = host_cpu_info()
     default_threads = torch.get_num_threads()
 
@@ -162,11 +254,10 @@ def cpu_baseline(sd, d, nu, budget_s=30.0):
         ts = torch.full((K, 1), 0.05, dtype=torch.float64)
 
         def dynamics(st, window):
-            return st + tg.forward(st, window, ts, S=S_TERMS).view(st.shape)
+            return st + tg.forward(st, window, ts, S=S, ilt_algorithm=algo).view(st.shape)
 
         torch.manual_seed(0)
-        return omppi.MPPIOracle(dynamics, oenvs.RUNNING_COST[ENV], d, sig, K, T, 1.0, torch.tensor(-A_HIGH),
-                                torch.tensor(A_HIGH), A_HIGH)
+        return omppi.MPPIOracle(dynamics, oenvs.RUNNING_COST[env], d, sig, K, T, 1.0, torch.tensor(-A), torch.tensor(A), A)
 
     def timed(mppi, n):
         out = []
@@ -180,7 +271,7 @@ def cpu_baseline(sd, d, nu, budget_s=30.0):
     with torch.no_grad():
         # 1. thread-count sweep on a 1/8 population (warm-up + one command each): torch's default of one thread per
         #    logical CPU is far from the best setting for these small FP64 ops on a many-core host
-        K8 = K_SAMPLES // 8
+        K8 = max(K_full // 8, 128)
         small = make(K8)
         limit = info["usable_cpus"]
         cand = sorted({c for c in (8, 16, 32, info["physical_cores"]) if c <= limit} or {limit})
@@ -189,10 +280,13 @@ def cpu_baseline(sd, d, nu, budget_s=30.0):
             torch.set_num_threads(nt)
             timed(small, 1)
             sweep.append((nt, timed(small, 1)[0]))
-        best_nt = min(sweep, key=lambda x: x[1])[0]
-        # 2. the reported figure: full population, best thread count, one warm-up, median of >= 3
+        best_nt, best_small = min(sweep, key=lambda x: x[1])
+        # 2. the reported figure: full population when its 1 + 3 commands fit the budget (the headline config always is),
+        #    best thread count, one warm-up, median of >= 3
         torch.set_num_threads(best_nt)
-        full = make(K_SAMPLES)
+        full_size = cfg["key"] == "1" or best_small * (K_full / K8) * 4 < budget_s
+        K_meas = K_full if full_size else K8
+        full = make(K_meas) if full_size else small
         warm = timed(full, 1)[0]
         n_rep = 3
         if warm * 6 < budget_s - (time.perf_counter() - t_start):
@@ -203,25 +297,35 @@ def cpu_baseline(sd, d, nu, budget_s=30.0):
         #    (the work is linear in K; at 1/8 the per-op overheads weigh more, so the extrapolation favours neither)
         torch.set_num_threads(1)
         timed(small, 1)
-        one = timed(small, 1)[0] * 8.0
+        one = timed(small, 1)[0] * (K_full / K8)
         allc = dict(sweep).get(info["physical_cores"])
-        allc = allc * 8.0 if allc is not None else None
+        allc = allc * (K_full / K8) if allc is not None else None
     torch.set_num_threads(default_threads)
-    return dict(
-        value=1.0 / med, unit="planning steps/s", cores=best_nt, kind="port",
-        sample=(f"full workload (K={K_SAMPLES}, T={T}): 1 warm-up + median of {n_rep} command() calls at {best_nt} threads "
+    out = dict(
+        unit="planning steps/s", cores=best_nt, kind="port",
+        sample=(f"{'full workload' if full_size else 'BOUNDED SAMPLE: 1/8 of the population'} (K={K_meas}, T={T}): 1 warm-up + "
+                f"median of {n_rep} command() calls at {best_nt} threads "
                 f"(runs {[round(r, 2) for r in reps]} s, warm-up {warm:.2f} s); thread count picked by a sweep on K={K8}: "
                 f"{[(n, round(e, 3)) for n, e in sweep]} (threads, s)"),
         cpu_model=info["model"], physical_cores=info["physical_cores"], logical_cpus=info["logical_cpus"],
         usable_cpus=info["usable_cpus"],
         # NOT measurements at the quoted size: one command at K / 8, scaled by 8 (context for the measured figure above only)
         one_thread_extrapolated_x8=dict(value_extrapolated=1.0 / one, seconds_per_command_extrapolated=one, measured_at_K=K8,
-                                        note=f"EXTRAPOLATED: one command at K={K8}, time x 8"),
+                                        note=f"EXTRAPOLATED: one command at K={K8}, time x {K_full // K8}"),
         all_physical_cores_extrapolated_x8=(dict(value_extrapolated=1.0 / allc, seconds_per_command_extrapolated=allc,
                                                  threads=info["physical_cores"], measured_at_K=K8,
-                                                 note=f"EXTRAPOLATED: one command at K={K8}, time x 8") if allc else None),
+                                                 note=f"EXTRAPOLATED: one command at K={K8}, time x {K_full // K8}") if allc else None),
         torch=torch.__version__, oracle="oracle/ (torch-CPU float64, aten::gru encoder as in the reference)",
     )
+    if full_size:
+        out["value"] = 1.0 / med
+    else:
+        # the work is linear in K: the K / 8 time x 8.  Labelled: NOT a measurement at the config's population.
+        out["value"] = None
+        out["value_extrapolated"] = 1.0 / (med * (K_full / K8))
+        out["measured_at_K"] = K8
+        out["note"] = f"EXTRAPOLATED from K={K8} (time x {K_full // K8}); the full population would take ~{med * K_full / K8:.0f} s per command"
+    return out
 
 
 def free_port():
@@ -232,23 +336,244 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def self_launch(n, argv, result_fd):
+# ------------------------------------------------------------------------------------------------ watchdog plumbing
+PROGRESS_ENV = "NLC_BENCH_PROGRESS_FILE"
+
+
+def mark(phase):
+    """Worker side of the watchdog: append a progress marker to the file the supervisor watches (no-op without one)."""
+    path = os.environ.get(PROGRESS_ENV)
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{phase} {time.time():.3f}\n")
+
+
+def kill_group(proc, grace_s=5.0):
+    """End a child started with start_new_session=True together with everything it started: SIGTERM to the process
+    group, SIGKILL after `grace_s`.  Only the exact group this process created is signalled."""
+    if proc.poll() is not None:
+        return
+    try:
+        os.killpg(proc.pid, signal.SIGTERM)
+    except ProcessLookupError:
+        return
+    t0 = time.time()
+    while proc.poll() is None and time.time() - t0 < grace_s:
+        time.sleep(0.05)
+    if proc.poll() is None:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+
+
+def run_watched(cmd, env, init_s, step_s, total_s, peer_failed=None, stdout=subprocess.PIPE):
+    """Run `cmd` as a child in its own process group under a progress watchdog.  The child appends markers to a file
+    (mark()); it is killed when it has written none for `init_s` seconds at the start, no NEW one for `step_s` seconds
+    afterwards, when `total_s` is exceeded, or as soon as `peer_failed()` says another rank's child is gone (its peers
+    would only wait in a collective for a rank that will never come).  Returns (status, returncode, stdout bytes, last
+    marker) with status 'ok' | 'failed' | 'timeout' | 'peer'."""
+    with tempfile.TemporaryDirectory(prefix="nlcbench_") as tmp:
+        prog = os.path.join(tmp, "progress")
+        open(prog, "w").close()
+        env = dict(env, **{PROGRESS_ENV: prog})
+        out_path = os.path.join(tmp, "stdout")
+        with open(out_path, "wb") as out_f:
+            proc = subprocess.Popen(cmd, stdout=out_f if stdout == subprocess.PIPE else stdout, env=env, start_new_session=True)
+            t0 = last_change = time.time()
+            last_size, status = 0, None
+            while proc.poll() is None:
+                time.sleep(0.2)
+                now = time.time()
+                size = os.path.getsize(prog)
+                if size != last_size:
+                    last_size, last_change = size, now
+                budget = init_s if last_size == 0 else step_s
+                if now - last_change > budget or now - t0 > total_s:
+                    status = "timeout"
+                elif peer_failed is not None and peer_failed():
+                    status = "peer"
+                if status:
+                    kill_group(proc)
+                    break
+            rc = proc.wait()
+        data = open(out_path, "rb").read()
+        lines = open(prog).read().split("\n")
+        last = next((ln.split()[0] for ln in reversed(lines) if ln.strip()), None)
+    if status is None:
+        status = "ok" if rc == 0 else "failed"
+    return status, rc, data, last
+
+
+def last_json_line(data):
+    lines = [ln for ln in data.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    return lines[-1] if lines else None
+
+
+def watchdog_budgets(args):
+    step_s = args.watchdog_step_s if args.watchdog_step_s > 0 else 90.0 + 0.25 * (args.steps + args.warmup)
+    init_s = args.watchdog_init_s
+    return init_s, step_s, init_s + 12 * step_s
+
+
+def self_launch(n, argv, result_fd, args):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
-    as a child process (one rank per GPU), pass its stderr through, write its LAST stdout line -- rank 0's JSON line --
-    to the saved stdout, and return its exit code."""
+    as a child process (one rank per GPU; every rank is a supervisor, see supervise()), pass its stderr through, write its
+    LAST stdout line -- rank 0's JSON line -- to the saved stdout, and return its exit code.  The child runs under a
+    watchdog of its own (the supervisors' budgets for two attempts plus slack): on expiry its process group is killed
+    and the exit code is non-zero -- this process never touched the GPU and never execs."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between the ranks of one node)
     env.setdefault("OMP_NUM_THREADS", "8")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
-    if lines:
-        os.write(result_fd, (lines[-1] + "\n").encode())
-    elif proc.returncode == 0:
+    init_s, step_s, total_s = watchdog_budgets(args)
+    outer = 2 * total_s + 120.0
+    # the launcher itself writes no progress markers: only the total budget applies
+    status, rc, data, _ = run_watched(cmd, env, outer, outer, outer)
+    line = last_json_line(data)
+    if line:
+        os.write(result_fd, (line + "\n").encode())
+    if status == "timeout":
+        sys.stderr.write(f"bench.py: the launched ranks did not finish within {outer:.0f} s; their process group was killed\n")
+        return 124
+    if not line and rc == 0:
         sys.stderr.write("bench.py: the launched ranks printed no JSON line\n")
         return 1
-    return proc.returncode
+    return rc
+
+
+class SupervisorStore:
+    """The supervisors' own key space on the launcher's TCP store (torch.distributed.run hosts it at MASTER_ADDR:MASTER_PORT
+    and sets TORCHELASTIC_USE_AGENT_STORE; under any other launcher rank 0's supervisor hosts it and the children are told to
+    connect as clients).  CPU only: a supervisor never touches the GPU."""
+
+    def __init__(self, rank, world, timeout_s):
+        from datetime import timedelta
+
+        import torch.distributed as dist
+
+        addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+        self.agent_hosts = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+        self.tcp = dist.TCPStore(addr, port, None, (not self.agent_hosts) and rank == 0, timedelta(seconds=timeout_s),
+                                 wait_for_workers=False, multi_tenant=True)
+        self.store = dist.PrefixStore(f"nlcbench_sup/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}", self.tcp)
+        self.rank, self.world = rank, world
+
+    def set(self, key, value):
+        self.store.set(key, str(value))
+
+    def has(self, key):
+        try:
+            return bool(self.store.check([key]))
+        except Exception:
+            return False
+
+    def get(self, key, timeout_s):
+        from datetime import timedelta
+
+        self.store.wait([key], timedelta(seconds=timeout_s))
+        return self.store.get(key).decode()
+
+    def gather(self, prefix, timeout_s):
+        return [self.get(f"{prefix}/r{r}", timeout_s) for r in range(self.world)]
+
+
+def supervise(args, argv, result_fd):
+    """One rank of an N > 1 run under a launcher (RANK set): never touches the GPU.  Runs the measurement as a fresh child
+    process (`--worker`) under the progress watchdog, agrees with the other ranks' supervisors on the outcome, and -- see the
+    module docstring -- falls back from the library-owned collective to torch.distributed's, or measures both."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    init_s, step_s, total_s = watchdog_budgets(args)
+    sup = SupervisorStore(rank, world, total_s + 60.0)
+    base_env = dict(os.environ)  # (the store at MASTER_PORT outlives every attempt: children join it as clients, init_pg)
+
+    def attempt(idx, mode, extra=()):
+        env = dict(base_env)
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + ["--worker", "--attempt", str(idx), "--collective", mode]
+        cmd += list(extra)
+        status, rc, data, last = run_watched(cmd, env, init_s, step_s, total_s, peer_failed=lambda: sup.has(f"a{idx}/fail"))
+        if status != "ok":
+            sup.set(f"a{idx}/fail", rank)  # peers: stop waiting in a collective for this rank
+            sys.stderr.write(f"bench.py supervisor rank {rank}: attempt {idx} ({mode}) {status} (exit {rc}, last marker {last})\n")
+        sup.set(f"a{idx}/r{rank}", json.dumps(dict(status=status, rc=rc, last=last)))
+        results = [json.loads(v) for v in sup.gather(f"a{idx}", total_s + 60.0)]
+        ok = all(r["status"] == "ok" for r in results)
+        line = last_json_line(data) if rank == 0 else None
+        if rank == 0 and ok and line is None:
+            ok = False
+            results[0] = dict(status="failed", rc=rc, last="no JSON line")
+        # rank 0 has the last word (it alone sees whether a line was printed)
+        if rank == 0:
+            sup.set(f"a{idx}/verdict", int(ok))
+        ok = sup.get(f"a{idx}/verdict", 120.0) == "1"
+        return ok, line, results
+
+    def reason_of(results, mode):
+        bad = [f"rank {r}: {v['status']} (exit {v['rc']}, last progress marker {v['last']})" for r, v in enumerate(results)
+               if v["status"] != "ok"]
+        return f"--collective {mode}: " + "; ".join(bad) if bad else f"--collective {mode}: rank 0 printed no result line"
+
+    first = args.collective
+    ok, line, results = attempt(0, first)
+    final, fallback_reason, also = None, None, None
+    if ok:
+        final = json.loads(line) if rank == 0 else None
+        # both modes in one record: when the library's collective produced the line, measure torch.distributed's as well
+        want_also = False
+        if rank == 0:
+            native = bool((final.get("config") or {}).get("native_collective"))
+            want_also = bool(native and world > 1 and first == "auto" and not args.no_also_collective and not args.dry_launch)
+            sup.set("also", int(want_also))
+        want_also = sup.get("also", 120.0) == "1"
+        if want_also:
+            ok2, line2, results2 = attempt(1, "torch", ("--no-ilt", "--no-cpu-baseline"))
+            if rank == 0:
+                if ok2:
+                    l2 = json.loads(line2)
+                    also = dict(collective=l2["config"].get("collective"), value=l2["value"], ms_per_step=l2["ms_per_step"],
+                                kernels_avg_ms=l2.get("kernels_avg_ms"), collective_timing=l2["config"].get("collective_timing"),
+                                ranks_seen=l2["config"].get("ranks_seen"))
+                else:
+                    also = dict(error=reason_of(results2, "torch"))
+    elif first != "torch" and not args.dry_launch_no_fallback:
+        fallback_reason = reason_of(results, first)
+        ok, line, results = attempt(1, "torch")
+        if ok and rank == 0:
+            final = json.loads(line)
+    if rank == 0 and final is not None:
+        if fallback_reason:
+            final.setdefault("config", {})["collective_fallback_reason"] = fallback_reason
+        if also is not None:
+            final["also_collective"] = also
+        os.write(result_fd, (json.dumps(final) + "\n").encode())
+    if not ok and rank == 0:
+        sys.stderr.write("bench.py: no attempt produced a result: " + reason_of(results, "torch" if fallback_reason else first) + "\n")
+    # nobody leaves before everybody has read the last keys (rank 0's supervisor may host the store)
+    sup.set(f"done/r{rank}", 1)
+    try:
+        sup.gather("done", 60.0)
+    except Exception:
+        pass
+    return 0 if ok else 1
+
+
+def init_pg(backend, args, **kw):
+    """torch.distributed group of a measuring process.  Under a supervisor (--worker with RANK set) the store at
+    MASTER_ADDR:MASTER_PORT outlives the attempt, so the child joins it as a client under a key prefix of its own attempt --
+    a second child must not meet the first one's rendezvous / barrier keys."""
+    import torch.distributed as dist
+
+    if not (args.worker and "RANK" in os.environ):
+        return dist.init_process_group(backend, **kw)
+    from datetime import timedelta
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    tcp = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world, False,
+                        timedelta(seconds=300), multi_tenant=True)
+    store = dist.PrefixStore(f"nlcbench_attempt{args.attempt}/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}", tcp)
+    return dist.init_process_group(backend, store=store, rank=rank, world_size=world, **kw)
 
 
 def preheat(one_step, ms, group=None, device="cpu", chunk=16):
@@ -279,21 +604,32 @@ def git_commit():
     try:
         return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
-        return os.environ.get("NLC_COMMIT")  # the GPU box gets a snapshot without .git
+        # the GPU box gets a snapshot without .git: the commit __graft_entry__.build() recorded next to the library
+        return build_info().get("commit") or os.environ.get("NLC_COMMIT")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="1",
+                    help="BASELINE.json configs[i] (default 1 = the headline metric's config) or d4 = north_star's literal "
+                         "state_dim=4 cartpole; each at its whole population, sharded over --gpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--strict-pmc", action="store_true",
+                    help="fail instead of reporting `traffic: null` when the committed PMC summary was collected from other "
+                         "kernel sources than this library was built from")
     ap.add_argument("--collective", choices=("auto", "torch", "native"), default="auto",
                     help="N > 1: the per-command all-gather inside nlc_mppi_finish on the library's own RCCL communicator "
                          "(include/nlc.h, nlc_comm_init) or through torch.distributed between the two phases; auto (default) "
-                         "= the library's, falling back to torch's if any rank cannot bring the communicator up")
+                         "= the library's, falling back to torch's if any rank cannot bring the communicator up -- or, under "
+                         "the supervisors, if the run with it fails or hangs")
+    ap.add_argument("--no-also-collective", action="store_true",
+                    help="N > 1, --collective auto: do not measure torch.distributed's collective in a second child after the "
+                         "library's succeeded (also_collective)")
     ap.add_argument("--planner-opt", action="append", default=[], metavar="NAME=VALUE",
                     help="extra planner_options entries (experiments), e.g. --planner-opt host_spin=0")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
@@ -304,9 +640,26 @@ def main():
                     help="launch rehearsal WITH the GPU work (tests): every rank plans its shard on cuda:0 and the ranks talk "
                          "over gloo (RCCL refuses two ranks per device) -- the whole N > 1 flow of this file on a 1-GPU box; "
                          "its numbers mean nothing")
-    ap.add_argument("--samples", type=int, default=K_SAMPLES,
-                    help="override K (experiments only; the headline metric is quoted at the default 16384)")
-    args = ap.parse_args()
+    ap.add_argument("--samples", type=int, default=None,
+                    help="override K (experiments only; the headline metric is quoted at the config's own population)")
+    ap.add_argument("--watchdog-init-s", type=float, default=300.0,
+                    help="N > 1: a rank's child is killed when it has reported no progress for this long after its start "
+                         "(covers `import torch` on a cold box, HIP and RCCL bring-up)")
+    ap.add_argument("--watchdog-step-s", type=float, default=0.0,
+                    help="N > 1: ... or no NEW progress marker for this long afterwards (0 = 90 s + 0.25 s per step)")
+    # internal / tests
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)  # the measuring child of a supervisor
+    ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--test-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)  # this rank's worker sleeps forever ...
+    ap.add_argument("--test-hang-attempts", type=int, default=99, help=argparse.SUPPRESS)  # ... in attempts < this
+    ap.add_argument("--dry-launch-no-fallback", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def main():
+    global STRICT_PMC
+    args = parse_args()
+    STRICT_PMC = args.strict_pmc
     # stdout carries exactly ONE JSON line (driver contract).  Libraries write there too -- RCCL prints its
     # NCCL_DEBUG=VERSION banner (set by the box image) to stdout at communicator creation -- so everything else this
     # process and its libraries print goes to stderr, and the result line is written to the saved stdout at the end.
@@ -314,30 +667,47 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus > 1 and "RANK" not in os.environ:
         # invoked bare (`python bench.py --gpus N`): start the ranks ourselves, as a CHILD process (nothing in this
         # process has touched the GPU yet), relay its one JSON line and exit with its code
-        sys.exit(self_launch(args.gpus, sys.argv[1:], result_fd))
+        sys.exit(self_launch(args.gpus, sys.argv[1:], result_fd, args))
+    if "RANK" in os.environ and not args.worker:
+        # under a launcher: this process supervises, a fresh child measures (see supervise())
+        sys.exit(supervise(args, sys.argv[1:], result_fd))
+    sys.exit(worker(args, result_fd))
+
+
+def worker(args, result_fd):
+    mark("start")
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         args.gpus = world
     import torch.distributed as dist
+
+    def test_hang():
+        if args.test_hang_rank == rank and args.attempt < args.test_hang_attempts:
+            while True:  # (tests) a rank that never arrives: the watchdog's case
+                time.sleep(3600)
 
     if args.dry_launch:
         # launch rehearsal (CPU test): every rank reports the environment torch.distributed.run gave it over a gloo
         # group; rank 0 prints them as the one JSON line.  No GPU call is made.
         envs = [None] * world
         if "RANK" in os.environ:
-            dist.init_process_group("gloo")
+            init_pg("gloo", args)
+            mark("pg_ready")
+            test_hang()
             dist.all_gather_object(envs, {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")})
             dist.destroy_process_group()
         else:
             envs = [{"RANK": None, "LOCAL_RANK": None, "WORLD_SIZE": None, "MASTER_ADDR": None}]
         if rank == 0:
-            os.write(result_fd, (json.dumps(dict(dry_launch=True, n_gpus=world, ranks=envs)) + "\n").encode())
-        return
+            os.write(result_fd, (json.dumps(dict(dry_launch=True, n_gpus=world, ranks=envs, attempt=args.attempt,
+                                                 config=dict(collective=args.collective, native_collective=False))) + "\n").encode())
+        mark("line_written")
+        return 0
 
     import neurallaplacecontrol_amd as nlc
 
@@ -349,26 +719,35 @@ def main():
     pg = None
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run even a 1-rank job goes through RCCL
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            init_pg("gloo", args)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            init_pg("nccl", args, device_id=torch.device("cuda", local))
         pg = dist.group.WORLD
-    K_total = args.samples
+    mark("pg_ready")
+    test_hang()
 
-    d, nu = 5, 1
-    model = synthetic_state_dict(d, nu, S_TERMS).to(f"cuda:{local}")
+    cfg = dict(CONFIGS[args.config], key=args.config)
+    env_name, T, B, algo, S = cfg["env"], cfg["T"], cfg["B"], cfg["algo"], cfg["S"]
+    d, nu, A, _ = ENV_SHAPES[env_name]
+    K_total = args.samples if args.samples is not None else cfg["K"]
+    headline = args.config == "1"
+
+    model = synthetic_state_dict(d, nu, S, env=env_name, algo=algo).to(f"cuda:{local}")
     sd_cpu = {k: v.detach().cpu().to(torch.float64) for k, v in model.state_dict().items()}
     planner = nlc.MPPIDelay(
-        nlc.NLDynamics(model, 0.05), nlc.EnvCost(ENV), d, nlc.noise_sigma(nu), num_samples=K_total, horizon=HORIZON,
+        nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K_total, horizon=T,
         # device="cpu": U and the returned action live on the host, as the harness's env.step needs them (the merge kernel
         # stores the action straight into pinned host memory); every kernel runs on compute_device
-        device="cpu", compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A_HIGH), u_max=torch.tensor(A_HIGH), u_scale=A_HIGH,
-        noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(HORIZON, nu, dtype=torch.float64),
+        device="cpu", compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+        noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(T, nu, dtype=torch.float64),
+        # the large configs do not keep the (K, T, nx) rollout (configs[3]: 755 MB per command; tools/configs_bench.py alike)
+        store_rollouts=headline or K_total * T <= 16384 * 40,
         planner_options=dict({} if args.collective == "auto" else {"native_collective": int(args.collective == "native")},
                              **{kv.split("=", 1)[0]: float(kv.split("=", 1)[1]) for kv in args.planner_opt}),
     )
-    state = nlc.initial_state(ENV, torch.Generator().manual_seed(0))
-    abuf = torch.zeros(ABUF, nu, dtype=torch.float64)
+    state = nlc.initial_state(env_name, torch.Generator().manual_seed(0))
+    abuf = torch.zeros(B, nu, dtype=torch.float64)
+    mark("planner_ready")
 
     def step(ab):
         a = planner.command(state, ab)
@@ -390,20 +769,25 @@ def main():
     def one_step():
         holder[0] = step(holder[0])
 
+    one_step()  # the first command configures the planner (and, sharded, is the first collective-bearing call)
+    mark("first_command")
     preheat(one_step, args.preheat_ms, pg, coll_dev)
     abuf = holder[0]
+    mark("preheat_done")
     for _ in range(args.warmup):
         abuf = step(abuf)
     fence()
+    mark("warmup_done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         abuf = step(abuf)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed = time.perf_counter() - t0
     if pg is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    mark("timed_done")
     # second, untimed pass: the same steps with hipEvent pairs around every launch (on the launch stream)
     planner.ctx.profile_reset()
     planner.ctx.profile(True)
@@ -412,95 +796,49 @@ def main():
     fence()
     planner.ctx.profile(False)
     prof = planner.ctx.profile_read()
+    mark("profile_done")
+    kernels = {k: dict(avg_ms=v["total_ms"] / max(v["launches"], 1), launches=v["launches"],
+                       per_command_ms=v["total_ms"] / max(args.steps, 1)) for k, v in prof.items()}
+
+    # the collective by itself (N > 1): the all-gather of 2 + T*nu doubles per rank exactly as a command issues it, timed
+    # over 50 calls between fences -- torch.distributed's here; the library's own appears as kernels["rccl_all_gather"]
+    coll_timing = None
+    if pg is not None:
+        part = torch.zeros(2 + T * nu, dtype=torch.float64, device=f"cuda:{local}")
+        gath = torch.empty(world * (2 + T * nu), dtype=torch.float64, device=f"cuda:{local}")
+        from neurallaplacecontrol_amd.sharding import gather_partials
+
+        for _ in range(5):
+            gather_partials(part, gath, pg)
+        fence()
+        tc = time.perf_counter()
+        for _ in range(50):
+            gather_partials(part, gath, pg)
+        torch.cuda.synchronize()
+        coll_timing = dict(torch_all_gather_avg_ms=(time.perf_counter() - tc) / 50 * 1e3, backend=str(dist.get_backend(pg)),
+                           library_all_gather_avg_ms=(kernels.get("rccl_all_gather") or {}).get("avg_ms"),
+                           doubles_per_rank=2 + T * nu)
+        fence()
+    # what every rank saw (rank 0 prints it): "did the collective see N ranks", which body ran, per-rank kernel averages
+    info = planner.ctx.device_info()
+    mine = dict(rank=rank, local_rank=local, device=info["name"], torch_world=(dist.get_world_size(pg) if pg is not None else 1),
+                library_comm_world=int(planner.ctx.get_stat("comm_world")), native_collective=bool(planner.native_collective),
+                rollout_body=planner.rollout_body, fused_timeouts=planner.fused_timeouts, fused_fallbacks=planner.fused_fallbacks,
+                timed_s=elapsed_local, kernels_avg_ms={k: v["avg_ms"] for k, v in kernels.items()},
+                collective_timing=coll_timing)
+    per_rank = [mine]
+    if pg is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    mark("ranks_gathered")
 
     pmc_name, pj = load_pmc()
 
-    # ---- stand-alone ILT kernel at N = K*T points (the BASELINE 'ILT GB/s vs HBM peak' figure)
+    # ---- stand-alone ILT kernel at N = K*T points (the BASELINE 'ILT GB/s vs HBM peak' figure; headline shape d=5)
     ilt = None
     if rank == 0 and not args.no_ilt:
-        N = K_SAMPLES * HORIZON
-        g = torch.Generator(device="cuda").manual_seed(1)
-        theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
-        phi = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2)
-        tt = torch.full((N,), 0.125, dtype=torch.float64, device="cuda")
-        from neurallaplacecontrol_amd.laplace import default_ctx
-
-        ictx = default_ctx(local)
-        for _ in range(3):
-            nlc.ilt_reconstruct(theta, phi, tt)
-        ictx.profile_reset()
-        ictx.profile(True)
-        for _ in range(20):
-            nlc.ilt_reconstruct(theta, phi, tt)
-        torch.cuda.synchronize()
-        ictx.profile(False)
-        p = ictx.profile_read()["ilt_fourier_kernel"]
-        ms = p["total_ms"] / p["launches"]
-        nbytes = N * (2 * d * S_TERMS + d) * 8
-        traffic, traffic_src = pmc_traffic(pmc_name, pj, "ilt_fourier_kernel")
-        ilt = dict(bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                   frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                   algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
-                   avg_launch_ms=ms, points=N, bytes_per_point=(2 * d * S_TERMS + d) * 8)
-        del theta, phi
-        # the ablation's second kernel (BASELINE configs[4]): de Hoog with 33 terms at the same N.  FP64-VALU bound
-        # (about 150 VALU instructions per 8-byte term), so its HBM fraction is a utilisation figure, not a target.
-        S2 = 33
-        theta = (torch.rand(N, d, S2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
-        phi = (torch.rand(N, d, S2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.9
-        for _ in range(2):
-            nlc.ilt_reconstruct(theta, phi, tt, "dehoog")
-        ictx.profile_reset()
-        ictx.profile(True)
-        for _ in range(10):
-            nlc.ilt_reconstruct(theta, phi, tt, "dehoog")
-        torch.cuda.synchronize()
-        ictx.profile(False)
-        p = ictx.profile_read()["ilt_dehoog_kernel"]
-        ms2 = p["total_ms"] / p["launches"]
-        nb2 = N * (2 * d * S2 + d) * 8
-        tr2, tr2_src = pmc_traffic(pmc_name, pj, "ilt_dehoog_kernel")
-        ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
-                               algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
-                               frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=tr2, traffic_source=tr2_src)
-        del theta, phi
-        # fixed Talbot at the Fourier kernel's shape: the same coalesced stream with the algorithm's per-term phase / weight
-        theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
-        phi = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.9
-        for _ in range(2):
-            nlc.ilt_reconstruct(theta, phi, tt, "fixed_tablot")
-        ictx.profile_reset()
-        ictx.profile(True)
-        for _ in range(10):
-            nlc.ilt_reconstruct(theta, phi, tt, "fixed_tablot")
-        torch.cuda.synchronize()
-        ictx.profile(False)
-        p = ictx.profile_read()["ilt_linear_stream_kernel"]
-        ms4 = p["total_ms"] / p["launches"]
-        ilt["fixed_tablot17"] = dict(bound="hbm", kernel="ilt_fourier_kernel<.., LIN> (ilt_linear_stream_kernel)", avg_launch_ms=ms4,
-                                     points=N, algorithmic_bytes=nbytes, achieved=nbytes / (ms4 * 1e-3) / 1e9, unit="GB/s",
-                                     frac=nbytes / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
-        del theta, phi
-        # backward of the Fourier ILT (training through laplace_reconstruct): reads theta, phi, writes both gradients
-        theta = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi).requires_grad_()
-        phi = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.99).requires_grad_()
-        gx = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
-        for it in range(13):
-            if it == 3:
-                ictx.profile_reset()
-                ictx.profile(True)
-            torch.autograd.grad(nlc.ilt_reconstruct(theta, phi, tt), (theta, phi), gx)
-        torch.cuda.synchronize()
-        ictx.profile(False)
-        p = ictx.profile_read()["ilt_fourier_bwd_kernel"]
-        ms3 = p["total_ms"] / p["launches"]
-        nb3 = N * 4 * d * S_TERMS * 8
-        tr3, tr3_src = pmc_traffic(pmc_name, pj, "ilt_fourier_bwd_kernel")
-        ilt["backward"] = dict(bound="hbm", kernel="ilt_fourier_bwd_kernel", avg_launch_ms=ms3, points=N,
-                               algorithmic_bytes=nb3, bytes_per_point=4 * d * S_TERMS * 8,
-                               achieved=nb3 / (ms3 * 1e-3) / 1e9, unit="GB/s", frac=nb3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               traffic=tr3, traffic_source=tr3_src)
-        del theta, phi, gx
+        ilt = standalone_ilt_section(nlc, local, pmc_name, pj)
+        mark("ilt_done")
 
     def teardown():
         # orderly end: rank 0 arrives late (stand-alone ILT section); nobody tears a communicator down under a peer
@@ -509,24 +847,26 @@ def main():
             if planner.native_collective:
                 planner.ctx.comm_destroy()
             dist.destroy_process_group()
+        mark("teardown_done")
 
     if rank != 0:
         teardown()
-        return
+        return 0
 
-    kernels = {k: dict(avg_ms=v["total_ms"] / max(v["launches"], 1), launches=v["launches"]) for k, v in prof.items()}
     k_local = K_total // world
-    windows = k_local * HORIZON
+    windows = k_local * T
     g_hidden = HIDDEN // 2
-    gru_need = flops_gru_needed_per_window(g_hidden, nu, ABUF) * windows
-    gru_iss = flops_gru_issued_per_window(g_hidden, ABUF) * windows
-    roll_need = flops_rollout_needed_per_sample_step(HIDDEN, d, S_TERMS) * windows
-    roll_iss = flops_rollout_issued_per_sample_step(HIDDEN, 11) * windows  # nt3 = 11 layer-3 tiles for d=5, S=17
+    nt3 = int(planner.ctx.get_stat("model_nt3"))
+    gru_need = flops_gru_needed_per_window(g_hidden, nu, B) * windows
+    gru_iss = flops_gru_issued_per_window(g_hidden, B) * windows
+    roll_need = flops_rollout_needed_per_sample_step(HIDDEN, d, S) * windows
+    roll_iss = flops_rollout_issued_per_sample_step(HIDDEN, nt3) * windows
 
-    def mfma_entry(kernel, need, issued, alg_bytes):
+    def mfma_entry(kernel, need, issued, alg_bytes, launches_per_command=1):
         k = kernels[kernel]
         sec = k["avg_ms"] * 1e-3
-        traffic, src = (pmc_traffic(pmc_name, pj, kernel) if k_local == K_SAMPLES else (None, None))
+        need, issued, alg_bytes = need / launches_per_command, issued / launches_per_command, alg_bytes / launches_per_command
+        traffic, src = (pmc_traffic(pmc_name, pj, kernel) if headline and k_local == K_SAMPLES and kernel in PMC_KEYS else (None, None))
         return dict(bound="mfma", achieved=need / sec / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=need / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, traffic=traffic, traffic_source=src,
                     kernel=kernel, avg_launch_ms=k["avg_ms"], flops_per_launch=need,
@@ -541,24 +881,33 @@ def main():
                               (8 * nu + 16 + 16 + 8 * (2 * nu + d)) * windows)
     else:
         roofline = mfma_entry("gru_encode_kernel", gru_need, gru_iss, (8 * nu + 16) * windows)
-        roofline["also"] = mfma_entry("nl_rollout_kernel", roll_need, roll_iss, (16 + 8 * (2 * nu + d)) * windows)
+        if "nl_rollout_kernel" in kernels:
+            roofline["also"] = mfma_entry("nl_rollout_kernel", roll_need, roll_iss, (16 + 8 * (2 * nu + d)) * windows)
+        elif "nl_repfunc_kernel" in kernels:
+            # staged step chain (de Hoog): the representation MLP is one launch per horizon step and stream part; F_k leaves
+            # the launch (2 d S doubles per sample-step written, read again by the de Hoog kernel)
+            n_launch = max(kernels["nl_repfunc_kernel"]["launches"] // max(args.steps, 1), 1)
+            roofline["also"] = mfma_entry("nl_repfunc_kernel", roll_need - 2 * d * S * windows, roll_iss - 2 * nt3 * 128 * windows,
+                                          (16 + 8 * d + 16 * d * S) * windows, launches_per_command=n_launch)
     # whole step against the same roof: every algorithmic flop of one command() (GRU encode + rollout, all ranks) over the
-    # measured wall time per step -- the sampling / weighting / merge kernels add time but no matrix flops
+    # measured wall time per step -- the sampling / weighting / merge kernels add time but no matrix flops (nor does the
+    # de Hoog recurrence: FP64 VALU work, not counted)
     step_flops = (gru_need + roll_need) * world
     roofline["step"] = dict(flops=step_flops, achieved=step_flops / (elapsed / args.steps) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS * world,
                             unit="TFLOP/s", frac=step_flops / (elapsed / args.steps) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
                             note="algorithmic flops of one command() (GRU encode + rollout; SURVEY 8d) / ms_per_step / FP64-MFMA peak")
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sd_cpu, d, nu, args.cpu_budget)
-    info = planner.ctx.device_info()
-    workload = (f"oderl-cartpole (nx=5, nu=1), K={K_total} MPPI samples sharded over the ranks, H={HORIZON}, "
-                f"action_buffer_size={ABUF}, NL dynamics h={HIDDEN} S={S_TERMS} fourier ILT")
-    workload += " (BASELINE configs[1])" if K_total == K_SAMPLES else " -- EXPERIMENT: not the headline population of 16384"
+        cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget)
+        mark("cpu_baseline_done")
+    workload = (f"{env_name} (nx={d}, nu={nu}), K={K_total} MPPI samples sharded over the ranks, H={T}, "
+                f"action_buffer_size={B}, NL dynamics h={HIDDEN} S={S} {algo} ILT")
+    workload += f" ({cfg['name']})" if K_total == cfg["K"] else f" -- EXPERIMENT: not {cfg['name']}'s population of {cfg['K']}"
     if args.rehearse_on_one_gpu:
         workload += " -- REHEARSAL: every rank on cuda:0 over gloo, not a measurement"
+    bi = build_info()
     out = dict(
-        metric=f"MPPI planning steps/sec ({K_total} samples, H={HORIZON})",
+        metric=f"MPPI planning steps/sec ({K_total} samples, H={T})",
         value=args.steps / elapsed,
         unit="planning steps/s",
         n_gpus=world,
@@ -570,11 +919,15 @@ def main():
         vs_baseline=None,
         dtype="f64",
         data="synthetic",
-        config=dict(workload=workload, samples_per_gpu=k_local, noise="device Philox4x32-10", device=info["name"],
-                    commit=git_commit(), preheat_ms=args.preheat_ms,
+        config=dict(workload=workload, baseline_config=args.config, samples_per_gpu=k_local, noise="device Philox4x32-10",
+                    device=info["name"], commit=git_commit(), library_build=bi or None, preheat_ms=args.preheat_ms,
+                    attempt=args.attempt, native_collective=bool(planner.native_collective),
                     collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
                                                         if planner.native_collective else
-                                                        f"{dist.get_backend(pg)} all-gather via torch.distributed between the two phases")),
+                                                        f"{dist.get_backend(pg)} all-gather via torch.distributed between the two phases"),
+                    collective_timing=coll_timing,
+                    ranks_seen=dict(torch_world=mine["torch_world"], library_comm_world=mine["library_comm_world"],
+                                    devices=[r["device"] for r in per_rank], per_rank=per_rank)),
         roofline=roofline,
         roofline_ilt=ilt,
         cpu_baseline=cpu,
@@ -582,10 +935,102 @@ def main():
         kernels_note="per-launch hipEvent averages from a second, untimed pass of the same steps",
     )
     if cpu:
-        out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        ref = cpu["value"] if cpu.get("value") else cpu.get("value_extrapolated")
+        out["speedup_vs_cpu_baseline" if cpu.get("value") else "speedup_vs_cpu_baseline_extrapolated"] = out["value"] / ref
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
+    mark("line_written")
     teardown()
+    return 0
+
+
+def standalone_ilt_section(nlc, local, pmc_name, pj):
+    """Stand-alone ILT kernels at N = 16384 * 40 points, d = 5 (the headline shape): Fourier S = 17 (HBM-bound), de Hoog
+    S = 33, fixed Talbot S = 17, Fourier backward."""
+    d = 5
+    N = K_SAMPLES * HORIZON
+    g = torch.Generator(device="cuda").manual_seed(1)
+    theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2)
+    tt = torch.full((N,), 0.125, dtype=torch.float64, device="cuda")
+    from neurallaplacecontrol_amd.laplace import default_ctx
+
+    ictx = default_ctx(local)
+    for _ in range(3):
+        nlc.ilt_reconstruct(theta, phi, tt)
+    ictx.profile_reset()
+    ictx.profile(True)
+    for _ in range(20):
+        nlc.ilt_reconstruct(theta, phi, tt)
+    torch.cuda.synchronize()
+    ictx.profile(False)
+    p = ictx.profile_read()["ilt_fourier_kernel"]
+    ms = p["total_ms"] / p["launches"]
+    nbytes = N * (2 * d * S_TERMS + d) * 8
+    traffic, traffic_src = pmc_traffic(pmc_name, pj, "ilt_fourier_kernel")
+    ilt = dict(bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+               algorithmic_bytes=nbytes, kernel="ilt_fourier_kernel",
+               avg_launch_ms=ms, points=N, bytes_per_point=(2 * d * S_TERMS + d) * 8)
+    del theta, phi
+    # the ablation's second kernel (BASELINE configs[4]): de Hoog with 33 terms at the same N.  FP64-VALU bound
+    # (about 150 VALU instructions per 8-byte term), so its HBM fraction is a utilisation figure, not a target.
+    S2 = 33
+    theta = (torch.rand(N, d, S2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.9
+    for _ in range(2):
+        nlc.ilt_reconstruct(theta, phi, tt, "dehoog")
+    ictx.profile_reset()
+    ictx.profile(True)
+    for _ in range(10):
+        nlc.ilt_reconstruct(theta, phi, tt, "dehoog")
+    torch.cuda.synchronize()
+    ictx.profile(False)
+    p = ictx.profile_read()["ilt_dehoog_kernel"]
+    ms2 = p["total_ms"] / p["launches"]
+    nb2 = N * (2 * d * S2 + d) * 8
+    tr2, tr2_src = pmc_traffic(pmc_name, pj, "ilt_dehoog_kernel")
+    ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
+                           algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
+                           frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=tr2, traffic_source=tr2_src)
+    del theta, phi
+    # fixed Talbot at the Fourier kernel's shape: the same coalesced stream with the algorithm's per-term phase / weight
+    theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.9
+    for _ in range(2):
+        nlc.ilt_reconstruct(theta, phi, tt, "fixed_tablot")
+    ictx.profile_reset()
+    ictx.profile(True)
+    for _ in range(10):
+        nlc.ilt_reconstruct(theta, phi, tt, "fixed_tablot")
+    torch.cuda.synchronize()
+    ictx.profile(False)
+    p = ictx.profile_read()["ilt_linear_stream_kernel"]
+    ms4 = p["total_ms"] / p["launches"]
+    ilt["fixed_tablot17"] = dict(bound="hbm", kernel="ilt_fourier_kernel<.., LIN> (ilt_linear_stream_kernel)", avg_launch_ms=ms4,
+                                 points=N, algorithmic_bytes=nbytes, achieved=nbytes / (ms4 * 1e-3) / 1e9, unit="GB/s",
+                                 frac=nbytes / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
+    del theta, phi
+    # backward of the Fourier ILT (training through laplace_reconstruct): reads theta, phi, writes both gradients
+    theta = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi).requires_grad_()
+    phi = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.99).requires_grad_()
+    gx = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    for it in range(13):
+        if it == 3:
+            ictx.profile_reset()
+            ictx.profile(True)
+        torch.autograd.grad(nlc.ilt_reconstruct(theta, phi, tt), (theta, phi), gx)
+    torch.cuda.synchronize()
+    ictx.profile(False)
+    p = ictx.profile_read()["ilt_fourier_bwd_kernel"]
+    ms3 = p["total_ms"] / p["launches"]
+    nb3 = N * 4 * d * S_TERMS * 8
+    tr3, tr3_src = pmc_traffic(pmc_name, pj, "ilt_fourier_bwd_kernel")
+    ilt["backward"] = dict(bound="hbm", kernel="ilt_fourier_bwd_kernel", avg_launch_ms=ms3, points=N,
+                           algorithmic_bytes=nb3, bytes_per_point=4 * d * S_TERMS * 8,
+                           achieved=nb3 / (ms3 * 1e-3) / 1e9, unit="GB/s", frac=nb3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           traffic=tr3, traffic_source=tr3_src)
+    return ilt
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 8
+#define NLC_ABI_VERSION 9
 
 #define NLC_OK 0
 #define NLC_ERR_BAD_ARG (-1)
@@ -49,7 +49,8 @@ extern "C" {
 #define NLC_ILT_FOURIER 0
 #define NLC_ILT_DEHOOG 1
 /* the closed-form LINEAR algorithms torchlaplace also offers (reference knob config.py:36 nl_ilt_algorithm): stand-alone
- * reconstruction only (nlc_ilt_rep_inputs / nlc_ilt_reconstruct; models with these algorithms plan on the generic path) */
+ * reconstruction (nlc_ilt_rep_inputs / nlc_ilt_reconstruct / its backward), nlc_model_forward, and the planner -- on LIN
+ * instances of the rollout kernels by default, on the staged all-HIP path with option "linear_fused" = 0 (see nlc_set_option) */
 #define NLC_ILT_FIXED_TALBOT 2 /* "fixed_tablot": Abate & Valko, M = terms nodes, r = 2M/5 (mpmath FixedTalbot) */
 #define NLC_ILT_STEHFEST 3     /* "stehfest": Gaver-Stehfest, terms even (mpmath Stehfest) */
 
@@ -165,6 +166,24 @@ int nlc_synchronize(nlc_ctx* ctx);
  * two-launch body from then on (setting "rollout_variant" again re-arms it).
  * Unknown names / out-of-range values: NLC_ERR_BAD_ARG. */
 int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
+/* Read-only counters of the ctx's planner (ABI v9), so that a caller -- and the reference's deployment of several planner
+ * processes on ONE GPU (run_exp_multi.py:145-165 fans out Pool(12) workers of K = 1000, config.py:52) -- can see which body
+ * its commands run on and whether the fused body's bounded waits ever expired:
+ *   "rollout_body"         body phase 1 of the LAST command ran on: 1 wave-per-tile | 2 latency-split | 3 fused one-launch
+ *                          | 4 staged step chain (de Hoog / linear algorithms) | 5 persistent de Hoog chain | 6 oracle
+ *                          | 7 Delta-t RNN | 8 NODE | 9 caller's callables; 0 = no command yet
+ *   "fused_timeouts"       fused launches of this ctx that gave up waiting (each one: a re-run, or a lost command)
+ *   "fused_fallbacks"      commands re-run on the two-launch body inside nlc_mppi_finish (give-up here OR on another rank)
+ *   "fused_lost"           1 = this ctx has left the fused body for good ("rollout_variant" re-arms it)
+ *   "last_giveup_command"  0-based index of the last command (count of nlc_mppi_rollout calls) that saw a give-up, -1 = none
+ *   "commands"             nlc_mppi_rollout calls so far
+ *   "comm_world", "comm_rank"  size / rank of the library-owned RCCL communicator (0 / -1 = none: nlc_comm_init not called)
+ *   "fused_blocks_per_cu"  resident workgroups per CU the occupancy query returned for the fused kernel (-1 = not queried yet)
+ *   "fused_spin_limit"     the option's current value
+ *   "model_nt3"            16-wide output tiles of the representation MLP's last layer as packed by nlc_set_model (the bench's
+ *                          issued-flop count needs it), 0 = no model
+ * Unknown names: NLC_ERR_BAD_ARG. */
+int nlc_get_stat(nlc_ctx* ctx, const char* name, double* out);
 /* device properties the bench reports next to its roofline numbers */
 int nlc_device_info(nlc_ctx* ctx, char* name, int name_len, int* num_cus, int* clock_mhz, double* hbm_gib);
 

@@ -43,6 +43,7 @@ SYMBOLS = [
     "nlc_last_error",
     "nlc_set_stream",
     "nlc_set_option",
+    "nlc_get_stat",
     "nlc_synchronize",
     "nlc_device_info",
     "nlc_ilt_rep_inputs",
@@ -224,6 +225,7 @@ def load_library():
         lib.nlc_env_obs.argtypes = [vp, i32, i64, vp, vp]
         lib.nlc_rep_func.argtypes = [vp, vp, i64, vp, vp]
         lib.nlc_set_option.argtypes = [vp, C.c_char_p, dbl]
+        lib.nlc_get_stat.argtypes = [vp, C.c_char_p, P(dbl)]
         lib.nlc_mppi_configure.argtypes = [vp, P(MppiDesc)]
         lib.nlc_mppi_workspace_bytes.argtypes = [vp]
         lib.nlc_mppi_workspace_bytes.restype = i64
@@ -278,6 +280,12 @@ class Ctx:
     def set_option(self, name, value):
         """Planner tuning knob of ``include/nlc.h`` (``nlc_set_option``)."""
         self.check(self.lib.nlc_set_option(self.h, name.encode(), float(value)))
+
+    def get_stat(self, name):
+        """Read-only planner counter of ``include/nlc.h`` (``nlc_get_stat``), as a float."""
+        v = C.c_double()
+        self.check(self.lib.nlc_get_stat(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def comm_unique_id(self):
         """Rank 0: the NLC_COMM_ID_BYTES bytes every rank passes to ``comm_init`` (``nlc_comm_unique_id``)."""

@@ -8,20 +8,19 @@ using namespace nlc::host;
 
 namespace nlc {
 namespace host {
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return &r;
-  tried = true;
+static void bind_rccl(Rccl& r) {
   void* h = nullptr;
+  std::string last;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // already in the process (torch.distributed's)?
     if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (h) break;
+    const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
+    if (e) last = e;
   }
   if (!h) {
-    r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
-    return &r;
+    r.why = std::string("librccl.so.1 not found: ") + last;
+    return;
   }
   r.GetUniqueId = (int (*)(Rccl::UniqueId*))dlsym(h, "ncclGetUniqueId");
   r.CommInitRank = (int (*)(void**, int, Rccl::UniqueId, int))dlsym(h, "ncclCommInitRank");
@@ -30,7 +29,15 @@ Rccl* rccl() {
   r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
   if (!r.ok) r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
-  return &r;
+}
+Rccl* rccl() {
+  // bound once, thread-safely (function-local static initialisation): ctxs of different threads may ask at the same time
+  static Rccl* r = [] {
+    static Rccl inst;
+    bind_rccl(inst);
+    return &inst;
+  }();
+  return r;
 }
 }  // namespace host
 }  // namespace nlc

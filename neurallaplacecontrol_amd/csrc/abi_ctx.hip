@@ -213,6 +213,25 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   return NLC_OK;
 }
 
+extern "C" int nlc_get_stat(nlc_ctx* c, const char* name, double* out) {
+  if (!c) return NLC_ERR_BAD_ARG;
+  if (!name || !out) return fail(c, NLC_ERR_BAD_ARG, "NULL stat name / out");
+  const std::string n(name);
+  if (n == "rollout_body") *out = (double)c->last_body;
+  else if (n == "fused_timeouts") *out = (double)c->fused_timeouts;
+  else if (n == "fused_fallbacks") *out = (double)c->fused_fallbacks;
+  else if (n == "fused_lost") *out = c->fused_lost ? 1.0 : 0.0;
+  else if (n == "last_giveup_command") *out = (double)c->last_giveup_command;
+  else if (n == "commands") *out = (double)c->commands;
+  else if (n == "comm_world") *out = c->comm ? (double)c->comm_world : 0.0;
+  else if (n == "comm_rank") *out = c->comm ? (double)c->comm_rank : -1.0;
+  else if (n == "fused_blocks_per_cu") *out = (double)c->fused_blocks_per_cu;
+  else if (n == "fused_spin_limit") *out = (double)c->opt_fused_spin_limit;
+  else if (n == "model_nt3") *out = c->has_model ? (double)c->net.nt3 : 0.0;
+  else return fail(c, NLC_ERR_BAD_ARG, "unknown stat: " + n);
+  return NLC_OK;
+}
+
 extern "C" int nlc_synchronize(nlc_ctx* c) {
   if (!c) return NLC_ERR_BAD_ARG;
   NLC_HIP(c, hipStreamSynchronize(c->stream));

@@ -219,7 +219,11 @@ WeightArgs make_weight_args(nlc_ctx* c, const nlc_mppi_buffers* buf) {
 }
 
 int run_weights(nlc_ctx* c, const nlc_mppi_buffers* buf) {
-  const WeightArgs wa = make_weight_args(c, buf);
+  WeightArgs wa = make_weight_args(c, buf);
+  // behind a fused launch that left the fold to us: its give-up word marks the partial rows here -- the launch of
+  // THIS command only; a re-run on the two-launch body (last_body 2) must not read the word the failed launch left set
+  if (c->last_body == 3 && buf->workspace && c->pd.dynamics == NLC_DYN_NL)
+    wa.gave_up = reinterpret_cast<const unsigned*>((const double*)buf->workspace + ws_layout(c).sync) + kFusedTimeout;
   ProfScope ps(c, "weight_kernels");
   NLC_HIP(c, launch_weights(wa, c->stream));
   return NLC_OK;
@@ -281,9 +285,15 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
     return fail(c, NLC_ERR_BAD_ARG, "NULL required device buffer");
   if (d.cost_external && !buf->states) return fail(c, NLC_ERR_BAD_ARG, "cost_external needs buf->states");
   NLC_HIP(c, hipSetDevice(c->device));
+  if (!replay) c->commands += 1;
+  c->last_body = 0;
   if (!replay) {  // (a device-resident caller never synchronised inside nlc_mppi_finish)
     const bool lost_here = fused_gave_up(c), marked = merge_reported_invalid(c);
-    if (lost_here) c->fused_lost = true;  // from here on the two-launch body
+    if (lost_here) {
+      c->fused_lost = true;  // from here on the two-launch body
+      c->fused_timeouts += 1;
+      c->last_giveup_command = c->commands - 2;  // the command before this one
+    }
     if (lost_here || marked)  // `marked` is set on every rank of a sharded planner: they all fail here, none waits in a collective
       return fail(c, NLC_ERR_HIP, "fused planner body: the PREVIOUS command timed out waiting inside the launch (on this or "
                                   "another rank; its action was NaN and U was left alone); later commands run the two-launch body");
@@ -393,8 +403,12 @@ static int mppi_rollout_impl(nlc_ctx* c, const double* state, int state_per_samp
   // perturb kernel on the paths that still need it)
   if (!nl_fourier)
     if (int rc2 = launch_shift_perturb(c, call)) return rc2;
-  if (external) return NLC_OK;  // the caller runs the horizon loop, then nlc_mppi_weights
+  if (external) {
+    c->last_body = 9;
+    return NLC_OK;  // the caller runs the horizon loop, then nlc_mppi_weights
+  }
   if (d.dynamics == NLC_DYN_NL) return rollout_nl(c, call);
+  c->last_body = d.dynamics == NLC_DYN_NODE ? 8 : (d.dynamics == NLC_DYN_DTRNN ? 7 : 6);
   if (d.dynamics == NLC_DYN_NODE) {
     NodeRolloutArgs r{};
     r.net = c->node;
@@ -648,8 +662,12 @@ extern "C" int nlc_mppi_finish(nlc_ctx* c, const double* gathered, int G, int ra
   // (the control sequence's ping-pong partner is untouched), gather again, merge again.
   const bool lost_here = fused_gave_up(c);
   const bool marked = merge_reported_invalid(c);
-  if (lost_here) c->fused_lost = true;
+  if (lost_here) {
+    c->fused_lost = true;
+    c->fused_timeouts += 1;
+  }
   if (lost_here || marked) {
+    c->last_giveup_command = c->commands - 1;
     if (G > 1 && !marked)  // (a sharded command whose weights were folded outside the launch: the peers cannot know)
       return fail(c, NLC_ERR_HIP, "fused planner body: a workgroup timed out waiting inside the launch and the shard's partials "
                                   "were not marked; command lost (later commands run the two-launch body)");

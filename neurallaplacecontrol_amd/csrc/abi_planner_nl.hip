@@ -98,6 +98,7 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
     ProfScope ps(c, "gru_encode_kernel");
     NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
   }
+  c->last_body = chain ? 5 : 4;
   if (chain) {
     DehoogChainArgs ca{};
     ca.net = r.net;
@@ -395,6 +396,7 @@ int rollout_nl_fused(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r, 
   c->sync_clean_ws = nullptr;
   c->sync_dirty = true;
   c->last.fused = true;
+  c->last_body = 3;
   f.p = p;
   if (fc.inline_weights) f.w = make_weight_args(c, buf);
   // every workgroup must be resident at once: a rollout workgroup waits for encoder workgroups of the same launch
@@ -561,6 +563,8 @@ int nlc::host::rollout_nl(nlc_ctx* c, RolloutCall& call) {
     if (weights_done) return NLC_OK;
   } else {
     if (int rc2 = rollout_nl_two_launch(c, call, g, r, variant)) return rc2;
+    // (launch_nl_rollout: 2 = latency-split, 1 = wave-per-tile, 0 = its own pick: split up to 8192 samples)
+    c->last_body = (variant == 2 || (variant == 0 && KE <= 8192)) ? 2 : 1;
   }
   return d.cost_external ? NLC_OK : run_weights(c, buf);
 }

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void weight_tile_kernel(const WeightArgs a) {
 __global__ __launch_bounds__(256) void weight_rank_kernel(const WeightArgs a) {
   __shared__ double lds[kWeightRankLds];
   weight_rank<MemPlain>(a, (int64_t)blockIdx.y, lds);
+  // (thread 0 stored eta_r) the fused launch before this fold gave up: mark the row, every rank sees it after the all-gather
+  if (a.gave_up != nullptr && threadIdx.x == 0 && __hip_atomic_load(a.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    a.partials[(int64_t)blockIdx.y * (2 + a.T * a.nu) + 1] = kPartialInvalidEta;
 }
 // large populations: one workgroup per 64-tile chunk, then one per episode adds the chunk values in ascending order --
 // the same additions in the same order as weight_rank
@@ -129,7 +132,12 @@ __global__ __launch_bounds__(128) void weight_final_kernel(const WeightArgs a, i
     }
     a.partials[e * W + 1 + i] = tot;
   }
-  if (threadIdx.x == 0) a.partials[e * W] = cp[0];
+  if (threadIdx.x == 0) {
+    a.partials[e * W] = cp[0];
+    // (this thread stored eta_r above: i = 0) see weight_rank_kernel
+    if (a.gave_up != nullptr && __hip_atomic_load(a.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+      a.partials[e * W + 1] = kPartialInvalidEta;
+  }
 }
 
 hipError_t launch_weights(const WeightArgs& a, hipStream_t s) {

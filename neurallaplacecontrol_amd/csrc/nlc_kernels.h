@@ -459,6 +459,10 @@ struct WeightArgs {
   double* chunk_part;   // (E, ceil(nblk/64), 2 + T*nu): 64-tile chunk sums (large populations: launch_weights)
   double* partials;     // (E, 2 + T*nu)
   int nblk;             // weight tiles per episode
+  // non-NULL after a fused launch that did NOT fold the weights itself (batched episodes, fused_inline without bit 1, cost
+  // callables): the sync block's kFusedTimeout word -- non-zero = a workgroup of that launch gave up, and the workgroup that
+  // stores eta_r marks every episode's partial row (kPartialInvalidEta) exactly as the in-launch fold does (fused_weight_rank)
+  const unsigned* gave_up;
 };
 // partial rows are (beta_r, eta_r, S_r[T*nu]); eta_r = kPartialInvalidEta marks a shard whose rollout launch gave up (the
 // fused planner body's bounded waits): merge_kernel on every rank then leaves U alone and reports it (MergeArgs::status_pinned)

@@ -422,6 +422,27 @@ class MPPIDelay:
     def state(self, value):
         self._state_in = value
 
+    # ---- what the library did (include/nlc.h, nlc_get_stat); not in the reference
+    _BODIES = {0: None, 1: "wave-per-tile", 2: "latency-split", 3: "fused", 4: "staged", 5: "dehoog-chain", 6: "oracle",
+               7: "dtrnn", 8: "node", 9: "callables"}
+
+    @property
+    def rollout_body(self):
+        """Which hand-written body phase 1 of the LAST command ran on ("fused": the one-launch body, which assumes the
+        device to itself; "latency-split" / "wave-per-tile": GRU launch + rollout launch; ...); None before the first."""
+        return self._BODIES.get(int(self.ctx.get_stat("rollout_body")))
+
+    @property
+    def fused_timeouts(self):
+        """Fused launches of this planner whose bounded waits expired (each one: a command re-run on the two-launch body, or
+        lost).  Non-zero means the GPU is shared with work the fused body cannot see: the planner has left that body."""
+        return int(self.ctx.get_stat("fused_timeouts"))
+
+    @property
+    def fused_fallbacks(self):
+        """Commands re-run on the two-launch body inside nlc_mppi_finish (a give-up here or on another rank)."""
+        return int(self.ctx.get_stat("fused_fallbacks"))
+
     noise = property(lambda self: self._out(self._noise))
     perturbed_action = property(lambda self: self._out(self._perturbed))
     states = property(lambda self: self._out(self._states))

@@ -107,6 +107,15 @@ def test_bench_weights_equal_oracle_synthetic_weights():
     sd = model.state_dict()
     for k, v in ref.items():
         assert torch.equal(sd[k].to(torch.float64), v), k
+    # every --config's model: the other envs, and the de Hoog taming of configs[4]
+    for key, cfg in bench.CONFIGS.items():
+        d, nu, A, std = bench.ENV_SHAPES[cfg["env"]]
+        model = bench.synthetic_state_dict(d, nu, cfg["S"], env=cfg["env"], algo=cfg["algo"])
+        ref = onl.make_synthetic_state_dict(0, d, nu, 128, cfg["S"], std, [A / 2.0], tame="dehoog" if cfg["algo"] == "dehoog" else True)
+        sd = model.state_dict()
+        for k, v in ref.items():
+            assert torch.equal(sd[k].to(torch.float64), v), (key, k)
+        assert onl.ENV_STATS[cfg["env"]]["state_std"] == std and onl.ENV_STATS[cfg["env"]]["act_high"] == A
 
 
 WORKER = r"""
@@ -258,6 +267,65 @@ def test_bench_bare_multi_gpu_invocation_launches_its_own_ranks():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.strip().startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["ranks"][0]["RANK"] == "0"
+
+
+def _bare_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_watchdog_ends_a_run_whose_rank_never_arrives():
+    """a rank that sleeps forever (in every attempt) must not hang `bench.py --gpus N`: each rank's
+    supervisor kills its measuring child when the progress markers stop, the fallback attempt ends the same way, and the
+    parent exits non-zero well within its own watchdog -- no JSON line, no process left behind."""
+    import time
+
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch", "--test-hang-rank", "1",
+                          "--watchdog-step-s", "4", "--watchdog-init-s", "120"], env=_bare_env(), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    took = time.time() - t0
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.decode().splitlines() if ln.strip()], out.stdout
+    err = out.stderr.decode()
+    assert "attempt 0 (auto) timeout" in err and "attempt 1 (torch) timeout" in err, err[-3000:]
+    assert took < 120, took  # two attempts of ~4 s of silence each + process start-up, nowhere near the 600 s above
+
+
+def test_bench_falls_back_to_the_torch_collective_when_the_first_attempt_hangs():
+    """... and a hang in the FIRST attempt only (the shape of a library-owned RCCL all-gather misbehaving at G > 1, the path no
+    hardware run has exercised) costs the watchdog's patience, not the record: every rank starts a fresh child with
+    --collective torch and the one JSON line says why."""
+    import json
+
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch", "--test-hang-rank", "1",
+                          "--test-hang-attempts", "1", "--watchdog-step-s", "4", "--watchdog-init-s", "120"], env=_bare_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["attempt"] == 1 and rec["config"]["collective"] == "torch"
+    why = rec["config"]["collective_fallback_reason"]
+    assert "--collective auto" in why and "rank 1: timeout" in why and "last progress marker pg_ready" in why
+    assert [r["RANK"] for r in rec["ranks"]] == ["0", "1"]
+
+
+def test_bench_run_watched_reports_a_failing_child_and_kills_a_silent_one(tmp_path):
+    sys.path.insert(0, REPO)
+    import bench
+
+    status, rc, data, last = bench.run_watched([sys.executable, "-c", "import sys; print('{\"a\": 1}'); sys.exit(3)"], dict(os.environ),
+                                               30, 30, 60)
+    assert (status, rc, last) == ("failed", 3, None) and bench.last_json_line(data) == '{"a": 1}'
+    code = ("import os, time\n"
+            f"open(os.environ[{bench.PROGRESS_ENV!r}], 'a').write('phase_one 0\\n')\n"
+            "time.sleep(600)\n")
+    status, rc, data, last = bench.run_watched([sys.executable, "-c", code], dict(os.environ), 30, 1.5, 60)
+    assert status == "timeout" and rc != 0 and last == "phase_one"
+    # a peer's failure ends the wait at once
+    status, rc, data, last = bench.run_watched([sys.executable, "-c", "import time; time.sleep(600)"], dict(os.environ), 30, 30, 60,
+                                               peer_failed=lambda: True)
+    assert status == "peer"
 
 
 def test_graft_entry_build_runs(lib):

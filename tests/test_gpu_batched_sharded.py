@@ -541,3 +541,12 @@ def test_bench_ranks_rehearsed_on_one_gpu(ranks, samples):
         assert "nl_plan_fused_kernel" in rec["kernels_avg_ms"], "a 2048-sample shard plans on the one-launch fused body"
     else:
         assert "nl_rollout_kernel" in rec["kernels_avg_ms"]
+    # round 5: what the ranks saw -- the group size, one entry per rank with its body, its give-ups and its kernel averages
+    seen = rec["config"]["ranks_seen"]
+    assert seen["torch_world"] == ranks and seen["library_comm_world"] == 0 and len(seen["per_rank"]) == ranks
+    assert sorted(r["rank"] for r in seen["per_rank"]) == list(range(ranks))
+    for r in seen["per_rank"]:
+        assert r["rollout_body"] == ("fused" if samples // ranks <= 4096 else "latency-split"), r
+        assert r["fused_timeouts"] == 0 and r["fused_fallbacks"] == 0, "ranks sharing one GPU must not lose fused launches silently"
+        assert r["collective_timing"]["torch_all_gather_avg_ms"] > 0 and r["kernels_avg_ms"]
+    assert rec["config"]["commit"] and rec["config"]["library_build"]["csrc_sha"]
