@@ -18,15 +18,24 @@ also has the harness closures' STRUCTURE: its code object may reference nothing 
 (``_DYN_NAMES`` / ``_COST_NAMES``: the torch calls that append the time channel; the env's two reward methods), close over
 nothing but their free variables, and carry no constants of its own beyond None / booleans / small integers / the strings
 they use -- a closure with a ``clamp``, a ``where``, a threshold constant or a helper call fails this and stays on the
-generic path.  ``planner_options={"recognise_closures": 0}`` switches recognition off altogether.
+generic path.  Names and constants say nothing about OPERATORS (``state - model(...)``, ``out[out[:, 0] > 2] = 2``
+use none), so the bytecode is held to the harness closures' operations as well (``_ops_ok``): every instruction must come
+from a small set of opcodes (loads, calls, the branch on the closure's flags, store to a local, return) plus exactly the
+arithmetic those closures do -- ONE ``+`` and no other binary operator in the dynamics closure, one ``+`` per reward
+branch and one unary minus in the cost closure, one ``== "nl"`` comparison at most, subscripts only by a small constant
+index (``perturbed_action.shape[0]``), no subscript or attribute store, no ``in`` / ``is`` / ``not``, no loops.
+``planner_options={"recognise_closures": 0}`` switches recognition off altogether.
 
 A twin built from a reference model instance (``NeuralLaplaceModel.from_reference``) is a weight SNAPSHOT; the dynamics
 object keeps the source module and re-copies its weights whenever their ``(data_ptr, _version)`` key has moved since the last
 command (``refresh_twin``), so a ``load_state_dict`` / optimizer step on the closed-over model is seen by the fused path as
-it is by the literal closure.
+it is by the literal closure.  A write through ``.data`` moves no version counter: it is caught by a per-tensor content
+check every ``TWIN_CONTENT_CHECK_EVERY`` commands (so the fused path may lag such a write by up to that many commands), or
+at once by ``MPPIDelay.refresh_model()``.
 Nothing here executes or imports reference code: only attribute and type inspection of objects the caller passed in.
 """
 
+import dis
 import functools
 import inspect
 
@@ -67,9 +76,50 @@ def _consts_ok(consts, strings, doc):
     return True
 
 
+# Opcodes the harness closures compile to, CPython 3.8 .. 3.13 spellings (an opcode outside this set -- a subscript store, a
+# comparison chain, an in-place operator, a loop, an import, ... -- is something those closures do not do).  Arithmetic,
+# comparisons and subscripts are in the set but COUNTED and checked separately below.
+_PLAIN_OPS = frozenset({
+    "RESUME", "CACHE", "NOP", "EXTENDED_ARG", "COPY_FREE_VARS", "MAKE_CELL", "PUSH_NULL", "PRECALL", "KW_NAMES", "POP_TOP",
+    "LOAD_FAST", "LOAD_FAST_CHECK", "LOAD_FAST_LOAD_FAST", "LOAD_DEREF", "LOAD_CLOSURE", "LOAD_GLOBAL", "LOAD_CONST", "LOAD_ATTR",
+    "LOAD_METHOD", "STORE_FAST", "STORE_FAST_LOAD_FAST", "BUILD_TUPLE", "CALL", "CALL_KW", "CALL_FUNCTION", "CALL_FUNCTION_KW",
+    "CALL_METHOD", "RETURN_VALUE", "RETURN_CONST", "JUMP_FORWARD", "JUMP_ABSOLUTE", "POP_JUMP_IF_FALSE", "POP_JUMP_IF_TRUE",
+    "POP_JUMP_FORWARD_IF_FALSE", "POP_JUMP_FORWARD_IF_TRUE", "JUMP_IF_FALSE_OR_POP", "JUMP_IF_TRUE_OR_POP", "TO_BOOL", "COPY",
+})
+
+
+def _ops_ok(code, kind):
+    """The operation fingerprint (module docstring): every instruction is a plain load / call / branch / local store, and the
+    arithmetic is exactly the harness closure's."""
+    adds = negs = 0
+    compares, subscripts = [], []
+    prev = None
+    for ins in dis.get_instructions(code):
+        op = ins.opname
+        if op == "BINARY_ADD" or (op == "BINARY_OP" and ins.argrepr == "+"):
+            adds += 1
+        elif op == "UNARY_NEGATIVE":
+            negs += 1
+        elif op == "COMPARE_OP":
+            # (argrepr "==" up to 3.12, "bool(==)" from 3.13) against the constant loaded just before it
+            compares.append((ins.argrepr.replace("bool(", "").replace(")", ""), prev.argval if prev is not None and prev.opname == "LOAD_CONST" else None))
+        elif op == "BINARY_SUBSCR":
+            subscripts.append(prev.argval if prev is not None and prev.opname == "LOAD_CONST" else None)
+        elif op not in _PLAIN_OPS:
+            return False  # BINARY_SUBTRACT / BINARY_OP other than +, STORE_SUBSCR, CONTAINS_OP, IS_OP, UNARY_NOT, FOR_ITER, ...
+        if op not in ("CACHE", "EXTENDED_ARG"):
+            prev = ins
+    small = lambda v: type(v) is int and 0 <= v <= 3  # noqa: E731
+    if kind == "dynamics":
+        return (adds == 1 and negs == 0 and all(c == ("==", "nl") for c in compares) and len(compares) <= 1
+                and all(small(i) for i in subscripts) and len(subscripts) <= 1)
+    # (one `+` per reward branch; the compiler may copy the function's tail -- the negation -- into every branch)
+    return 1 <= adds <= 3 and 1 <= negs <= adds and not compares and not subscripts
+
+
 def has_harness_structure(fn, kind):
-    """True iff the function `fn` references nothing the harness's `kind` closure ("dynamics" / "cost") does not: names, free
-    variables, leading argument names and constants (see the module docstring)."""
+    """True iff the function `fn` references nothing the harness's `kind` closure ("dynamics" / "cost") does not -- names, free
+    variables, leading argument names, constants -- and performs no operation it does not (see the module docstring)."""
     if not inspect.isfunction(fn):
         return False
     code = fn.__code__
@@ -82,27 +132,49 @@ def has_harness_structure(fn, kind):
         return False
     if any(inspect.iscode(c) for c in code.co_consts):  # nested functions / comprehensions: not the harness's closure
         return False
-    return _consts_ok(code.co_consts, strs, fn.__doc__)
+    return _consts_ok(code.co_consts, strs, fn.__doc__) and _ops_ok(code, kind)
 
 
 def _module_key(mod):
     return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
 
 
-def refresh_twin(twin):
+TWIN_CONTENT_CHECK_EVERY = 32  # commands between two content checks of a twin's source (writes through .data)
+
+
+def _module_checksum(mod):
+    """One number per tensor (its float64 sum), gathered in ONE host transfer: catches a write that bypassed the version
+    counter (``p.data.mul_()``, ``p.data.copy_()`` -- EMA / target-network code, some hand-written optimisers)."""
+    ts = [t.detach() for t in list(mod.parameters()) + list(mod.buffers())]
+    if not ts:
+        return ()
+    return tuple(torch.stack([t.to(torch.float64).sum().to("cpu") for t in ts]).tolist())
+
+
+def refresh_twin(twin, force=False):
     """Re-copy the weights of a twin built by ``_model_twin`` from a foreign (reference) module if that module's tensors
-    have been written or replaced since the last look.  No-op for the package's own models."""
+    have been written or replaced since the last look.  No-op for the package's own models.
+    The look is the tensors' ``(data_ptr, _version)`` key at every command; a write through ``.data`` does not move that
+    key, so every ``TWIN_CONTENT_CHECK_EVERY``-th look also compares per-tensor sums, and ``force=True`` --
+    ``MPPIDelay.refresh_model()`` -- copies unconditionally."""
     src = twin.__dict__.get("_twin_source")
     if src is None:
         return
     key = _module_key(src)
-    if key != twin.__dict__["_twin_source_key"]:
+    looks = twin.__dict__["_twin_looks"] = twin.__dict__.get("_twin_looks", 0) + 1
+    moved = force or key != twin.__dict__["_twin_source_key"]
+    if not moved and looks % TWIN_CONTENT_CHECK_EVERY == 0:
+        moved = _module_checksum(src) != twin.__dict__.get("_twin_source_sum")
+    if moved:
         with torch.no_grad():
             for name in ("state_mean", "state_std", "action_mean", "action_std", "dt"):
                 if hasattr(src, name):
                     getattr(twin, name).copy_(getattr(src, name).detach().to(getattr(twin, name).device))
             twin.load_state_dict({k: v.detach() for k, v in src.state_dict().items()})
         twin.__dict__["_twin_source_key"] = key
+        twin.__dict__["_twin_source_sum"] = _module_checksum(src)
+        if hasattr(twin, "mark_weights_dirty"):
+            twin.mark_weights_dirty()  # (load_state_dict moved the twin's own key already; a forced copy of equal values did not)
 
 
 def _free_variables(fn):
@@ -151,6 +223,7 @@ def _model_twin(obj):
         # a snapshot: remember where it came from, so that later weight updates of `obj` reach the fused path (refresh_twin)
         # (through __dict__: a plain attribute assignment would register `obj` as a sub-module of the twin)
         twin.__dict__["_twin_source"], twin.__dict__["_twin_source_key"] = obj, _module_key(obj)
+        twin.__dict__["_twin_source_sum"] = _module_checksum(obj)
         return twin
     return None
 

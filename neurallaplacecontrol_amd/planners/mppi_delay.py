@@ -611,6 +611,19 @@ class MPPIDelay:
         if self._states is not None:
             self._states.copy_(states.reshape(K, T, self.nx))
 
+    def refresh_model(self):
+        """Not in the reference.  Re-read the dynamics model's weights NOW: after a write the automatic look cannot see at
+        once -- ``p.data.copy_()`` / ``p.data.mul_()`` on the model a recognised harness closure closes over (its
+        ``(data_ptr, _version)`` key does not move; the content check runs every ``_recognise.TWIN_CONTENT_CHECK_EVERY``
+        commands), or on one of this package's own models (``mark_weights_dirty``).  The next command() uploads them."""
+        holder = self.F if isinstance(self.F, NLDynamics) else (
+            self._candidate[0] if self._candidate is not None and isinstance(self._candidate[0], NLDynamics) else None)
+        if holder is None:
+            return
+        _recognise.refresh_twin(holder.model, force=True)
+        if hasattr(holder.model, "mark_weights_dirty"):
+            holder.model.mark_weights_dirty()
+
     # ------------------------------------------------------------------ misc reference API
     def reset(self):
         """Clear controller state after finishing a trial (re-draws U, reference :226-230)."""

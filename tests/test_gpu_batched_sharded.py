@@ -383,7 +383,7 @@ model = n.NeuralLaplaceModel(d, nu, d, hidden_units=128, s_recon_terms=17, ilt_a
                              normalize=True, normalize_time=True).double()
 model.load_state_dict(sd)
 model = model.cuda()
-opts = {"rollout_variant": 3}
+opts = {"rollout_variant": 3, "fused_inline": int(sys.argv[5])}
 if rank == bad_rank:                       # one encoder tile of THIS rank is never published: its chain gives up
     opts.update({"fused_test_drop_tile": 37, "fused_spin_limit": 3000})
 p = n.MPPIDelay(n.NLDynamics(model, 0.05), n.EnvCost("oderl-cartpole"), d, n.noise_sigma(nu), K, T, "cpu",
@@ -403,19 +403,23 @@ with torch.no_grad():
         acts.append(a.clone())
         ab = torch.roll(ab, -1, 0); ab[-1] = a
 torch.save(dict(acts=torch.stack(acts), U=p.U.cpu(), cost=p.cost_total.cpu(), fused_first=fused_first,
-                last_fused="nl_plan_fused_kernel" in prof), os.path.join(sys.argv[2], f"r{rank}.pt"))
+                last_fused="nl_plan_fused_kernel" in prof, body=p.rollout_body, timeouts=p.fused_timeouts,
+                fallbacks=p.fused_fallbacks, giveup_at=int(p.ctx.get_stat("last_giveup_command"))),
+           os.path.join(sys.argv[2], f"r{rank}.pt"))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,K,bad_rank", [(2, 1024, 1), (4, 2048, 2)])
-def test_sharded_fused_timeout_is_recovered_on_every_rank(nlc, tmp_path, world, K, bad_rank):
+@pytest.mark.parametrize("world,K,bad_rank,inline", [(2, 1024, 1, 3), (4, 2048, 2, 3), (2, 1024, 0, 2), (2, 1024, 1, 0)])
+def test_sharded_fused_timeout_is_recovered_on_every_rank(nlc, tmp_path, world, K, bad_rank, inline):
     """VERDICT r3 weak 6 / ADVICE r3: a fused-body time-out on ONE rank of a K-sharded planner.  The rank that gave up marks its
     partial row (eta = -1); after the all-gather merge_kernel on every rank sees the mark, skips the update and tells its
     host; every rank re-runs the command on the two-launch body, the partials are gathered again (NLC_AGAIN: the collective
     is the caller's here) and merged -- no rank is left waiting in a collective, every rank returns the same action, and it
-    is the unsharded planner's.  The rank that timed out stays on the two-launch body, its peers keep the fused one."""
+    is the unsharded planner's.  The rank that timed out stays on the two-launch body, its peers keep the fused one.
+    ADVICE r4 (medium): the same when the weights are folded OUTSIDE the launch (fused_inline 0 / 2): the weight kernels read the
+    launch's give-up word and mark the row, so the peers learn of the loss there too."""
     import subprocess
     import sys
 
@@ -432,7 +436,7 @@ def test_sharded_fused_timeout_is_recovered_on_every_rank(nlc, tmp_path, world, 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     subprocess.check_call(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-         "--master-port", port, str(script), repo, str(tmp_path), str(K), str(bad_rank)], env=env, timeout=600)
+         "--master-port", port, str(script), repo, str(tmp_path), str(K), str(bad_rank), str(inline)], env=env, timeout=600)
     rs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     for r in range(1, world):
         assert torch.equal(rs[0]["acts"], rs[r]["acts"]) and torch.equal(rs[0]["U"], rs[r]["U"]), r
@@ -441,6 +445,9 @@ def test_sharded_fused_timeout_is_recovered_on_every_rank(nlc, tmp_path, world, 
         # first command: one fused launch everywhere, then the re-run's rollout launch everywhere
         assert rs[r]["fused_first"] == (1, 1), (r, rs[r]["fused_first"])
         assert rs[r]["last_fused"] == (r != bad_rank), r
+        # nlc_get_stat (ABI v9): the give-up is visible -- one launch lost on the bad rank, one re-run everywhere, in command 0
+        assert rs[r]["timeouts"] == (1 if r == bad_rank else 0) and rs[r]["fallbacks"] == 1 and rs[r]["giveup_at"] == 0, rs[r]
+        assert rs[r]["body"] == ("latency-split" if r == bad_rank else "fused"), rs[r]["body"]
     model = build_model(nlc, sd)
     p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-cartpole"), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
                       u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64),

@@ -107,9 +107,10 @@ def test_literal_oracle_partial_is_recognised_and_plans_fused_g1(nlc, path):
 
 def test_closure_that_differs_from_its_candidate_stays_generic(nlc):
     """Two gates.  Structure: a closure over a model + constant ts_pred that ALSO clamps the state references a
-    name the harness closure does not (`clamp`) and carries constants of its own: it is never a candidate.  Probe: a closure
-    with the harness closure's structure that computes something else (here: state MINUS the model's prediction -- no name,
-    no constant gives it away) is a candidate, fails the probe and keeps the generic path with the closure's own semantics."""
+    name the harness closure does not (`clamp`) and carries constants of its own: it is never a candidate; nor is state MINUS
+    the model's prediction (round 5, ADVICE r4: no name, no constant gives it away, its one operator does).  Probe: a closure
+    with the harness closure's names, constants AND operations that computes something else (the prediction added to itself,
+    the state dropped) is a candidate, fails the probe and keeps the generic path with the closure's own semantics."""
     g = np.load(f"{GOLD}/g3_nl_cartpole.npz")
     model = build_model(nlc, load_sd(g))
     K, T, d, nu, A = int(g["K"]), int(g["T"]), int(g["d"]), int(g["nu"]), float(g["A"])
@@ -122,9 +123,13 @@ def test_closure_that_differs_from_its_candidate_stays_generic(nlc):
         state_diff_pred = model(state, perturbed_action, ts_pred)
         return state - state_diff_pred
 
+    def doubled(state, perturbed_action):
+        state_diff_pred = model(state, perturbed_action, ts_pred)
+        return state_diff_pred + state_diff_pred
+
     cost = nlc.EnvCost("oderl-cartpole")
     with torch.no_grad():
-        for dynamics, is_candidate in ((clamped, False), (minus, True)):
+        for dynamics, is_candidate in ((clamped, False), (minus, False), (doubled, True)):
             p = nlc.MPPIDelay(dynamics, cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A),
                               u_max=torch.tensor(A), u_scale=A, U_init=torch.zeros(T, nu, dtype=torch.float64))
             assert (p._candidate is not None) == is_candidate, dynamics.__name__

@@ -195,6 +195,12 @@ def test_fused_timeout_reruns_command_on_two_launch_body(nlc):
     bad.command(state, ab)
     bad.ctx.profile(False)
     assert "nl_plan_fused_kernel" not in bad.ctx.profile_read(), "the ctx must stay on the two-launch body after a time-out"
+    # the give-up is not silent (ABI v9, nlc_get_stat): one lost launch, one re-run, in command 0; the body in use now
+    assert (bad.fused_timeouts, bad.fused_fallbacks, bad.rollout_body) == (1, 1, "latency-split")
+    assert int(bad.ctx.get_stat("last_giveup_command")) == 0 and int(bad.ctx.get_stat("fused_lost")) == 1
+    assert (ref.fused_timeouts, ref.fused_fallbacks, ref.rollout_body) == (0, 0, "latency-split")
+    with pytest.raises(nlc._lib.NlcError):
+        bad.ctx.get_stat("no_such_counter")
 
 
 @pytest.mark.parametrize("algo,S,K,h", [("fixed_tablot", 17, 2500, 128), ("stehfest", 12, 700, 128), ("fixed_tablot", 9, 16500, 128),

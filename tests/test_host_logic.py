@@ -164,11 +164,46 @@ def test_recognise_literal_harness_closures_without_gpu():
     def cost_scaled(state, action):
         return -(env.diff_obs_reward_(state, exp_reward=False) + 0.5 * env.diff_ac_reward_(action))
 
-    for f in (clamped, thresholded, wrong_args):
+    # operators and small integers need no names -- the gate fingerprints the OPERATIONS too
+    def masked_store(state, perturbed_action):
+        out = state + model(state, perturbed_action, ts_pred)
+        out[out[:, 0] > 2] = 2
+        return out
+
+    def minus(state, perturbed_action):
+        return state - model(state, perturbed_action, ts_pred)
+
+    def small_mask(state, perturbed_action):
+        out = state + model(state, perturbed_action, ts_pred)
+        return out * (out < 3)
+
+    def twice(state, perturbed_action):
+        return state + model(state, perturbed_action, ts_pred) + model(state, perturbed_action, ts_pred)
+
+    def sliced(state, perturbed_action):
+        return state + model(state, perturbed_action[:, 1:], ts_pred)
+
+    def inplace(state, perturbed_action):
+        state += model(state, perturbed_action, ts_pred)
+        return state
+
+    def cost_not_negated(state, action):
+        return env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action)
+
+    def cost_minus(state, action):
+        return -(env.diff_obs_reward_(state, exp_reward=False) - env.diff_ac_reward_(action))
+
+    def cost_first_dim(state, action):
+        return -(env.diff_obs_reward_(state, exp_reward=False) + env.diff_ac_reward_(action))[0]
+
+    for f in (clamped, thresholded, wrong_args, masked_store, minus, small_mask, twice, sliced, inplace):
         assert not R.has_harness_structure(f, "dynamics") and R.candidate_dynamics(f) is None, f.__name__
-    for f in (cost_plus_barrier, cost_scaled):
+    for f in (cost_plus_barrier, cost_scaled, cost_not_negated, cost_minus, cost_first_dim):
         assert not R.has_harness_structure(f, "cost") and R.candidate_cost(f) is None, f.__name__
     assert R.has_harness_structure(dyn, "dynamics") and R.has_harness_structure(cost, "cost")
+    # the encode_obs_time variant of the same closure (its time-channel branch taken or not) is the same code object
+    dyn_t, _ = _harness_style_closures(model, CTCartpole(), ts_pred, encode_obs_time=True)
+    assert R.has_harness_structure(dyn_t, "dynamics")
 
 
 def test_twin_of_a_foreign_model_follows_its_weight_updates():
@@ -212,3 +247,15 @@ def test_twin_of_a_foreign_model_follows_its_weight_updates():
     src.state_std = torch.full((3,), 2.0, dtype=torch.float64)  # a replaced buffer
     R.refresh_twin(twin)
     assert torch.equal(twin.state_std, src.state_std)
+    # a write through .data moves no version counter -- the per-tensor content check (every
+    # TWIN_CONTENT_CHECK_EVERY looks) catches it, refresh_twin(force=True) (= MPPIDelay.refresh_model()) at once
+    w_src.data.mul_(0.25)
+    R.refresh_twin(twin)
+    assert not torch.equal(w_src, w_twin)  # not seen by the key
+    for _ in range(R.TWIN_CONTENT_CHECK_EVERY):
+        R.refresh_twin(twin)
+    assert torch.equal(w_src, w_twin)
+    w_src.data.add_(1.0)
+    key1 = twin._weights_key()
+    R.refresh_twin(twin, force=True)
+    assert torch.equal(w_src, w_twin) and twin._weights_key() != key1
