@@ -363,10 +363,12 @@ def test_plain_c_client_compiles_and_fails_loudly_without_gpu(lib, tmp_path):
     """tests/helpers/cabi_client.c is C99 against include/nlc.h (gcc, no Python): it must build here and report the
     missing device through nlc_last_error (exit code 3), not crash."""
     libdir = os.path.join(REPO, "neurallaplacecontrol_amd")
-    exe = str(tmp_path / "cabi_client")
-    subprocess.check_call(
-        ["gcc", "-std=c99", "-Wall", os.path.join(REPO, "tests", "helpers", "cabi_client.c"), "-I", os.path.join(REPO, "include"),
-         "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L" + libdir, "-lnlc_hip", "-L/opt/rocm/lib", "-lamdhip64",
-         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
-    r = subprocess.run([exe], capture_output=True, timeout=120)
-    assert r.returncode == 3 and b"nlc_create" in r.stderr
+    # cabi_client: single planner, env step, ILT; cabi_sharded_client: two ctxs walking the sharded protocol (NLC_AGAIN loop)
+    for name, code in (("cabi_client", 3), ("cabi_sharded_client", 7)):
+        exe = str(tmp_path / name)
+        subprocess.check_call(
+            ["gcc", "-std=c99", "-Wall", "-Werror", os.path.join(REPO, "tests", "helpers", name + ".c"), "-I", os.path.join(REPO, "include"),
+             "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L" + libdir, "-lnlc_hip", "-L/opt/rocm/lib", "-lamdhip64",
+             "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+        r = subprocess.run([exe], capture_output=True, timeout=120)
+        assert r.returncode == code and b"nlc_create" in r.stderr, (name, r.returncode, r.stderr)

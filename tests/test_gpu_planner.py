@@ -520,3 +520,66 @@ def test_state_dim_4_cartpole_without_trig_vs_reference_golden(nlc, case):
 
     with torch.no_grad():
         check_command_steps(nlc, _Prefixed(g, case), make)
+
+
+def test_plain_c_client_walks_the_sharded_protocol_with_a_forced_give_up(nlc, tmp_path):
+    """the protocol a C caller with its OWN collective implements, walked by a C99 program
+    (tests/helpers/cabi_sharded_client.c): one population of 1024 samples as two shards on two ctxs, Neural-Laplace dynamics on
+    the fused one-launch body, the collective = two device copies.  In command 0 shard 1's fused launch gives up
+    (fused_test_drop_tile): nlc_mppi_finish returns NLC_AGAIN on BOTH ctxs, the client gathers the re-run's rows again and calls
+    again.  Both ctxs return the same bits in every command, those are the unsharded Python planner's (same weights from the
+    same LCG, same Philox seed / counters), only shard 1 leaves the fused body, and nlc_get_stat says so."""
+    import subprocess
+
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    libdir = os.path.join(repo, "neurallaplacecontrol_amd")
+    exe = str(tmp_path / "cabi_sharded_client")
+    subprocess.check_call(
+        ["gcc", "-std=c99", os.path.join(repo, "tests", "helpers", "cabi_sharded_client.c"), "-I", os.path.join(repo, "include"),
+         "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L" + libdir, "-lnlc_hip", "-L/opt/rocm/lib", "-lamdhip64",
+         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+    lines = subprocess.check_output([exe], timeout=300).decode().strip().splitlines()
+    nblob = int(lines[0])
+    cmds = [ln.split() for ln in lines[1:4]]
+    stats = [[float(x) for x in lines[4].split()], [float(x) for x in lines[6].split()]]
+    U_c = [[float(x) for x in lines[5].split()], [float(x) for x in lines[7].split()]]
+    # both ranks asked for the second gather in command 0 only, and returned the same bits every time
+    assert [(c[2], c[3]) for c in cmds] == [("1", "1"), ("0", "0"), ("0", "0")], cmds
+    assert all(c[0] == c[1] for c in cmds) and U_c[0] == U_c[1]
+    # rank 0 still plans on the fused body (3) and lost nothing itself; rank 1 lost one launch and stays on the latency-split
+    # body (2); both re-ran one command, command 0
+    assert stats[0] == [3.0, 0.0, 1.0, 0.0] and stats[1] == [2.0, 1.0, 1.0, 0.0], stats
+    # the same model in the Python mirror: weights from the same 64-bit LCG, blob order = state_dict order (include/nlc.h)
+    d, nu, S, h, T, K, A = 5, 1, 17, 128, 12, 1024, 3.0
+    x, vals, mask = 0x9E3779B97F4A7C15, [], (1 << 64) - 1
+    for _ in range(nblob):
+        x = (x * 6364136223846793005 + 1442695040888963407) & mask
+        vals.append(((x >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 0.3)
+    blob = torch.tensor(vals, dtype=torch.float64)
+    blob[nblob - 2 * d * S + d * S:] += -3.0
+    model = nlc.NeuralLaplaceModel(d, nu, d, hidden_units=h, s_recon_terms=S, ilt_algorithm="fourier", state_mean=np.zeros(d),
+                                   state_std=np.array([2.88646771, 11.54556671, 0.70729307, 0.70692035, 17.3199048]),
+                                   action_mean=np.array([0]), action_std=np.array([1.5]), normalize=True, normalize_time=True).double()
+    order = ([f"action_encoder.gru.{n}_l{l}" for l in (0, 1) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+             + ["action_encoder.linear_out.weight", "action_encoder.linear_out.bias"]
+             + [f"laplace_rep_func.linear_tanh_stack.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")])
+    sd, at = model.state_dict(), 0
+    for name in order:
+        n = sd[name].numel()
+        sd[name] = blob[at:at + n].view(sd[name].shape).clone()
+        at += n
+    assert at == nblob
+    model.load_state_dict(sd)
+    model = model.cuda()
+    p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost("oderl-cartpole"), d, torch.tensor(1.0).double(), K, T, "cpu",
+                      lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
+                      U_init=torch.zeros(T, nu, dtype=torch.float64), noise_rng="philox", seed=23)
+    state = torch.tensor([0.01, 0.0, -1.0, 0.02, 0.0], dtype=torch.float64)
+    ab = torch.tensor([[0.5], [-0.25], [0.0], [1.0]], dtype=torch.float64)
+    for cmd in range(3):
+        act = p.command(state, ab)
+        # (two shards merged through the beta-shifted sums vs one population: the reductions associate differently)
+        np.testing.assert_allclose(float(cmds[cmd][0]), float(act[0]), rtol=1e-10, atol=1e-12)
+        ab = torch.roll(ab, -1, 0)
+        ab[-1] = float(cmds[cmd][0])
+    np.testing.assert_allclose(np.array(U_c[0]), p.U.reshape(-1).numpy(), rtol=1e-9, atol=1e-12)
