@@ -22,6 +22,7 @@ DYN_NL, DYN_ORACLE, DYN_EXTERNAL, DYN_DTRNN, DYN_NODE = 0, 1, 2, 3, 4
 
 ERRORS = {-1: "BAD_ARG", -2: "BAD_SHAPE", -3: "HIP_ERROR", -4: "UNSUPPORTED", -5: "STATE", -6: "COMM"}
 COMM_ID_BYTES = 128
+NLC_ERR_UNSUPPORTED = -4
 NLC_AGAIN = 1  # include/nlc.h: nlc_mppi_finish re-ran the command on every rank; gather the partials again and call again
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnlc_hip.so")

@@ -13,7 +13,8 @@ extern "C" int nlc_mppi_configure(nlc_ctx* c, const nlc_mppi_desc* d) {
   if (d->K < 1 || d->T < 1 || d->K_global < d->K || d->k_offset < 0 || d->k_offset + d->K > d->K_global)
     return fail(c, NLC_ERR_BAD_SHAPE, "bad K / K_global / k_offset / T");
   if (d->nu < 1 || d->nu > NLC_MAX_NU) return fail(c, NLC_ERR_UNSUPPORTED, "nu must be 1 or 2");
-  if (d->d < 1 || d->d > NLC_MAX_D) return fail(c, NLC_ERR_BAD_SHAPE, "bad nx");
+  // (caller-supplied dynamics: the library never touches a state, any nx goes)
+  if (d->d < 1 || (d->d > NLC_MAX_D && d->dynamics != NLC_DYN_EXTERNAL)) return fail(c, NLC_ERR_BAD_SHAPE, "bad nx");
   if (d->B < 1) return fail(c, NLC_ERR_BAD_SHAPE, "action_buffer needs at least one row");
   if (!(d->lambda_ > 0.0) || d->u_scale == 0.0) return fail(c, NLC_ERR_BAD_ARG, "lambda_ must be > 0, u_scale != 0");
   if (d->u_per_command < 1 || d->u_per_command > d->T) return fail(c, NLC_ERR_BAD_ARG, "bad u_per_command");

@@ -11,10 +11,17 @@ Fourier ILT fused (the (N, 2dS) theta/phi tensor never reaches HBM), float64 onl
 ``model.double()`` under ``torch.no_grad()``: ``mppi_with_model.py:101,319``).  In grad mode (training,
 ``train_utils.py:388-407``) ``forward`` runs the reference's op sequence with the GRU / MLP on PyTorch-ROCm and the
 line integral -- forward and backward -- in HIP, so the class is trainable on the GPU without torchlaplace.
+
+The reference constructors take ANY ``hidden_units`` / ``state_dim`` (``w_nl.py:67-83``); the MFMA kernels are instantiated
+for hidden_units 64 / 128 / 256, state_dim <= 6 and GRU input dim <= 3.  Any other shape is not an error (round 5, SURVEY
+8b "falls back to the torch path on UNSUPPORTED"): when ``nlc_set_model`` answers ``NLC_ERR_UNSUPPORTED`` the no-grad forward
+runs the same op sequence as the grad-mode one -- GRU and MLP as PyTorch-ROCm ops on the GPU, contour / sphere map / line
+integral in the HIP ILT kernels -- with a one-time warning, and a planner over such a model takes its callables path.
 """
 
 import copy
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -113,6 +120,18 @@ def _cme_terms(s_recon_terms):
     return int(terms[np.argmin(terms < s_recon_terms) - 2])
 
 
+class _DeviceCopy(nn.Module):
+    """Sub-modules and buffers of a host-resident model on the GPU (the generic forward's operands; re-made when the
+    source's weights key moves)."""
+
+    def __init__(self, src, dev):
+        super().__init__()
+        self.action_encoder = copy.deepcopy(src.action_encoder).to(dev)
+        self.laplace_rep_func = copy.deepcopy(src.laplace_rep_func).to(dev)
+        for name in ("state_mean", "state_std", "action_mean", "action_std", "dt"):
+            self.register_buffer(name, getattr(src, name).detach().to(dev))
+
+
 class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
     _dyn_id = _lib.DYN_NL  # rollout the fused planner selects for NLDynamics(model, dt)
 
@@ -196,6 +215,9 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
 
     def model_desc(self):
         d, nin = self.output_dim, self.action_dim + (1 if self.encode_obs_time else 0)
+        if d > _lib.NLC_MAX_D or nin > _lib.NLC_MAX_NIN:  # (the descriptor's arrays end there: same answer as the library's)
+            raise _lib.NlcError(_lib.NLC_ERR_UNSUPPORTED, f"state_dim {d} / GRU input dim {nin} exceed the descriptor's "
+                                                          f"{_lib.NLC_MAX_D} / {_lib.NLC_MAX_NIN}")
         desc = _lib.ModelDesc()
         desc.d, desc.nin, desc.h = d, nin, self.hidden_units
         # fourier: fused forward and planner kernels; dehoog / fixed_tablot / stehfest: staged all-HIP forward (representation
@@ -285,33 +307,71 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
             ctx.check(ctx.lib.nlc_rep_func(ctx.h, _lib.ptr(rows), N, _lib.ptr(theta), _lib.ptr(phi)))
         return theta, phi
 
-    def _forward_train(self, in_batch_obs, in_batch_action, ts_pred):
+    def _forward_train(self, in_batch_obs, in_batch_action, ts_pred, mod=None):
         """Grad-mode forward (the reference trains through ``model(...)``, ``train_utils.py:388-407``): the op sequence of
         ``w_nl.py:117-145`` with the GRU encoder and the representation MLP on PyTorch-ROCm (their backward is
-        autograd's) and the line integral in HIP, forward AND backward (``nlc_ilt_reconstruct_backward``)."""
-        dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
-        if next(self.parameters()).device != dev:
+        autograd's) and the line integral in HIP, forward AND backward (``nlc_ilt_reconstruct_backward``).
+        ``mod``: the module whose sub-modules / buffers to use (``_forward_generic``'s device copy); default ``self``."""
+        mod = self if mod is None else mod
+        dev = compute_device(in_batch_obs, in_batch_action, next(mod.parameters()))
+        if next(mod.parameters()).device != dev:
             raise RuntimeError("training forward: move the model to the GPU first (model.to('cuda'))")
         obs = in_batch_obs.to(dev, torch.float64)
         act = in_batch_action.to(dev, torch.float64)
         ts = torch.as_tensor(ts_pred).to(dev, torch.float64)
         if self.normalize:
-            batch_obs = (obs - self.state_mean) / self.state_std
-            batch_action = (act - self.action_mean) / self.action_std
+            batch_obs = (obs - mod.state_mean) / mod.state_std
+            batch_action = (act - mod.action_mean) / mod.action_std
             if self.normalize_time:
-                ts = ts / (self.dt * 8.0)
+                ts = ts / (mod.dt * 8.0)
         else:
             batch_obs = obs
             batch_action = act / 3.0
         if batch_action.dim() == 2:
             batch_action = batch_action.unsqueeze(1)
-        p = torch.cat((batch_obs, self.action_encoder(batch_action)), dim=1)
+        p = torch.cat((batch_obs, mod.action_encoder(batch_action)), dim=1)
         return torch.squeeze(
             laplace_reconstruct(
-                self.laplace_rep_func, p, ts, recon_dim=self.output_dim, ilt_algorithm=self.ilt_algorithm,
+                mod.laplace_rep_func, p, ts, recon_dim=self.output_dim, ilt_algorithm=self.ilt_algorithm,
                 ilt_reconstruction_terms=self.s_recon_terms, options=self.ilt_options,
             )
         ).to(in_batch_obs.device)
+
+    # ------------------------------------------------------------------ shapes the MFMA kernels are not instantiated for
+    def _shape_key(self):
+        return (self.hidden_units, self.output_dim, self.action_dim, self.encode_obs_time, self.ilt_algorithm,
+                self.s_recon_terms, repr(self.ilt_options))
+
+    def hip_unsupported(self):
+        """The library's reason if ``nlc_set_model`` rejects this model's SHAPE (``NLC_ERR_UNSUPPORTED``), else None.  Asked
+        once per shape; other failures (a float32 model, a wrong blob) raise as before."""
+        hit = getattr(self, "_unsupported", None)
+        if hit is not None and hit[0] == self._shape_key():
+            return hit[1]
+        why = None
+        try:
+            self.hip_ctx()
+        except _lib.NlcError as err:
+            if err.code != _lib.NLC_ERR_UNSUPPORTED:
+                raise
+            why = str(err)
+            warnings.warn(f"neurallaplacecontrol_amd.NeuralLaplaceModel: {why} -- this shape runs the reference's op sequence on "
+                          "PyTorch-ROCm (GRU / MLP) + the HIP ILT kernels instead of the fused MFMA kernels", stacklevel=3)
+        self._unsupported = (self._shape_key(), why)
+        return why
+
+    def _forward_generic(self, in_batch_obs, in_batch_action, ts_pred):
+        """No-grad forward of a shape the fused kernels do not take: ``_forward_train``'s op sequence (w_nl.py:117-145) under
+        ``no_grad`` on the GPU -- through a device copy of the weights if the model itself lives on the host."""
+        dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
+        mod = self
+        if next(self.parameters()).device != dev:
+            key = (self._weights_key(), str(dev))
+            if getattr(self, "_generic_dev", None) is None or self._generic_dev[0] != key:
+                self._generic_dev = (key, _DeviceCopy(self, dev))
+            mod = self._generic_dev[1]
+        with torch.no_grad():
+            return self._forward_train(in_batch_obs, in_batch_action, ts_pred, mod=mod)
 
     def _constant_ts(self, ts_pred, N):
         """The value of ts_pred if it is ONE query time per row and the same for every row (a Python number, or an
@@ -340,6 +400,8 @@ class NeuralLaplaceModel(WeightsKeyMixin, nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(in_batch_obs, in_batch_action, ts_pred)
         self._no_grad_only()
+        if self.hip_unsupported() is not None:
+            return self._forward_generic(in_batch_obs, in_batch_action, ts_pred)
         out_device = in_batch_obs.device
         dev = compute_device(in_batch_obs, in_batch_action, next(self.parameters()))
         ctx = self.hip_ctx(dev)

@@ -163,6 +163,7 @@ class MPPIDelay:
         self._candidate = None
         opts_in = dict(planner_options or {})
         self.recognised = False  # True once literal closures have been verified and replaced by their fused twins
+        self.unsupported_shape = None  # the library's reason when the model's shape sent the planner to the callables path
         if (bool(float(opts_in.pop("recognise_closures", 1))) and not self.fused_dynamics and not step_dependent_dynamics
                 and self.E == 1 and type(self) is MPPIDelay):
             cd = _recognise.candidate_dynamics(dynamics)
@@ -380,7 +381,22 @@ class MPPIDelay:
             if model._weights_key() != self._model_key:
                 if self._buf is not None:  # nlc_set_model drops the planner configuration: carry U over
                     self._pending_U, self._buf, self._B = self.U, None, None
-                self._model_key = model.upload(self.ctx)
+                try:
+                    self._model_key = model.upload(self.ctx)
+                except _lib.NlcError as err:
+                    if err.code != _lib.NLC_ERR_UNSUPPORTED:
+                        raise
+                    # a model shape the rollout kernels are not instantiated for (hidden_units other than 64 / 128 / 256,
+                    # state_dim > 6, ...): the reference's constructors accept it (w_nl.py:67-83), so plan on the callables
+                    # path -- sampling, bounding, weighting and the U update stay HIP kernels, the T-step loop calls
+                    # NLDynamics.__call__ -> model.forward (PyTorch-ROCm GRU / MLP + HIP ILT) and the cost callable
+                    import warnings
+
+                    warnings.warn(f"neurallaplacecontrol_amd.MPPIDelay: {err} -- planning on the callables path "
+                                  "(NLC_DYN_EXTERNAL) with the model's PyTorch-ROCm forward", stacklevel=3)
+                    self.fused_dynamics = self.fused = self.cost_external = False
+                    self.unsupported_shape = str(err)
+                    return self._ensure_configured(B)
                 stale = True  # the constant sphere inputs are folded into the layer-1 bias at configure time
         if stale:
             self._configure(B)

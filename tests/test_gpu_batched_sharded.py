@@ -557,3 +557,65 @@ def test_bench_ranks_rehearsed_on_one_gpu(ranks, samples):
         assert r["fused_timeouts"] == 0 and r["fused_fallbacks"] == 0, "ranks sharing one GPU must not lose fused launches silently"
         assert r["collective_timing"]["torch_all_gather_avg_ms"] > 0 and r["kernels_avg_ms"]
     assert rec["config"]["commit"] and rec["config"]["library_build"]["csrc_sha"]
+
+
+def _independent_planner(idx, K, T, commands, barrier, q, opts):
+    """One of the reference's evaluation workers (run_exp_multi.py:145-165): its own process, its own planner, cuda:0."""
+    import torch
+
+    import bench
+    import neurallaplacecontrol_amd as nlc
+
+    torch.set_num_threads(1)
+    d, nu = 5, 1
+    model = bench.synthetic_state_dict(d, nu, bench.S_TERMS).to("cuda:0")
+    state = nlc.initial_state(bench.ENV, torch.Generator().manual_seed(idx))
+    p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(bench.ENV), d, nlc.noise_sigma(nu), num_samples=K, horizon=T,
+                      device="cpu", compute_device="cuda:0", lambda_=1.0, u_min=torch.tensor(-3.0), u_max=torch.tensor(3.0),
+                      u_scale=3.0, noise_rng="philox", seed=100 + idx, U_init=torch.zeros(T, nu, dtype=torch.float64),
+                      planner_options=opts)
+    ab = torch.zeros(4, nu, dtype=torch.float64)
+    if barrier is not None:
+        barrier.wait()  # the FIRST commands of all workers start together: nothing warmed up, nothing swallowed
+    acts, first_body = [], None
+    with torch.no_grad():
+        for i in range(commands):
+            a = p.command(state, ab)
+            if i == 0:
+                first_body = p.rollout_body
+            acts.append(a.clone())
+            ab = torch.roll(ab, -1, 0)
+            ab[-1] = a
+    out = dict(idx=idx, acts=torch.stack(acts).numpy(), first_body=first_body, last_body=p.rollout_body, timeouts=p.fused_timeouts,
+               fallbacks=p.fused_fallbacks, lost=int(p.ctx.get_stat("fused_lost")))
+    if q is None:
+        return out
+    q.put(out)
+    barrier.wait()
+
+
+def test_independent_planner_processes_sharing_one_gpu_keep_the_fused_body(nlc):
+    """the reference's deployment is many evaluation workers on ONE GPU, one MPPIDelay of K = 1000, T = 40
+    each (run_exp_multi.py:145-165, config.py:52), and `rollout_variant` auto gives every one of them the fused one-launch
+    body, which waits inside the launch for workgroups of the same launch.  Four such processes, 200 commands each, counted
+    from the first command: every action equals the same planner's solo run bit for bit, no fused launch gave up, nobody was
+    moved off the fused body behind the caller's back (measured at 1 / 3 / 6 processes: profiles/r5_fused_sharing.json)."""
+    import multiprocessing as mp
+
+    P, K, T, commands = 4, 1000, 40, 200
+    ctx = mp.get_context("spawn")
+    barrier, q = ctx.Barrier(P), ctx.Queue()
+    procs = [ctx.Process(target=_independent_planner, args=(i, K, T, commands, barrier, q, {})) for i in range(P)]
+    for pr in procs:
+        pr.start()
+    res = sorted((q.get(timeout=600) for _ in range(P)), key=lambda r: r["idx"])
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    for r in res:
+        assert (r["first_body"], r["last_body"]) == ("fused", "fused"), r
+        assert (r["timeouts"], r["fallbacks"], r["lost"]) == (0, 0, 0), "a fused launch gave up while the GPU was shared"
+        # the same planner alone on the GPU, on the two-launch body: the bodies are bit-identical, sharing changed nothing
+        solo = _independent_planner(r["idx"], K, T, commands, None, None, {"rollout_variant": 2})
+        assert solo["last_body"] == "latency-split"
+        assert np.array_equal(solo["acts"], r["acts"]), r["idx"]

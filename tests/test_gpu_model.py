@@ -375,3 +375,63 @@ def test_nl_model_with_time_channel_vs_reference_golden(nlc, env):
 
         check_command_steps(nlc, g, make)
         check_command_steps(nlc, g, lambda U0: make(U0, fused=False))
+
+
+def test_shapes_without_an_mfma_instance_run_the_reference_op_sequence_on_the_gpu(nlc):
+    """VERDICT r4 item 5 / SURVEY 8b ("falls back to the torch path on UNSUPPORTED"): the reference constructors take any
+    hidden_units / state_dim (w_nl.py:67-83); the MFMA kernels exist for hidden_units 64 / 128 / 256 and state_dim <= 6.
+    hidden_units = 96 with state_dim = 7 must not raise: model.forward runs the op sequence of w_nl.py:117-145 with the GRU /
+    MLP on PyTorch-ROCm and the contour / sphere map / line integral in the HIP ILT kernels (one warning), and MPPIDelay plans
+    on its callables path (sampling, bounding, weights, U update still the HIP kernels) -- both against the oracle at 1e-9."""
+    import warnings
+
+    from oracle import mppi as omppi
+    from oracle import nl_model as onl
+
+    d, nu, h, S, K, T, A = 7, 1, 96, 17, 300, 8, 2.0
+    sd = onl.make_synthetic_state_dict(4, d, nu, h, S, [1.0 + 0.3 * i for i in range(d)], [A / 2], tame=True)
+    for where in ("cuda", "cpu"):  # weights on the GPU, and a host-resident model (device copy of the sub-modules)
+        model = build_model(nlc, sd, S=S, device=where)
+        torch.manual_seed(5)
+        N = 37
+        obs = torch.randn(N, d, dtype=torch.float64)
+        win = torch.randn(N, 4, nu, dtype=torch.float64)
+        ts = torch.full((N, 1), 0.05, dtype=torch.float64)
+        ref = onl.nl_forward(sd, obs, win, ts, S=S).reshape(N, d)
+        with warnings.catch_warnings(record=True) as seen, torch.no_grad():
+            warnings.simplefilter("always")
+            got = model(obs.cuda(), win.cuda(), ts.cuda()).cpu().reshape(N, d)
+            model(obs.cuda(), win.cuda(), ts.cuda())
+        assert sum("hidden_units must be 64, 128 or 256" in str(w.message) for w in seen) == 1, [str(w.message) for w in seen]
+        assert "hidden_units" in model.hip_unsupported()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), **TOL)
+    # the planner: a 7-dim state has no env cost kernel -- the running cost is the caller's callable, as in the reference
+    model = build_model(nlc, sd, S=S)
+    cost = lambda x, u: (x * x).sum(-1) + 0.01 * (u * u).sum(-1)  # noqa: E731
+    torch.manual_seed(6)
+    raw = torch.randn(K, T, nu, dtype=torch.float64)
+    U0 = torch.randn(T, nu, dtype=torch.float64) * 0.1
+    state, ab = torch.randn(d, dtype=torch.float64) * 0.1, torch.zeros(4, nu, dtype=torch.float64)
+    with warnings.catch_warnings(record=True) as seen, torch.no_grad():
+        warnings.simplefilter("always")
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), cost, d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A),
+                          u_max=torch.tensor(A), u_scale=A, U_init=U0.clone())
+        p.noise_dist = _Replay(raw)
+        action = p.command(state, ab)
+    assert p.unsupported_shape and p.fused_dynamics is False and p.rollout_body == "callables"
+    assert any("planning on the callables path" in str(w.message) for w in seen)
+    ts = torch.full((K, 1), 0.05, dtype=torch.float64)
+    ref = omppi.mppi_command(U0.clone(), state, ab, raw.clone(), onl.nl_dynamics(sd, ts, S=S), cost, d,
+                             torch.inverse(nlc.noise_sigma(nu)), 1.0, A, torch.tensor(-A), torch.tensor(A))
+    np.testing.assert_allclose(action.numpy(), ref["action"].numpy(), **TOL)
+    np.testing.assert_allclose(p.cost_total.numpy(), ref["cost_total"].numpy(), **TOL)
+    np.testing.assert_allclose(p.states.numpy(), ref["states"].numpy(), **TOL)
+    np.testing.assert_allclose(p.U.numpy(), ref["U"].numpy(), **TOL)
+    # a state_dim beyond the descriptor (9 > NLC_MAX_D) is the same story, not an IndexError
+    sd9 = onl.make_synthetic_state_dict(4, 9, nu, 64, 9, [1.0] * 9, [A / 2], tame=True)
+    m9 = build_model(nlc, sd9, S=9)
+    obs9 = torch.randn(5, 9, dtype=torch.float64)
+    with warnings.catch_warnings(), torch.no_grad():
+        warnings.simplefilter("ignore")
+        got9 = m9(obs9.cuda(), win[:5].cuda(), ts[:5].cuda()).cpu()
+    np.testing.assert_allclose(got9.numpy(), onl.nl_forward(sd9, obs9, win[:5], ts[:5], S=9).numpy(), **TOL)

@@ -2,7 +2,10 @@
 multiprocessing.Pool(12) (run_exp_multi.py:145), one planner per worker, all on one GPU.  P planner processes share cuda:0
 here (P <= 6: the GPU pool's process guard allows six processes on a card) and each runs the harness's control loop
 (command -> roll the action buffer) for a fixed wall time, with host_spin = 0 (hipStreamSynchronize), 1 (spin on the pinned
-sequence word until it changes) and the bounded form (spin for at most `host_spin_us`, then hipStreamSynchronize).
+sequence word until it changes) and 2 (sleep through the predicted wait -- the shortest of the last eight -- then spin).
+Every row also says which rollout body the processes ran on and whether a fused launch ever gave up (nlc_get_stat), counted
+from each process's FIRST command (the 30 warm-up commands are included in those counters): the spin comparison is not
+confounded by a silent fall-back to the two-launch body (tools/fused_sharing.py measures that question itself).
 Reported per setting: aggregate planning steps/s, the host CPU seconds the workers burned per wall second (user + system,
 from os.times) and -- with `--cpus C` -- the same with the workers confined to C cores (sched_setaffinity), i.e. the
 oversubscribed host a Pool(12) on a small node is.
@@ -42,7 +45,8 @@ def worker(idx, P, K, T, opts, seconds, cpus, barrier, q):
         n += 1
     wall = time.perf_counter() - t0
     c1 = os.times()
-    q.put(dict(idx=idx, steps=n, wall=wall, cpu=(c1.user - c0.user) + (c1.system - c0.system)))
+    q.put(dict(idx=idx, steps=n, wall=wall, cpu=(c1.user - c0.user) + (c1.system - c0.system), body=p.rollout_body,
+               fused_timeouts=p.fused_timeouts, fused_fallbacks=p.fused_fallbacks))
     barrier.wait()
 
 
@@ -68,7 +72,7 @@ if __name__ == "__main__":
     ap.add_argument("--T", type=int, default=40)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--cpus", default="0,2")
-    ap.add_argument("--modes", default="0,1,auto")
+    ap.add_argument("--modes", default="0,1,2")
     a = ap.parse_args()
     out = []
     for cpus in [int(c) for c in a.cpus.split(",")]:
