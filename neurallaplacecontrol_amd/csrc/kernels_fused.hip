@@ -31,3 +31,8 @@ hipError_t launch_nl_plan_fused(const FusedArgs& a, int g, unsigned grid, int bp
 }
 
 }  // namespace nlc
+
+// tools/split_phase_clocks.py (a -DNLC_PHASE_CLOCKS=1 build of this unit): phase sums of the latency-split bodies launched from here
+namespace nlc {
+NLC_DEFINE_SPLIT_CLK_READER(nlc_debug_split_clocks_fused)
+}

@@ -56,6 +56,51 @@ struct PhaseClk {
 extern __device__ unsigned long long nlc_phase_clk[16];  // kernels_nl.hip
 #endif
 
+// The same for the LATENCY-SPLIT bodies (round 5: rollout_split_tile -- stand-alone and as the chain of the fused one-launch body --
+// and repfunc_split_mlp of the staged de Hoog planner): four waves share a 16-sample tile and meet at two / three workgroup barriers
+// per model evaluation, so next to the arithmetic phases the stamps separate what a wave WAITS for -- the barriers, the hand-over of
+// latents from another workgroup -- from what it computes.  Every translation unit that instantiates such a kernel owns a copy of the
+// sums (static: no relocatable device code) and exports a reader (NLC_DEFINE_SPLIT_CLK_READER; tools/split_phase_clocks.py).
+struct SplitClk {
+  static constexpr int kN = 12;
+  enum { kHead = 0, kL1, kBar1, kL2, kTanh2, kBar2, kL3, kEpi, kBar3, kTail, kWait, kOther };
+  uint64_t last;
+  uint64_t acc[kN];
+  __device__ __forceinline__ void start() {
+    if (!NLC_PHASE_CLOCKS) return;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) acc[i] = 0;
+    last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    if (!NLC_PHASE_CLOCKS) return;
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    acc[i] += now - last;
+    last = now;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+#if NLC_PHASE_CLOCKS
+// [wave index 0..3][phase 0..11] sums, then [48 + wave] = waves counted, [52] = model evaluations (tile-steps) of wave 0
+static __device__ unsigned long long nlc_split_clk[64];
+__device__ __forceinline__ void split_clk_flush(const SplitClk& clk, int wv, int lane, unsigned long long evals) {
+  if (lane != 0) return;
+  for (int i = 0; i < SplitClk::kN; ++i) atomicAdd(&nlc_split_clk[(wv & 3) * SplitClk::kN + i], (unsigned long long)clk.acc[i]);
+  atomicAdd(&nlc_split_clk[48 + (wv & 3)], 1ull);
+  if ((wv & 3) == 0) atomicAdd(&nlc_split_clk[52], evals);
+}
+#define NLC_DEFINE_SPLIT_CLK_READER(name)                                                                                  \
+  extern "C" int name(unsigned long long* out64) {                                                                         \
+    if (hipDeviceSynchronize() != hipSuccess) return -1;                                                                   \
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(nlc::nlc_split_clk), 64 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+    const unsigned long long zero[64] = {0};                                                                               \
+    return hipMemcpyToSymbol(HIP_SYMBOL(nlc::nlc_split_clk), zero, sizeof(zero)) == hipSuccess ? 0 : -1;                   \
+  }
+#else
+#define NLC_DEFINE_SPLIT_CLK_READER(name)
+#endif
+
 // ------------------------------------------------------------------ one model evaluation
 // p0/p1: layer-1 latent B fragments (index 4s+q).  Returns acc_x: ILT sums, rows = dims (reg r -> dim q+4r).
 // |F| times the component the Fourier phase i^k keeps, as (num * trig, den): even-k groups need cos(theta), odd-k
@@ -526,11 +571,15 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     cost = a.ccarry[kc * 2];
     pcost = a.ccarry[kc * 2 + 1];
   }
+  SplitClk clk;
+  clk.start();
   src.begin(a.t_begin, wv, lane, kc);
+  clk.mark(SplitClk::kWait);
   for (int t = a.t_begin; t < a.t_end; ++t) {
     const double pa0 = src.cur0, pa1 = src.cur1;
     const double p0 = (i0 < d) ? (x0 - m0) / s0 : (i0 == d ? pa0 : (i0 == d + 1 ? pa1 : 0.0));
     const double p1 = (i1 < d) ? (x1 - m1) / s1 : (i1 == d ? pa0 : (i1 == d + 1 ? pa1 : 0.0));
+    clk.mark(SplitClk::kHead);
     // ---- layer 1: output tiles TW*wv .. TW*wv+TW-1
     {
       v4d acc[TW];
@@ -553,8 +602,11 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
           H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
         }
     }
+    clk.mark(SplitClk::kL1);
     __syncthreads();
+    clk.mark(SplitClk::kBar1);
     src.after_barrier1(t, a.t_end, wv, lane);
+    clk.mark(SplitClk::kWait);
     // ---- layer 2
     {
       v4d acc[TW];
@@ -579,6 +631,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
         for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
         b_cur = b_nxt;
       }
+      clk.mark(SplitClk::kL2);
 #pragma unroll
       for (int i = 0; i < TW; ++i)
 #pragma unroll
@@ -589,7 +642,9 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
           H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
         }
     }
+    clk.mark(SplitClk::kTanh2);
     __syncthreads();
+    clk.mark(SplitClk::kBar2);
     src.after_barrier2(t, a.t_end, kc);
     // ---- layer 3 (own tiles) + sphere->complex + partial ILT sum
     v4d ax = splat(0.0);
@@ -616,6 +671,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
         for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
         b_cur = b_nxt;
       }
+      clk.mark(SplitClk::kL3);
       gptr cp = opaque(n.Cp);
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
@@ -639,7 +695,9 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     }
     AX[(wv * 2 + 0) * 64 + lane] = ax[0];
     AX[(wv * 2 + 1) * 64 + lane] = ax[1];
+    clk.mark(SplitClk::kEpi);
     __syncthreads();
+    clk.mark(SplitClk::kBar3);
     // every wave forms the same full sums (fixed order) and keeps its own copy of the state
     const double ax0 = ((AX[0 * 64 + lane] + AX[2 * 64 + lane]) + AX[4 * 64 + lane]) + AX[6 * 64 + lane];
     const double ax1 = ((AX[1 * 64 + lane] + AX[3 * 64 + lane]) + AX[5 * 64 + lane]) + AX[7 * 64 + lane];
@@ -670,7 +728,11 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
       pcost += pc;
     }
     src.advance();
+    clk.mark(SplitClk::kTail);
   }
+#if NLC_PHASE_CLOCKS
+  split_clk_flush(clk, wv, lane, (unsigned long long)(a.t_end - a.t_begin));
+#endif
   if (wv == 0 && valid) {
     if (last_chunk) {
       if (q == 0) src.store_cost(a, k, cost + pcost);
@@ -704,11 +766,15 @@ template <int HT, int NT3, class AfterL1>
 __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const double p0, const double p1, const bool valid,
                                                   const int64_t k, const int64_t n_cols, const int* __restrict__ slot,
                                                   double* __restrict__ fre, double* __restrict__ fim, double* __restrict__ H1,
-                                                  double* __restrict__ H2, const int wv, const int lane, AfterL1 after_l1) {
+                                                  double* __restrict__ H2, const int wv, const int lane, AfterL1 after_l1,
+                                                  SplitClk* pclk = nullptr) {
   constexpr int KS = HT * 4;
   constexpr int TW = HT / 4;
   constexpr int NTW = (NT3 + 3) / 4;
   const int q = lane >> 4;
+  SplitClk dummy_clk;
+  SplitClk& clk = (NLC_PHASE_CLOCKS && pclk != nullptr) ? *pclk : dummy_clk;
+  if (NLC_PHASE_CLOCKS && pclk == nullptr) clk.start();
   // (the bias tiles are loaded through laundered pointers: inside a persistent horizon loop the compiler would otherwise hoist
   // these loop-invariant loads and keep ~80 VGPRs live across the QD phase of kernels_dehoog_chain.hip)
   int j3[NTW];
@@ -736,7 +802,9 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
         H1[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
       }
   }
+  clk.mark(SplitClk::kL1);
   __syncthreads();
+  clk.mark(SplitClk::kBar1);
   after_l1();
   // ---- layer 2
   {
@@ -762,6 +830,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
       for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
       b_cur = b_nxt;
     }
+    clk.mark(SplitClk::kL2);
 #pragma unroll
     for (int i = 0; i < TW; ++i)
 #pragma unroll
@@ -772,7 +841,9 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
         H2[(4 * (TW * wv + i) + r + 1) * 64 + lane] = tb;
       }
   }
+  clk.mark(SplitClk::kTanh2);
   __syncthreads();
+  clk.mark(SplitClk::kBar2);
   // ---- layer 3 (own tiles) + sphere -> complex, F_k stored slot-major
   {
     v4d o[NTW];
@@ -797,6 +868,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
       for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
       b_cur = b_nxt;
     }
+    clk.mark(SplitClk::kL3);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       if (wv + 4 * i < NT3) {  // wave-uniform
@@ -821,6 +893,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
       }
     }
   }
+  clk.mark(SplitClk::kEpi);
 }
 
 // The same MLP for NS 16-sample tiles at once by a workgroup of NW = 2 NS waves (hidden_units 128: HT = 8), the form the
@@ -1006,6 +1079,8 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
   const int64_t kc = valid ? k : a.N - 1;
   const int d = n.d;
   const int i0 = q, i1 = 4 + q;
+  SplitClk clk;
+  clk.start();
   const double* ob = a.obs + (a.obs_per_sample ? kc : kc / a.Kep) * a.obs_stride;
   const double* pa = a.pa + kc * a.pa_stride;
   double x0 = (i0 < d) ? ob[i0] : 0.0, x1 = (i1 < d) ? ob[i1] : 0.0;
@@ -1041,12 +1116,16 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
                              : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
   const double p1 = (i1 < d) ? (x1 - n.state_mean[i1]) / n.state_std[i1]
                              : (i1 == d ? pa[0] : (i1 == d + 1 ? pa[1] : 0.0));
+  clk.mark(SplitClk::kHead);
   repfunc_split_mlp<HT, NT3>(n, p0, p1, valid, k, a.N, a.slot, a.fre, a.fim, H1, H2, wv, lane, [&]() {
     if (a.tail_prev && wv == 0 && valid) {  // every wave has read the previous state: now it may be replaced
       if (i0 < d) a.tail.x[k * d + i0] = x0;
       if (i1 < d) a.tail.x[k * d + i1] = x1;
     }
-  });
+  }, &clk);
+#if NLC_PHASE_CLOCKS
+  split_clk_flush(clk, wv, lane, 1ull);
+#endif
 }
 
 }  // namespace nlc
