@@ -80,20 +80,23 @@ struct PaHandoff {
   // in-launch sampling / weights (FusedCtl::inline_perturb / inline_weights)
   int inl, inw, nu;
   unsigned* cu_state;         // this CU's state word when the chain was taken at the census (partners read it), else NULL
-  bool w0;                    // this wave evaluates the costs (wave 0)
+  bool w0;                    // this wave evaluates the costs (wave kSplitCostWave)
   const double* state_in;     // the command's state in the kernel-argument segment (inl)
   const double* U_old;        // control sequence BEFORE the shift (inl)
   const double* u_init;       // in the kernel-argument segment
   const double* pert_g;       // perturbed / bounded noise, published by the encoder tiles of this launch (or an earlier launch)
   const double* noise_g;
   static_assert(NLC_MAX_NU == 2, "two named slots per value below");
-  double pc0, pc1, nc0, nc1, pn0, pn1, nn0, nn1;  // (wave 0) perturbed / noise of step t (c) and of step t + 1 (n)
+  double pc0, pc1, nc0, nc1, pn0, pn1, nn0, nn1;  // (cost wave) perturbed / noise of step t (c) and of step t + 1 (n)
+  double pp0, pp1, np0, np1;                      // ... and of step t - 1 (kSplitCostWave != 0: the cost is evaluated one step late)
 
   __device__ __forceinline__ const double* state0(const RolloutArgs& a, int64_t kc, int ep) const {
     return inl ? state_in : a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * a.net.d;
   }
   __device__ __forceinline__ double pert(const RolloutArgs&, int64_t, int, int j) const { return j == 0 ? pc0 : pc1; }
   __device__ __forceinline__ double noise(const RolloutArgs&, int64_t, int, int i) const { return i == 0 ? nc0 : nc1; }
+  __device__ __forceinline__ double pert_prev(const RolloutArgs&, int64_t, int, int j) const { return j == 0 ? pp0 : pp1; }
+  __device__ __forceinline__ double noise_prev(const RolloutArgs&, int64_t, int, int i) const { return i == 0 ? np0 : np1; }
   __device__ __forceinline__ double U(const RolloutArgs& a, int uoff, int t, int j) const {
     return inl ? mppi_shifted_U(U_old, u_init, 0, T, nu, t, j) : a.U[uoff + t * a.nu + j];
   }
@@ -172,6 +175,10 @@ struct PaHandoff {
   __device__ __forceinline__ void advance() {
     cur0 = nxt0;
     cur1 = nxt1;
+    pp0 = pc0;
+    pp1 = pc1;
+    np0 = nc0;
+    np1 = nc1;
     pc0 = pn0;
     pc1 = pn1;
     nc0 = nn0;
@@ -298,13 +305,14 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* 
   src.inw = a.ctl.inline_weights;
   src.nu = a.r.nu;
   src.cu_state = cu_state;
-  src.w0 = wv == 0;
+  src.w0 = wv == kSplitCostWave;
   src.state_in = args_in_memory()->p.state_in;
   src.u_init = args_in_memory()->p.u_init;
   src.U_old = a.p.U_old;
   src.pert_g = a.r.perturbed;
   src.noise_g = a.r.noise;
   src.pc0 = src.pc1 = src.nc0 = src.nc1 = src.pn0 = src.pn1 = src.nn0 = src.nn1 = 0.0;
+  src.pp0 = src.pp1 = src.np0 = src.np1 = 0.0;
   // the sequential chain is the command's critical path: its waves win the issue arbitration on their SIMDs
   if (NLC_FUSED_TRACE && wv == 0) wave_add_one(a.ctl.sync + kFusedStatRollStart, lane);
   __builtin_amdgcn_s_setprio(3);
@@ -314,7 +322,7 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* 
     // this tile's costs are final: fold its 16 samples (weight_tile), drain the write-through partial, count the tile
     // done (ONE lane adds); the workgroup whose add comes last folds all tile partials into the shard's partials
     int* s_last = reinterpret_cast<int*>(smem);  // (H1 region: dead since the last step's second barrier)
-    if (wv == 0) {
+    if (wv == kSplitCostWave) {  // (the wave that holds the tile's costs)
       const bool valid = (int64_t)tile * 16 + (lane & 15) < a.r.K;
       fused_weight_tile(a.w, tile, lane, cost, valid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -473,6 +473,77 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
   return nl_eval_impl<HT, NT3, GENERAL_T, WRITE_F, LIN>(n, lane, q, p0, p1, tn, fo, sph_row, pc, none);
 }
 
+// ---- the k loops of the latency-split bodies (round 5).  Four waves share a tile, so a k-step is only TW = 2 (layer 2) or
+// NTW = 2 .. 6 (layer 3) MFMAs per wave -- 128 .. 192 clocks at hidden_units 128 -- while a weight fragment takes ~250 clocks from
+// the L2: with the fragments of step ks + 1 requested at step ks (the wave-per-tile kernels' distance, where a k-step is 8 MFMAs)
+// every k-step waits for its operands (tools/split_phase_clocks.py: layer 3 at 256 clocks per k-step against 192 of MFMA, layer 2
+// at 162 against 128).  NLC_SPLIT_PREFETCH = D keeps D k-steps of fragments in flight (a ring of D x NT registers, every index a
+// compile-time constant of the unrolled loop).  Same MFMAs in the same order: bit-identical results for every D.
+#ifndef NLC_SPLIT_PREFETCH
+#define NLC_SPLIT_PREFETCH 1
+#endif
+// acc[i] += sum_ks A_frag(ks, i) * Hb[ks]: `base` = fragment (ks = 0, tile 0) of this wave's tiles, `step` doubles between k-steps,
+// off(i) = offset in doubles of the wave's i-th output tile (compile-time i), Hb = the (KS, 64) activation image in LDS.
+template <int NT, int KS, int D, class OFF>
+__device__ __forceinline__ void split_gemm(v4d (&acc)[NT], gptr base, const int step, OFF off, const double* __restrict__ Hb,
+                                           const int lane) {
+  if constexpr (D <= 1) {
+    gptr p = base;
+    double a_cur[NT], a_nxt[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) a_cur[i] = p[off(i) + lane];
+    double b_cur = Hb[lane], b_nxt = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        p = opaque(p + step);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) a_nxt[i] = p[off(i) + lane];
+        b_nxt = Hb[(ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) a_cur[i] = a_nxt[i];
+      b_cur = b_nxt;
+    }
+  } else {
+    constexpr int DD = D < KS ? D : KS;
+    double ring[DD][NT];
+    gptr p = base;
+#pragma unroll
+    for (int st = 0; st < DD; ++st) {
+      if (st > 0) p = opaque(p + step);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) ring[st][i] = p[off(i) + lane];
+    }
+    double b_cur = Hb[lane], b_nxt = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) b_nxt = Hb[(ks + 1) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = mfma(ring[ks % DD][i], b_cur, acc[i]);
+      if (ks + DD < KS) {  // the slot just consumed takes the fragments of step ks + D
+        p = opaque(p + step);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) ring[ks % DD][i] = p[off(i) + lane];
+      }
+      b_cur = b_nxt;
+    }
+  }
+}
+
+// Which of the four waves evaluates the running cost / perturbation cost of a sample (rollout_split_tile).  0 (rounds 1-4): wave 0,
+// right after the state update -- 1.6 k clocks per step during which the other three waves already wait at the next step's first
+// barrier, while the wave with one layer-3 tile less (wave 3 whenever NT3 % 4 != 0) idles 2.3 k clocks at the THIRD barrier of every
+// step (tools/split_phase_clocks.py).  3: that wave evaluates the cost of step t - 1 inside its idle time of step t (the state
+// entering step t IS the state after step t - 1; the sampled action / noise of t - 1 are read again or kept one step longer), and
+// the cost of the last step after the loop.  Same operations on the same operands in the same order: bit-identical.
+#ifndef NLC_SPLIT_COST_WAVE
+#define NLC_SPLIT_COST_WAVE 0
+#endif
+constexpr int kSplitCostWave = NLC_SPLIT_COST_WAVE;
+
 // ------------------------------------------------------------------ latency-split rollout of one 16-sample tile
 // nl_rollout_kernel gives every wavefront a whole 16-sample tile, which fills the chip only when K/16 >= 1024
 // wavefronts.  When the population is sharded over several GPUs (K/G = 2048 at 8 GPUs) most SIMDs would idle
@@ -514,6 +585,9 @@ struct PaDirect {
   __device__ __forceinline__ double noise(const RolloutArgs& a, int64_t kc, int t, int i) const {
     return a.noise[(kc * a.T + t) * a.nu + i];
   }
+  // (deferred cost, kSplitCostWave != 0: the values of an EARLIER step t are simply read at their index)
+  __device__ __forceinline__ double pert_prev(const RolloutArgs& a, int64_t kc, int t, int j) const { return pert(a, kc, t, j); }
+  __device__ __forceinline__ double noise_prev(const RolloutArgs& a, int64_t kc, int t, int i) const { return noise(a, kc, t, i); }
   __device__ __forceinline__ double U(const RolloutArgs& a, int uoff, int t, int j) const { return a.U[uoff + t * a.nu + j]; }
   __device__ __forceinline__ void store_cost(const RolloutArgs& a, int64_t k, double v) const { a.cost_total[k] = v; }
   __device__ __forceinline__ void begin(int t0, int, int, int64_t kc) { load(t0, kc, &cur0, &cur1); }
@@ -527,7 +601,7 @@ struct PaDirect {
   }
 };
 
-// Returns the sample's total cost (meaningful in wave 0 when the launch runs the last horizon chunk).
+// Returns the sample's total cost (meaningful in wave kSplitCostWave when the launch runs the last horizon chunk).
 template <int HT, int NT3, class PA, bool LIN = false>
 __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64_t tile, PA& src, double* __restrict__ H1,
                                                      double* __restrict__ H2, double* __restrict__ AX) {
@@ -571,6 +645,28 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     cost = a.ccarry[kc * 2];
     pcost = a.ccarry[kc * 2 + 1];
   }
+  // running cost (mppi_with_model.py:145-171) and perturbation cost (:343-344) of horizon step tc from the state AFTER that step,
+  // which the calling wave holds in (x0, x1).  `earlier`: called one step late (kSplitCostWave != 0), the source hands back the
+  // sampled action / noise of the step before its current one.
+  auto step_cost = [&](int tc, bool earlier) {
+    double xs[NLC_MAX_D];
+#pragma unroll
+    for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+    double u[NLC_MAX_NU] = {0.0, 0.0};
+    double pc = 0.0;
+    for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * (earlier ? src.pert_prev(a, kc, tc, j) : src.pert(a, kc, tc, j));
+    for (int j = 0; j < a.nu; ++j) {
+      double acj = 0.0;
+      for (int i = 0; i < a.nu; ++i) {
+        double e = earlier ? src.noise_prev(a, kc, tc, i) : src.noise(a, kc, tc, i);
+        if (a.noise_abs_cost) e = fabs(e);
+        acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
+      }
+      pc += src.U(a, uoff, tc, j) * acj;
+    }
+    cost += running_cost(a.env, xs, u, a.nu);
+    pcost += pc;
+  };
   SplitClk clk;
   clk.start();
   src.begin(a.t_begin, wv, lane, kc);
@@ -612,25 +708,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
       v4d acc[TW];
 #pragma unroll
       for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b2, TW * wv + i, q);
-      gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
-      double a_cur[TW], a_nxt[TW];
-#pragma unroll
-      for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
-      double b_cur = H1[lane], b_nxt = 0.0;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-          p = opaque(p + HT * 64);
-#pragma unroll
-          for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
-          b_nxt = H1[(ks + 1) * 64 + lane];
-        }
-#pragma unroll
-        for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
-#pragma unroll
-        for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
-        b_cur = b_nxt;
-      }
+      split_gemm<TW, KS, NLC_SPLIT_PREFETCH>(acc, opaque(n.W2p + (size_t)TW * wv * 64), HT * 64, [](int i) { return i * 64; }, H1, lane);
       clk.mark(SplitClk::kL2);
 #pragma unroll
       for (int i = 0; i < TW; ++i)
@@ -652,25 +730,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
       v4d o[NTW];
 #pragma unroll
       for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile(n.b3p, j3[i], q);
-      gptr p = opaque(n.W3p);
-      double a_cur[NTW], a_nxt[NTW];
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
-      double b_cur = H2[lane], b_nxt = 0.0;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-          p = opaque(p + NT3 * 64);
-#pragma unroll
-          for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
-          b_nxt = H2[(ks + 1) * 64 + lane];
-        }
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
-        b_cur = b_nxt;
-      }
+      split_gemm<NTW, KS, NLC_SPLIT_PREFETCH>(o, opaque(n.W3p), NT3 * 64, [&](int i) { return j3[i] * 64; }, H2, lane);
       clk.mark(SplitClk::kL3);
       gptr cp = opaque(n.Cp);
 #pragma unroll
@@ -696,6 +756,9 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     AX[(wv * 2 + 0) * 64 + lane] = ax[0];
     AX[(wv * 2 + 1) * 64 + lane] = ax[1];
     clk.mark(SplitClk::kEpi);
+    // (x0, x1) still hold the state after step t - 1: its cost, in the time this wave would wait at the barrier below
+    if (kSplitCostWave != 0 && wv == kSplitCostWave && t > a.t_begin) step_cost(t - 1, true);
+    clk.mark(SplitClk::kTail);
     __syncthreads();
     clk.mark(SplitClk::kBar3);
     // every wave forms the same full sums (fixed order) and keeps its own copy of the state
@@ -703,37 +766,20 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     const double ax1 = ((AX[1 * 64 + lane] + AX[3 * 64 + lane]) + AX[5 * 64 + lane]) + AX[7 * 64 + lane];
     if (i0 < d) x0 = x0 + factor * ax0;
     if (i1 < d) x1 = x1 + factor * ax1;
-    if (wv == 0) {
-      if (valid && a.states != nullptr) {
-        double* so = a.states + (k * a.T + t) * d;
-        if (i0 < d) so[i0] = x0;
-        if (i1 < d) so[i1] = x1;
-      }
-      double xs[NLC_MAX_D];
-#pragma unroll
-      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
-      double u[NLC_MAX_NU] = {0.0, 0.0};
-      double pc = 0.0;
-      for (int j = 0; j < a.nu; ++j) u[j] = a.u_scale * src.pert(a, kc, t, j);
-      for (int j = 0; j < a.nu; ++j) {
-        double acj = 0.0;
-        for (int i = 0; i < a.nu; ++i) {
-          double e = src.noise(a, kc, t, i);
-          if (a.noise_abs_cost) e = fabs(e);
-          acj += (a.lambda_ * e) * a.sigma_inv[i * a.nu + j];
-        }
-        pc += src.U(a, uoff, t, j) * acj;
-      }
-      cost += running_cost(a.env, xs, u, a.nu);
-      pcost += pc;
+    if (wv == 0 && valid && a.states != nullptr) {
+      double* so = a.states + (k * a.T + t) * d;
+      if (i0 < d) so[i0] = x0;
+      if (i1 < d) so[i1] = x1;
     }
+    if (kSplitCostWave == 0 && wv == 0) step_cost(t, false);
     src.advance();
     clk.mark(SplitClk::kTail);
   }
+  if (kSplitCostWave != 0 && wv == kSplitCostWave && a.t_end > a.t_begin) step_cost(a.t_end - 1, true);  // the last step's
 #if NLC_PHASE_CLOCKS
   split_clk_flush(clk, wv, lane, (unsigned long long)(a.t_end - a.t_begin));
 #endif
-  if (wv == 0 && valid) {
+  if (wv == kSplitCostWave && valid) {
     if (last_chunk) {
       if (q == 0) src.store_cost(a, k, cost + pcost);
     } else {
@@ -767,14 +813,11 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
                                                   const int64_t k, const int64_t n_cols, const int* __restrict__ slot,
                                                   double* __restrict__ fre, double* __restrict__ fim, double* __restrict__ H1,
                                                   double* __restrict__ H2, const int wv, const int lane, AfterL1 after_l1,
-                                                  SplitClk* pclk = nullptr) {
+                                                  SplitClk& clk) {
   constexpr int KS = HT * 4;
   constexpr int TW = HT / 4;
   constexpr int NTW = (NT3 + 3) / 4;
   const int q = lane >> 4;
-  SplitClk dummy_clk;
-  SplitClk& clk = (NLC_PHASE_CLOCKS && pclk != nullptr) ? *pclk : dummy_clk;
-  if (NLC_PHASE_CLOCKS && pclk == nullptr) clk.start();
   // (the bias tiles are loaded through laundered pointers: inside a persistent horizon loop the compiler would otherwise hoist
   // these loop-invariant loads and keep ~80 VGPRs live across the QD phase of kernels_dehoog_chain.hip)
   int j3[NTW];
@@ -811,25 +854,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
     v4d acc[TW];
 #pragma unroll
     for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile((const double*)opaque(n.b2), TW * wv + i, q);
-    gptr p = opaque(n.W2p + (size_t)TW * wv * 64);
-    double a_cur[TW], a_nxt[TW];
-#pragma unroll
-    for (int i = 0; i < TW; ++i) a_cur[i] = p[i * 64 + lane];
-    double b_cur = H1[lane], b_nxt = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        p = opaque(p + HT * 64);
-#pragma unroll
-        for (int i = 0; i < TW; ++i) a_nxt[i] = p[i * 64 + lane];
-        b_nxt = H1[(ks + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int i = 0; i < TW; ++i) acc[i] = mfma(a_cur[i], b_cur, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TW; ++i) a_cur[i] = a_nxt[i];
-      b_cur = b_nxt;
-    }
+    split_gemm<TW, KS, NLC_SPLIT_PREFETCH>(acc, opaque(n.W2p + (size_t)TW * wv * 64), HT * 64, [](int i) { return i * 64; }, H1, lane);
     clk.mark(SplitClk::kL2);
 #pragma unroll
     for (int i = 0; i < TW; ++i)
@@ -849,25 +874,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
     v4d o[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile((const double*)opaque(n.b3p), j3[i], q);
-    gptr p = opaque(n.W3p);
-    double a_cur[NTW], a_nxt[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) a_cur[i] = p[j3[i] * 64 + lane];
-    double b_cur = H2[lane], b_nxt = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        p = opaque(p + NT3 * 64);
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) a_nxt[i] = p[j3[i] * 64 + lane];
-        b_nxt = H2[(ks + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) o[i] = mfma(a_cur[i], b_cur, o[i]);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) a_cur[i] = a_nxt[i];
-      b_cur = b_nxt;
-    }
+    split_gemm<NTW, KS, NLC_SPLIT_PREFETCH>(o, opaque(n.W3p), NT3 * 64, [&](int i) { return j3[i] * 64; }, H2, lane);
     clk.mark(SplitClk::kL3);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -1122,7 +1129,7 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
       if (i0 < d) a.tail.x[k * d + i0] = x0;
       if (i1 < d) a.tail.x[k * d + i1] = x1;
     }
-  }, &clk);
+  }, clk);
 #if NLC_PHASE_CLOCKS
   split_clk_flush(clk, wv, lane, 1ull);
 #endif
