@@ -134,7 +134,11 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
   double* tconst = ws + w.tconst;
   NLC_HIP(c, hipMemcpyAsync(tconst, &c->tn, sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (C > 1) {
-    if (!c->gru_stream) NLC_HIP(c, hipStreamCreateWithFlags(&c->gru_stream, hipStreamNonBlocking));
+    if (!c->gru_stream) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = lowest priority: the step chain's workgroups go first
+      NLC_HIP(c, hipStreamCreateWithPriority(&c->gru_stream, hipStreamNonBlocking, lo));
+    }
     if (!c->ev_fork) NLC_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     while ((int)c->ev_gru.size() < C) {
       hipEvent_t e2 = nullptr;
@@ -150,7 +154,9 @@ int rollout_nl_staged(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs& r,
       g.N = KE * g.Tc;
       {
         ProfScope ps(c, "gru_encode_kernel", c->gru_stream, true);
-        NLC_HIP(c, launch_gru_encode(g, c->g, c->gru_stream, true, (unsigned)c->opt_dehoog_gru_lds_pad));
+        // (cooperative kernel at reduced occupancy unless "gru_coop" = 0 asks for the wave-per-tile one)
+        const bool coop = c->opt_gru_coop != 0;
+        NLC_HIP(c, launch_gru_encode(g, c->g, c->gru_stream, coop, coop ? (unsigned)c->opt_dehoog_gru_lds_pad : 0u));
       }
       NLC_HIP(c, hipEventRecord(c->ev_gru[ch], c->gru_stream));
     }

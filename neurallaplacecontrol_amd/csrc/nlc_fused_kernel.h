@@ -80,7 +80,7 @@ struct PaHandoff {
   // in-launch sampling / weights (FusedCtl::inline_perturb / inline_weights)
   int inl, inw, nu;
   unsigned* cu_state;         // this CU's state word when the chain was taken at the census (partners read it), else NULL
-  bool w0;                    // this wave evaluates the costs (wave kSplitCostWave)
+  bool w0;                    // this wave evaluates the costs (wave kCwFused)
   const double* state_in;     // the command's state in the kernel-argument segment (inl)
   const double* U_old;        // control sequence BEFORE the shift (inl)
   const double* u_init;       // in the kernel-argument segment
@@ -88,7 +88,7 @@ struct PaHandoff {
   const double* noise_g;
   static_assert(NLC_MAX_NU == 2, "two named slots per value below");
   double pc0, pc1, nc0, nc1, pn0, pn1, nn0, nn1;  // (cost wave) perturbed / noise of step t (c) and of step t + 1 (n)
-  double pp0, pp1, np0, np1;                      // ... and of step t - 1 (kSplitCostWave != 0: the cost is evaluated one step late)
+  double pp0, pp1, np0, np1;                      // ... and of step t - 1 (kCwFused != 0: the cost is evaluated one step late)
 
   __device__ __forceinline__ const double* state0(const RolloutArgs& a, int64_t kc, int ep) const {
     return inl ? state_in : a.state0 + (a.state_per_sample ? kc : (int64_t)ep) * a.net.d;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* 
   src.inw = a.ctl.inline_weights;
   src.nu = a.r.nu;
   src.cu_state = cu_state;
-  src.w0 = wv == kSplitCostWave;
+  src.w0 = wv == kCwFused;
   src.state_in = args_in_memory()->p.state_in;
   src.u_init = args_in_memory()->p.u_init;
   src.U_old = a.p.U_old;
@@ -316,13 +316,14 @@ __device__ __forceinline__ void fused_rollout(int tile, double* smem, unsigned* 
   // the sequential chain is the command's critical path: its waves win the issue arbitration on their SIMDs
   if (NLC_FUSED_TRACE && wv == 0) wave_add_one(a.ctl.sync + kFusedStatRollStart, lane);
   __builtin_amdgcn_s_setprio(3);
-  const double cost = rollout_split_tile<HT, NT3>(a.r, (int64_t)tile, src, smem, smem + KS * 64, smem + 2 * KS * 64);
+  const double cost = rollout_split_tile<HT, NT3, PaHandoff, false, kCwFused, kSplitPrefetchFused>(a.r, (int64_t)tile, src, smem, smem + KS * 64,
+                                                                                                     smem + 2 * KS * 64);
   __builtin_amdgcn_s_setprio(0);
   if (a.ctl.inline_weights) {
     // this tile's costs are final: fold its 16 samples (weight_tile), drain the write-through partial, count the tile
     // done (ONE lane adds); the workgroup whose add comes last folds all tile partials into the shard's partials
     int* s_last = reinterpret_cast<int*>(smem);  // (H1 region: dead since the last step's second barrier)
-    if (wv == kSplitCostWave) {  // (the wave that holds the tile's costs)
+    if (wv == kCwFused) {  // (the wave that holds the tile's costs)
       const bool valid = (int64_t)tile * 16 + (lane & 15) < a.r.K;
       fused_weight_tile(a.w, tile, lane, cost, valid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

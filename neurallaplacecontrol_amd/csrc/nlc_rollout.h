@@ -84,8 +84,10 @@ struct SplitClk {
 #if NLC_PHASE_CLOCKS
 // [wave index 0..3][phase 0..11] sums, then [48 + wave] = waves counted, [52] = model evaluations (tile-steps) of wave 0
 static __device__ unsigned long long nlc_split_clk[64];
-__device__ __forceinline__ void split_clk_flush(const SplitClk& clk, int wv, int lane, unsigned long long evals) {
-  if (lane != 0) return;
+// (`sampled`: only one workgroup in 64 adds its sums -- a launch of one-evaluation workgroups would otherwise spend its time in
+// 50 k same-line atomics, and every phase would measure the L2 queueing behind them)
+__device__ __forceinline__ void split_clk_flush(const SplitClk& clk, int wv, int lane, unsigned long long evals, bool sampled = false) {
+  if (lane != 0 || (sampled && (blockIdx.x & 63) != 0)) return;
   for (int i = 0; i < SplitClk::kN; ++i) atomicAdd(&nlc_split_clk[(wv & 3) * SplitClk::kN + i], (unsigned long long)clk.acc[i]);
   atomicAdd(&nlc_split_clk[48 + (wv & 3)], 1ull);
   if ((wv & 3) == 0) atomicAdd(&nlc_split_clk[52], evals);
@@ -475,12 +477,17 @@ __device__ __forceinline__ v4d nl_eval(const NlNetArgs& n, int lane, int q, doub
 
 // ---- the k loops of the latency-split bodies (round 5).  Four waves share a tile, so a k-step is only TW = 2 (layer 2) or
 // NTW = 2 .. 6 (layer 3) MFMAs per wave -- 128 .. 192 clocks at hidden_units 128 -- while a weight fragment takes ~250 clocks from
-// the L2: with the fragments of step ks + 1 requested at step ks (the wave-per-tile kernels' distance, where a k-step is 8 MFMAs)
-// every k-step waits for its operands (tools/split_phase_clocks.py: layer 3 at 256 clocks per k-step against 192 of MFMA, layer 2
-// at 162 against 128).  NLC_SPLIT_PREFETCH = D keeps D k-steps of fragments in flight (a ring of D x NT registers, every index a
-// compile-time constant of the unrolled loop).  Same MFMAs in the same order: bit-identical results for every D.
-#ifndef NLC_SPLIT_PREFETCH
-#define NLC_SPLIT_PREFETCH 1
+// the L2.  split_gemm<.., D> keeps D k-steps of fragments in flight (a ring of D x NT registers, every index a compile-time
+// constant of the unrolled loop); D = 1 is the loop of rounds 1-4 (fragments of step ks + 1 requested at step ks).  Same MFMAs in
+// the same order: bit-identical results for every D.  MEASURED (same box, K = 2048 / 8192 / cfg5; tools/split_ab.py): the
+// stand-alone split rollout and the de Hoog planner's representation launch do not move for D = 2 .. 6 (the compiler already
+// hoists ~5 k-steps of loads to the loop head; D = 4 costs cfg5 4 % through the launch's registers); the fused body's chains,
+// whose fragment loads compete with the encoder role's weight streams, gain 1.3 % at D = 4 (675.6 -> 667.1 us per launch):
+// D = 4 there, 1 elsewhere.
+#ifdef NLC_SPLIT_PREFETCH
+constexpr int kSplitPrefetch = NLC_SPLIT_PREFETCH, kSplitPrefetchFused = NLC_SPLIT_PREFETCH;
+#else
+constexpr int kSplitPrefetch = 1, kSplitPrefetchFused = 4;
 #endif
 // acc[i] += sum_ks A_frag(ks, i) * Hb[ks]: `base` = fragment (ks = 0, tile 0) of this wave's tiles, `step` doubles between k-steps,
 // off(i) = offset in doubles of the wave's i-th output tile (compile-time i), Hb = the (KS, 64) activation image in LDS.
@@ -533,16 +540,22 @@ __device__ __forceinline__ void split_gemm(v4d (&acc)[NT], gptr base, const int 
   }
 }
 
-// Which of the four waves evaluates the running cost / perturbation cost of a sample (rollout_split_tile).  0 (rounds 1-4): wave 0,
-// right after the state update -- 1.6 k clocks per step during which the other three waves already wait at the next step's first
-// barrier, while the wave with one layer-3 tile less (wave 3 whenever NT3 % 4 != 0) idles 2.3 k clocks at the THIRD barrier of every
-// step (tools/split_phase_clocks.py).  3: that wave evaluates the cost of step t - 1 inside its idle time of step t (the state
-// entering step t IS the state after step t - 1; the sampled action / noise of t - 1 are read again or kept one step longer), and
-// the cost of the last step after the loop.  Same operations on the same operands in the same order: bit-identical.
-#ifndef NLC_SPLIT_COST_WAVE
-#define NLC_SPLIT_COST_WAVE 0
+// Which of the four waves evaluates the running cost / perturbation cost of a sample (rollout_split_tile's CW).  0 (rounds 1-4):
+// wave 0, right after the state update -- 1.6 k clocks per step during which the other three waves already wait at the next step's
+// first barrier, while the wave with one layer-3 tile less (wave 3: tiles j = wave + 4 i, and no instantiated NT3 is a multiple of
+// four) idles 2.3 k clocks at the THIRD barrier of every step (tools/split_phase_clocks.py, profiles/r5_split_phase_clocks.md).
+// 3: that wave evaluates the cost of step t - 1 inside its idle time of step t (the state entering step t IS the state after step
+// t - 1; the sampled action / noise of t - 1 are read again or kept one step longer), and the cost of the last step after the loop.
+// Same operations on the same operands in the same order: bit-identical.  Measured (K = 2048 / 8192, T = 40, same box):
+// nl_rollout_split_kernel 425.8 -> 402.9 us / 714 -> 694 us; the fused one-launch body, whose chains are paced by the encoder
+// role beside them, does not gain (675.6 -> 683.9 us: the extra live values cost registers) and keeps wave 0.
+constexpr int kSplitCostWaveStandalone = 3, kSplitCostWaveFused = 0;
+// (tools: -DNLC_SPLIT_COST_WAVE=n / -DNLC_SPLIT_PREFETCH=n override both bodies' settings for A/B builds, tools/build_split_variants.sh)
+#ifdef NLC_SPLIT_COST_WAVE
+constexpr int kCwStandalone = NLC_SPLIT_COST_WAVE, kCwFused = NLC_SPLIT_COST_WAVE;
+#else
+constexpr int kCwStandalone = kSplitCostWaveStandalone, kCwFused = kSplitCostWaveFused;
 #endif
-constexpr int kSplitCostWave = NLC_SPLIT_COST_WAVE;
 
 // ------------------------------------------------------------------ latency-split rollout of one 16-sample tile
 // nl_rollout_kernel gives every wavefront a whole 16-sample tile, which fills the chip only when K/16 >= 1024
@@ -585,7 +598,7 @@ struct PaDirect {
   __device__ __forceinline__ double noise(const RolloutArgs& a, int64_t kc, int t, int i) const {
     return a.noise[(kc * a.T + t) * a.nu + i];
   }
-  // (deferred cost, kSplitCostWave != 0: the values of an EARLIER step t are simply read at their index)
+  // (deferred cost, CW != 0: the values of an EARLIER step t are simply read at their index)
   __device__ __forceinline__ double pert_prev(const RolloutArgs& a, int64_t kc, int t, int j) const { return pert(a, kc, t, j); }
   __device__ __forceinline__ double noise_prev(const RolloutArgs& a, int64_t kc, int t, int i) const { return noise(a, kc, t, i); }
   __device__ __forceinline__ double U(const RolloutArgs& a, int uoff, int t, int j) const { return a.U[uoff + t * a.nu + j]; }
@@ -601,8 +614,8 @@ struct PaDirect {
   }
 };
 
-// Returns the sample's total cost (meaningful in wave kSplitCostWave when the launch runs the last horizon chunk).
-template <int HT, int NT3, class PA, bool LIN = false>
+// Returns the sample's total cost (meaningful in wave CW when the launch runs the last horizon chunk).
+template <int HT, int NT3, class PA, bool LIN = false, int CW = kCwStandalone, int D = kSplitPrefetch>
 __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64_t tile, PA& src, double* __restrict__ H1,
                                                      double* __restrict__ H2, double* __restrict__ AX) {
   constexpr int KS = HT * 4;           // k-steps over the hidden dimension
@@ -646,7 +659,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     pcost = a.ccarry[kc * 2 + 1];
   }
   // running cost (mppi_with_model.py:145-171) and perturbation cost (:343-344) of horizon step tc from the state AFTER that step,
-  // which the calling wave holds in (x0, x1).  `earlier`: called one step late (kSplitCostWave != 0), the source hands back the
+  // which the calling wave holds in (x0, x1).  `earlier`: called one step late (CW != 0), the source hands back the
   // sampled action / noise of the step before its current one.
   auto step_cost = [&](int tc, bool earlier) {
     double xs[NLC_MAX_D];
@@ -708,7 +721,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
       v4d acc[TW];
 #pragma unroll
       for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile(n.b2, TW * wv + i, q);
-      split_gemm<TW, KS, NLC_SPLIT_PREFETCH>(acc, opaque(n.W2p + (size_t)TW * wv * 64), HT * 64, [](int i) { return i * 64; }, H1, lane);
+      split_gemm<TW, KS, D>(acc, opaque(n.W2p + (size_t)TW * wv * 64), HT * 64, [](int i) { return i * 64; }, H1, lane);
       clk.mark(SplitClk::kL2);
 #pragma unroll
       for (int i = 0; i < TW; ++i)
@@ -730,7 +743,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
       v4d o[NTW];
 #pragma unroll
       for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile(n.b3p, j3[i], q);
-      split_gemm<NTW, KS, NLC_SPLIT_PREFETCH>(o, opaque(n.W3p), NT3 * 64, [&](int i) { return j3[i] * 64; }, H2, lane);
+      split_gemm<NTW, KS, D>(o, opaque(n.W3p), NT3 * 64, [&](int i) { return j3[i] * 64; }, H2, lane);
       clk.mark(SplitClk::kL3);
       gptr cp = opaque(n.Cp);
 #pragma unroll
@@ -757,7 +770,7 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
     AX[(wv * 2 + 1) * 64 + lane] = ax[1];
     clk.mark(SplitClk::kEpi);
     // (x0, x1) still hold the state after step t - 1: its cost, in the time this wave would wait at the barrier below
-    if (kSplitCostWave != 0 && wv == kSplitCostWave && t > a.t_begin) step_cost(t - 1, true);
+    if (CW != 0 && wv == CW && t > a.t_begin) step_cost(t - 1, true);
     clk.mark(SplitClk::kTail);
     __syncthreads();
     clk.mark(SplitClk::kBar3);
@@ -771,15 +784,15 @@ __device__ __forceinline__ double rollout_split_tile(const RolloutArgs& a, int64
       if (i0 < d) so[i0] = x0;
       if (i1 < d) so[i1] = x1;
     }
-    if (kSplitCostWave == 0 && wv == 0) step_cost(t, false);
+    if (CW == 0 && wv == 0) step_cost(t, false);
     src.advance();
     clk.mark(SplitClk::kTail);
   }
-  if (kSplitCostWave != 0 && wv == kSplitCostWave && a.t_end > a.t_begin) step_cost(a.t_end - 1, true);  // the last step's
+  if (CW != 0 && wv == CW && a.t_end > a.t_begin) step_cost(a.t_end - 1, true);  // the last step's
 #if NLC_PHASE_CLOCKS
   split_clk_flush(clk, wv, lane, (unsigned long long)(a.t_end - a.t_begin));
 #endif
-  if (wv == kSplitCostWave && valid) {
+  if (wv == CW && valid) {
     if (last_chunk) {
       if (q == 0) src.store_cost(a, k, cost + pcost);
     } else {
@@ -854,7 +867,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
     v4d acc[TW];
 #pragma unroll
     for (int i = 0; i < TW; ++i) acc[i] = load_bias_tile((const double*)opaque(n.b2), TW * wv + i, q);
-    split_gemm<TW, KS, NLC_SPLIT_PREFETCH>(acc, opaque(n.W2p + (size_t)TW * wv * 64), HT * 64, [](int i) { return i * 64; }, H1, lane);
+    split_gemm<TW, KS, kSplitPrefetch>(acc, opaque(n.W2p + (size_t)TW * wv * 64), HT * 64, [](int i) { return i * 64; }, H1, lane);
     clk.mark(SplitClk::kL2);
 #pragma unroll
     for (int i = 0; i < TW; ++i)
@@ -874,7 +887,7 @@ __device__ __forceinline__ void repfunc_split_mlp(const NlNetArgs& n, const doub
     v4d o[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) o[i] = load_bias_tile((const double*)opaque(n.b3p), j3[i], q);
-    split_gemm<NTW, KS, NLC_SPLIT_PREFETCH>(o, opaque(n.W3p), NT3 * 64, [&](int i) { return j3[i] * 64; }, H2, lane);
+    split_gemm<NTW, KS, kSplitPrefetch>(o, opaque(n.W3p), NT3 * 64, [&](int i) { return j3[i] * 64; }, H2, lane);
     clk.mark(SplitClk::kL3);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -1131,7 +1144,7 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
     }
   }, clk);
 #if NLC_PHASE_CLOCKS
-  split_clk_flush(clk, wv, lane, 1ull);
+  split_clk_flush(clk, wv, lane, 1ull, true);
 #endif
 }
 
