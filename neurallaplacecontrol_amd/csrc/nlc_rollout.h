@@ -1111,26 +1111,14 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
     const double* src = s.first ? s.state0 + (s.state_per_sample ? kc : e) * d : s.x + kc * d;
     if (i0 < d) x0 = src[i0] + s.dx[kc * d + i0];
     if (i1 < d) x1 = src[i1] + s.dx[kc * d + i1];
-    if (wv == 0) {
-      double xs[NLC_MAX_D];
-#pragma unroll
-      for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
-      if (valid && s.states != nullptr) {
-        if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
-        if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
-      }
-      // (the carried state s.x is stored BEHIND the first barrier below: the other three waves read it above, and a
-      // store from here could overtake their loads -- seen as wrong states from the third horizon step on once another
-      // stream's kernels shared the CUs, round 3)
-      if (q == 0 && valid) {
-        double u[NLC_MAX_NU] = {0.0, 0.0};
-        for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
-        const double pc = perturbation_cost_step(s.noise + (k * s.T + s.t) * s.nu, s.U + (e * s.T + s.t) * s.nu, s.sigma_inv,
-                                                 s.lambda_, s.nu, s.noise_abs_cost);
-        s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
-        s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
-      }
+    if (wv == 0 && valid && s.states != nullptr) {
+      if (i0 < d) s.states[(k * s.T + s.t) * d + i0] = x0;
+      if (i1 < d) s.states[(k * s.T + s.t) * d + i1] = x1;
     }
+    // (the carried state s.x is stored BEHIND the first barrier below: the other three waves read it above, and a
+    // store from here could overtake their loads -- seen as wrong states from the third horizon step on once another
+    // stream's kernels shared the CUs, round 3)
+    // (the previous step's COSTS are evaluated at the END of this function, by wave kTailCostWave: round 5)
   }
   const double p0 = (i0 < d) ? (x0 - n.state_mean[i0]) / n.state_std[i0]
                              : (i0 == d ? pa[0] : (i0 == d + 1 ? pa[1] : 0.0));
@@ -1143,6 +1131,28 @@ __device__ __forceinline__ void repfunc_split_tile(const RepFuncArgs& a, int64_t
       if (i1 < d) a.tail.x[k * d + i1] = x1;
     }
   }, clk);
+  // Running cost and perturbation cost of the previous horizon step (mppi_with_model.py:145-171, mppi_delay.py:343-344), from the
+  // state this workgroup started from.  Rounds 2-4 evaluated them in wave 0 BEFORE layer 1: 10 k clocks during which the other three
+  // waves waited at the first barrier -- 4 us of the launch's 56 at cfg5's size, in the wave that also owns the extra layer-3 tile
+  // (tools/split_phase_clocks.py, profiles/r5_split_phase_clocks.md).  Nothing in this launch needs them: the wave with the fewest
+  // layer-3 tiles (wave 3; no instantiated NT3 is a multiple of four) evaluates them behind its own epilogue.  Same operations.
+  constexpr int kTailCostWave = 3;
+  if (a.tail_prev && wv == kTailCostWave) {
+    const StepTailArgs& s = a.tail;
+    const int64_t e = kc / s.Kep;
+    double xs[NLC_MAX_D];
+#pragma unroll
+    for (int i = 0; i < NLC_MAX_D; ++i) xs[i] = __shfl((i < 4) ? x0 : x1, ((i & 3) << 4) | c, 64);
+    if (q == 0 && valid) {
+      double u[NLC_MAX_NU] = {0.0, 0.0};
+      for (int j = 0; j < s.nu; ++j) u[j] = s.u_scale * s.perturbed[(k * s.T + s.t) * s.nu + j];
+      const double pc = perturbation_cost_step(s.noise + (k * s.T + s.t) * s.nu, s.U + (e * s.T + s.t) * s.nu, s.sigma_inv,
+                                               s.lambda_, s.nu, s.noise_abs_cost);
+      s.ccarry[k * 2] = (s.first ? 0.0 : s.ccarry[k * 2]) + running_cost(s.env, xs, u, s.nu);
+      s.ccarry[k * 2 + 1] = (s.first ? 0.0 : s.ccarry[k * 2 + 1]) + pc;
+    }
+  }
+  clk.mark(SplitClk::kTail);
 #if NLC_PHASE_CLOCKS
   split_clk_flush(clk, wv, lane, 1ull, true);
 #endif
