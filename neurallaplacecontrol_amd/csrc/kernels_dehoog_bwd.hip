@@ -15,9 +15,13 @@
 //   * the continued-fraction adjoint recurrence runs lazily, two steps before each column, so its seeds dbar_i never leave
 //     registers either.
 // What travels per row: the value tape (10 KB written + 10 KB read at M = 16), theta / phi in, both gradients out -- 28.2 KB per
-// row at the memory counters, i.e. 92 GB for the bench's 3.3 M rows in 19.8-22.2 ms = 4.2-4.7 TB/s, which is what a read + write
-// stream attains on this chip (tools/ubench_hbm_copy.hip: 4.5-5.5): at 33 terms the kernel is bound by its own tape, and getting
-// under ~19 ms needs a smaller tape (checkpointed columns + recomputation: the forward sweep is 1.35 ms), not a better schedule.
+// row at the memory counters in round 4, i.e. 92 GB for the bench's 3.3 M rows in 19.8-22.2 ms = 4.2-4.7 TB/s, which is what a
+// read + write stream attains on this chip (tools/ubench_hbm_copy.hip: 4.5-5.5): at 33 terms the kernel is bound by its own tape.
+// Round 5 took the 8 KB that were NOT tape out of that figure: the rows' inputs and gradients go through an LDS image of the
+// wavefront's 64 rows as whole lines (NLC_DHB_LDS_IO below; before, 64 lines per load instruction and eight useful bytes per
+// 32-byte sector of every gradient store), and the terms a_k are rebuilt in the epilogue instead of taped: forward + backward
+// 22.0 -> 17.0-17.3 ms at 3.3 M rows, 0.78 -> 0.63 ms at 81 920 (same box, interleaved; gradients bit-identical).  Checkpointed
+// columns with recomputation do not pay on top of that: DESIGN.md section 9b.
 // The scratch belongs to the launch: the grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries
 // are [entry][lane] so every access is one 1-KB line per wavefront.
 //
@@ -31,6 +35,15 @@
 // MI355X at 3.3 M rows, M = 16: 8 -> 23.5 ms with 197 spilled VGPRs, 4 -> 21.5 ms with 93, no prefetch 25.6 ms)
 #ifndef NLC_DHB_GROUP
 #define NLC_DHB_GROUP 4
+#endif
+// Round 5: the rows' inputs and gradients travel through an LDS image of the wavefront's 64 rows -- (64, S) doubles each for
+// theta and phi, read from and written to HBM as whole contiguous lines (a wavefront's 64 consecutive rows ARE one contiguous
+// block of 64 S doubles); the gradients overwrite the image in place (term k of a row is read, then written, by the same lane)
+// and leave as whole lines.  Before, every lane read and wrote its own row with a stride of S doubles: 64 lines per instruction,
+// eight useful bytes per 32-byte sector on the way out.  And the terms a_k are not taped any more: the epilogue rebuilds them from
+// theta / phi (the same three operations), 2 x 33 entries = 1 KB per row less on the tape.  0 = the round-4 form.
+#ifndef NLC_DHB_LDS_IO
+#define NLC_DHB_LDS_IO 1
 #endif
 
 namespace nlc {
@@ -86,20 +99,50 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
   const int64_t nblk = (rows_total + 63) / 64;
   const Tape tp{(tape_ptr)(reinterpret_cast<double*>(a.scratch) + (size_t)blockIdx.x * L.entries() * 128), lane};
   const cplx one = {1.0, 0.0}, zero = {0.0, 0.0};
+#if NLC_DHB_LDS_IO
+  __shared__ double io_th[64 * S], io_ph[64 * S];  // the wavefront's rows: theta / phi in, the two gradients out (in place)
+#endif
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int64_t row = blk * 64 + lane;
+#if NLC_DHB_LDS_IO
+    // one wavefront = one workgroup: the image is private to it, program order + s_waitcnt order its accesses (no barrier)
+    const int64_t base = blk * 64 * S;
+    // (both copy loops have a WAVE-UNIFORM trip count and a per-lane predicate inside.  A per-lane loop condition -- `for (i = lane;
+    // i < n; i += 64)` -- is compiled into a loop that runs until EXEC is empty, and ROCm 7.2 placed the reload of a spilled loop
+    // invariant of the persistent block loop behind the second copy loop, BEFORE the point where EXEC is restored: the reload was
+    // skipped, the second block of a wavefront divided by garbage and read a.t[] out of bounds -- a memory fault from 1025 blocks
+    // on, invisible to every test with at most 1024.  Found in the ISA: `scratch_load ... ; Folded Reload` at a label reached with
+    // EXEC = 0.)
+    const int live = (int)(rows_total - blk * 64 < 64 ? rows_total - blk * 64 : 64);  // rows of this block (uniform)
+    const int n_io = live * S;
+    for (int i0 = 0; i0 < n_io; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < n_io) {
+        io_th[i] = a.theta[base + i];
+        io_ph[i] = a.phi[base + i];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#endif
     if (row >= rows_total) continue;  // (no barriers in this kernel: a lane may skip)
     const double t = a.t[row / a.d] / a.t_div;
     const double Tt = a.scale * t;
     const double gamma = a.alpha - a.log_tol / (a.scale * Tt);
     const double ang = kPi * (t / Tt);
     const cplx z = {cos(ang), sin(ang)};
+#if NLC_DHB_LDS_IO
+    const double* th = io_th + lane * S;
+    const double* ph = io_ph + lane * S;
+#else
     const double* th = a.theta + row * S;
     const double* ph = a.phi + row * S;
+#endif
 
     // ---------------------------------------------------------------- forward, taped
     // a_k = F_k = R e^{i theta}, R = tan(phi/2 + pi/4); a_0 enters halved.  Column 1: q_1^(i) = a_{i+1} / a_i
     cplx Q[2 * M], E[2 * M];  // the live columns: Q[i] = q_r^(i), E[i] = e_(r-1)^(i)
+    cplx a0 = zero;
     {
       cplx prev = zero;
 #pragma unroll
@@ -109,7 +152,8 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
         m::sincos_bounded(th[k], &sn, &cs);
         cplx ak = {rad * cs, rad * sn};
         if (k == 0) ak = cscale(ak, 0.5);
-        tp.st(L.a(k), ak);
+        if (k == 0) a0 = ak;
+        if (!NLC_DHB_LDS_IO) tp.st(L.a(k), ak);
         if (k > 0) {
           Q[k - 1] = cdiv(ak, prev);
           tp.st(L.q(1, k - 1), Q[k - 1]);
@@ -121,7 +165,7 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
     for (int i = 0; i < 2 * M; ++i) E[i] = zero;
     // continued fraction: d_0 = a_0, d_(2r-1) = -q_r^(0), d_(2r) = -e_r^(0);  A_i = A_(i-1) + d_i z A_(i-2), fed as the columns
     // produce the coefficients
-    cplx A_prev = zero, A_cur = tp.ld(L.a(0)), B_prev = one, B_cur = one;
+    cplx A_prev = zero, A_cur = a0, B_prev = one, B_cur = one;
     tp.st(L.A(-1), A_prev);
     tp.st(L.A(0), A_cur);
     tp.st(L.B(-1), B_prev);
@@ -325,19 +369,47 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
     cplx h_prev = zero;
 #pragma unroll
     for (int k = 0; k <= 2 * M; ++k) {
+      const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
+      double sn, cs;
+      m::sincos_bounded(th[k], &sn, &cs);
       cplx gF = k == 0 ? g_a0_seed : h_prev;
       if (k <= 2 * M - 1) {
-        const cplx h = cdiv(W[k], cconj(tp.ld(L.a(k))));
+#if NLC_DHB_LDS_IO
+        cplx ak = {rad * cs, rad * sn};  // a_k as the forward built it (same operations)
+        if (k == 0) ak = cscale(ak, 0.5);
+#else
+        const cplx ak = tp.ld(L.a(k));
+#endif
+        const cplx h = cdiv(W[k], cconj(ak));
         gF = csub(gF, cmul(h, cconj(tp.ld(L.q(1, k)))));
         h_prev = h;
       }
       if (k == 0) gF = cscale(gF, 0.5);
-      const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
-      double sn, cs;
-      m::sincos_bounded(th[k], &sn, &cs);
-      a.gtheta[row * S + k] = rad * (gF.im * cs - gF.re * sn);
-      a.gphi[row * S + k] = (gF.re * cs + gF.im * sn) * (0.5 * (1.0 + rad * rad));
+      const double g_th = rad * (gF.im * cs - gF.re * sn);
+      const double g_ph = (gF.re * cs + gF.im * sn) * (0.5 * (1.0 + rad * rad));
+#if NLC_DHB_LDS_IO
+      io_th[lane * S + k] = g_th;  // in place: term k of this row is not read again
+      io_ph[lane * S + k] = g_ph;
+#else
+      a.gtheta[row * S + k] = g_th;
+      a.gphi[row * S + k] = g_ph;
+#endif
     }
+#if NLC_DHB_LDS_IO
+    // (lanes past the last row skipped the body with `continue`: in a partial block they do not reach this point, the live
+    // lanes copy the whole image out)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < n_io; i0 += live) {  // (the live lanes are 0 .. live - 1)
+      const int i = i0 + lane;
+      if (i < n_io) {
+        a.gtheta[base + i] = io_th[i];
+        a.gphi[base + i] = io_ph[i];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#endif
   }
 }
 
