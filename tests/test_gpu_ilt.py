@@ -315,6 +315,30 @@ def test_dehoog_autograd_path(nlc, monkeypatch, S, N, d):
         np.testing.assert_allclose((got_ / sc).numpy(), (ref_ / sc).numpy(), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("S,N,d", [(33, 13200, 5), (17, 26300, 5)])
+def test_dehoog_backward_when_a_wavefront_walks_more_than_one_block(nlc, S, N, d):
+    """The backward kernel's grid is persistent (at most 1024 / 2048 slabs of tape): from 1025 / 2049 blocks of 64 rows on, a
+    wavefront walks a SECOND block.  Round 5 found that path broken by a compiler placement (a spill reload behind a loop that
+    leaves EXEC empty: kernels_dehoog_bwd.hip) -- no test had more than 1024 blocks.  The rows of a big batch must give the
+    bits the same rows give in a small one (one block per wavefront), first, last and a ragged final block included."""
+    g = torch.Generator(device="cuda").manual_seed(S)
+    theta = (torch.rand(N, d, S, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * 3.0
+    phi = (torch.rand(N, d, S, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * 1.2
+    t = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 2 + 0.05
+    w = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    assert (N * d + 63) // 64 > (1024 if S > 17 else 2048) and (N * d) % 64 != 0
+
+    def grads(sl):
+        th, ph = theta[sl].clone().requires_grad_(), phi[sl].clone().requires_grad_()
+        return torch.autograd.grad(nlc.ilt_reconstruct(th, ph, t[sl], "dehoog"), (th, ph), w[sl])
+
+    big = grads(slice(0, N))
+    assert torch.isfinite(big[0]).all() and torch.isfinite(big[1]).all()
+    for lo, hi in ((0, 300), (N // 2 - 7, N // 2 + 250), (N - 333, N)):
+        small = grads(slice(lo, hi))
+        assert torch.equal(big[0][lo:hi], small[0]) and torch.equal(big[1][lo:hi], small[1]), (lo, hi)
+
+
 def test_dehoog_backward_owns_its_scratch_across_streams(nlc):
     """The QD tape of ilt_dehoog_bwd_kernel is stream-ordered scratch of each call (no ctx state): backward calls issued
     back to back on two streams give the bits of a lone call."""
