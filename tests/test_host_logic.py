@@ -1,5 +1,6 @@
 """Host-side logic of the Python mirror that needs no GPU."""
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -259,3 +260,37 @@ def test_twin_of_a_foreign_model_follows_its_weight_updates():
     key1 = twin._weights_key()
     R.refresh_twin(twin, force=True)
     assert torch.equal(w_src, w_twin) and twin._weights_key() != key1
+
+
+def test_no_spill_reload_behind_an_exec_empty_loop_exit_in_the_dehoog_backward_kernel(tmp_path):
+    """Round 5: ROCm 7.2 compiled a per-lane copy loop of ilt_dehoog_bwd_kernel into a loop that leaves EXEC empty and placed the
+    reload of a spilled loop invariant behind it, before EXEC is restored -- a no-op reload, a division by garbage, a memory
+    fault from 1025 blocks on.  tools/scan_exec_hazard.py finds that signature in the assembly; the kernel as written now
+    (wave-uniform trip counts) must scan clean, and the scanner must still recognise the pattern (synthetic snippet)."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import scan_exec_hazard as sc
+
+    bad = tmp_path / "bad.s"
+    bad.write_text("""kern:
+.LBB0_1:
+\tglobal_store_dwordx2 v[8:9], v[6:7], off
+\ts_andn2_b64 exec, exec, s[6:7]
+\ts_cbranch_execnz .LBB0_1
+\ts_branch .LBB0_2
+.LBB0_2:
+\tscratch_load_dwordx2 v[12:13], off, off offset:8 ; 8-byte Folded Reload
+.LBB0_3:
+\ts_or_b64 exec, exec, s[94:95]
+\ts_endpgm
+""")
+    hits = [h for h in sc.scan(str(bad)) if h[4]]
+    assert len(hits) == 1 and "offset:8" in hits[0][2]
+    asm = tmp_path / "dhb.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", str(asm),
+                           os.path.join(repo, "neurallaplacecontrol_amd", "csrc", "kernels_dehoog_bwd.hip")],
+                          stderr=subprocess.DEVNULL, timeout=900)
+    assert [h for h in sc.scan(str(asm)) if h[4]] == []
