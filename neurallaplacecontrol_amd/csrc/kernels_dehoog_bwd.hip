@@ -20,8 +20,10 @@
 // Round 5 took the 8 KB that were NOT tape out of that figure: the rows' inputs and gradients go through an LDS image of the
 // wavefront's 64 rows as whole lines (NLC_DHB_LDS_IO below; before, 64 lines per load instruction and eight useful bytes per
 // 32-byte sector of every gradient store), and the terms a_k are rebuilt in the epilogue instead of taped: forward + backward
-// 22.0 -> 17.0-17.3 ms at 3.3 M rows, 0.78 -> 0.63 ms at 81 920 (same box, interleaved; gradients bit-identical).  Checkpointed
-// columns with recomputation do not pay on top of that: DESIGN.md section 9b.
+// 22.3 -> 17.1 ms at 3.3 M rows; then the e columns of odd r are rebuilt from their even neighbours instead of taped
+// (NLC_DHB_SKIP_ODD_E: 136 of 594 entries not written, and 63 fewer spilled VGPRs): **14.9-15.0 ms**, 0.78 -> 0.58 ms at 81 920
+// rows (same box, interleaved; gradients bit-identical to round 4 at every step).  Checkpointed columns with recomputation do
+// not pay on top of that: DESIGN.md section 9b.
 // The scratch belongs to the launch: the grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries
 // are [entry][lane] so every access is one 1-KB line per wavefront.
 //
@@ -44,6 +46,13 @@
 // theta / phi (the same three operations), 2 x 33 entries = 1 KB per row less on the tape.  0 = the round-4 form.
 #ifndef NLC_DHB_LDS_IO
 #define NLC_DHB_LDS_IO 1
+#endif
+// Round 5: the e columns of ODD r are not taped (except their first entry, the continued fraction's coefficient): the backward
+// sweep rebuilds e_r^(i) = (q_r^(i+1) - q_r^(i)) + e_(r-1)^(i+1) from the q column it loads anyway and the EVEN column below it
+// (zero below column 1) -- the forward's own three operands in the forward's own order, so the rebuilt values are the taped ones
+// bit for bit.  136 of the 594 entries per row are not written (2.1 KB), column 1 needs no e loads at all.  0 = tape every column.
+#ifndef NLC_DHB_SKIP_ODD_E
+#define NLC_DHB_SKIP_ODD_E 1
 #endif
 
 namespace nlc {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
       for (int i = 0; i < mr; ++i) {
         const cplx qhi = Q[i + 1];
         const cplx ei = cadd(csub(qhi, qlo), E[i + 1]);
-        tp.st(L.e(r, i), ei);
+        if (!NLC_DHB_SKIP_ODD_E || (r & 1) == 0 || i == 0) tp.st(L.e(r, i), ei);
         if (r != M && i >= 1) {
           Q[i - 1] = cdiv(cmul(qlo, ei), elo);
           tp.st(L.q(r + 1, i - 1), Q[i - 1]);
@@ -288,11 +297,23 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
       cplx qn[2][kChunk], en[2][kChunk];  // qn[b][j] = q_r^(i+1), en[b][j] = e_r^(i+1) for sweep iteration i = c kChunk + j
       // first chunk + the sweep's first entries
       cplx e_i = tp.ld(L.e(r, 0)), q_i = tp.ld(L.q(r, 0));
+      // odd columns (NLC_DHB_SKIP_ODD_E): e_r is rebuilt, so the q buffers run TWO entries ahead (qn = q_r^(i+2), q_roll =
+      // q_r^(i+1)) and the e buffers hold the even column below, en = e_(r-1)^(i+2)
+      const bool odd = NLC_DHB_SKIP_ODD_E && (r & 1) != 0;
+      cplx q_roll = (odd && 1 <= mr) ? tp.ld(L.q(r, 1)) : zero;
+      auto load_q = [&](int i) -> cplx {  // the q entry iteration i's buffer slot holds
+        const int at = odd ? i + 2 : i + 1;
+        return (i <= mr && at <= mr) ? tp.ld(L.q(r, at)) : zero;
+      };
+      auto load_e = [&](int i) -> cplx {  // ... and the e entry (even: e_r^(i+1); odd: e_(r-1)^(i+2), zero below column 1)
+        if (!(i <= mr && i + 1 <= mr - 1)) return one;
+        if (!odd) return tp.ld(L.e(r, i + 1));
+        return r > 1 ? tp.ld(L.e(r - 1, i + 2)) : zero;
+      };
 #pragma unroll
       for (int j = 0; j < kChunk; ++j) {
-        const int i = j;
-        qn[0][j] = (i <= mr && i + 1 <= mr) ? tp.ld(L.q(r, i + 1)) : zero;
-        en[0][j] = (i <= mr && i + 1 <= mr - 1) ? tp.ld(L.e(r, i + 1)) : one;
+        qn[0][j] = load_q(j);
+        en[0][j] = load_e(j);
       }
       // the recurrence steps of THIS column (operands loaded during the previous column), then the next column's operands
       const cplx dbar_even = r == M ? g_dend : unfeed(2 * r, uo_even);  // dbar_(2r)
@@ -309,8 +330,8 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
 #pragma unroll
           for (int j = 0; j < kChunk; ++j) {
             const int i = (c + 1) * kChunk + j;
-            qn[(c + 1) & 1][j] = (i <= mr && i + 1 <= mr) ? tp.ld(L.q(r, i + 1)) : zero;
-            en[(c + 1) & 1][j] = (i <= mr && i + 1 <= mr - 1) ? tp.ld(L.e(r, i + 1)) : one;
+            qn[(c + 1) & 1][j] = load_q(i);
+            en[(c + 1) & 1][j] = load_e(i);
           }
         }
         // (the next chunk's loads are issued before this chunk's arithmetic and cannot sink below it)
@@ -322,8 +343,15 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
           if (i <= mr) {
             const bool has_e = i <= mr - 1;
             const bool has_w = inner && i <= mr - 2;  // q_(r+1)^(i) exists
-            const cplx q_nxt = qn[c & 1][j];
-            const cplx e_nxt = en[c & 1][j];
+            cplx q_nxt = qn[c & 1][j];
+            cplx e_nxt = en[c & 1][j];
+            if (odd) {
+              const cplx q_nn = q_nxt;  // q_r^(i+2)
+              q_nxt = q_roll;           // q_r^(i+1)
+              // e_r^(i+1) as the forward built it: (q_r^(i+2) - q_r^(i+1)) + e_(r-1)^(i+2)
+              if (i + 1 <= mr - 1) e_nxt = cadd(csub(q_nn, q_nxt), e_nxt);
+              q_roll = q_nn;
+            }
             const cplx wbar_i = has_w ? W[i] : zero;
             const cplx park_nxt = (i + 1 < 2 * M) ? P[i + 1] : zero;  // old value, before this iteration parks into it
             cplx g = zero;
