@@ -21,8 +21,9 @@
 // wavefront's 64 rows as whole lines (NLC_DHB_LDS_IO below; before, 64 lines per load instruction and eight useful bytes per
 // 32-byte sector of every gradient store), and the terms a_k are rebuilt in the epilogue instead of taped: forward + backward
 // 22.3 -> 17.1 ms at 3.3 M rows; then the e columns of odd r are rebuilt from their even neighbours instead of taped
-// (NLC_DHB_SKIP_ODD_E: 136 of 594 entries not written, and 63 fewer spilled VGPRs): **14.9-15.0 ms**, 0.78 -> 0.58 ms at 81 920
-// rows (same box, interleaved; gradients bit-identical to round 4 at every step).  Checkpointed columns with recomputation do
+// (NLC_DHB_SKIP_ODD_E: 136 of 594 entries not written, and 63 fewer spilled VGPRs): **14.5-15.0 ms**, 0.78 -> 0.58 ms at 81 920
+// rows (same box, interleaved; gradients bit-identical to round 4 at every step; the epilogue rebuilds q_1^(k) = a_(k+1) / a_k
+// instead of reading column 1 a second time).  Checkpointed columns with recomputation do
 // not pay on top of that: DESIGN.md section 9b.
 // The scratch belongs to the launch: the grid is persistent, each workgroup (one wavefront, 64 rows) owns one slab, entries
 // are [entry][lane] so every access is one 1-KB line per wavefront.
@@ -395,21 +396,30 @@ __global__ __launch_bounds__(64, M <= 8 ? 2 : 1) void ilt_dehoog_bwd_kernel(cons
     //   abar_k = [k = 0] dbar_0 + h_(k-1) - h_k conj(q_1^(k)),  h_k = qbar_1^(k) / conj(a_k)  (k <= 2M-1)
     //   F_k = R (cos theta + i sin theta), R = tan(phi/2 + pi/4), dR/dphi = (1 + R^2) / 2;  a_0 = F_0 / 2
     cplx h_prev = zero;
+    // (rad, sn, cs) of term k + 1 are computed one iteration ahead: a_(k+1) / a_k IS q_1^(k), by the forward's own division, so
+    // column 1 is not read a second time here (NLC_DHB_LDS_IO; the image still holds theta / phi of every term > k)
+    double rad_n = m::tan_0_halfpi(ph[0] / 2.0 + kPi / 4.0), sn_n, cs_n;
+    m::sincos_bounded(th[0], &sn_n, &cs_n);
 #pragma unroll
     for (int k = 0; k <= 2 * M; ++k) {
-      const double rad = m::tan_0_halfpi(ph[k] / 2.0 + kPi / 4.0);
-      double sn, cs;
-      m::sincos_bounded(th[k], &sn, &cs);
+      const double rad = rad_n, sn = sn_n, cs = cs_n;
+      if (k + 1 <= 2 * M) {
+        rad_n = m::tan_0_halfpi(ph[k + 1] / 2.0 + kPi / 4.0);
+        m::sincos_bounded(th[k + 1], &sn_n, &cs_n);
+      }
       cplx gF = k == 0 ? g_a0_seed : h_prev;
       if (k <= 2 * M - 1) {
 #if NLC_DHB_LDS_IO
         cplx ak = {rad * cs, rad * sn};  // a_k as the forward built it (same operations)
         if (k == 0) ak = cscale(ak, 0.5);
+        const cplx ak1 = {rad_n * cs_n, rad_n * sn_n};
+        const cplx q1k = cdiv(ak1, ak);
 #else
         const cplx ak = tp.ld(L.a(k));
+        const cplx q1k = tp.ld(L.q(1, k));
 #endif
         const cplx h = cdiv(W[k], cconj(ak));
-        gF = csub(gF, cmul(h, cconj(tp.ld(L.q(1, k)))));
+        gF = csub(gF, cmul(h, cconj(q1k)));
         h_prev = h;
       }
       if (k == 0) gF = cscale(gF, 0.5);

@@ -5,11 +5,11 @@ timeout -k 10 120 python tools/_dhb_repro.py 16384 > $O/n16384.txt 2>&1; rc=$?; 
 [ $rc -ne 0 ] && exit 1
 timeout -k 10 300 python -m pytest tests/test_gpu_ilt.py tests/test_gpu_model.py -x -q -m gpu -k "dehoog or backward or trains" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
 for rep in 1 2; do
-  for lib in tools/_ab/libnlc_dhb_old.so tools/_ab/libnlc_dhb_lds.so neurallaplacecontrol_amd/libnlc_hip.so; do
+  for lib in tools/_ab/libnlc_dhb_old.so neurallaplacecontrol_amd/libnlc_hip.so; do
     NLC_LIB_PATH=$lib timeout -k 10 200 python tools/dehoog_bwd_bench.py 16384 655360 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', [(r['N'], round(r['hip_forward_backward_ms'],3), round(r['hip_forward_only_ms'],3)) for r in d['results']])" || exit 1
   done
 done | tee $O/dhb_ab.txt
-for lib in tools/_ab/libnlc_dhb_old.so tools/_ab/libnlc_dhb_lds.so neurallaplacecontrol_amd/libnlc_hip.so; do
+for lib in tools/_ab/libnlc_dhb_old.so neurallaplacecontrol_amd/libnlc_hip.so; do
 NLC_LIB_PATH=$lib python - <<'PY'
 import os, sys, hashlib, torch
 sys.path.insert(0, '.')
