@@ -213,7 +213,8 @@ int nlc_ilt_reconstruct(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* th
  * w_nl.py:137-144).  grad_x_dev (N, d) upstream gradient -> grad_theta_dev, grad_phi_dev (N, d, S).  No gradient
  * with respect to t.  Fourier / fixed Talbot / Stehfest: HBM-bound streaming kernels, algorithmic bytes 4dS*8 per point.
  * de Hoog: reverse mode through the quotient-difference table, taped in stream-ordered scratch of the call
- * (hipMallocAsync / hipFreeAsync on the bound stream: about 19 KB per row in flight at S = 33, at most 2.4 GB). */
+ * (hipMallocAsync / hipFreeAsync on the bound stream: 7.5 KB per row in flight at S = 33 -- 466 complex values: the q columns,
+ * the even e columns, the continued fraction's recurrence -- for at most 1024 resident wavefronts of 64 rows: 0.49 GB). */
 int nlc_ilt_reconstruct_backward(nlc_ctx* ctx, const nlc_ilt_desc* desc, const double* theta_dev,
                                  const double* phi_dev, const double* t_dev, const double* grad_x_dev, int64_t N,
                                  int d, double* grad_theta_dev, double* grad_phi_dev);

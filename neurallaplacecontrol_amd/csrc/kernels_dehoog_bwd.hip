@@ -21,7 +21,7 @@
 // wavefront's 64 rows as whole lines (NLC_DHB_LDS_IO below; before, 64 lines per load instruction and eight useful bytes per
 // 32-byte sector of every gradient store), and the terms a_k are rebuilt in the epilogue instead of taped: forward + backward
 // 22.3 -> 17.1 ms at 3.3 M rows; then the e columns of odd r are rebuilt from their even neighbours instead of taped
-// (NLC_DHB_SKIP_ODD_E: 136 of 594 entries not written, and 63 fewer spilled VGPRs): **14.5-15.0 ms**, 0.78 -> 0.58 ms at 81 920
+// (NLC_DHB_SKIP_ODD_E: 136 of 594 entries not written, and 63 fewer spilled VGPRs): **14.5-15.1 ms**, 0.78 -> 0.58 ms at 81 920
 // rows (same box, interleaved; gradients bit-identical to round 4 at every step; the epilogue rebuilds q_1^(k) = a_(k+1) / a_k
 // instead of reading column 1 a second time).  Checkpointed columns with recomputation do
 // not pay on top of that: DESIGN.md section 9b.
@@ -62,14 +62,29 @@ namespace {
 
 struct DhLayout {
   int M;
+  // Round 5: with the defaults (NLC_DHB_LDS_IO, NLC_DHB_SKIP_ODD_E) the terms a_k and the odd e columns are not taped, and the slab
+  // is laid out without them: q columns | even e columns | first entry of every odd e column | A | B -- 466 entries per row at M = 16
+  // instead of 627 (0.49 GB of scratch for 1024 resident wavefronts instead of 0.66).
+  static constexpr bool kCompact = NLC_DHB_LDS_IO && NLC_DHB_SKIP_ODD_E;
   // value tape
   __host__ __device__ constexpr int q(int r, int i) const { return (r - 1) * (2 * M + 2 - r) + i; }                 // r = 1..M, i = 0..2(M-r)+1
-  __host__ __device__ constexpr int e(int r, int i) const { return M * (M + 1) + (r - 1) * (2 * M + 1 - r) + i; }   // r = 1..M, i = 0..2(M-r)
-  __host__ __device__ constexpr int a(int i) const { return M * (M + 1) + M * M + i; }                              // i = 0..2M
-  __host__ __device__ constexpr int A(int i) const { return M * (M + 1) + M * M + (2 * M + 1) + (i + 1); }          // i = -1..2M-1
-  __host__ __device__ constexpr int B(int i) const { return M * (M + 1) + M * M + 2 * (2 * M + 1) + (i + 1); }      // i = -1..2M-1
-  __host__ __device__ constexpr int entries() const { return M * (M + 1) + M * M + 3 * (2 * M + 1); }
+  __host__ __device__ constexpr int even_before(int n) const { return n * (2 * M + 1) - 2 * n * (n + 1); }            // entries of the even columns 2 .. 2n
+  __host__ __device__ constexpr int e(int r, int i) const {                                                          // r = 1..M, i = 0..2(M-r)
+    if (!kCompact) return M * (M + 1) + (r - 1) * (2 * M + 1 - r) + i;
+    if ((r & 1) == 0) return M * (M + 1) + even_before((r - 2) / 2) + i;
+    return M * (M + 1) + even_before(M / 2) + (r - 1) / 2;  // odd column: only i == 0 is taped
+  }
+  __host__ __device__ constexpr int e_end() const { return kCompact ? M * (M + 1) + even_before(M / 2) + (M + 1) / 2 : M * (M + 1) + M * M; }
+  __host__ __device__ constexpr int a_n() const { return kCompact ? 0 : 2 * M + 1; }
+  __host__ __device__ constexpr int a(int i) const { return e_end() + i; }                                            // i = 0..2M (not compact)
+  __host__ __device__ constexpr int A(int i) const { return e_end() + a_n() + (i + 1); }                             // i = -1..2M-1
+  __host__ __device__ constexpr int B(int i) const { return e_end() + a_n() + (2 * M + 1) + (i + 1); }               // i = -1..2M-1
+  __host__ __device__ constexpr int entries() const { return e_end() + a_n() + 2 * (2 * M + 1); }
 };
+static_assert(!DhLayout::kCompact || DhLayout{16}.entries() == 466, "compact tape layout at M = 16");
+static_assert(!DhLayout::kCompact || (DhLayout{16}.e(4, 0) - DhLayout{16}.e(2, 0) == 2 * 14 + 1 && DhLayout{16}.e(16, 0) + 1 == DhLayout{16}.e(1, 0) &&
+                                      DhLayout{5}.e(5, 0) + 1 == DhLayout{5}.A(-1) && DhLayout{1}.entries() == 2 + 0 + 1 + 6),
+              "compact tape layout: columns are contiguous and disjoint");
 
 // Tape accesses go through a wave-uniform (SGPR) slab pointer that is laundered at every access: the entry offsets are
 // compile-time constants of the unrolled sweeps, and left alone the compiler hoists ~1300 per-lane 64-bit addresses out of the
