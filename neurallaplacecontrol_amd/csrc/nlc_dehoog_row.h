@@ -55,6 +55,17 @@ struct DehoogSlotTermsLane {
 
 // SRC: stage<S>(n) is called before term n whenever n % CH == 0 (it makes terms [n, n + CH) available), term(n) returns a_n.
 // Returns A_2M / B_2M, the continued fraction with the improved remainder; the caller scales Re by e^{gamma t} / T.
+//
+// Round 5: TWO anti-diagonals per pass.  Along a diagonal every entry depends on the one before it (column c on column c - 1), so a
+// lone wavefront walked a chain of ~530 dependent complex divisions / sums per row at the FP64 pipe's dependent-issue latency -- the
+// planner's QD launch (640 wavefronts on 1 024 SIMDs) is exactly one such chain long, 25 us.  Entry (n + 1, c) needs (n + 1, c - 1),
+// (n, c - 1) and (n, c - 2) only, so diagonal n + 1 can run ONE column behind diagonal n: the pass below issues column c + 1 of
+// diagonal n and column c of diagonal n + 1 together -- two independent chains, the same operations on the same operands in every
+// entry (bit-identical), D[] still updated in place (diagonal n + 1 reads what diagonal n has just written).
+// NLC_DEHOOG_PAIR = 0 restores the one-diagonal-per-pass loop (tools A/B).
+#ifndef NLC_DEHOOG_PAIR
+#define NLC_DEHOOG_PAIR 1
+#endif
 template <int M, int CH, class SRC>
 __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
 #pragma clang fp contract(off)
@@ -64,33 +75,9 @@ __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
   // A/B continued-fraction recurrence, fed with d_1, d_2, ... as the diagonals produce them
   cplx A_prev = {0.0, 0.0}, A_cur = {0.0, 0.0}, B_prev = {1.0, 0.0}, B_cur = {1.0, 0.0};
   cplx d_last = {0.0, 0.0}, d_cur = {0.0, 0.0};
-#pragma clang loop unroll(full)
-  for (int n = 0; n <= 2 * M; ++n) {
-    if (n % CH == 0) src.template stage<S>(n);
-    const cplx an = src.term(n);
-    if (n == 0) {
-      d0 = {0.5 * an.re, 0.5 * an.im};  // a_0 enters halved
-      a_prev = d0;
-      A_cur = d0;
-      continue;
-    }
-    cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
-    a_prev = an;
-    cplx old1 = D[0];              // previous diagonal, column c-1
-    cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
-    D[0] = newv;
-#pragma unroll
-    for (int c = 2; c <= n; ++c) {
-      const cplx oldc = D[c - 1];
-      const cplx val = (c & 1) ? cdiv(cmul(old2, newv), old1) : cadd(csub(newv, old1), old2);
-      D[c - 1] = val;
-      old2 = old1;
-      old1 = oldc;
-      newv = val;
-    }
-    // d_n = -(entry at i = 0); d_2M only enters the remainder
+  auto feed = [&](int n, const cplx last) {  // d_n = -(entry at i = 0); d_2M only enters the remainder
     d_last = d_cur;
-    d_cur = {-newv.re, -newv.im};
+    d_cur = {-last.re, -last.im};
     if (n != 2 * M) {
       const cplx dz = cmul(d_cur, z);
       const cplx An = cadd(A_cur, cmul(dz, A_prev));
@@ -100,14 +87,73 @@ __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
       B_prev = B_cur;
       B_cur = Bn;
     }
-    // keep the diagonals apart: hoisting the next terms' reads / interleaving diagonals only costs registers
-    // (the asm ties this diagonal's results -- including BOTH continued-fraction recurrences, which the compiler
+  };
+  // one entry of a diagonal: column c (c = 3: q_2, 4: e_2, ...) from the diagonal's previous entry `newv` and the previous
+  // diagonal's columns c - 1 (`old1`) and c - 2 (`old2`); D[c - 1] is replaced in place
+  auto step = [&](int c, cplx& newv, cplx& old1, cplx& old2) {
+    const cplx oldc = D[c - 1];
+    const cplx val = (c & 1) ? cdiv(cmul(old2, newv), old1) : cadd(csub(newv, old1), old2);
+    D[c - 1] = val;
+    old2 = old1;
+    old1 = oldc;
+    newv = val;
+  };
+  {
+    src.template stage<S>(0);
+    const cplx a0 = src.term(0);
+    d0 = {0.5 * a0.re, 0.5 * a0.im};  // a_0 enters halved
+    a_prev = d0;
+    A_cur = d0;
+  }
+#if NLC_DEHOOG_PAIR
+#pragma clang loop unroll(full)
+  for (int n = 1; n <= 2 * M; n += 2) {  // diagonals n ("A") and n + 1 ("B"); 2M is even, so the last pair is (2M - 1, 2M)
+    if (n % CH == 0) src.template stage<S>(n);
+    const cplx an = src.term(n);  // (read before a staging for term n + 1 can refill the buffer)
+    if ((n + 1) % CH == 0) src.template stage<S>(n + 1);
+    const cplx an1 = src.term(n + 1);
+    // column 1 of both: q_1^(n-1) = a_n / a_(n-1), q_1^(n) = a_(n+1) / a_n
+    cplx vA = cdiv(an, a_prev), vB = cdiv(an1, an);
+    a_prev = an1;
+    cplx o1A = D[0], o2A = {0.0, 0.0};  // previous diagonal, columns c - 1 and c - 2 (column 0: e_0 = 0)
+    D[0] = vA;
+    cplx o1B = vA, o2B = {0.0, 0.0};    // diagonal B's "previous diagonal" is A: its column 1 is what A has just stored
+    D[0] = vB;
+    // A's column 2 reads D[1] (untouched so far) and its own saved o1A: B's store into D[0] does not disturb it
+#pragma unroll
+    for (int c = 2; c <= n + 1; ++c) {  // A's column c together with B's column c - 1 (B's column 1 is done: start B at 2)
+      if (c <= n) step(c, vA, o1A, o2A);
+      if (c - 1 >= 2) step(c - 1, vB, o1B, o2B);
+    }
+    step(n + 1, vB, o1B, o2B);  // B's last column (n + 1 >= 2 always)
+    feed(n, vA);
+    feed(n + 1, vB);
+    // keep the passes apart: hoisting the next terms' reads / interleaving further diagonals only costs registers
+    // (the asm ties this pass's results -- including BOTH continued-fraction recurrences, which the compiler
     // otherwise defers to the end of the kernel, spilling every d_n z to scratch: 1 GB of HBM writes per launch --
     // to a memory barrier, so the arithmetic cannot sink below the following reads either)
     asm volatile(""
                  : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
     __builtin_amdgcn_sched_barrier(0);
   }
+#else
+#pragma clang loop unroll(full)
+  for (int n = 1; n <= 2 * M; ++n) {
+    if (n % CH == 0) src.template stage<S>(n);
+    const cplx an = src.term(n);
+    cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
+    a_prev = an;
+    cplx old1 = D[0];              // previous diagonal, column c-1
+    cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
+    D[0] = newv;
+#pragma unroll
+    for (int c = 2; c <= n; ++c) step(c, newv, old1, old2);
+    feed(n, newv);
+    asm volatile(""
+                 : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
   // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
   const cplx diff = csub(d_last, d_cur);
   const cplx one = {1.0, 0.0};
