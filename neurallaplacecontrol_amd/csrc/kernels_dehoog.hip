@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64, W) void ilt_dehoog_kernel(const IltArgs a) {
     if constexpr (SLOT) {
       // wave-uniform slot of every term; one coalesced line per term and array
       DehoogSlotTerms<CH> src{a.fre, a.fim, a.eidx + cdim * S, a.N, nsmp, {}};
-      res = dehoog_row<M, CH>(src, z);
+      res = dehoog_row<M, CH, kDehoogSkewAlone>(src, z);  // the planner's launch: one wavefront per SIMD at most
     } else {
       DehoogLdsTerms<CH, FDIRECT> src{a, fr, fi, lane, rows_here, row0};
       res = dehoog_row<M, CH>(src, z);

@@ -89,10 +89,10 @@ __global__ __launch_bounds__(128 * NS, NS == 4 ? 1 : 2) void nl_dehoog_chain_ker
           cplx res;
           if constexpr (NS == 4) {
             DehoogSlotTerms<CH> src{fre, fim, a.eidx + slot_w * S, (int64_t)SPB, (int64_t)smc, {}};
-            res = dehoog_row<M, CH>(src, z);
+            res = dehoog_row<M, CH, kDehoogSkewAlone>(src, z);
           } else {
             DehoogSlotTermsLane<CH> src{fre, fim, a.eidx + dimc * S, (int64_t)SPB, (int64_t)smc, {}};
-            res = dehoog_row<M, CH>(src, z);
+            res = dehoog_row<M, CH, kDehoogSkewAlone>(src, z);
           }
           if (row_ok) {
             // dx is a ROUNDED product, as the staged path's ilt_dehoog_kernel stores it, and the update a separate addition

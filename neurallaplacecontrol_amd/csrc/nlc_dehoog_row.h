@@ -53,20 +53,28 @@ struct DehoogSlotTermsLane {
   __device__ __forceinline__ cplx term(int n) const { return buf[n % CH]; }
 };
 
+// diagonals per pass of dehoog_row (below): where a wavefront has its SIMD to itself / where two share one
+// (tools A/B: -DNLC_DEHOOG_SKEW_ALONE=n / -DNLC_DEHOOG_SKEW_SHARED=n, n = 1, 2, 4)
+#ifndef NLC_DEHOOG_SKEW_ALONE
+#define NLC_DEHOOG_SKEW_ALONE 4
+#endif
+#ifndef NLC_DEHOOG_SKEW_SHARED
+#define NLC_DEHOOG_SKEW_SHARED 2
+#endif
+constexpr int kDehoogSkewAlone = NLC_DEHOOG_SKEW_ALONE, kDehoogSkewShared = NLC_DEHOOG_SKEW_SHARED;
+
 // SRC: stage<S>(n) is called before term n whenever n % CH == 0 (it makes terms [n, n + CH) available), term(n) returns a_n.
 // Returns A_2M / B_2M, the continued fraction with the improved remainder; the caller scales Re by e^{gamma t} / T.
 //
-// Round 5: TWO anti-diagonals per pass.  Along a diagonal every entry depends on the one before it (column c on column c - 1), so a
+// Round 5: W anti-diagonals per pass.  Along a diagonal every entry depends on the one before it (column c on column c - 1), so a
 // lone wavefront walked a chain of ~530 dependent complex divisions / sums per row at the FP64 pipe's dependent-issue latency -- the
 // planner's QD launch (640 wavefronts on 1 024 SIMDs) is exactly one such chain long, 25 us.  Entry (n + 1, c) needs (n + 1, c - 1),
-// (n, c - 1) and (n, c - 2) only, so diagonal n + 1 can run ONE column behind diagonal n: the pass below issues column c + 1 of
-// diagonal n and column c of diagonal n + 1 together -- two independent chains, the same operations on the same operands in every
-// entry (bit-identical), D[] still updated in place (diagonal n + 1 reads what diagonal n has just written).
-// NLC_DEHOOG_PAIR = 0 restores the one-diagonal-per-pass loop (tools A/B).
-#ifndef NLC_DEHOOG_PAIR
-#define NLC_DEHOOG_PAIR 1
-#endif
-template <int M, int CH, class SRC>
+// (n, c - 1) and (n, c - 2) only, so diagonal n + 1 can run ONE column behind diagonal n, n + 2 one behind that, ...: a pass issues
+// column c of diagonal n, c - 1 of n + 1, ..., c - W + 1 of n + W - 1 together -- W independent chains, the same operations on the
+// same operands in every entry (bit-identical for every W), D[] still updated in place (diagonal n + j reads what n + j - 1 wrote one
+// step earlier).  W = 2 where two wavefronts share a SIMD anyway (the stand-alone row kernels: +12 VGPRs per chain must stay
+// under 256), W = 4 where a wavefront is alone (the planner's slot-major launch, the persistent chain kernel).  W = 1: rounds 1-4.
+template <int M, int CH, int W = kDehoogSkewShared, class SRC>
 __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
 #pragma clang fp contract(off)
   constexpr int S = 2 * M + 1;
@@ -98,36 +106,33 @@ __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
     old1 = oldc;
     newv = val;
   };
-  {
-    src.template stage<S>(0);
-    const cplx a0 = src.term(0);
-    d0 = {0.5 * a0.re, 0.5 * a0.im};  // a_0 enters halved
-    a_prev = d0;
-    A_cur = d0;
-  }
-#if NLC_DEHOOG_PAIR
-#pragma clang loop unroll(full)
-  for (int n = 1; n <= 2 * M; n += 2) {  // diagonals n ("A") and n + 1 ("B"); 2M is even, so the last pair is (2M - 1, 2M)
-    if (n % CH == 0) src.template stage<S>(n);
-    const cplx an = src.term(n);  // (read before a staging for term n + 1 can refill the buffer)
-    if ((n + 1) % CH == 0) src.template stage<S>(n + 1);
-    const cplx an1 = src.term(n + 1);
-    // column 1 of both: q_1^(n-1) = a_n / a_(n-1), q_1^(n) = a_(n+1) / a_n
-    cplx vA = cdiv(an, a_prev), vB = cdiv(an1, an);
-    a_prev = an1;
-    cplx o1A = D[0], o2A = {0.0, 0.0};  // previous diagonal, columns c - 1 and c - 2 (column 0: e_0 = 0)
-    D[0] = vA;
-    cplx o1B = vA, o2B = {0.0, 0.0};    // diagonal B's "previous diagonal" is A: its column 1 is what A has just stored
-    D[0] = vB;
-    // A's column 2 reads D[1] (untouched so far) and its own saved o1A: B's store into D[0] does not disturb it
+  // diagonals n .. n + WW - 1 in one pass (WW a compile-time width, every index below a constant of the unrolled code)
+  auto pass = [&](int n, auto ww) {
+    constexpr int WW = decltype(ww)::value;
+    cplx v[WW], o1[WW], o2[WW];
+    // column 1 of each: q_1^(n+j-1) = a_(n+j) / a_(n+j-1); a diagonal's "previous diagonal" is the one before it in the pass
 #pragma unroll
-    for (int c = 2; c <= n + 1; ++c) {  // A's column c together with B's column c - 1 (B's column 1 is done: start B at 2)
-      if (c <= n) step(c, vA, o1A, o2A);
-      if (c - 1 >= 2) step(c - 1, vB, o1B, o2B);
+    for (int j = 0; j < WW; ++j) {
+      if ((n + j) % CH == 0) src.template stage<S>(n + j);  // (earlier terms of the pass are in registers already)
+      const cplx an = src.term(n + j);
+      v[j] = cdiv(an, a_prev);
+      a_prev = an;
+      o1[j] = j == 0 ? D[0] : v[j - 1];
+      o2[j] = {0.0, 0.0};  // column 0: e_0 = 0
     }
-    step(n + 1, vB, o1B, o2B);  // B's last column (n + 1 >= 2 always)
-    feed(n, vA);
-    feed(n + 1, vB);
+    D[0] = v[WW - 1];
+    // time step s: diagonal n + j works on column s - j (columns 2 .. n + j); diagonal n + j reads D[s - j - 1] as diagonal
+    // n + j - 1 left it at step s - 1, and its own store does not touch what the diagonals ahead of it read in this step
+#pragma unroll
+    for (int s = 2; s <= n + 2 * (WW - 1); ++s) {
+#pragma unroll
+      for (int j = 0; j < WW; ++j) {
+        const int c = s - j;
+        if (c >= 2 && c <= n + j) step(c, v[j], o1[j], o2[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WW; ++j) feed(n + j, v[j]);
     // keep the passes apart: hoisting the next terms' reads / interleaving further diagonals only costs registers
     // (the asm ties this pass's results -- including BOTH continued-fraction recurrences, which the compiler
     // otherwise defers to the end of the kernel, spilling every d_n z to scratch: 1 GB of HBM writes per launch --
@@ -135,25 +140,19 @@ __device__ __forceinline__ cplx dehoog_row(SRC& src, const cplx z) {
     asm volatile(""
                  : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
     __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    src.template stage<S>(0);
+    const cplx a0 = src.term(0);
+    d0 = {0.5 * a0.re, 0.5 * a0.im};  // a_0 enters halved
+    a_prev = d0;
+    A_cur = d0;
   }
-#else
+  constexpr int kFull = (2 * M) / W, kRest = (2 * M) % W;  // 2M is even: the rest is 0 for W = 1, 2 and 0 or 2 for W = 4
+  static_assert(W == 1 || W == 2 || W == 4, "dehoog_row: 1, 2 or 4 diagonals per pass");
 #pragma clang loop unroll(full)
-  for (int n = 1; n <= 2 * M; ++n) {
-    if (n % CH == 0) src.template stage<S>(n);
-    const cplx an = src.term(n);
-    cplx newv = cdiv(an, a_prev);  // column 1: q_1^(n-1) = a_n / a_(n-1)
-    a_prev = an;
-    cplx old1 = D[0];              // previous diagonal, column c-1
-    cplx old2 = {0.0, 0.0};        // previous diagonal, column c-2 (column 0: e_0 = 0)
-    D[0] = newv;
-#pragma unroll
-    for (int c = 2; c <= n; ++c) step(c, newv, old1, old2);
-    feed(n, newv);
-    asm volatile(""
-                 : "+v"(A_cur.re), "+v"(A_cur.im), "+v"(B_cur.re), "+v"(B_cur.im), "+v"(d_cur.re), "+v"(d_cur.im)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
+  for (int p = 0; p < kFull; ++p) pass(1 + p * W, std::integral_constant<int, W>{});
+  if constexpr (kRest == 2) pass(1 + kFull * W, std::integral_constant<int, 2>{});
   // here d_last = d_{2M-1}, d_cur = d_{2M}; the recurrence has run for i = 1 .. 2M-1
   const cplx diff = csub(d_last, d_cur);
   const cplx one = {1.0, 0.0};
