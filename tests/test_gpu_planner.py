@@ -583,3 +583,36 @@ def test_plain_c_client_walks_the_sharded_protocol_with_a_forced_give_up(nlc, tm
         ab = torch.roll(ab, -1, 0)
         ab[-1] = float(cmds[cmd][0])
     np.testing.assert_allclose(np.array(U_c[0]), p.U.reshape(-1).numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_refresh_model_picks_up_a_write_through_data(nlc):
+    """A write through `.data` moves no version counter (documented in _weights.py): the planner keeps planning with the weights
+    it uploaded until `MPPIDelay.refresh_model()` (round 5) -- after which a command equals a fresh planner's."""
+    from oracle import nl_model as onl
+
+    env, K, T = "oderl-cartpole", 256, 8
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(2, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+
+    def make():
+        return nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=9,
+                             U_init=torch.zeros(T, nu, dtype=torch.float64))
+
+    state, ab = nlc.initial_state(env), torch.zeros(4, nu, dtype=torch.float64)
+    p = make()
+    a0 = p.command(state, ab).clone()
+    with torch.no_grad():
+        model.laplace_rep_func.linear_tanh_stack[4].weight.data.mul_(1.7)
+    p.U = torch.zeros(T, nu, dtype=torch.float64)
+    p._commands = 0  # the same Philox counters as the first command
+    a_stale = p.command(state, ab).clone()
+    assert torch.equal(a_stale, a0), "a .data write is invisible to the weights key: the planner still holds the old weights"
+    p.refresh_model()
+    p.U = torch.zeros(T, nu, dtype=torch.float64)
+    p._commands = 0
+    a_new = p.command(state, ab).clone()
+    fresh = make().command(state, ab)
+    assert torch.equal(a_new, fresh) and not torch.equal(a_new, a0)
