@@ -541,6 +541,8 @@ def supervise(args, argv, result_fd):
     sup = SupervisorStore(rank, world, total_s + 60.0)
     base_env = dict(os.environ)  # (the store at MASTER_PORT outlives every attempt: children join it as clients, init_pg)
 
+    attempts_log = []
+
     def attempt(idx, mode, extra=()):
         env = dict(base_env)
         cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + ["--worker", "--attempt", str(idx), "--collective", mode]
@@ -551,6 +553,7 @@ def supervise(args, argv, result_fd):
             sys.stderr.write(f"bench.py supervisor rank {rank}: attempt {idx} ({mode}) {status} (exit {rc}, last marker {last})\n")
         sup.set(f"a{idx}/r{rank}", json.dumps(dict(status=status, rc=rc, last=last)))
         results = [json.loads(v) for v in sup.gather(f"a{idx}", total_s + 60.0)]
+        attempts_log.append((mode, results))
         ok = all(r["status"] == "ok" for r in results)
         line = last_json_line(data) if rank == 0 else None
         if rank == 0 and ok and line is None:
@@ -595,6 +598,10 @@ def supervise(args, argv, result_fd):
         if ok and rank == 0:
             final = json.loads(line)
     if rank == 0 and final is not None:
+        # what the supervisors did: one entry per attempt with every rank's outcome and last progress marker
+        final.setdefault("config", {})["supervisor"] = dict(
+            watchdog_s=dict(init=init_s, step=step_s, total=total_s), requested_collective=first,
+            attempts=[dict(collective=m, ranks=r) for m, r in attempts_log])
         if fallback_reason:
             final.setdefault("config", {})["collective_fallback_reason"] = fallback_reason
         if also is not None:
