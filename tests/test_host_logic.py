@@ -294,3 +294,37 @@ def test_no_spill_reload_behind_an_exec_empty_loop_exit_in_the_dehoog_backward_k
                            os.path.join(repo, "neurallaplacecontrol_amd", "csrc", "kernels_dehoog_bwd.hip")],
                           stderr=subprocess.DEVNULL, timeout=900)
     assert [h for h in sc.scan(str(asm)) if h[4]] == []
+
+
+def test_bench_quotes_pmc_traffic_only_from_the_library_s_own_sources(monkeypatch):
+    """`roofline.traffic` comes from a committed PMC summary; a summary collected from OTHER kernel sources
+    than the library in use was built from (content hash recorded by __graft_entry__.build() / tools/collect_profiles.sh) is not
+    quoted: traffic null + the reason, an error under --strict-pmc; one that names kernels the library does not have fails loudly."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+
+    sys.path.insert(0, repo)
+    import bench
+
+    pj = {"_meta": {"commit": "abc1234", "csrc_sha": "1111", "device": "MI355X", "date": "2026-10-05",
+                    "kernel_names": {"gru_encode": ["void nlc::gru_encode_kernel<64>"]}},
+          "gru_encode": {"hbm_bytes_per_launch": 123.0}}
+    monkeypatch.setattr(bench, "build_info", lambda: {"commit": "def5678", "csrc_sha": "1111"})
+    traffic, src = bench.pmc_traffic("x.json", pj, "gru_encode_kernel")
+    assert traffic == 123.0 and "abc1234" in src and "= this build" in src
+    monkeypatch.setattr(bench, "build_info", lambda: {"commit": "def5678", "csrc_sha": "2222"})
+    traffic, src = bench.pmc_traffic("x.json", pj, "gru_encode_kernel")
+    assert traffic is None and src.startswith("STALE") and "1111" in src and "2222" in src
+    monkeypatch.setattr(bench, "STRICT_PMC", True)
+    with pytest.raises(RuntimeError, match="STALE"):
+        bench.pmc_traffic("x.json", pj, "gru_encode_kernel")
+    monkeypatch.setattr(bench, "STRICT_PMC", False)
+    pj["_meta"]["kernel_names"]["gru_encode"] = ["void nlc::some_other_kernel"]
+    with pytest.raises(RuntimeError, match="stale PMC summary"):
+        bench.pmc_traffic("x.json", pj, "gru_encode_kernel")
+    assert bench.pmc_traffic("x.json", pj, "nl_rollout_kernel") == (None, None)  # no such entry: nothing to quote
+    # the hash itself: content of csrc + nlc.h, independent of .git
+    import __graft_entry__ as g
+
+    h = g.csrc_sha()
+    assert len(h) == 16 and h == g.csrc_sha()
