@@ -9,6 +9,9 @@ OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 DEV="$(python -c "import torch;print(torch.cuda.get_device_name(0))" 2>/dev/null)"
+# provenance as in collect_profiles.sh: the commit the build recorded beside the library, the content hash of the kernel sources
+COMMIT="${NLC_COMMIT:-$(python -c "from neurallaplacecontrol_amd import _build_info as b; print(b.COMMIT)" 2>/dev/null || echo unknown)}"
+SHA="$(python -c "import __graft_entry__ as g; print(g.csrc_sha())")"
 PMC_MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
 run() {  # name, counters, program args...
   local name=$1 ctr=$2; shift 2
@@ -27,9 +30,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   CFG5_ALGO=fixed_tablot CFG5_S=17 run linroll_$C $C tools/cfg5_breakdown.py
 done
 CFG5_ALGO=fixed_tablot CFG5_S=17 run linroll_mfma "$PMC_MFMA" tools/cfg5_breakdown.py
-python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_linroll_* > $OUT/${TAG}_pmc_lin_rollout.json
-python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_lin_* $OUT/${TAG}_new_dhb_* > $OUT/${TAG}_pmc_new_ilt.json
-python tools/pmc_summarize.py --commit "${NLC_COMMIT:-unknown}" --device "$DEV" $OUT/${TAG}_new_slot_* > $OUT/${TAG}_pmc_linear_planner.json
+python tools/pmc_summarize.py --commit "$COMMIT" --csrc_sha "$SHA" --device "$DEV" $OUT/${TAG}_new_linroll_* > $OUT/${TAG}_pmc_lin_rollout.json
+python tools/pmc_summarize.py --commit "$COMMIT" --csrc_sha "$SHA" --device "$DEV" $OUT/${TAG}_new_lin_* $OUT/${TAG}_new_dhb_* > $OUT/${TAG}_pmc_new_ilt.json
+python tools/pmc_summarize.py --commit "$COMMIT" --csrc_sha "$SHA" --device "$DEV" $OUT/${TAG}_new_slot_* > $OUT/${TAG}_pmc_linear_planner.json
 CFG5_ALGO=fixed_tablot CFG5_S=17 CFG5_OPTS=linear_fused=0 timeout -k 10 120 python tools/cfg5_breakdown.py > $OUT/${TAG}_linear_planner_breakdown.txt 2>/dev/null
 cat $OUT/${TAG}_linear_planner_breakdown.txt
 python - <<PY
