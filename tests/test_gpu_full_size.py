@@ -385,3 +385,32 @@ def test_untamed_random_weights_short_horizon(nlc, env):
         scale = float(want[:, t].abs().max())
         err = float((got[:, t] - want[:, t]).abs().max()) / scale
         assert err < 1e-9 * 10.0 ** (3 * t), (t, err, scale)  # chaotic amplification: ~1000x per step at most
+
+
+@pytest.mark.parametrize("key", ["0", "d4"])
+def test_bench_other_configs_emit_a_complete_line(key):
+    """`bench.py --config k` measures the other BASELINE configs at their own population with the same contract
+    fields, its own roofline (dominant kernel + whole step) and a CPU baseline on a budget; `config.commit` is never null and the
+    library's source hash travels with the line."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--config", key, "--steps", "10", "--warmup", "2", "--no-ilt",
+                          "--cpu-budget", "8", "--preheat-ms", "50"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    want_K = {"0": 1024, "d4": 16384}[key]
+    assert rec["n_gpus"] == 1 and rec["steps"] == 10 and rec["dtype"] == "f64" and rec["vs_baseline"] is None and rec["value"] > 0
+    assert f"K={want_K}" in rec["config"]["workload"] and rec["config"]["baseline_config"] == key
+    assert rec["config"]["commit"] and rec["config"]["library_build"]["csrc_sha"]
+    roof = rec["roofline"]
+    assert roof["bound"] == "mfma" and 0.0 < roof["frac"] < 1.0 and 0.0 < roof["step"]["frac"] < 1.0
+    assert roof["kernel"] == ("nl_plan_fused_kernel" if key == "0" else "gru_encode_kernel")
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and (cpu["value"] or cpu["value_extrapolated"]) and "sample" in cpu
+    assert rec["config"]["ranks_seen"]["per_rank"][0]["rollout_body"] == ("fused" if key == "0" else "wave-per-tile")
