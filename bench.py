@@ -677,6 +677,9 @@ def parse_args(argv=None):
                          "state_dim=4 cartpole; each at its whole population, sharded over --gpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default config: skip the short runs of the other BASELINE configs (`other_configs` in the line); "
+                         "profiling passes use this so that only the headline workload's kernels are counted")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     ap.add_argument("--strict-pmc", action="store_true",
                     help="fail instead of reporting `traffic: null` when the committed PMC summary was collected from other "
@@ -959,6 +962,12 @@ def worker(args, result_fd):
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_cpu, cfg, args.cpu_budget)
         mark("cpu_baseline_done")
+    # the other BASELINE configs, each at its whole population on this GPU, in the SAME driver-run line (VERDICT r4 missing 3):
+    # short fenced loops, no profiling pass, no CPU baseline -- `bench.py --config k` gives each one's full line
+    others = None
+    if world == 1 and headline and args.samples is None and not args.no_other_configs:
+        others = other_configs_section(nlc, local)
+        mark("other_configs_done")
     workload = (f"{env_name} (nx={d}, nu={nu}), K={K_total} MPPI samples sharded over the ranks, H={T}, "
                 f"action_buffer_size={B}, NL dynamics h={HIDDEN} S={S} {algo} ILT")
     workload += f" ({cfg['name']})" if K_total == cfg["K"] else f" -- EXPERIMENT: not {cfg['name']}'s population of {cfg['K']}"
@@ -992,6 +1001,7 @@ def worker(args, result_fd):
         cpu_baseline=cpu,
         kernels_avg_ms=kernels,
         kernels_note="per-launch hipEvent averages from a second, untimed pass of the same steps",
+        other_configs=others,
     )
     if cpu:
         ref = cpu["value"] if cpu.get("value") else cpu.get("value_extrapolated")
@@ -1001,6 +1011,52 @@ def worker(args, result_fd):
     mark("line_written")
     teardown()
     return 0
+
+
+def other_configs_section(nlc, local, steps=12, warmup=3):
+    """Planning steps/s of BASELINE configs[0], [2], [3], [4] and north_star's literal state_dim = 4 shape, each at its WHOLE
+    population on this one GPU (configs[2] / [3] are worded for 2 / 8 GPUs: `--config k --gpus N` shards them): `warmup` + `steps`
+    fenced commands after a time-boxed pre-heat (the de Hoog planner measures its chain forms during its first half second)."""
+    out = {}
+    for key in ("0", "2", "3", "4", "d4"):
+        cfg = CONFIGS[key]
+        env_name, T, B, algo, S, K = cfg["env"], cfg["T"], cfg["B"], cfg["algo"], cfg["S"], cfg["K"]
+        d, nu, A, _ = ENV_SHAPES[env_name]
+        model = synthetic_state_dict(d, nu, S, env=env_name, algo=algo).to(f"cuda:{local}")
+        planner = nlc.MPPIDelay(
+            nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
+            compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
+            seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False)
+        state = nlc.initial_state(env_name, torch.Generator().manual_seed(0))
+        ab = torch.zeros(B, nu, dtype=torch.float64)
+
+        def step(ab):
+            a = planner.command(state, ab)
+            ab = torch.roll(ab, -1, dims=0)
+            ab[-1] = a.cpu()
+            return ab
+
+        t_end = time.perf_counter() + (0.8 if algo == "dehoog" else 0.1)
+        ab = step(ab)
+        while time.perf_counter() < t_end:
+            ab = step(ab)
+        for _ in range(warmup):
+            ab = step(ab)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ab = step(ab)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        windows = K * T
+        flops = (flops_gru_needed_per_window(HIDDEN // 2, nu, B) + flops_rollout_needed_per_sample_step(HIDDEN, d, S)) * windows
+        out[key] = dict(name=cfg["name"], workload=f"{env_name} (nx={d}, nu={nu}), K={K}, H={T}, action_buffer_size={B}, h={HIDDEN} S={S} {algo}",
+                        value=steps / el, unit="planning steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
+                        rollout_body=planner.rollout_body, gpus_the_config_is_worded_for=cfg["gpus"],
+                        roofline_step_frac=flops / (el / steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS)
+        del planner, model
+        torch.cuda.empty_cache()
+    return out
 
 
 def standalone_ilt_section(nlc, local, pmc_name, pj):
