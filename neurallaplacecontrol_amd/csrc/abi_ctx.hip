@@ -204,6 +204,12 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
   } else if (n == "gru_coop") {
     if (value != 0 && value != 1 && value != -1) return fail(c, NLC_ERR_BAD_ARG, "gru_coop must be -1 (auto), 0 or 1");
     c->opt_gru_coop = (int)value;
+  } else if (n == "gru_gemm") {
+    // 0: FP64 MFMAs (default); 1: the encoder's hidden-state GEMMs as int8-sliced fixed-point products (kernels_gru_i8.hip;
+    // hidden_units = 128, wave-sized tiles; the cooperative and fused forms keep their FP64 MFMAs)
+    if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "gru_gemm must be 0 (FP64 MFMA) or 1 (int8-sliced)");
+    c->opt_gru_gemm = (int)value;
+    if (c->has_model) c->gru.use_i8 = (c->g == 64 && value == 1) ? 1 : 0;
   } else if (n == "fused_max_samples") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_max_samples must be >= 0");
     c->opt_fused_max_samples = (int64_t)value;

@@ -92,6 +92,7 @@ hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop, 
     return hipGetLastError();
   }
   const unsigned grid = (unsigned)((a.N + 63) / 64);
+  if (g == 64 && a.use_i8) return launch_gru_encode_i8(a, s);
   if (g == 64) {
     hipLaunchKernelGGL((gru_encode_kernel<64>), dim3(grid), dim3(256), 0, s, a);
   } else if (g == 32) {

@@ -126,6 +126,7 @@ struct nlc_ctx {
   int64_t commands = 0;                 // nlc_mppi_rollout calls since nlc_create
   int64_t last_giveup_command = -1;     // value of `commands` (0-based) at the last give-up seen by this ctx, -1 = none
   int last_body = 0;                    // body phase 1 of the last command ran on (nlc_get_stat "rollout_body")
+  int opt_gru_gemm = 0;                 // 1: encoder hidden-state GEMMs on the INT8 matrix pipe (kernels_gru_i8.hip), g == 64 only
   int opt_horizon_chunks = 1;           // Fourier planner, wave-per-tile body (K > 8192): GRU encode of later horizon chunks beside the rollout of earlier ones
   int opt_dehoog_gru_chunks = 0;        // staged de Hoog planner: GRU encode in this many horizon chunks beside the step chain (0 / 1: one launch up front)
   int opt_dehoog_gru_lds_pad = 49152;   // unused dynamic LDS of those chunk launches (bytes): 32 KB + 48 KB -> two workgroups per CU

@@ -1,6 +1,7 @@
 // Host-side weight re-packing for the MFMA kernels: pure C++ (no HIP), shared by abi_model.hip and the CPU
 // emulation test (tests/helpers/pack_host.cpp), which replays the kernels' dataflow lane by lane.
 #pragma once
+#include <cmath>
 #include <cstddef>
 #include <utility>
 #include <vector>
@@ -90,6 +91,62 @@ inline IltSlots make_ilt_slots(int d, int S, int nt3) {
       s.Cp[(size_t)g * 64 + lane] = ((k == 0) ? 0.5 : 1.0) * (((k & 3) == 0 || (k & 3) == 3) ? 1.0 : -1.0);
     }
   return s;
+}
+
+// ---- int8 digit fragments of a GRU gate matrix for the INT8 matrix pipe (nlc_i8gemm.h: FP64 GEMMs with bounded operands as
+// sliced fixed-point products).  Row m of the matrix is scaled by 2^-e_m into [-1, 1] (e_m from rowexp: the caller makes two
+// matrices that feed ONE accumulator share their exponents), written as X = rint(w 2^(54 - e_m)) and cut into seven signed
+// digits, X = sum_i d_i 256^i (d_0 .. d_5 in [-128, 127] by the 128-per-digit bias, d_6 the signed rest).
+constexpr int kI8Digits = 7;
+constexpr int kI8Frac = 54;                          // nlc_i8gemm.h: kFrac
+constexpr int kI8RowExp2 = 8 * 12 - 2 * kI8Frac;     // nlc_i8gemm.h: kRowExp2 (the recombined sum is in units of 256^12 2^-108)
+inline void i8_digits(double x, signed char d[kI8Digits]) {  // |x| <= 1
+  const long long X = std::llrint(std::ldexp(x, kI8Frac));
+  const unsigned long long Xb = (unsigned long long)X + 0x0000808080808080ull;
+  for (int i = 0; i < 6; ++i) d[i] = (signed char)(unsigned char)(((Xb >> (8 * i)) & 0xff) ^ 0x80);
+  d[6] = (signed char)(unsigned char)((Xb >> 48) & 0xff);
+}
+// smallest e with max |row| <= 2^e (0 for a zero row)
+inline std::vector<int> i8_row_exponents(const double* W, int rows, int K) {
+  std::vector<int> e((size_t)rows, 0);
+  for (int r = 0; r < rows; ++r) {
+    double mx = 0.0;
+    for (int k = 0; k < K; ++k) mx = std::fmax(mx, std::fabs(W[(size_t)r * K + k]));
+    if (mx > 0.0) {
+      int ex;
+      const double f = std::frexp(mx, &ex);  // mx = f 2^ex, f in [0.5, 1)
+      e[r] = (f == 0.5) ? ex - 1 : ex;       // mx == 2^(ex - 1) exactly: |w| / 2^(ex - 1) <= 1 holds already
+    }
+  }
+  return e;
+}
+// Fragments of the (3 G) x G gate matrix W (K = G = 64: ONE v_mfma_i32_16x16x64_i8 per digit pair):
+//   out[(((j * 3 + g) * 7 + i) * 64 + lane) * 16 + b],  chunk j, gate g, digit i
+//   lane: output row m = lane & 15 of the tile -- the i32 accumulator holds row 4 q + r in register r of lane group q, and the
+//         kernels keep feature 16 j + 4 r + q there (the FP64 MFMA's layout), so tile row m is feature 16 j + 4 (m & 3) + (m >> 2);
+//   byte b of lane group kq = lane >> 4: K entry 16 (b >> 2) + 4 (b & 3) + kq -- the entry the B operand's lane group kq holds
+//         in byte b (dword = chunk, byte = accumulator register: i8::slice_chunk).
+inline std::vector<signed char> pack_gru_i8(const double* W, int G, const std::vector<int>& rowexp) {
+  const int GT = G / 16;
+  std::vector<signed char> out((size_t)GT * 3 * kI8Digits * 64 * 16, 0);
+  for (int j = 0; j < GT; ++j)
+    for (int g = 0; g < 3; ++g)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 15, kq = lane >> 4;
+        const int row = g * G + 16 * j + 4 * (m & 3) + (m >> 2);
+        for (int b = 0; b < 16; ++b) {
+          const int k = 16 * (b >> 2) + 4 * (b & 3) + kq;
+          signed char d[kI8Digits];
+          i8_digits(std::ldexp(W[(size_t)row * G + k], -rowexp[row]), d);
+          for (int i = 0; i < kI8Digits; ++i) out[((((size_t)j * 3 + g) * kI8Digits + i) * 64 + lane) * 16 + b] = d[i];
+        }
+      }
+  return out;
+}
+inline std::vector<double> i8_row_factors(const std::vector<int>& rowexp) {
+  std::vector<double> f(rowexp.size());
+  for (size_t r = 0; r < rowexp.size(); ++r) f[r] = std::ldexp(1.0, rowexp[r] + kI8RowExp2);
+  return f;
 }
 
 }  // namespace nlc
