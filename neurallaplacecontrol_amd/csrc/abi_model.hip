@@ -65,23 +65,13 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
       bhn1(bhh1 + 2 * g, bhh1 + 3 * g);
   for (int r = 0; r < 2 * g; ++r) brz1[r] = bih1[r] + bhh1[r];
   const size_t o_bhn0 = ar.push(bhn0), o_brz1 = ar.push(brz1), o_bin1 = ar.push(bin1), o_bhn1 = ar.push(bhn1);
-  // the same hidden-state matrices as int8 digit fragments (kernels_gru_i8.hip; g == 64: one i8 MFMA covers K = 64)
-  size_t o_Whh0d = 0, o_Wih1d = 0, o_Whh1d = 0, o_rs_hh0 = 0, o_rs_ih1 = 0, o_rs_hh1 = 0;
+  // the same hidden-state matrices as the int8 weight stream of kernels_gru_i8.hip (g == 64: one i8 MFMA covers K = 64)
+  size_t o_i8 = 0;
   if (g == 64) {
-    const auto as_doubles = [](const std::vector<signed char>& b) {
-      std::vector<double> v((b.size() + 7) / 8, 0.0);
-      std::memcpy(v.data(), b.data(), b.size());
-      return v;
-    };
-    const std::vector<int> e_hh0 = i8_row_exponents(Whh0, 3 * g, g);
-    std::vector<int> e_ih1 = i8_row_exponents(Wih1, 3 * g, g), e_hh1 = i8_row_exponents(Whh1, 3 * g, g);
-    for (int r = 0; r < 2 * g; ++r) e_ih1[r] = e_hh1[r] = std::max(e_ih1[r], e_hh1[r]);  // reset / update rows: one accumulator
-    o_Whh0d = ar.push(as_doubles(pack_gru_i8(Whh0, g, e_hh0)));
-    o_Wih1d = ar.push(as_doubles(pack_gru_i8(Wih1, g, e_ih1)));
-    o_Whh1d = ar.push(as_doubles(pack_gru_i8(Whh1, g, e_hh1)));
-    o_rs_hh0 = ar.push(i8_row_factors(e_hh0));
-    o_rs_ih1 = ar.push(i8_row_factors(e_ih1));
-    o_rs_hh1 = ar.push(i8_row_factors(e_hh1));
+    const std::vector<signed char> st = pack_gru_i8_stream(Whh0, Wih1, Whh1, bhn0.data(), brz1.data(), bin1.data(), bhn1.data(), g);
+    std::vector<double> v((st.size() + 7) / 8, 0.0);
+    std::memcpy(v.data(), st.data(), st.size());
+    o_i8 = ar.push(v);
   }
 
   // ---- representation MLP
@@ -163,14 +153,7 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   G.bhn1 = base + o_bhn1;
   G.bo[0] = bo[0];
   G.bo[1] = bo[1];
-  if (g == 64) {
-    G.Whh0d = (const signed char*)(base + o_Whh0d);
-    G.Wih1d = (const signed char*)(base + o_Wih1d);
-    G.Whh1d = (const signed char*)(base + o_Whh1d);
-    G.rs_hh0 = base + o_rs_hh0;
-    G.rs_ih1 = base + o_rs_ih1;
-    G.rs_hh1 = base + o_rs_hh1;
-  }
+  if (g == 64) G.i8_stream = (const signed char*)(base + o_i8);
   G.use_i8 = (g == 64 && c->opt_gru_gemm == 1) ? 1 : 0;
 
   NlNetArgs& N = c->net;

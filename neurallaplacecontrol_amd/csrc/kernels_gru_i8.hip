@@ -18,42 +18,62 @@
 
 namespace nlc {
 
-// pre += W_tile h for one 16-row gate tile: seven digit fragments of the tile (16 B per lane each), 34 i8 MFMAs, recombination
-template <bool MERGE>
-__device__ __forceinline__ v4d i8_gate(const signed char* __restrict__ tile, const i8::v4i (&dig)[i8::kDigits], const double* __restrict__ rs,
-                                       int j, int q, int lane, const v4d& pre) {
-  i8::v4i a[i8::kDigits], acc[i8::kLevels];
-  i8::load_tile(a, tile, lane);
-#pragma unroll
-  for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
-  i8::tile_mfma(acc, a, dig);
-  return i8::recombine<MERGE>(acc, load_bias_tile(rs, j, q), pre);
-}
-// the same for an accumulator two GEMMs feed (layer 1's reset / update gates: W_ih h0 + W_hh h1, one row scale)
-__device__ __forceinline__ v4d i8_gate2(const signed char* __restrict__ tile_a, const i8::v4i (&dig_a)[i8::kDigits], const signed char* __restrict__ tile_b,
-                                        const i8::v4i (&dig_b)[i8::kDigits], bool second, const double* __restrict__ rs, int j, int q, int lane,
-                                        const v4d& pre) {
-  i8::v4i a[i8::kDigits], acc[i8::kLevels];
-  i8::load_tile(a, tile_a, lane);
-#pragma unroll
-  for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
-  i8::tile_mfma(acc, a, dig_a);
-  if (second) {
-    i8::load_tile(a, tile_b, lane);
-    i8::tile_mfma(acc, a, dig_b);
+// ---- the weight stream.  A GRU step consumes 36 gate tiles in a fixed order (kI8Seq* below); every workgroup reads the same
+// 36 x 7.25 KB, so its four wavefronts fetch each block ONCE, two tiles ahead of its use, and pass it through LDS: the loads'
+// latency (L2: the stream is 261 KB) is off the waves' critical path and the L1 -> register traffic is a quarter of four private
+// streams.  (First version: every wave loaded its own fragments right before their MFMAs -- 44 % of all wave cycles parked in
+// s_waitcnt, 3.36 ms against the FP64 kernel's 2.99; profiles/r5_i8_gemm.md.)
+// Block layout (nlc_pack.h: pack_gru_i8_stream): seven digit fragments [digit][lane][16 B], then the tile's 16 recombination
+// factors and its 16 biases (feature order of the tile, f = 4 r + q).
+constexpr int kI8DigitBytes = i8::kDigits * 64 * 16;   // 7168
+constexpr int kI8Block = kI8DigitBytes + 2 * 16 * 8;   // 7424 = 232 x 32
+constexpr int kI8StageThreads = kI8Block / 32;
+struct WeightStream {
+  const signed char* base;  // 36 blocks, consumption order of a step s >= 1
+  char* lds;                // 2 x kI8Block
+  int tid;
+  i8::v4i st0, st1;         // this thread's 32 bytes of the block after next
+  __device__ __forceinline__ void fetch(int t) {
+    typedef const __attribute__((address_space(1))) i8::v4i* g4;
+    const int off = (tid < kI8StageThreads ? tid : kI8StageThreads - 1) * 32;  // (no divergent load: the last threads re-read)
+    g4 p = (g4)(base + (size_t)t * kI8Block + off);
+    st0 = p[0];
+    st1 = p[1];
   }
-  return i8::recombine<false>(acc, load_bias_tile(rs, j, q), pre);
-}
+  __device__ __forceinline__ void put(int buf) {
+    if (tid < kI8StageThreads) {
+      i8::v4i* d = (i8::v4i*)(lds + buf * kI8Block + tid * 32);
+      d[0] = st0;
+      d[1] = st1;
+    }
+  }
+};
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// position p of step 0 (h = 0: only layer 1's input-side tiles, 12 of them) -> block; step s >= 1 consumes blocks 0 .. 35 in order
+__device__ __forceinline__ constexpr int i8_seq0(int p) { return 12 + 6 * (p / 3) + 2 * (p % 3); }
+__device__ __forceinline__ constexpr int i8_next2_step0(int p) { return p + 2 < 12 ? i8_seq0(p + 2) : p + 2 - 12; }
+__device__ __forceinline__ constexpr int i8_next2(int p) { return (p + 2) % 36; }
 
-#ifdef NLC_I8_SAME_TILE  // tools only (timing experiment): every tile reads the first one's fragments -- L1-resident weights, wrong results
-constexpr size_t kI8TileBytes = 0;
-#else
-constexpr size_t kI8TileBytes = (size_t)i8::kDigits * 64 * 16;  // one gate tile's digit fragments
-#endif
+// one tile of the stream: hand the staged block on, fetch the block after next, run `body` on the current block, barrier
+template <class F>
+__device__ __forceinline__ void i8_op(WeightStream& ws, int parity, int next2, F body) {
+  ws.put(parity ^ 1);
+  ws.fetch(next2);
+  body((const char*)(ws.lds + parity * kI8Block));
+  lds_barrier();
+}
+__device__ __forceinline__ void i8_read_digits(i8::v4i (&a)[i8::kDigits], const char* tb, int lane) {
+#pragma unroll
+  for (int i = 0; i < i8::kDigits; ++i) a[i] = *(const i8::v4i*)(tb + (i * 64 + lane) * 16);
+}
+__device__ __forceinline__ v4d i8_read_tile16(const char* tb, int which, int q) {  // which: 0 factors, 1 biases; register r <-> f = 4 r + q
+  const double* p = (const double*)(tb + kI8DigitBytes + which * 128) + q;
+  return v4d{p[0], p[4], p[8], p[12]};
+}
 
 template <int G>
-__device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, int lane, int64_t wc, int64_t kk, int tt, double* __restrict__ H0,
-                                                     double* __restrict__ H1) {
+__device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStream& ws, int lane, int64_t wc, int64_t kk, int tt,
+                                                     double* __restrict__ H0, double* __restrict__ H1) {
   static_assert(G == 64, "one i8 MFMA covers K = 64");
   constexpr int GT = G / 16, KS = G / 4;
   const int q = lane >> 4;
@@ -68,14 +88,9 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, int lane,
     H0[ks * 64 + lane] = 0.0;
     H1[ks * 64 + lane] = 0.0;
   }
-  // digits of the two layers' states (h_0 = 0: every digit is 0), dig[i][c] = digit i of the lane's entries 4 c .. 4 c + 3
+  // digits of the two layers' states, dig[i][c] = digit i of the lane's entries 4 c .. 4 c + 3
   i8::v4i S0[i8::kDigits], S1[i8::kDigits];
-#pragma unroll
-  for (int i = 0; i < i8::kDigits; ++i) {
-    S0[i] = i8::v4i{0, 0, 0, 0};
-    S1[i] = i8::v4i{0, 0, 0, 0};
-  }
-  for (int s = 0; s < a.B; ++s) {
+  auto window_input = [&](int s) {
     // reversed time: GRU step s consumes window element B-1-s  (torch.flip, w_nl.py:27)
     const int j_win = a.B - 1 - s;
     double xin = 0.0;
@@ -95,53 +110,128 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, int lane,
     } else if (q == 3) {
       xin = 1.0;
     }
-    // ---------------- layer 0: input side one FP64 k-step (as gru_encode_tile), hidden side on the i8 pipe
-    i8::v4i Sn[i8::kDigits];
+    return xin;
+  };
+  // the stream's first two blocks
+  ws.fetch(i8_seq0(0));
+  ws.put(0);
+  ws.fetch(i8_seq0(1));
+  lds_barrier();
+
+  // ================= step 0: both states are 0 -- layer 0 has no hidden-state GEMM, layer 1 only its input side (12 tiles)
+  {
+    const double xin = window_input(0);
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
-      v4d ar = mfma(wp[lane], xin, splat(0.0));
-      v4d az = mfma(wp[64 + lane], xin, splat(0.0));
+      const v4d ar = mfma(wp[lane], xin, splat(0.0));
+      const v4d az = mfma(wp[64 + lane], xin, splat(0.0));
       const v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
-      v4d ahn = load_bias_tile(a.bhn0, j, q);
-      if (s > 0) {
-        const signed char* t = a.Whh0d + (size_t)j * 3 * kI8TileBytes;
-        ar = i8_gate<true>(t, S0, a.rs_hh0, j, q, lane, ar);
-        az = i8_gate<true>(t + kI8TileBytes, S0, a.rs_hh0 + G, j, q, lane, az);
-        ahn = i8_gate<true>(t + 2 * kI8TileBytes, S0, a.rs_hh0 + 2 * G, j, q, lane, ahn);
+      const v4d ahn = load_bias_tile(a.bhn0, j, q);
+      const v4d hn = gru_gates(ar, az, ain, ahn, splat(0.0));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H0[(4 * j + r) * 64 + lane] = hn[r];
+      i8::slice_chunk(S0, j, hn);
+    }
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      v4d pre[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int p = 3 * j + g;
+        i8_op(ws, p & 1, i8_next2_step0(p), [&](const char* tb) {
+          i8::v4i w[i8::kDigits], acc[i8::kLevels];
+          i8_read_digits(w, tb, lane);
+#pragma unroll
+          for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+          i8::tile_mfma(acc, w, S0);
+          if (g < 2)  // (reset / update blocks carry the factors of the level-by-level sum)
+            pre[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+          else
+            pre[g] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+        });
+      }
+      const v4d hn = gru_gates(pre[0], pre[1], pre[2], load_bias_tile(a.bhn1, j, q), splat(0.0));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1[(4 * j + r) * 64 + lane] = hn[r];
+      i8::slice_chunk(S1, j, hn);
+    }
+  }
+  // ================= steps 1 .. B - 1: 36 tiles each
+  for (int s = 1; s < a.B; ++s) {
+    const double xin = window_input(s);
+    // ---------------- layer 0: input side one FP64 k-step (as gru_encode_tile), hidden side on the i8 pipe
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
+      v4d pre[3];
+      pre[0] = mfma(wp[lane], xin, splat(0.0));
+      pre[1] = mfma(wp[64 + lane], xin, splat(0.0));
+      const v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int p = 3 * j + g;
+        i8_op(ws, p & 1, i8_next2(p), [&](const char* tb) {
+          i8::v4i w[i8::kDigits], acc[i8::kLevels];
+          i8_read_digits(w, tb, lane);
+#pragma unroll
+          for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+          i8::tile_mfma(acc, w, S0);
+          pre[g] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), g < 2 ? pre[g] : i8_read_tile16(tb, 1, q));
+        });
       }
       const v4d hold = {H0[(4 * j + 0) * 64 + lane], H0[(4 * j + 1) * 64 + lane], H0[(4 * j + 2) * 64 + lane],
                         H0[(4 * j + 3) * 64 + lane]};
-      const v4d hn = gru_gates(ar, az, ain, ahn, hold);
+      const v4d hn = gru_gates(pre[0], pre[1], ain, pre[2], hold);
       // (the image is only read back for this chunk's own update: the GEMMs read the digits)
 #pragma unroll
       for (int r = 0; r < 4; ++r) H0[(4 * j + r) * 64 + lane] = hn[r];
-      i8::slice_chunk(Sn, j, hn);
     }
+    // the digits of the new state, once every chunk's GEMMs have read the old ones (cut from the image: a second digit set in
+    // registers beside the old one costs 28 VGPRs the scheduler needs)
 #pragma unroll
-    for (int i = 0; i < i8::kDigits; ++i) S0[i] = Sn[i];
-    // ---------------- layer 1
+    for (int j = 0; j < GT; ++j)
+      i8::slice_chunk(S0, j, v4d{H0[(4 * j + 0) * 64 + lane], H0[(4 * j + 1) * 64 + lane], H0[(4 * j + 2) * 64 + lane], H0[(4 * j + 3) * 64 + lane]});
+    // ---------------- layer 1: per chunk W_ih h0 (r), W_hh h1 (r), (z), (z), (n input side), (n hidden side)
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
-      v4d ar = load_bias_tile(a.brz1, j, q);
-      v4d az = load_bias_tile(a.brz1, GT + j, q);
-      v4d ain = load_bias_tile(a.bin1, j, q);
-      v4d ahn = load_bias_tile(a.bhn1, j, q);
-      const signed char* ti = a.Wih1d + (size_t)j * 3 * kI8TileBytes;
-      const signed char* th = a.Whh1d + (size_t)j * 3 * kI8TileBytes;
-      ar = i8_gate2(ti, S0, th, S1, s > 0, a.rs_ih1, j, q, lane, ar);
-      az = i8_gate2(ti + kI8TileBytes, S0, th + kI8TileBytes, S1, s > 0, a.rs_ih1 + G, j, q, lane, az);
-      ain = i8_gate<true>(ti + 2 * kI8TileBytes, S0, a.rs_ih1 + 2 * G, j, q, lane, ain);
-      if (s > 0) ahn = i8_gate<true>(th + 2 * kI8TileBytes, S1, a.rs_hh1 + 2 * G, j, q, lane, ahn);
+      v4d pre[4];  // r, z, n input side, n hidden side
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int p = 12 + 6 * j + 2 * g;
+        i8::v4i acc[i8::kLevels];
+#pragma unroll
+        for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+        i8_op(ws, p & 1, i8_next2(p), [&](const char* tb) {
+          i8::v4i w[i8::kDigits];
+          i8_read_digits(w, tb, lane);
+          i8::tile_mfma(acc, w, S0);
+          if (g == 2) {
+            pre[2] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+#pragma unroll
+            for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+          }
+        });
+        i8_op(ws, (p + 1) & 1, i8_next2(p + 1), [&](const char* tb) {
+          i8::v4i w[i8::kDigits];
+          i8_read_digits(w, tb, lane);
+          i8::tile_mfma(acc, w, S1);
+          // reset / update: one accumulator for both GEMMs (the two tiles carry the same factors and the same bias)
+          if (g < 2)
+            pre[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+          else
+            pre[3] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+        });
+      }
       const v4d hold = {H1[(4 * j + 0) * 64 + lane], H1[(4 * j + 1) * 64 + lane], H1[(4 * j + 2) * 64 + lane],
                         H1[(4 * j + 3) * 64 + lane]};
-      const v4d hn = gru_gates(ar, az, ain, ahn, hold);
+      const v4d hn = gru_gates(pre[0], pre[1], pre[2], pre[3], hold);
 #pragma unroll
       for (int r = 0; r < 4; ++r) H1[(4 * j + r) * 64 + lane] = hn[r];
-      i8::slice_chunk(Sn, j, hn);
     }
 #pragma unroll
-    for (int i = 0; i < i8::kDigits; ++i) S1[i] = Sn[i];
+    for (int j = 0; j < GT; ++j)
+      i8::slice_chunk(S1, j, v4d{H1[(4 * j + 0) * 64 + lane], H1[(4 * j + 1) * 64 + lane], H1[(4 * j + 2) * 64 + lane], H1[(4 * j + 3) * 64 + lane]});
   }
   // ---------------- linear_out (2 x g): rows 0,1 of one output tile, FP64
   v4d o[1];
@@ -166,12 +256,15 @@ __global__ __launch_bounds__(256, NLC_I8_WAVES) void gru_encode_i8_kernel(const 
     kk = wc / a.Tc;
     tt = a.t0 + (int)(wc - kk * a.Tc);
   }
+  // 64 KB of state images + 14.5 KB of weight staging: two workgroups per CU (160 KB)
   __shared__ double Hs[4][2][KS * 64];
+  __shared__ __attribute__((aligned(16))) char Wst[2 * kI8Block];
 #if NLC_I8_WAVES == 1
   __shared__ double pad_[4096];  // + 32 KB: a second workgroup does not fit the CU
   if (a.N < 0) pad_[threadIdx.x] = 0.0;
 #endif
-  const double o = gru_encode_tile_i8<G>(a, lane, wc, kk, tt, Hs[wave][0], Hs[wave][1]);
+  WeightStream ws{a.i8_stream, Wst, (int)threadIdx.x, {}, {}};
+  const double o = gru_encode_tile_i8<G>(a, ws, lane, wc, kk, tt, Hs[wave][0], Hs[wave][1]);
   if (valid && q < 2) {
     const int64_t wo = (a.mode == 1) ? kk * a.T + tt : w;
     a.out[wo * 2 + q] = o;

@@ -82,25 +82,51 @@ __device__ __forceinline__ void slice_chunk(v4i (&dig)[kDigits], int c, const v4
   for (int i = 4; i < kDigits; ++i) dig[i][c] = (int)th[i - 4];
 }
 
-// acc[L - kLmin] += A_i . B_j for every digit pair of level L = i + j >= kLmin.  Consecutive MFMAs write different accumulators
-// (a dependent i8 MFMA waits ~44 clocks, tools/ubench_i8emu.hip).
-__device__ __forceinline__ void tile_mfma(v4i (&acc)[kLevels], const v4i (&a)[kDigits], const v4i (&b)[kDigits]) {
-#pragma unroll
-  for (int i = 0; i < kDigits; ++i)
-#pragma unroll
-    for (int j = 0; j < kDigits; ++j)
-      if (i + j >= kLmin) {
-#if NLC_I8_DBG == 1  // tools only (timing): no MFMAs, the operands stay live
-        asm volatile("" : "+v"(acc[i + j - kLmin]) : "v"(a[i]), "v"(b[j]));
-#else
-        acc[i + j - kLmin] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i + j - kLmin], 0, 0, 0);
-#endif
+// acc[L - kLmin] += A_i . B_j for every digit pair of level L = i + j >= kLmin, in ROUND-ROBIN order over the levels (first pair
+// of every level, second pair of every level, ...): an i8 MFMA that accumulates onto the previous one's result waits ~44 clocks
+// against 17 for an independent one (tools/ubench_i8emu.hip), so consecutive MFMAs must write different accumulators.
+struct PairOrder {
+  int i[kDigits * kDigits], j[kDigits * kDigits], n;
+};
+constexpr PairOrder pair_order() {
+  PairOrder o{};
+  o.n = 0;
+  for (int round = 0; round < kDigits; ++round)
+    for (int L = kLmin; L <= kTop; ++L) {
+      // the round-th pair (i, L - i) of level L, i ascending
+      int seen = 0;
+      for (int i = 0; i < kDigits; ++i) {
+        const int j = L - i;
+        if (j < 0 || j >= kDigits) continue;
+        if (seen == round) {
+          o.i[o.n] = i;
+          o.j[o.n] = j;
+          ++o.n;
+        }
+        ++seen;
       }
+    }
+  return o;
+}
+__device__ __forceinline__ void tile_mfma(v4i (&acc)[kLevels], const v4i (&a)[kDigits], const v4i (&b)[kDigits]) {
+  constexpr PairOrder o = pair_order();
+#pragma unroll
+  for (int k = 0; k < o.n; ++k) {
+    const int i = o.i[k], j = o.j[k];
+#if NLC_I8_DBG == 1  // tools only (timing): no MFMAs, the operands stay live
+    asm volatile("" : "+v"(acc[i + j - kLmin]) : "v"(a[i]), "v"(b[j]));
+#else
+    acc[i + j - kLmin] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i + j - kLmin], 0, 0, 0);
+#endif
+  }
 }
 
-// pre + rs (x) sum_L 256^(L - kTop) acc[L]: Horner from the lowest level up (the small terms first).  MERGE: adjacent levels
-// are first joined in int32, (c_(L+1) << 8) + c_L -- safe while one GEMM's digit products feed an accumulator (|c| < 2^23); an
-// accumulator shared by two GEMMs (layer 1's reset / update gates: W_ih h0 + W_hh h1) is recombined level by level.
+// pre + rs (x) sum_L 256^(L - kTop) acc[L]: Horner from the lowest level up (the small terms first), the four registers side by
+// side (four independent chains: a dependent FP64 instruction waits for its producer).  MERGE: adjacent levels are first joined in
+// int32, (c_(L+1) << 8) + c_L -- safe while one GEMM's digit products feed an accumulator (|c| < 2^23); an accumulator shared by
+// two GEMMs (layer 1's reset / update gates: W_ih h0 + W_hh h1) is recombined level by level.  With an even number of levels the
+// merged sum ends one level below the top: ITS row factors carry the extra 2^-8 (nlc_pack.h: pack_gru_i8_stream).
+constexpr bool kMergedFactorShift = kLevels % 2 == 0;
 template <bool MERGE>
 __device__ __forceinline__ v4d recombine(const v4i (&acc)[kLevels], const v4d& rs, const v4d& pre) {
   v4d out;
@@ -114,22 +140,31 @@ __device__ __forceinline__ v4d recombine(const v4i (&acc)[kLevels], const v4d& r
   }
   return out;
 #endif
+  double s[4];
+  if (MERGE) {
+    constexpr int NP = (kLevels + 1) / 2;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double s = 0.0;
-    if (MERGE) {
+    for (int p = 0; p < NP; ++p) {
+      const int l = 2 * p;
 #pragma unroll
-      for (int l = 0; l < kLevels; l += 2) {
+      for (int r = 0; r < 4; ++r) {
         const int m = (l + 1 < kLevels) ? (int)(((unsigned)acc[l + 1][r] << 8) + (unsigned)acc[l][r]) : acc[l][r];
-        s = (l == 0) ? (double)m : fma(s, 0x1p-16, (double)m);
+        s[r] = (p == 0) ? (double)m : fma(s[r], 0x1p-16, (double)m);
       }
-      if (kLevels % 2 == 0) s = s * 0x1p-8;  // the last pair's base is level kTop - 1
-    } else {
-#pragma unroll
-      for (int l = 0; l < kLevels; ++l) s = (l == 0) ? (double)acc[l][r] : fma(s, 0x1p-8, (double)acc[l][r]);
+      // (left alone the compiler lays the four chains out one after the other, cvt, fma, cvt, fma ... back to back; tying the four
+      // partial sums to one empty asm keeps them side by side)
+      asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
     }
-    out[r] = fma(s, rs[r], pre[r]);
+  } else {
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] = (l == 0) ? (double)acc[l][r] : fma(s[r], 0x1p-8, (double)acc[l][r]);
+      asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+    }
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[r] = fma(s[r], rs[r], pre[r]);
   return out;
 }
 // digit fragments of one 16-row weight tile: frag[i] = 16 bytes per lane, [digit i][lane][16]

@@ -150,16 +150,11 @@ struct GruArgs {
   const double* bhn1;   // (g)
   double bo[2];
   double* out;  // (N, 2)
-  // hidden-state GEMMs on the INT8 matrix pipe (kernels_gru_i8.hip, `gru_gemm = 1`; g == 64, wave-sized tiles): digit fragments
-  // [GT chunks][3 gates][7 digits][64 lanes][16 bytes] (nlc_pack.h: pack_gru_i8) and the rows' recombination factors (3g each;
-  // layer 1's reset / update rows share theirs between W_ih and W_hh)
+  // hidden-state GEMMs on the INT8 matrix pipe (kernels_gru_i8.hip, `gru_gemm = 1`; g == 64, wave-sized tiles): the 36 gate
+  // tiles of a GRU step in the order it consumes them, each block = digit fragments + recombination factors + biases
+  // (nlc_pack.h: pack_gru_i8_stream)
   int use_i8;
-  const signed char* Whh0d;
-  const signed char* Wih1d;
-  const signed char* Whh1d;
-  const double* rs_hh0;
-  const double* rs_ih1;
-  const double* rs_hh1;
+  const signed char* i8_stream;
 };
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop = false, unsigned lds_pad_bytes = 0);
 hipError_t launch_gru_encode_i8(const GruArgs& a, hipStream_t s);

@@ -3,6 +3,7 @@
 #pragma once
 #include <cmath>
 #include <cstddef>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -99,6 +100,10 @@ inline IltSlots make_ilt_slots(int d, int S, int nt3) {
 // digits, X = sum_i d_i 256^i (d_0 .. d_5 in [-128, 127] by the 128-per-digit bias, d_6 the signed rest).
 constexpr int kI8Digits = 7;
 constexpr int kI8Frac = 54;                          // nlc_i8gemm.h: kFrac
+#ifndef NLC_I8_LMIN
+#define NLC_I8_LMIN 5
+#endif
+constexpr int kI8Lmin = NLC_I8_LMIN;                 // nlc_i8gemm.h: kLmin
 constexpr int kI8RowExp2 = 8 * 12 - 2 * kI8Frac;     // nlc_i8gemm.h: kRowExp2 (the recombined sum is in units of 256^12 2^-108)
 inline void i8_digits(double x, signed char d[kI8Digits]) {  // |x| <= 1
   const long long X = std::llrint(std::ldexp(x, kI8Frac));
@@ -147,6 +152,51 @@ inline std::vector<double> i8_row_factors(const std::vector<int>& rowexp) {
   std::vector<double> f(rowexp.size());
   for (size_t r = 0; r < rowexp.size(); ++r) f[r] = std::ldexp(1.0, rowexp[r] + kI8RowExp2);
   return f;
+}
+
+// The encoder's weight stream (kernels_gru_i8.hip): the 36 gate tiles of one GRU step in the order the kernel consumes them --
+//   blocks 0 .. 11   layer 0, W_hh:   chunk j, gate g (r, z, n)                         -> 3 j + g
+//   blocks 12 .. 35  layer 1:         chunk j, gate g: W_ih tile, then W_hh tile        -> 12 + 6 j + 2 g (+ 1)
+// -- each block = the tile's seven digit fragments (7 168 B), its 16 recombination factors and its 16 biases (doubles, feature
+// order f = 0 .. 15 of the tile).  Biases: layer 0's reset / update biases ride in the input GEMM (none here), its n tile carries
+// b_hn; layer 1's reset / update tiles BOTH carry b_ih + b_hh (one accumulator, recombined after the second tile; step 0 has no
+// second tile), its n tiles b_in and b_hn.  Reset / update rows of layer 1 share their exponents between W_ih and W_hh.
+constexpr int kI8StreamBlocks = 36;
+constexpr int kI8BlockBytes = kI8Digits * 64 * 16 + 2 * 16 * 8;
+inline std::vector<signed char> pack_gru_i8_stream(const double* Whh0, const double* Wih1, const double* Whh1, const double* bhn0,
+                                                   const double* brz1, const double* bin1, const double* bhn1, int G) {
+  const int GT = G / 16;
+  const std::vector<int> e_hh0 = i8_row_exponents(Whh0, 3 * G, G);
+  std::vector<int> e_ih1 = i8_row_exponents(Wih1, 3 * G, G), e_hh1 = i8_row_exponents(Whh1, 3 * G, G);
+  for (int r = 0; r < 2 * G; ++r) e_ih1[r] = e_hh1[r] = (e_ih1[r] > e_hh1[r] ? e_ih1[r] : e_hh1[r]);
+  const std::vector<signed char> f_hh0 = pack_gru_i8(Whh0, G, e_hh0), f_ih1 = pack_gru_i8(Wih1, G, e_ih1), f_hh1 = pack_gru_i8(Whh1, G, e_hh1);
+  const std::vector<double> r_hh0 = i8_row_factors(e_hh0), r_ih1 = i8_row_factors(e_ih1), r_hh1 = i8_row_factors(e_hh1);
+  std::vector<signed char> out((size_t)kI8StreamBlocks * kI8BlockBytes, 0);
+  const size_t frag = (size_t)kI8Digits * 64 * 16;
+  // (i8::recombine<MERGE = true> with an even level count ends one level below the top: the tiles it serves -- every tile but
+  // layer 1's reset / update pairs -- carry their factors times 2^-8)
+  constexpr int kLevels = 2 * (kI8Digits - 1) - kI8Lmin + 1;
+  auto block = [&](int t, const std::vector<signed char>& f, const std::vector<double>& rf, int j, int g, const double* bias /*16 or null*/,
+                   bool merged) {
+    signed char* b = out.data() + (size_t)t * kI8BlockBytes;
+    std::memcpy(b, f.data() + ((size_t)j * 3 + g) * frag, frag);
+    const double shift = (merged && kLevels % 2 == 0) ? 0x1p-8 : 1.0;
+    double tail[32];
+    for (int i = 0; i < 16; ++i) {
+      tail[i] = rf[(size_t)g * G + 16 * j + i] * shift;
+      tail[16 + i] = bias ? bias[i] : 0.0;
+    }
+    std::memcpy(b + frag, tail, sizeof(tail));
+  };
+  for (int j = 0; j < GT; ++j)
+    for (int g = 0; g < 3; ++g) {
+      block(3 * j + g, f_hh0, r_hh0, j, g, g == 2 ? bhn0 + 16 * j : nullptr, true);
+      const double* b_ih = g < 2 ? brz1 + g * G + 16 * j : bin1 + 16 * j;
+      const double* b_hh = g < 2 ? brz1 + g * G + 16 * j : bhn1 + 16 * j;
+      block(12 + 6 * j + 2 * g, f_ih1, r_ih1, j, g, b_ih, g == 2);
+      block(12 + 6 * j + 2 * g + 1, f_hh1, r_hh1, j, g, b_hh, g == 2);
+    }
+  return out;
 }
 
 }  // namespace nlc

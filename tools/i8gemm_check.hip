@@ -58,7 +58,8 @@ __global__ void k_gemm(const signed char* wfrag, const double* rowfac /*16, tile
 #pragma unroll
   for (int l = 0; l < i8::kLevels; ++l) acc[l] = v4i{0, 0, 0, 0};
   i8::tile_mfma(acc, a, dig);
-  const v4d rs = {rowfac[q + 0], rowfac[q + 4], rowfac[q + 8], rowfac[q + 12]};  // register r <-> feature 4 r + q
+  const double shift = (MERGE && i8::kMergedFactorShift) ? 0x1p-8 : 1.0;  // (the stream's blocks carry it: pack_gru_i8_stream)
+  const v4d rs = {rowfac[q + 0] * shift, rowfac[q + 4] * shift, rowfac[q + 8] * shift, rowfac[q + 12] * shift};  // register r <-> feature 4 r + q
   const v4d res = i8::recombine<MERGE>(acc, rs, v4d{0, 0, 0, 0});
   for (int r = 0; r < 4; ++r) out[lane * 4 + r] = res[r];
 }

@@ -133,7 +133,69 @@ void probe(const char* name) {
          name, a1[0], a2[0], m1[0], m2[0], s[0], s[4], sf[0], sf[4], a2_wall, m2_wall);
 }
 
+
+// ---- phases: every wave alternates a burst of NM i8 MFMAs (8 accumulators in rotation) and a burst of NV independent v_fma_f64 --
+// what one gate tile of the sliced encoder looks like from the SIMD.  ANTI: waves 4 .. 7 of the workgroup (the SIMDs' second waves)
+// start with the VALU burst.
+template <int NM, int NV, bool ANTI>
+__global__ __launch_bounds__(512) void k_phase(double* out, int iters, unsigned long long* clk) {
+  v4i acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = v4i{0, 0, 0, 0};
+  const v4i a = {(int)threadIdx.x * 0x01010101, 0x01020304, 0x7f807f80, (int)threadIdx.x};
+  const v4i b = {0x01010101, (int)threadIdx.x * 0x00010203, 0x10203040, 0x7f7f7f7f};
+  const double da = threadIdx.x * 1e-3, db = 1.0 + threadIdx.x * 1e-6;
+  double f[16];
+  for (int i = 0; i < 16; ++i) f[i] = 1.0 + da + i;
+  const bool second = ANTI && (threadIdx.x >> 8);
+  auto valu = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) f[i & 15] = __builtin_fma(f[i & 15], db, da);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) acc[i & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i & 7], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (second) valu();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    mfmas();
+    valu();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  double s = 0;
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 16; ++i) s += f[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) clk[threadIdx.x >> 6] = t1 - t0;
+}
+template <int NM, int NV, bool ANTI>
+double run_phase(int threads) {
+  hipDeviceProp_t p;
+  (void)hipGetDeviceProperties(&p, 0);
+  const int blocks = p.multiProcessorCount, iters = 2000;
+  double* out;
+  unsigned long long* clk;
+  (void)hipMalloc(&out, (size_t)blocks * 512 * 8);
+  (void)hipMalloc(&clk, 64);
+  (void)hipFuncSetAttribute((const void*)k_phase<NM, NV, ANTI>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  hipLaunchKernelGGL((k_phase<NM, NV, ANTI>), dim3(blocks), dim3(threads), 100 * 1024, 0, out, iters, clk);
+  hipLaunchKernelGGL((k_phase<NM, NV, ANTI>), dim3(blocks), dim3(threads), 100 * 1024, 0, out, iters, clk);
+  (void)hipDeviceSynchronize();
+  unsigned long long c[8];
+  (void)hipMemcpy(c, clk, 64, hipMemcpyDeviceToHost);
+  (void)hipFree(out);
+  (void)hipFree(clk);
+  return (double)c[0] / iters;
+}
+
 int main() {
+  printf("phases (34 i8 MFMAs, then 128 v_fma_f64), ticks per iteration and wave: one wave per SIMD %.0f | two waves in phase %.0f | two waves, the second starting with its VALU burst %.0f\n",
+         run_phase<34, 128, false>(256), run_phase<34, 128, false>(512), run_phase<34, 128, true>(512));
+  printf("phases (34 i8 MFMAs, then 64 v_fma_f64): one wave %.0f | two in phase %.0f | two in anti-phase %.0f\n", run_phase<34, 64, false>(256), run_phase<34, 64, false>(512),
+         run_phase<34, 64, true>(512));
+
   double t[8];
   launch<0, 8, false, 0, 0>(256, t, 1);
   printf("8 x v_mfma_i32_16x16x64_i8, one wave per SIMD: %.1f ticks per iteration (%.1f each)\n", t[0], t[0] / 8);
