@@ -677,6 +677,8 @@ def parse_args(argv=None):
                          "state_dim=4 cartpole; each at its whole population, sharded over --gpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ilt", action="store_true", help="skip the stand-alone ILT kernel section (experiments)")
+    ap.add_argument("--no-sliced-encoder", action="store_true",
+                    help="N = 1, default config: skip the run with the experimental int8-sliced encoder (`encoder_int8_sliced` in the line)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1, default config: skip the short runs of the other BASELINE configs (`other_configs` in the line); "
                          "profiling passes use this so that only the headline workload's kernels are counted")
@@ -968,6 +970,12 @@ def worker(args, result_fd):
     if world == 1 and headline and args.samples is None and not args.no_other_configs:
         others = other_configs_section(nlc, local)
         mark("other_configs_done")
+    # EXPERIMENTAL, reported beside the headline and never as `value`: the same steps with the encoder's hidden-state GEMMs as
+    # int8-sliced fixed-point products on the INT8 matrix pipe (planner option gru_gemm = 1, csrc/kernels_gru_i8.hip)
+    sliced = None
+    if world == 1 and headline and args.samples is None and not args.no_sliced_encoder:
+        sliced = sliced_encoder_section(nlc, local, args.steps, args.warmup)
+        mark("sliced_encoder_done")
     workload = (f"{env_name} (nx={d}, nu={nu}), K={K_total} MPPI samples sharded over the ranks, H={T}, "
                 f"action_buffer_size={B}, NL dynamics h={HIDDEN} S={S} {algo} ILT")
     workload += f" ({cfg['name']})" if K_total == cfg["K"] else f" -- EXPERIMENT: not {cfg['name']}'s population of {cfg['K']}"
@@ -1002,6 +1010,7 @@ def worker(args, result_fd):
         kernels_avg_ms=kernels,
         kernels_note="per-launch hipEvent averages from a second, untimed pass of the same steps",
         other_configs=others,
+        encoder_int8_sliced=sliced,
     )
     if cpu:
         ref = cpu["value"] if cpu.get("value") else cpu.get("value_extrapolated")
@@ -1056,6 +1065,71 @@ def other_configs_section(nlc, local, steps=12, warmup=3):
                         roofline_step_frac=flops / (el / steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS)
         del planner, model
         torch.cuda.empty_cache()
+    return out
+
+
+def sliced_encoder_section(nlc, local, steps, warmup):
+    """BASELINE configs[1] once more with planner option gru_gemm = 1: the GRU encoder's hidden-state GEMMs as int8-sliced fixed-point
+    products on the INT8 matrix pipe (csrc/kernels_gru_i8.hip: 54-bit fixed point in seven signed digits, exact integer
+    accumulation, FP64 recombination) instead of FP64 MFMAs -- same fenced loop as the headline, the per-kernel averages from a
+    second pass, and how far the two encoders' latents are apart on 65 536 random action windows."""
+    cfg = CONFIGS["1"]
+    env_name, T, B, S, K = cfg["env"], cfg["T"], cfg["B"], cfg["S"], cfg["K"]
+    d, nu, A, _ = ENV_SHAPES[env_name]
+    model = synthetic_state_dict(d, nu, S, env=env_name).to(f"cuda:{local}")
+    planner = nlc.MPPIDelay(
+        nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
+        compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
+        seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False, planner_options={"gru_gemm": 1})
+    state = nlc.initial_state(env_name, torch.Generator().manual_seed(0))
+    ab = torch.zeros(B, nu, dtype=torch.float64)
+
+    def step(ab):
+        a = planner.command(state, ab)
+        ab = torch.roll(ab, -1, dims=0)
+        ab[-1] = a.cpu()
+        return ab
+
+    t_end = time.perf_counter() + 0.3
+    ab = step(ab)
+    while time.perf_counter() < t_end:
+        ab = step(ab)
+    for _ in range(warmup):
+        ab = step(ab)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ab = step(ab)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    planner.ctx.profile_reset()
+    planner.ctx.profile(True)
+    for _ in range(max(steps // 2, 2)):
+        ab = step(ab)
+    torch.cuda.synchronize()
+    planner.ctx.profile(False)
+    kern = {k: v["total_ms"] / max(v["launches"], 1) for k, v in planner.ctx.profile_read().items()}
+    uses = planner.ctx.get_stat("gru_gemm")
+    g = torch.Generator().manual_seed(11)
+    win = ((torch.rand(65536, B, nu, dtype=torch.float64, generator=g) * 2 - 1) * A).to(f"cuda:{local}")
+    mctx = model.hip_ctx(torch.device(f"cuda:{local}"))
+    with torch.no_grad():
+        mctx.set_option("gru_gemm", 0)
+        lat_f64 = model.encode_actions(win)
+        mctx.set_option("gru_gemm", 1)
+        lat_i8 = model.encode_actions(win)
+        mctx.set_option("gru_gemm", 0)
+    gru_flops = flops_gru_needed_per_window(HIDDEN // 2, nu, B) * K * T
+    out = dict(planner_option="gru_gemm=1", encoder_kernel="gru_encode_i8_kernel" if uses else "gru_encode_kernel (option not taken)",
+               value=steps / el, unit="planning steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
+               kernels_avg_ms=kern, latents_max_abs_diff_vs_fp64_encoder=float((lat_i8 - lat_f64).abs().max()),
+               latents_max_abs=float(lat_f64.abs().max()),
+               encoder_fp64_equivalent_tflops=gru_flops / (kern.get("gru_encode_kernel", float("nan")) * 1e-3) / 1e12,
+               note="EXPERIMENTAL and not the headline: `value` above is measured with the FP64-MFMA encoder.  Operands: GRU states and "
+                    "row-scaled weights as 54-bit fixed point; error against the exact product within 5 x 2^-53 of the row's sum of "
+                    "|w h|, as the FP64 MFMA chain's (tools/i8gemm_check.hip, profiles/r5_i8gemm_check.txt)")
+    del planner, model
+    torch.cuda.empty_cache()
     return out
 
 

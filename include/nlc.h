@@ -97,6 +97,13 @@ int nlc_synchronize(nlc_ctx* ctx);
  *   "gru_coop"           stand-alone GRU encodes (nlc_gru_encode, nlc_model_forward, the two-launch planner bodies) with the
  *                        cooperative kernel -- one 16-window tile per workgroup, one gate chunk per wavefront, a third of
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
+ *   "gru_gemm"           EXPERIMENTAL.  0 (default): the GRU encoder's hidden-state GEMMs on FP64 MFMAs.  1: the same GEMMs as
+ *                        int8-sliced fixed-point products on the INT8 matrix pipe (csrc/kernels_gru_i8.hip, nlc_i8gemm.h; models with
+ *                        hidden_units = 128, every stand-alone encode launch; the one-launch planner body keeps its FP64 encoder
+ *                        role): GRU states and row-scaled weights as 54-bit fixed point in seven signed 8-bit digits, one
+ *                        v_mfma_i32_16x16x64_i8 per digit pair, exact integer accumulation, FP64 recombination.  Latents
+ *                        agree with the FP64 kernel's to 3e-16; against the exact product either form is within 5 x 2^-53 of
+ *                        the row's sum of |w h| (tools/i8gemm_check.hip).  2.5 ms against 3.0 ms for BASELINE configs[1]'s encode
  *   "horizon_chunks"     Fourier planner, wave-per-tile body (more than 8192 local samples): the GRU encode in this many horizon
  *                        chunks on a low-priority stream of its own, each chunk's rollout launch behind its event, so that the
  *                        encoder of later steps runs beside the rollout of earlier ones (one wave of each kernel fits a SIMD:
@@ -180,6 +187,7 @@ int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
  *   "comm_world", "comm_rank"  size / rank of the library-owned RCCL communicator (0 / -1 = none: nlc_comm_init not called)
  *   "fused_blocks_per_cu"  resident workgroups per CU the occupancy query returned for the fused kernel (-1 = not queried yet)
  *   "fused_spin_limit"     the option's current value
+ *   "gru_gemm"             1 when encode launches run the int8-sliced kernel (option "gru_gemm" = 1 and a hidden_units = 128 model)
  *   "model_nt3"            16-wide output tiles of the representation MLP's last layer as packed by nlc_set_model (the bench's
  *                          issued-flop count needs it), 0 = no model
  * Unknown names: NLC_ERR_BAD_ARG. */

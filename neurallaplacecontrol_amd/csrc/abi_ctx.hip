@@ -206,7 +206,7 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     c->opt_gru_coop = (int)value;
   } else if (n == "gru_gemm") {
     // 0: FP64 MFMAs (default); 1: the encoder's hidden-state GEMMs as int8-sliced fixed-point products (kernels_gru_i8.hip;
-    // hidden_units = 128, wave-sized tiles; the cooperative and fused forms keep their FP64 MFMAs)
+    // hidden_units = 128: every stand-alone encoder launch; the one-launch planner body keeps its FP64 encoder role)
     if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "gru_gemm must be 0 (FP64 MFMA) or 1 (int8-sliced)");
     c->opt_gru_gemm = (int)value;
     if (c->has_model) c->gru.use_i8 = (c->g == 64 && value == 1) ? 1 : 0;
@@ -234,6 +234,7 @@ extern "C" int nlc_get_stat(nlc_ctx* c, const char* name, double* out) {
   else if (n == "fused_blocks_per_cu") *out = (double)c->fused_blocks_per_cu;
   else if (n == "fused_spin_limit") *out = (double)c->opt_fused_spin_limit;
   else if (n == "model_nt3") *out = c->has_model ? (double)c->net.nt3 : 0.0;
+  else if (n == "gru_gemm") *out = (c->has_model && c->gru.use_i8) ? 1.0 : 0.0;  // 1: the encoder launches run kernels_gru_i8.hip
   else return fail(c, NLC_ERR_BAD_ARG, "unknown stat: " + n);
   return NLC_OK;
 }

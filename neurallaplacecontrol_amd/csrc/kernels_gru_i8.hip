@@ -50,7 +50,8 @@ struct WeightStream {
 };
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // position p of step 0 (h = 0: only layer 1's input-side tiles, 12 of them) -> block; step s >= 1 consumes blocks 0 .. 35 in order
-__device__ __forceinline__ constexpr int i8_seq0(int p) { return 12 + 6 * (p / 3) + 2 * (p % 3); }
+// (layer 1: the hidden-side tile of a gate BEFORE its input-side tile, see gru_encode_tile_i8)
+__device__ __forceinline__ constexpr int i8_seq0(int p) { return 12 + 6 * (p / 3) + 2 * (p % 3) + 1; }
 __device__ __forceinline__ constexpr int i8_next2_step0(int p) { return p + 2 < 12 ? i8_seq0(p + 2) : p + 2 - 12; }
 __device__ __forceinline__ constexpr int i8_next2(int p) { return (p + 2) % 36; }
 
@@ -70,7 +71,23 @@ __device__ __forceinline__ v4d i8_read_tile16(const char* tb, int which, int q) 
   const double* p = (const double*)(tb + kI8DigitBytes + which * 128) + q;
   return v4d{p[0], p[4], p[8], p[12]};
 }
+// issue order of a tile whose MFMAs run beside independent VALU work of the same wave (the previous chunk's gate math): one
+// MFMA, then `per` VALU instructions in its shadow -- the i8 MFMA occupies the matrix pipe for 16 clocks and the vector issue
+// for 4 (tools/ubench_i8emu.hip: 8 MFMAs + 16 FP64 FMAs of one wave take 156 clocks against 136 + 100)
+template <int PER>
+__device__ __forceinline__ void i8_mfma_valu_order() {
+  constexpr int n = i8::pair_order().n;
+#pragma unroll
+  for (int m = 0; m < n; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+  }
+}
 
+// Software pipeline of a GRU step: the gate math of chunk j (260 FP64 VALU instructions per lane, the update of its state image)
+// runs in the shadow of the FIRST tile of chunk j + 1 -- that tile's 34 MFMAs do not depend on it: within a layer every GEMM reads
+// the OLD state's digits; across layers, layer 1 starts with a hidden-side tile (old h1) while layer 0's last chunk finishes and
+// the new h0 is cut into digits, and the next step's layer 0 starts (old h0) while layer 1's last chunk finishes.
 template <int G>
 __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStream& ws, int lane, int64_t wc, int64_t kk, int tt,
                                                      double* __restrict__ H0, double* __restrict__ H1) {
@@ -112,6 +129,23 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
     }
     return xin;
   };
+  // the pre-activations of the chunk whose gate math is pending: reset, update, n input side, n hidden side
+  v4d pre[4];
+  auto finish = [&](double* __restrict__ H, int j) {  // gates of the pending chunk j, update of its rows of the state image
+    const v4d hold = {H[(4 * j + 0) * 64 + lane], H[(4 * j + 1) * 64 + lane], H[(4 * j + 2) * 64 + lane], H[(4 * j + 3) * 64 + lane]};
+    const v4d hn = gru_gates(pre[0], pre[1], pre[2], pre[3], hold);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H[(4 * j + r) * 64 + lane] = hn[r];
+  };
+  auto digits_of = [&](i8::v4i (&S)[i8::kDigits], const double* __restrict__ H) {  // the whole state, from its image
+#pragma unroll
+    for (int j = 0; j < GT; ++j)
+      i8::slice_chunk(S, j, v4d{H[(4 * j + 0) * 64 + lane], H[(4 * j + 1) * 64 + lane], H[(4 * j + 2) * 64 + lane], H[(4 * j + 3) * 64 + lane]});
+  };
+  auto zero = [](i8::v4i (&acc)[i8::kLevels]) {
+#pragma unroll
+    for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+  };
   // the stream's first two blocks
   ws.fetch(i8_seq0(0));
   ws.put(0);
@@ -135,27 +169,31 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
     }
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
-      v4d pre[3];
+      v4d nxt[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const int p = 3 * j + g;
         i8_op(ws, p & 1, i8_next2_step0(p), [&](const char* tb) {
           i8::v4i w[i8::kDigits], acc[i8::kLevels];
           i8_read_digits(w, tb, lane);
-#pragma unroll
-          for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+          zero(acc);
           i8::tile_mfma(acc, w, S0);
+          if (g == 0 && j > 0) {
+            finish(H1, j - 1);
+            i8_mfma_valu_order<8>();
+          }
           if (g < 2)  // (reset / update blocks carry the factors of the level-by-level sum)
-            pre[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+            nxt[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
           else
-            pre[g] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+            nxt[g] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
         });
       }
-      const v4d hn = gru_gates(pre[0], pre[1], pre[2], load_bias_tile(a.bhn1, j, q), splat(0.0));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H1[(4 * j + r) * 64 + lane] = hn[r];
-      i8::slice_chunk(S1, j, hn);
+      pre[0] = nxt[0];
+      pre[1] = nxt[1];
+      pre[2] = nxt[2];
+      pre[3] = load_bias_tile(a.bhn1, j, q);  // h1 = 0: the hidden side of n is its bias
     }
+    // (layer 1's chunk 3 is pending)
   }
   // ================= steps 1 .. B - 1: 36 tiles each
   for (int s = 1; s < a.B; ++s) {
@@ -163,76 +201,80 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
     // ---------------- layer 0: input side one FP64 k-step (as gru_encode_tile), hidden side on the i8 pipe
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
-      gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
-      v4d pre[3];
-      pre[0] = mfma(wp[lane], xin, splat(0.0));
-      pre[1] = mfma(wp[64 + lane], xin, splat(0.0));
-      const v4d ain = mfma(wp[128 + lane], xin, splat(0.0));
+      v4d in[3], nxt[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const int p = 3 * j + g;
         i8_op(ws, p & 1, i8_next2(p), [&](const char* tb) {
           i8::v4i w[i8::kDigits], acc[i8::kLevels];
           i8_read_digits(w, tb, lane);
-#pragma unroll
-          for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+          zero(acc);
           i8::tile_mfma(acc, w, S0);
-          pre[g] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), g < 2 ? pre[g] : i8_read_tile16(tb, 1, q));
+          if (g == 0) {
+            // in the MFMAs' shadow: the pending chunk (the previous step's last chunk of layer 1, or this layer's chunk j - 1)
+            if (j == 0) {
+              finish(H1, GT - 1);
+              digits_of(S1, H1);
+            } else {
+              finish(H0, j - 1);
+            }
+            i8_mfma_valu_order<8>();
+            gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
+            in[0] = mfma(wp[lane], xin, splat(0.0));
+            in[1] = mfma(wp[64 + lane], xin, splat(0.0));
+            in[2] = mfma(wp[128 + lane], xin, splat(0.0));
+          }
+          nxt[g] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), g < 2 ? in[g] : i8_read_tile16(tb, 1, q));
         });
       }
-      const v4d hold = {H0[(4 * j + 0) * 64 + lane], H0[(4 * j + 1) * 64 + lane], H0[(4 * j + 2) * 64 + lane],
-                        H0[(4 * j + 3) * 64 + lane]};
-      const v4d hn = gru_gates(pre[0], pre[1], ain, pre[2], hold);
-      // (the image is only read back for this chunk's own update: the GEMMs read the digits)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H0[(4 * j + r) * 64 + lane] = hn[r];
+      pre[0] = nxt[0];
+      pre[1] = nxt[1];
+      pre[2] = in[2];
+      pre[3] = nxt[2];
     }
-    // the digits of the new state, once every chunk's GEMMs have read the old ones (cut from the image: a second digit set in
-    // registers beside the old one costs 28 VGPRs the scheduler needs)
-#pragma unroll
-    for (int j = 0; j < GT; ++j)
-      i8::slice_chunk(S0, j, v4d{H0[(4 * j + 0) * 64 + lane], H0[(4 * j + 1) * 64 + lane], H0[(4 * j + 2) * 64 + lane], H0[(4 * j + 3) * 64 + lane]});
-    // ---------------- layer 1: per chunk W_ih h0 (r), W_hh h1 (r), (z), (z), (n input side), (n hidden side)
+    // ---------------- layer 1: per chunk and gate the hidden-side tile (old h1), then the input-side tile (new h0)
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
-      v4d pre[4];  // r, z, n input side, n hidden side
+      v4d nxt[4];
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const int p = 12 + 6 * j + 2 * g;
         i8::v4i acc[i8::kLevels];
-#pragma unroll
-        for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+        zero(acc);
         i8_op(ws, p & 1, i8_next2(p), [&](const char* tb) {
           i8::v4i w[i8::kDigits];
           i8_read_digits(w, tb, lane);
-          i8::tile_mfma(acc, w, S0);
+          i8::tile_mfma(acc, w, S1);
+          if (g == 0) {
+            if (j == 0) {
+              finish(H0, GT - 1);
+              digits_of(S0, H0);  // (complete before the next tile, the first to read the new h0)
+            } else {
+              finish(H1, j - 1);
+            }
+            i8_mfma_valu_order<8>();
+          }
           if (g == 2) {
-            pre[2] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
-#pragma unroll
-            for (int l = 0; l < i8::kLevels; ++l) acc[l] = i8::v4i{0, 0, 0, 0};
+            nxt[3] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+            zero(acc);
           }
         });
         i8_op(ws, (p + 1) & 1, i8_next2(p + 1), [&](const char* tb) {
           i8::v4i w[i8::kDigits];
           i8_read_digits(w, tb, lane);
-          i8::tile_mfma(acc, w, S1);
+          i8::tile_mfma(acc, w, S0);
           // reset / update: one accumulator for both GEMMs (the two tiles carry the same factors and the same bias)
           if (g < 2)
-            pre[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+            nxt[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
           else
-            pre[3] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
+            nxt[2] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
         });
       }
-      const v4d hold = {H1[(4 * j + 0) * 64 + lane], H1[(4 * j + 1) * 64 + lane], H1[(4 * j + 2) * 64 + lane],
-                        H1[(4 * j + 3) * 64 + lane]};
-      const v4d hn = gru_gates(pre[0], pre[1], pre[2], pre[3], hold);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H1[(4 * j + r) * 64 + lane] = hn[r];
+      for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
     }
-#pragma unroll
-    for (int j = 0; j < GT; ++j)
-      i8::slice_chunk(S1, j, v4d{H1[(4 * j + 0) * 64 + lane], H1[(4 * j + 1) * 64 + lane], H1[(4 * j + 2) * 64 + lane], H1[(4 * j + 3) * 64 + lane]});
   }
+  finish(H1, GT - 1);  // layer 1's last chunk
   // ---------------- linear_out (2 x g): rows 0,1 of one output tile, FP64
   v4d o[1];
   o[0] = splat(0.0);

@@ -156,7 +156,8 @@ inline std::vector<double> i8_row_factors(const std::vector<int>& rowexp) {
 
 // The encoder's weight stream (kernels_gru_i8.hip): the 36 gate tiles of one GRU step in the order the kernel consumes them --
 //   blocks 0 .. 11   layer 0, W_hh:   chunk j, gate g (r, z, n)                         -> 3 j + g
-//   blocks 12 .. 35  layer 1:         chunk j, gate g: W_ih tile, then W_hh tile        -> 12 + 6 j + 2 g (+ 1)
+//   blocks 12 .. 35  layer 1:         chunk j, gate g: W_hh tile, then W_ih tile        -> 12 + 6 j + 2 g (+ 1)
+//                    (hidden side first: the tile that opens layer 1 must not need the new h0, whose digits are cut in its shadow)
 // -- each block = the tile's seven digit fragments (7 168 B), its 16 recombination factors and its 16 biases (doubles, feature
 // order f = 0 .. 15 of the tile).  Biases: layer 0's reset / update biases ride in the input GEMM (none here), its n tile carries
 // b_hn; layer 1's reset / update tiles BOTH carry b_ih + b_hh (one accumulator, recombined after the second tile; step 0 has no
@@ -193,8 +194,8 @@ inline std::vector<signed char> pack_gru_i8_stream(const double* Whh0, const dou
       block(3 * j + g, f_hh0, r_hh0, j, g, g == 2 ? bhn0 + 16 * j : nullptr, true);
       const double* b_ih = g < 2 ? brz1 + g * G + 16 * j : bin1 + 16 * j;
       const double* b_hh = g < 2 ? brz1 + g * G + 16 * j : bhn1 + 16 * j;
-      block(12 + 6 * j + 2 * g, f_ih1, r_ih1, j, g, b_ih, g == 2);
-      block(12 + 6 * j + 2 * g + 1, f_hh1, r_hh1, j, g, b_hh, g == 2);
+      block(12 + 6 * j + 2 * g, f_hh1, r_hh1, j, g, b_hh, g == 2);
+      block(12 + 6 * j + 2 * g + 1, f_ih1, r_ih1, j, g, b_ih, g == 2);
     }
   return out;
 }

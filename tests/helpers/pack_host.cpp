@@ -194,4 +194,125 @@ void emu_gru(const double* Wih0, const double* Whh0, const double* bih0, const d
   for (int l = 0; l < 64; ++l)
     if ((l >> 4) < 2) out[(l & 15) * 2 + (l >> 4)] = o[l][0] + bo[l >> 4];
 }
+
+// The same encoder with its hidden-state GEMMs as the int8-sliced kernel evaluates them (csrc/kernels_gru_i8.hip): weights from
+// the 36-block stream of pack_gru_i8_stream in the kernel's consumption order, states cut into seven signed digits of
+// rint(h 2^54), one integer dot product per digit pair (v_mfma_i32_16x16x64_i8: byte b of lane group kq on both operands is the
+// same K entry; accumulator register r of lane group q is tile row 4 q + r), level sums recombined as the kernel does.
+static void i8_tile(const signed char* blk, const std::vector<Acc>& h, long long lev[64][4][13]) {
+  // B operand: lane (kq, n), byte b <-> entry of chunk b >> 2, register b & 3
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 4; ++r) {
+      const int q = l >> 4, n = l & 15, m = 4 * q + r;  // tile row of this accumulator entry
+      for (int kq = 0; kq < 4; ++kq)
+        for (int b = 0; b < 16; ++b) {
+          signed char dh[kI8Digits];
+          i8_digits(h[b >> 2][16 * kq + n][b & 3], dh);
+          for (int i = 0; i < kI8Digits; ++i) {
+            const signed char dw = blk[(((size_t)i * 64) + (16 * kq + m)) * 16 + b];
+            for (int j = 0; j < kI8Digits; ++j)
+              if (i + j >= kI8Lmin) lev[l][r][i + j] += (long long)dw * dh[j];
+          }
+        }
+    }
+}
+static void i8_recombine(long long lev[64][4][13], const signed char* blk, bool merged, bool with_bias, Acc pre) {
+  const double* tail = (const double*)(blk + (size_t)kI8Digits * 64 * 16);
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 4; ++r) {
+      const int f = 4 * r + (l >> 4);
+      double s = 0.0;
+      if (merged) {
+        bool first = true;
+        for (int L = kI8Lmin; L <= 12; L += 2) {
+          const double m = (double)(L + 1 <= 12 ? lev[l][r][L + 1] * 256 + lev[l][r][L] : lev[l][r][L]);
+          s = first ? m : std::fma(s, 0x1p-16, m);
+          first = false;
+        }
+      } else {
+        for (int L = kI8Lmin; L <= 12; ++L) s = (L == kI8Lmin) ? (double)lev[l][r][L] : std::fma(s, 0x1p-8, (double)lev[l][r][L]);
+      }
+      pre[l][r] = std::fma(s, tail[f], with_bias ? tail[16 + f] : pre[l][r]);
+    }
+}
+void emu_gru_i8(const double* Wih0, const double* Whh0, const double* bih0, const double* bhh0, const double* Wih1,
+                const double* Whh1, const double* bih1, const double* bhh1, const double* Wo, const double* bo, int g,
+                int nin, int B, const double* win, double* out) {
+  const int GT = g / 16, KS = g / 4;
+  std::vector<double> Wih0b((size_t)3 * g * 4, 0.0);
+  for (int r = 0; r < 3 * g; ++r) {
+    for (int j = 0; j < nin; ++j) Wih0b[(size_t)r * 4 + j] = Wih0[(size_t)r * nin + j];
+    Wih0b[(size_t)r * 4 + 3] = bih0[r] + (r < 2 * g ? bhh0[r] : 0.0);
+  }
+  const auto Wih0p = pack_gru_chunked(Wih0b.data(), 4, 4, g);
+  const auto Wop = pack_A(Wo, g, g, identity_rows(2));
+  std::vector<double> brz1(2 * g);
+  for (int r = 0; r < 2 * g; ++r) brz1[r] = bih1[r] + bhh1[r];
+  const std::vector<signed char> st = pack_gru_i8_stream(Whh0, Wih1, Whh1, bhh0 + 2 * g, brz1.data(), bih1 + 2 * g, bhh1 + 2 * g, g);
+  auto block = [&](int t) { return st.data() + (size_t)t * kI8BlockBytes; };
+  std::vector<Acc> h0(GT), h1(GT), hn(GT);
+  for (int j = 0; j < GT; ++j) {
+    std::memset(h0[j], 0, sizeof(Acc));
+    std::memset(h1[j], 0, sizeof(Acc));
+  }
+  auto sig = [](double x) { return 1.0 / (1.0 + std::exp(-x)); };
+  auto gates = [&](Acc ar, Acc az, Acc ain, Acc ahn, Acc hold, Acc hnew) {
+    for (int l = 0; l < 64; ++l)
+      for (int r = 0; r < 4; ++r) {
+        const double rg = sig(ar[l][r]), zg = sig(az[l][r]);
+        const double ng = std::tanh(ain[l][r] + rg * ahn[l][r]);
+        hnew[l][r] = (1.0 - zg) * ng + zg * hold[l][r];
+      }
+  };
+  static long long lev[64][4][13];
+  for (int s = 0; s < B; ++s) {
+    double xin[64];
+    for (int l = 0; l < 64; ++l) {
+      const int q = l >> 4, c = l & 15;
+      xin[l] = q < nin ? win[((size_t)c * B + (B - 1 - s)) * nin + q] : (q == 3 ? 1.0 : 0.0);
+    }
+    for (int j = 0; j < GT; ++j) {
+      Acc a3[3], ahn;
+      for (int gk = 0; gk < 3; ++gk) {
+        std::memset(a3[gk], 0, sizeof(Acc));
+        mfma(&Wih0p[((size_t)j * 3 + gk) * 64], xin, a3[gk]);
+      }
+      bias_tile(bhh0 + 2 * g, j, ahn);
+      if (s > 0)
+        for (int gk = 0; gk < 3; ++gk) {
+          std::memset(lev, 0, sizeof(lev));
+          i8_tile(block(3 * j + gk), h0, lev);
+          i8_recombine(lev, block(3 * j + gk), true, gk == 2, gk == 2 ? ahn : a3[gk]);
+        }
+      gates(a3[0], a3[1], a3[2], ahn, h0[j], hn[j]);
+    }
+    for (int j = 0; j < GT; ++j) std::memcpy(h0[j], hn[j], sizeof(Acc));
+    for (int j = 0; j < GT; ++j) {
+      Acc pre[4];  // r, z, n input side, n hidden side
+      bias_tile(bhh1 + 2 * g, j, pre[3]);
+      for (int gk = 0; gk < 3; ++gk) {
+        const int t = 12 + 6 * j + 2 * gk;  // hidden-side block, then input-side block
+        std::memset(lev, 0, sizeof(lev));
+        if (s > 0) i8_tile(block(t), h1, lev);
+        if (gk == 2) {
+          if (s > 0) i8_recombine(lev, block(t), true, true, pre[3]);
+          std::memset(lev, 0, sizeof(lev));
+        }
+        i8_tile(block(t + 1), h0, lev);
+        i8_recombine(lev, block(t + 1), gk == 2, true, pre[gk]);
+      }
+      gates(pre[0], pre[1], pre[2], pre[3], h1[j], hn[j]);
+    }
+    for (int j = 0; j < GT; ++j) std::memcpy(h1[j], hn[j], sizeof(Acc));
+  }
+  Acc o;
+  std::memset(o, 0, sizeof(Acc));
+  double b[64];
+  for (int ks = 0; ks < KS; ++ks) {
+    for (int l = 0; l < 64; ++l) b[l] = h1[ks >> 2][l][ks & 3];
+    mfma(&Wop[(size_t)ks * 64], b, o);
+  }
+  for (int l = 0; l < 64; ++l)
+    if ((l >> 4) < 2) out[(l & 15) * 2 + (l >> 4)] = o[l][0] + bo[l >> 4];
+}
 }

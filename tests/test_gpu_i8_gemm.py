@@ -1,0 +1,97 @@
+"""GPU tests (``-m gpu``) of the experimental int8-sliced encoder (``gru_gemm = 1``: csrc/kernels_gru_i8.hip, nlc_i8gemm.h): the
+GRU's hidden-state GEMMs as fixed-point digit products on the INT8 matrix pipe.  Bars: the unit check against exact integer /
+long-double arithmetic; the REAL reference ReverseGRUEncoder's outputs (G2) at the suite's tolerance; the FP64-MFMA kernel's
+latents to 1e-12; the planner's actions to 1e-9."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import *  # noqa: F401,F403
+from gpu_common import GOLD, TOL, T64, load_sd, build_model
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sliced_gemm_unit_check_against_exact_arithmetic():
+    """tools/i8gemm_check.hip: digits of rint(x 2^54) byte for byte, the i8 MFMA's operand / accumulator maps, and 51 200 outputs of
+    sliced 16 x 64 x 16 GEMM tiles against the exact product (the FP64 fused-multiply-add chain beside them)."""
+    exe = os.path.join(REPO, "tools", "i8gemm_check.bin")
+    if not os.path.exists(exe):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-I", os.path.join(REPO, "neurallaplacecontrol_amd", "csrc"),
+                               os.path.join(REPO, "tools", "i8gemm_check.hip"), "-o", exe])
+    res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = res.stdout.decode()
+    assert res.returncode == 0 and text.strip().endswith("OK"), text
+    assert "0 wrong bytes" in text and "row 4 q + r: 0 wrong" in text, text
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
+def test_sliced_encoder_vs_reference_golden(nlc, env):
+    """G2 again: the int8-sliced encoder against the REAL reference ReverseGRUEncoder (nn.GRU) outputs."""
+    g = np.load(f"{GOLD}/g2_stages_{env}.npz")
+    sd = load_sd(g)
+    model = build_model(nlc, sd)
+    ctx = model.hip_ctx(torch.device("cuda:0"))
+    ctx.set_option("gru_gemm", 1)
+    assert ctx.get_stat("gru_gemm") == 1
+    win = T64(g["gru_in"]) * sd["action_std"] + sd["action_mean"]
+    with torch.no_grad():
+        got = model.encode_actions(win.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), g["gru_out"], **TOL)
+
+
+@pytest.mark.parametrize("nu,B,N", [(1, 4, 70000), (2, 4, 4097), (1, 1, 1000), (1, 6, 2049), (2, 3, 17)])
+def test_sliced_encoder_agrees_with_fp64_encoder(nlc, nu, B, N):
+    """Random windows (ragged N, one to six GRU steps, one and two action dims): latents of the two encoders to 1e-12 -- measured
+    3e-16 -- and both against the torch float64 modules at the suite's tolerance."""
+    import oracle.nl_model as onl
+
+    d = 5 if nu == 1 else 6
+    sd = onl.make_synthetic_state_dict(3, d, nu, 128, 17)
+    model = build_model(nlc, sd)
+    ctx = model.hip_ctx(torch.device("cuda:0"))
+    g = torch.Generator().manual_seed(N + B)
+    win = (torch.rand(N, B, nu, dtype=torch.float64, generator=g) * 2 - 1) * 3.0
+    with torch.no_grad():
+        ctx.set_option("gru_coop", 0)
+        ctx.set_option("gru_gemm", 0)
+        f64 = model.encode_actions(win.cuda()).cpu()
+        ctx.set_option("gru_gemm", 1)
+        i8 = model.encode_actions(win.cuda()).cpu()
+    assert torch.isfinite(i8).all()
+    np.testing.assert_allclose(i8.numpy(), f64.numpy(), rtol=0, atol=1e-12)
+    ref = onl.gru_encoder(sd, (win[:512] - sd["action_mean"]) / sd["action_std"])
+    np.testing.assert_allclose(i8[:512].numpy(), ref.numpy(), **TOL)
+
+
+def test_planner_with_sliced_encoder(nlc):
+    """The two-launch planner (K = 8192: GRU launch + split rollout) with either encoder: the same actions to 1e-9 over three
+    commands; the option reaches the launch (stat), the FP64 planner is untouched by it."""
+    import bench
+
+    d, nu, A, T, K = 5, 1, 3.0, 12, 8192
+    model = bench.synthetic_state_dict(d, nu, 17).to("cuda")
+
+    def run(opts):
+        p = nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(bench.ENV), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                          u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox", seed=3,
+                          U_init=torch.zeros(T, nu, dtype=torch.float64), planner_options=dict(opts, rollout_variant=2))
+        st, ab = nlc.initial_state(bench.ENV, torch.Generator().manual_seed(0)), torch.zeros(4, nu, dtype=torch.float64)
+        acts = []
+        with torch.no_grad():
+            for _ in range(3):
+                act = p.command(st, ab)
+                acts.append(act.clone())
+                ab = torch.roll(ab, -1, 0)
+                ab[-1] = act
+        return torch.stack(acts), p.ctx.get_stat("gru_gemm"), p.cost_total.cpu().clone()
+
+    a0, s0, c0 = run({})
+    a1, s1, c1 = run({"gru_gemm": 1})
+    assert (s0, s1) == (0, 1)
+    np.testing.assert_allclose(a1.numpy(), a0.numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c1.numpy(), c0.numpy(), rtol=1e-9, atol=1e-9)

@@ -66,3 +66,21 @@ def test_gru_chunked_dataflow(lib, nu, B):
     lib.emu_gru(*[ctypes.c_void_p(a.ctypes.data) for a in keep], 64, nu, B, ctypes.c_void_p(w.ctypes.data),
                 ctypes.c_void_p(out.ctypes.data))
     np.testing.assert_allclose(out, onl.gru_encoder(sd, win).numpy(), rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("nu,B", [(1, 4), (2, 4), (1, 1), (3, 3)])
+def test_gru_int8_sliced_dataflow(lib, nu, B):
+    """csrc/kernels_gru_i8.hip's dataflow on the CPU: the 36-block weight stream of pack_gru_i8_stream (order, digit fragments,
+    recombination factors, biases), the digit cut of the states, the i8 MFMA's operand / accumulator maps as
+    tools/i8gemm_check.hip measured them, merged and level-by-level recombination -- against the oracle's float64 GRU."""
+    sd = onl.make_synthetic_state_dict(2, 4, nu, 128, 17)
+    torch.manual_seed(nu * 10 + B)
+    win = torch.randn(16, B, nu, dtype=torch.float64)
+    pre = "action_encoder.gru."
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1"]
+    keep = [arr(sd[pre + n]) for n in names] + [arr(sd["action_encoder.linear_out.weight"]), arr(sd["action_encoder.linear_out.bias"])]
+    out = np.zeros((16, 2))
+    w = arr(win)
+    lib.emu_gru_i8(*[ctypes.c_void_p(a.ctypes.data) for a in keep], 64, nu, B, ctypes.c_void_p(w.ctypes.data),
+                   ctypes.c_void_p(out.ctypes.data))
+    np.testing.assert_allclose(out, onl.gru_encoder(sd, win).numpy(), rtol=1e-11, atol=1e-13)

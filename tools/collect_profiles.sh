@@ -16,14 +16,14 @@ DEV="$(python -c "import torch;print(torch.cuda.get_device_name(0))" 2>/dev/null
 timeout -k 10 300 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err || exit 1
 echo "bench line done"
 timeout -k 10 120 python bench.py --samples 2048 --no-cpu-baseline --no-ilt > $OUT/${TAG}_bench_line_K2048_experiment.json 2>> $OUT/${TAG}_bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_stdout.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-sliced-encoder > $OUT/${TAG}_bench_stdout.log 2>&1 || exit 1
 echo "kernel stats done"
 PMC_MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-sliced-encoder > /dev/null 2>&1 || exit 1
   echo "pmc $C done"
 done
-timeout -k 10 300 rocprofv3 --pmc $PMC_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2>&1 || echo "mfma counter pass failed (continuing)"
+timeout -k 10 300 rocprofv3 --pmc $PMC_MFMA --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-sliced-encoder > /dev/null 2>&1 || echo "mfma counter pass failed (continuing)"
 python tools/pmc_summarize.py --commit "$COMMIT" --csrc_sha "$SHA" --device "$DEV" $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_mfma > $OUT/${TAG}_pmc_kernels.json
 cp $(ls $OUT/${TAG}_stats/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # cfg5 (de Hoog planner, staged path) and the fused small-shard body: their own PMC summaries

@@ -11,7 +11,7 @@ G3="SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VALU SQ_I
 i=0
 for G in "$G1" "$G2" "$G3"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/${TAG}_wait_g$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ilt > $OUT/${TAG}_wait_g$i.log 2>&1 || echo "group $i failed: $(tail -2 $OUT/${TAG}_wait_g$i.log)"
+  timeout -k 10 300 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/${TAG}_wait_g$i -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ilt --no-other-configs --no-sliced-encoder > $OUT/${TAG}_wait_g$i.log 2>&1 || echo "group $i failed: $(tail -2 $OUT/${TAG}_wait_g$i.log)"
 done
 python - <<PY
 import csv, glob, collections
