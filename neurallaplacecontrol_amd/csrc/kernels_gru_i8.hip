@@ -133,6 +133,8 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
   v4d pre[4];
   auto finish = [&](double* __restrict__ H, int j) {  // gates of the pending chunk j, update of its rows of the state image
     const v4d hold = {H[(4 * j + 0) * 64 + lane], H[(4 * j + 1) * 64 + lane], H[(4 * j + 2) * 64 + lane], H[(4 * j + 3) * 64 + lane]};
+    // (tried: both halves of the gate math side by side, four chains in lockstep behind empty asms -- no change, 2.49 ms: the
+    // partner wave covers the FP64 latency)
     const v4d hn = gru_gates(pre[0], pre[1], pre[2], pre[3], hold);
 #pragma unroll
     for (int r = 0; r < 4; ++r) H[(4 * j + r) * 64 + lane] = hn[r];
@@ -180,7 +182,7 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
           i8::tile_mfma(acc, w, S0);
           if (g == 0 && j > 0) {
             finish(H1, j - 1);
-            i8_mfma_valu_order<8>();
+            i8_mfma_valu_order<2>();
           }
           if (g < 2)  // (reset / update blocks carry the factors of the level-by-level sum)
             nxt[g] = i8::recombine<false>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));
@@ -218,7 +220,7 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
             } else {
               finish(H0, j - 1);
             }
-            i8_mfma_valu_order<8>();
+            i8_mfma_valu_order<2>();
             gptr wp = opaque(a.Wih0p + (size_t)j * 3 * 64);
             in[0] = mfma(wp[lane], xin, splat(0.0));
             in[1] = mfma(wp[64 + lane], xin, splat(0.0));
@@ -252,7 +254,7 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
             } else {
               finish(H1, j - 1);
             }
-            i8_mfma_valu_order<8>();
+            i8_mfma_valu_order<2>();
           }
           if (g == 2) {
             nxt[3] = i8::recombine<true>(acc, i8_read_tile16(tb, 0, q), i8_read_tile16(tb, 1, q));

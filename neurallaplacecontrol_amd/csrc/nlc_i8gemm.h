@@ -55,6 +55,8 @@ __device__ __forceinline__ void fixq(double x, unsigned& lo, unsigned& hi) {
   lo = (unsigned)X ^ 0x80808080u;
   hi = (unsigned)((unsigned long long)X >> 32) ^ 0x00008080u;
 }
+// (tried: the four entries of a chunk stage by stage behind empty asms, as recombine() does -- 2.47 -> 2.76 ms: the slicing sits
+// at the layer boundary, where the extra live values spill)
 
 // 4 x 4 byte transpose: o[i] = (w[0].byte i, w[1].byte i, w[2].byte i, w[3].byte i), eight v_perm_b32
 // (__builtin_amdgcn_perm(a, b, sel): selector values 0-3 take b's bytes, 4-7 take a's)

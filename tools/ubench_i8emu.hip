@@ -190,7 +190,62 @@ double run_phase(int threads) {
   return (double)c[0] / iters;
 }
 
+// ---- one wave per SIMD, MFMAs and independent FP64 FMAs interleaved in program order: 1 MFMA, PER FMAs, ... (what a wave that works
+// on TWO gate tiles in anti-phase would issue: one tile's MFMAs beside the other's recombination / gate math)
+template <int PER>
+__global__ __launch_bounds__(256) void k_mix(double* out, int iters, unsigned long long* clk) {
+  v4i acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = v4i{0, 0, 0, 0};
+  const v4i a = {(int)threadIdx.x * 0x01010101, 0x01020304, 0x7f807f80, (int)threadIdx.x};
+  const v4i b = {0x01010101, (int)threadIdx.x * 0x00010203, 0x10203040, 0x7f7f7f7f};
+  const double da = threadIdx.x * 1e-3, db = 1.0 + threadIdx.x * 1e-6;
+  double f[16];
+  for (int i = 0; i < 16; ++i) f[i] = 1.0 + da + i;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      acc[m & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[m & 7], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < PER; ++r) f[(m * PER + r) & 15] = __builtin_fma(f[(m * PER + r) & 15], db, da);
+    }
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  double s = 0;
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 16; ++i) s += f[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+template <int PER>
+double run_mix() {
+  hipDeviceProp_t p;
+  (void)hipGetDeviceProperties(&p, 0);
+  const int blocks = p.multiProcessorCount, iters = 2000;
+  double* out;
+  unsigned long long* clk;
+  (void)hipMalloc(&out, (size_t)blocks * 256 * 8);
+  (void)hipMalloc(&clk, 64);
+  (void)hipFuncSetAttribute((const void*)k_mix<PER>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  hipLaunchKernelGGL((k_mix<PER>), dim3(blocks), dim3(256), 100 * 1024, 0, out, iters, clk);
+  hipLaunchKernelGGL((k_mix<PER>), dim3(blocks), dim3(256), 100 * 1024, 0, out, iters, clk);
+  (void)hipDeviceSynchronize();
+  unsigned long long c = 0;
+  (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(out);
+  (void)hipFree(clk);
+  return (double)c / iters / 32;
+}
+
 int main() {
+  printf("one wave per SIMD, 1 i8 MFMA + PER independent v_fma_f64 interleaved: ticks per MFMA slot  PER=0 %.1f | 1 %.1f | 2 %.1f | 3 %.1f | 4 %.1f | 5 %.1f | 6 %.1f\n", run_mix<0>(), run_mix<1>(), run_mix<2>(), run_mix<3>(), run_mix<4>(), run_mix<5>(), run_mix<6>());
+
   printf("phases (34 i8 MFMAs, then 128 v_fma_f64), ticks per iteration and wave: one wave per SIMD %.0f | two waves in phase %.0f | two waves, the second starting with its VALU burst %.0f\n",
          run_phase<34, 128, false>(256), run_phase<34, 128, false>(512), run_phase<34, 128, true>(512));
   printf("phases (34 i8 MFMAs, then 64 v_fma_f64): one wave %.0f | two in phase %.0f | two in anti-phase %.0f\n", run_phase<34, 64, false>(256), run_phase<34, 64, false>(512),
