@@ -58,6 +58,10 @@ __device__ __forceinline__ constexpr int i8_next2(int p) { return (p + 2) % 36; 
 // one tile of the stream: hand the staged block on, fetch the block after next, run `body` on the current block, barrier
 template <class F>
 __device__ __forceinline__ void i8_op(WeightStream& ws, int parity, int next2, F body) {
+#if NLC_I8_DBG == 3  // tools only (timing): no staging, no barrier -- every tile reads the first block (wrong results)
+  body((const char*)ws.lds);
+  return;
+#endif
   ws.put(parity ^ 1);
   ws.fetch(next2);
   body((const char*)(ws.lds + parity * kI8Block));
@@ -135,11 +139,18 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
     const v4d hold = {H[(4 * j + 0) * 64 + lane], H[(4 * j + 1) * 64 + lane], H[(4 * j + 2) * 64 + lane], H[(4 * j + 3) * 64 + lane]};
     // (tried: both halves of the gate math side by side, four chains in lockstep behind empty asms -- no change, 2.49 ms: the
     // partner wave covers the FP64 latency)
+#if NLC_I8_DBG == 4  // tools only (timing): no gate math
+    const v4d hn = pre[0] + pre[1] + pre[2] + pre[3] + hold;
+#else
     const v4d hn = gru_gates(pre[0], pre[1], pre[2], pre[3], hold);
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) H[(4 * j + r) * 64 + lane] = hn[r];
   };
   auto digits_of = [&](i8::v4i (&S)[i8::kDigits], const double* __restrict__ H) {  // the whole state, from its image
+#if NLC_I8_DBG == 5  // tools only (timing): no digit cut
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < GT; ++j)
       i8::slice_chunk(S, j, v4d{H[(4 * j + 0) * 64 + lane], H[(4 * j + 1) * 64 + lane], H[(4 * j + 2) * 64 + lane], H[(4 * j + 3) * 64 + lane]});
