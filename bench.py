@@ -896,6 +896,14 @@ def worker(args, result_fd):
         dist.all_gather_object(per_rank, mine)
     mark("ranks_gathered")
 
+    # EXPERIMENTAL, reported beside the headline and never as `value`: the same steps with the encoder's hidden-state GEMMs as
+    # int8-sliced fixed-point products on the INT8 matrix pipe (planner option gru_gemm = 1, csrc/kernels_gru_i8.hip)
+    sliced = None
+    if world == 1 and headline and args.samples is None and not args.no_sliced_encoder:
+        sliced = sliced_encoder_section(nlc, local, args.steps, args.warmup)
+        mark("sliced_encoder_done")
+    # (measured right behind the headline's own steps: the same thermal state, before the long stand-alone sections)
+
     pmc_name, pj = load_pmc()
 
     # ---- stand-alone ILT kernel at N = K*T points (the BASELINE 'ILT GB/s vs HBM peak' figure; headline shape d=5)
@@ -970,12 +978,6 @@ def worker(args, result_fd):
     if world == 1 and headline and args.samples is None and not args.no_other_configs:
         others = other_configs_section(nlc, local)
         mark("other_configs_done")
-    # EXPERIMENTAL, reported beside the headline and never as `value`: the same steps with the encoder's hidden-state GEMMs as
-    # int8-sliced fixed-point products on the INT8 matrix pipe (planner option gru_gemm = 1, csrc/kernels_gru_i8.hip)
-    sliced = None
-    if world == 1 and headline and args.samples is None and not args.no_sliced_encoder:
-        sliced = sliced_encoder_section(nlc, local, args.steps, args.warmup)
-        mark("sliced_encoder_done")
     workload = (f"{env_name} (nx={d}, nu={nu}), K={K_total} MPPI samples sharded over the ranks, H={T}, "
                 f"action_buffer_size={B}, NL dynamics h={HIDDEN} S={S} {algo} ILT")
     workload += f" ({cfg['name']})" if K_total == cfg["K"] else f" -- EXPERIMENT: not {cfg['name']}'s population of {cfg['K']}"
