@@ -1024,12 +1024,12 @@ def worker(args, result_fd):
     return 0
 
 
-def other_configs_section(nlc, local, steps=12, warmup=3):
+def other_configs_section(nlc, local, steps=12, warmup=3, keys=("0", "2", "3", "4", "d4"), planner_options=None):
     """Planning steps/s of BASELINE configs[0], [2], [3], [4] and north_star's literal state_dim = 4 shape, each at its WHOLE
     population on this one GPU (configs[2] / [3] are worded for 2 / 8 GPUs: `--config k --gpus N` shards them): `warmup` + `steps`
     fenced commands after a time-boxed pre-heat (the de Hoog planner measures its chain forms during its first half second)."""
     out = {}
-    for key in ("0", "2", "3", "4", "d4"):
+    for key in keys:
         cfg = CONFIGS[key]
         env_name, T, B, algo, S, K = cfg["env"], cfg["T"], cfg["B"], cfg["algo"], cfg["S"], cfg["K"]
         d, nu, A, _ = ENV_SHAPES[env_name]
@@ -1037,7 +1037,7 @@ def other_configs_section(nlc, local, steps=12, warmup=3):
         planner = nlc.MPPIDelay(
             nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
             compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
-            seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False)
+            seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False, planner_options=planner_options)
         state = nlc.initial_state(env_name, torch.Generator().manual_seed(0))
         ab = torch.zeros(B, nu, dtype=torch.float64)
 
@@ -1132,6 +1132,10 @@ def sliced_encoder_section(nlc, local, steps, warmup):
                     "|w h|, as the FP64 MFMA chain's (tools/i8gemm_check.hip, profiles/r5_i8gemm_check.txt)")
     del planner, model
     torch.cuda.empty_cache()
+    # the option on two more BASELINE configs (short fenced loops as in other_configs): configs[4] (de Hoog, S = 33: the encoder is
+    # 2.99 of its 6.3 ms) and configs[3] (acrobot: two action dims, K = 262144, T = 60)
+    out["other_configs"] = {k: v for k, v in other_configs_section(nlc, local, steps=10, warmup=2, keys=("4", "3"),
+                                                                   planner_options={"gru_gemm": 1}).items()}
     return out
 
 
