@@ -209,7 +209,7 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     // hidden_units = 128: every stand-alone encoder launch; the one-launch planner body keeps its FP64 encoder role)
     if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "gru_gemm must be 0 (FP64 MFMA) or 1 (int8-sliced)");
     c->opt_gru_gemm = (int)value;
-    if (c->has_model) c->gru.use_i8 = (c->g == 64 && value == 1) ? 1 : 0;
+    if (c->has_model) c->gru.use_i8 = (c->gru.i8_stream != nullptr && value == 1) ? 1 : 0;
   } else if (n == "fused_max_samples") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_max_samples must be >= 0");
     c->opt_fused_max_samples = (int64_t)value;

@@ -67,7 +67,11 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   const size_t o_bhn0 = ar.push(bhn0), o_brz1 = ar.push(brz1), o_bin1 = ar.push(bin1), o_bhn1 = ar.push(bhn1);
   // the same hidden-state matrices as the int8 weight stream of kernels_gru_i8.hip (g == 64: one i8 MFMA covers K = 64)
   size_t o_i8 = 0;
-  if (g == 64) {
+  // (fixed point has no NaN / infinity: a model with a non-finite GRU weight or bias keeps the FP64 encoder, which propagates them)
+  bool i8_ok = g == 64;
+  for (int64_t i = 0; i8_ok && i < (int64_t)3 * g * g; ++i) i8_ok = std::isfinite(Whh0[i]) && std::isfinite(Wih1[i]) && std::isfinite(Whh1[i]);
+  for (int i = 0; i8_ok && i < 3 * g; ++i) i8_ok = std::isfinite(bih1[i]) && std::isfinite(bhh1[i]) && std::isfinite(bhh0[i]);
+  if (i8_ok) {
     const std::vector<signed char> st = pack_gru_i8_stream(Whh0, Wih1, Whh1, bhn0.data(), brz1.data(), bin1.data(), bhn1.data(), g);
     std::vector<double> v((st.size() + 7) / 8, 0.0);
     std::memcpy(v.data(), st.data(), st.size());
@@ -153,8 +157,8 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   G.bhn1 = base + o_bhn1;
   G.bo[0] = bo[0];
   G.bo[1] = bo[1];
-  if (g == 64) G.i8_stream = (const signed char*)(base + o_i8);
-  G.use_i8 = (g == 64 && c->opt_gru_gemm == 1) ? 1 : 0;
+  if (i8_ok) G.i8_stream = (const signed char*)(base + o_i8);
+  G.use_i8 = (i8_ok && c->opt_gru_gemm == 1) ? 1 : 0;  // (nlc_get_stat "gru_gemm" tells whether the option took)
 
   NlNetArgs& N = c->net;
   N = NlNetArgs{};
