@@ -67,7 +67,7 @@ extern "C" int nlc_set_model(nlc_ctx* c, const nlc_model_desc* d, const double* 
   const size_t o_bhn0 = ar.push(bhn0), o_brz1 = ar.push(brz1), o_bin1 = ar.push(bin1), o_bhn1 = ar.push(bhn1);
   // the same hidden-state matrices as the int8 weight stream of kernels_gru_i8.hip (g == 64: one i8 MFMA covers K = 64)
   size_t o_i8 = 0;
-  // (fixed point has no NaN / infinity: a model with a non-finite GRU weight or bias keeps the FP64 encoder, which propagates them)
+  // (fixed point has no NaN / infinity, and rint of one is undefined: a model with a non-finite GRU weight or bias keeps the FP64 encoder)
   bool i8_ok = g == 64;
   for (int64_t i = 0; i8_ok && i < (int64_t)3 * g * g; ++i) i8_ok = std::isfinite(Whh0[i]) && std::isfinite(Wih1[i]) && std::isfinite(Whh1[i]);
   for (int i = 0; i8_ok && i < 3 * g; ++i) i8_ok = std::isfinite(bih1[i]) && std::isfinite(bhh1[i]) && std::isfinite(bhh0[i]);
