@@ -99,8 +99,8 @@ int nlc_synchronize(nlc_ctx* ctx);
  *                        the latency -- 1 / 0; -1 = auto (default): up to 50 000 windows at hidden_units 128, 8 192 at 64, always at 256
  *   "gru_gemm"           EXPERIMENTAL.  0 (default): the GRU encoder's hidden-state GEMMs on FP64 MFMAs.  1: the same GEMMs as
  *                        int8-sliced fixed-point products on the INT8 matrix pipe (csrc/kernels_gru_i8.hip, nlc_i8gemm.h; models with
- *                        hidden_units = 128, every stand-alone encode launch; the one-launch planner body keeps its FP64 encoder
- *                        role): GRU states and row-scaled weights as 54-bit fixed point in seven signed 8-bit digits, one
+ *                        hidden_units = 128, the stand-alone encode launches that take the wave-sized form -- more than 50 000
+ *                        windows, or all of them with gru_coop = 0; the one-launch planner body keeps its FP64 encoder role): GRU states and row-scaled weights as 54-bit fixed point in seven signed 8-bit digits, one
  *                        v_mfma_i32_16x16x64_i8 per digit pair, exact integer accumulation, FP64 recombination.  Latents
  *                        agree with the FP64 kernel's to 3e-16; against the exact product either form is within 5 x 2^-53 of
  *                        the row's sum of |w h| (tools/i8gemm_check.hip).  2.5 ms against 3.0 ms for BASELINE configs[1]'s encode

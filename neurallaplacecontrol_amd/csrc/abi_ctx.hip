@@ -206,7 +206,8 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     c->opt_gru_coop = (int)value;
   } else if (n == "gru_gemm") {
     // 0: FP64 MFMAs (default); 1: the encoder's hidden-state GEMMs as int8-sliced fixed-point products (kernels_gru_i8.hip;
-    // hidden_units = 128: every stand-alone encoder launch; the one-launch planner body keeps its FP64 encoder role)
+    // hidden_units = 128: the stand-alone encoder launches that take the wave-sized form; the one-launch planner body keeps its FP64
+    // encoder role)
     if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "gru_gemm must be 0 (FP64 MFMA) or 1 (int8-sliced)");
     c->opt_gru_gemm = (int)value;
     if (c->has_model) c->gru.use_i8 = (c->gru.i8_stream != nullptr && value == 1) ? 1 : 0;

@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256, G <= 64 ? 4 : 2) void gru_encode_coop_kernel(c
 // step chain: two encoder workgroups per CU instead of four leave registers and issue slots for the chain's kernels)
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop, unsigned lds_pad_bytes) {
   if (a.N <= 0) return hipSuccess;
-  // `gru_gemm = 1`: the int8-sliced encoder serves every stand-alone launch of a g = 64 model (a launch that is meant to share
-  // the CUs -- lds_pad_bytes -- stays on the cooperative FP64 form)
-  if (g == 64 && a.use_i8 && lds_pad_bytes == 0) return launch_gru_encode_i8(a, s);
+  // `gru_gemm = 1`: the int8-sliced encoder takes the launches the wave-sized form would get (auto: more than 50 000 windows; below
+  // that the cooperative FP64 form's latency wins -- 0.115 vs 0.133 ms at 20 480 windows, level at 40 960, 0.395 vs 0.329 at 81 920;
+  // `gru_coop = 0` sends every launch here)
+  if (g == 64 && a.use_i8 && !coop) return launch_gru_encode_i8(a, s);
   if (coop) {
     const int64_t tiles = (a.N + 15) / 16;
     const dim3 cgrid((unsigned)(tiles < 65536 ? tiles : 65536));
