@@ -1,5 +1,5 @@
 """The encoder's hidden-state GEMMs on the INT8 matrix pipe (`gru_gemm = 1`, csrc/kernels_gru_i8.hip) against the FP64-MFMA
-encoder: latents on random action windows (against each other and against the torch CPU modules), then the headline planner
+encoder: latents on random action windows, then the headline planner
 (BASELINE configs[1]: K = 16384, T = 40) with either encoder -- ms per command, per-kernel hipEvent averages, and how far the
 actions of the first commands drift apart.
 
@@ -34,20 +34,8 @@ def main():
         ctx.set_option("gru_gemm", 1)
         lat_i8 = model.encode_actions(win.cuda()).cpu()
         ctx.set_option("gru_gemm", 0)
-    ref = None
-    try:
-        import copy
-        m2 = copy.deepcopy(model).cpu()
-        with torch.no_grad():
-            wn = (win - m2.action_mean) / m2.action_std if hasattr(m2, "action_mean") else win
-            ref = m2.action_encoder(wn[:20000])
-    except Exception as e:  # the torch modules are only a second opinion
-        out["torch_reference_error"] = repr(e)
     out["latents"] = dict(windows=a.windows, max_abs_i8_vs_f64=float((lat_i8 - lat_f64).abs().max()),
                           max_abs_latent=float(lat_f64.abs().max()))
-    if ref is not None:
-        out["latents"].update(max_abs_f64_vs_torch_cpu=float((lat_f64[:20000] - ref).abs().max()),
-                              max_abs_i8_vs_torch_cpu=float((lat_i8[:20000] - ref).abs().max()))
     print(json.dumps(out), flush=True)
 
     def planner(opts):
