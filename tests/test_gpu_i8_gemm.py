@@ -115,3 +115,41 @@ def test_non_finite_weights_keep_the_fp64_encoder(nlc):
         assert ctx.get_stat("gru_gemm") == 0
         on = model.encode_actions(win.cuda()).cpu()
     assert torch.equal(torch.nan_to_num(on, nan=7.0), torch.nan_to_num(off, nan=7.0))
+
+
+@pytest.mark.parametrize("env", ["cartpole", "pendulum"])
+def test_sliced_encoder_with_time_channel_vs_reference_golden(nlc, env):
+    """G5b with the int8-sliced encoder: an encode_obs_time model (GRU input nu + 1) -- forward() on explicit windows, and the
+    two-launch planner, whose encode launch builds the harness closure's constant time channel itself (mppi_with_model.py:110-119)
+    -- against the reference's outputs."""
+    from gpu_common import check_command_steps
+
+    g = np.load(f"{GOLD}/g5_nl_obs_time_{env}.npz")
+    sd = load_sd(g)
+    d, nu, K, T, A = int(g["d"]), int(g["nu"]), int(g["K"]), int(g["T"]), float(g["A"])
+    m = nlc.NeuralLaplaceModel(
+        d, nu, d, hidden_units=128, s_recon_terms=17, ilt_algorithm="fourier", encode_obs_time=True,
+        state_mean=np.zeros(d), state_std=np.ones(d), action_mean=np.array([0] * nu), action_std=np.array([1.0]),
+        normalize=True, normalize_time=True,
+    ).double()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    ctx = m.hip_ctx(torch.device("cuda:0"))
+    ctx.set_option("gru_gemm", 1)
+    ctx.set_option("gru_coop", 0)
+    with torch.no_grad():
+        out = m(T64(g["fwd_obs"]).cuda(), T64(g["fwd_window"]).cuda(), T64(g["fwd_ts"]).cuda())
+        np.testing.assert_allclose(out.cpu().numpy(), g["fwd_out"], **TOL)
+        planners = []
+
+        def make(U0):
+            p = nlc.MPPIDelay(
+                nlc.NLDynamics(m, 0.05), nlc.EnvCost("oderl-" + env), d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
+                lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0,
+                planner_options={"gru_gemm": 1, "gru_coop": 0, "rollout_variant": 2},
+            )
+            planners.append(p)
+            return p
+
+        check_command_steps(nlc, g, make)
+        assert planners[0].ctx.get_stat("gru_gemm") == 1 and planners[0].rollout_body != "fused"
