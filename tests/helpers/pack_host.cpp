@@ -315,4 +315,20 @@ void emu_gru_i8(const double* Wih0, const double* Whh0, const double* bih0, cons
   for (int l = 0; l < 64; ++l)
     if ((l >> 4) < 2) out[(l & 15) * 2 + (l >> 4)] = o[l][0] + bo[l >> 4];
 }
+
+// digits of rint(x 2^54) put back together (tests: exactness of the cut, the row exponent of a matrix row)
+void emu_i8_roundtrip(const double* x, int n, double* back, int* top_digit) {
+  for (int k = 0; k < n; ++k) {
+    signed char d[kI8Digits];
+    i8_digits(x[k], d);
+    long long X = 0;
+    for (int i = kI8Digits - 1; i >= 0; --i) X = X * 256 + d[i];
+    back[k] = std::ldexp((double)X, -kI8Frac);
+    top_digit[k] = d[kI8Digits - 1];
+  }
+}
+void emu_i8_row_exponents(const double* W, int rows, int K, int* e) {
+  const auto v = i8_row_exponents(W, rows, K);
+  for (int r = 0; r < rows; ++r) e[r] = v[r];
+}
 }

@@ -84,3 +84,24 @@ def test_gru_int8_sliced_dataflow(lib, nu, B):
     lib.emu_gru_i8(*[ctypes.c_void_p(a.ctypes.data) for a in keep], 64, nu, B, ctypes.c_void_p(w.ctypes.data),
                    ctypes.c_void_p(out.ctypes.data))
     np.testing.assert_allclose(out, onl.gru_encoder(sd, win).numpy(), rtol=1e-11, atol=1e-13)
+
+
+def test_int8_digit_cut_and_row_exponents(lib):
+    """nlc_pack.h: seven signed digits of rint(x 2^54) reassemble to the value rounded at 2^-55 (exactly for values on the grid), the
+    top digit stays inside int8 for |x| <= 1, and a row's exponent is the smallest e with max |w| <= 2^e."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-1, 1, 4000), np.array([0.0, 1.0, -1.0, 0.5, -0.5, 2.0 ** -54, -(2.0 ** -54), 2.0 ** -55 * 1.5, 1 - 2.0 ** -53,
+                                                            -1 + 2.0 ** -53, 2.0 ** -30, 1e-300, 0.999999, 2.0 ** -24 + 2.0 ** -54])])
+    back = np.zeros_like(x)
+    top = np.zeros(len(x), dtype=np.int32)
+    lib.emu_i8_roundtrip(ctypes.c_void_p(x.ctypes.data), len(x), ctypes.c_void_p(back.ctypes.data), ctypes.c_void_p(top.ctypes.data))
+    assert np.all(np.abs(back - x) <= 2.0 ** -55)
+    grid = np.round(x * 2.0 ** 54) / 2.0 ** 54
+    assert np.array_equal(back, grid)
+    assert np.all(np.abs(top) <= 65)
+    W = np.array([[0.0, 0.0, 0.0], [0.3, -0.9, 0.1], [1.0, 0.2, -0.5], [1.0000001, 0.0, 0.0], [2.0 ** -7, -(2.0 ** -9), 0.0], [3e4, 1.0, -2.0]])
+    e = np.zeros(len(W), dtype=np.int32)
+    lib.emu_i8_row_exponents(ctypes.c_void_p(W.ctypes.data), len(W), W.shape[1], ctypes.c_void_p(e.ctypes.data))
+    assert e.tolist() == [0, 0, 0, 1, -7, 15]
+    mx = np.abs(W).max(axis=1)
+    assert np.all(mx <= 2.0 ** e) and np.all((mx == 0) | (mx > 2.0 ** (e - 1.0)))
