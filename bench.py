@@ -713,6 +713,7 @@ def parse_args(argv=None):
                     help="N > 1: ... or no NEW progress marker for this long afterwards (0 = 90 s + 0.25 s per step)")
     # internal / tests
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)  # the measuring child of a supervisor
+    ap.add_argument("--sliced-encoder-child", action="store_true", help=argparse.SUPPRESS)  # the `encoder_int8_sliced` section alone
     ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--test-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)  # this rank's worker sleeps forever ...
     ap.add_argument("--test-hang-attempts", type=int, default=99, help=argparse.SUPPRESS)  # ... in attempts < this
@@ -731,6 +732,17 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.sliced_encoder_child:
+        # the experimental section in a process of its own (worker() starts it): a fault or a hang there cannot take the headline
+        # line with it
+        import neurallaplacecontrol_amd as nlc
+
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(local)
+        with torch.no_grad():
+            out = sliced_encoder_section(nlc, local, args.steps, args.warmup)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        sys.exit(0)
     if args.gpus > 1 and "RANK" not in os.environ:
         # invoked bare (`python bench.py --gpus N`): start the ranks ourselves, as a CHILD process (nothing in this
         # process has touched the GPU yet), relay its one JSON line and exit with its code
@@ -900,7 +912,7 @@ def worker(args, result_fd):
     # int8-sliced fixed-point products on the INT8 matrix pipe (planner option gru_gemm = 1, csrc/kernels_gru_i8.hip)
     sliced = None
     if world == 1 and headline and args.samples is None and not args.no_sliced_encoder:
-        sliced = sliced_encoder_section(nlc, local, args.steps, args.warmup)
+        sliced = sliced_encoder_child(args, local)
         mark("sliced_encoder_done")
     # (measured right behind the headline's own steps: the same thermal state, before the long stand-alone sections)
 
@@ -1068,6 +1080,23 @@ def other_configs_section(nlc, local, steps=12, warmup=3, keys=("0", "2", "3", "
         del planner, model
         torch.cuda.empty_cache()
     return out
+
+
+def sliced_encoder_child(args, local, timeout_s=240):
+    """`encoder_int8_sliced` measured by a CHILD process (same interpreter, `--sliced-encoder-child`), started right behind the
+    headline's steps: the section is experimental, and a fault, an exception or a hang in it must not cost the headline line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--sliced-encoder-child", "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    env = dict(os.environ, LOCAL_RANK=str(local))
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return dict(error=f"the section's process did not finish within {timeout_s} s")
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return dict(error=f"the section's process exited with {res.returncode}", stderr_tail=res.stderr.decode()[-400:])
+    return json.loads(lines[-1])
 
 
 def sliced_encoder_section(nlc, local, steps, warmup):

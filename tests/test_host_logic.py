@@ -328,3 +328,16 @@ def test_bench_quotes_pmc_traffic_only_from_the_library_s_own_sources(monkeypatc
 
     h = g.csrc_sha()
     assert len(h) == 16 and h == g.csrc_sha()
+
+
+def test_bench_sliced_encoder_section_failure_does_not_cost_the_line():
+    """bench.py measures `encoder_int8_sliced` (experimental) in a child process: when that process fails -- here: no GPU -- the
+    section becomes an error record and the caller goes on to print its line."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    args = bench.parse_args(["--steps", "2", "--warmup", "1"])
+    rec = bench.sliced_encoder_child(args, 0, timeout_s=300)
+    assert isinstance(rec, dict) and "error" in rec and "value" not in rec
