@@ -993,6 +993,8 @@ def worker(args, result_fd):
     workload = (f"{env_name} (nx={d}, nu={nu}), K={K_total} MPPI samples sharded over the ranks, H={T}, "
                 f"action_buffer_size={B}, NL dynamics h={HIDDEN} S={S} {algo} ILT")
     workload += f" ({cfg['name']})" if K_total == cfg["K"] else f" -- EXPERIMENT: not {cfg['name']}'s population of {cfg['K']}"
+    if args.planner_opt:
+        workload += f" -- EXPERIMENT: planner options {', '.join(args.planner_opt)}"
     if args.rehearse_on_one_gpu:
         workload += " -- REHEARSAL: every rank on cuda:0 over gloo, not a measurement"
     bi = build_info()
@@ -1011,6 +1013,7 @@ def worker(args, result_fd):
         data="synthetic",
         config=dict(workload=workload, baseline_config=args.config, samples_per_gpu=k_local, noise="device Philox4x32-10",
                     device=info["name"], commit=git_commit(), library_build=bi or None, preheat_ms=args.preheat_ms,
+                    planner_options=(args.planner_opt or None),
                     attempt=args.attempt, native_collective=bool(planner.native_collective),
                     collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
                                                         if planner.native_collective else
