@@ -39,6 +39,7 @@ import os
 import statistics
 import subprocess
 import sys
+import tempfile
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -575,14 +576,17 @@ def worker(args, result_fd):
 
     model = synthetic_state_dict(d, nu, S, env=env_name, algo=algo).to(f"cuda:{local}")
     sd_cpu = {k: v.detach().cpu().to(torch.float64) for k, v in model.state_dict().items()}
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
     planner = nlc.MPPIDelay(
         nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K_total, horizon=T,
         # device="cpu": U and the returned action live on the host, as the harness's env.step needs them (the merge kernel
         # stores the action straight into pinned host memory); every kernel runs on compute_device
         device="cpu", compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A,
         noise_rng="philox", seed=0, process_group=pg, U_init=torch.zeros(T, nu, dtype=torch.float64),
-        # the large configs do not keep the (K, T, nx) rollout (configs[3]: 755 MB per command; tools/configs_bench.py alike)
-        store_rollouts=headline or K_total * T <= 16384 * 40,
+        # every config keeps the (K, T, nx) / (K, T, nu) rollout like the reference (planners/mppi_delay.py:300-301; configs[3]:
+        # 1 GB per command per GPU at N = 1)
+        store_rollouts=True,
         planner_options=dict({} if args.collective == "auto" else {"native_collective": int(args.collective == "native")},
                              **{kv.split("=", 1)[0]: float(kv.split("=", 1)[1]) for kv in args.planner_opt}),
     )
@@ -590,10 +594,12 @@ def worker(args, result_fd):
     abuf = torch.zeros(B, nu, dtype=torch.float64)
     mark("planner_ready")
 
+    last_action = [None]
+
     def step(ab):
         a = planner.command(state, ab)
         ab = torch.roll(ab, -1, dims=0)  # harness get_action (mppi_with_model.py:25-28)
-        ab[-1] = a.cpu()
+        ab[-1] = last_action[0] = a.cpu()
         return ab
 
     def fence():
@@ -611,6 +617,7 @@ def worker(args, result_fd):
         holder[0] = step(holder[0])
 
     one_step()  # the first command configures the planner (and, sharded, is the first collective-bearing call)
+    first_command_ms = (time.perf_counter() - t_first) * 1e3  # construction -> first action on the host (mppi_with_model.py:250-259)
     mark("first_command")
     preheat(one_step, args.preheat_ms, pg, coll_dev)
     abuf = holder[0]
@@ -624,6 +631,7 @@ def worker(args, result_fd):
         abuf = step(abuf)
     fence()
     elapsed_local = elapsed = time.perf_counter() - t0
+    action_after_timed = last_action[0].tolist()  # (tests: a sharded run must return the one-GPU run's action)
     if pg is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -778,6 +786,8 @@ def worker(args, result_fd):
         data="synthetic",
         config=dict(workload=workload, baseline_config=args.config, samples_per_gpu=k_local, noise="device Philox4x32-10",
                     device=info["name"], commit=git_commit(), library_build=bi or None, preheat_ms=args.preheat_ms,
+                    store_rollouts=bool(planner.store_rollouts), first_command_ms=first_command_ms,
+                    last_action=action_after_timed,
                     planner_options=(args.planner_opt or None),
                     attempt=args.attempt, native_collective=bool(planner.native_collective),
                     collective=None if pg is None else ("rccl all-gather inside nlc_mppi_finish (library communicator)"
@@ -804,20 +814,62 @@ def worker(args, result_fd):
     return 0
 
 
+MFMA_KERNELS = ("gru_encode_kernel", "nl_rollout_kernel", "nl_plan_fused_kernel", "nl_repfunc_kernel", "nl_dehoog_chain_kernel")
+
+
+def dominant_kernel_roofline(kernels, d, nu, B, S, nt3, windows):
+    """The matrix kernel that takes the most time per command() in `kernels` (name -> avg_ms / launches / per_command_ms from the
+    library's hipEvent pairs) against the FP64-MFMA peak: the algorithm's flops of ALL its launches of one command (the
+    W_hh h0 = 0 products skipped) over the time they take.  For the other configs' entries and the sliced section."""
+    have = [k for k in MFMA_KERNELS if k in kernels]
+    if not have:
+        return None
+    name = max(have, key=lambda k: kernels[k]["per_command_ms"])
+    gru = flops_gru_needed_per_window(HIDDEN // 2, nu, B) * windows
+    roll = flops_rollout_needed_per_sample_step(HIDDEN, d, S) * windows
+    need = {"gru_encode_kernel": gru, "nl_rollout_kernel": roll, "nl_plan_fused_kernel": gru + roll,
+            # the staged / persistent de Hoog chain: the representation MLP's flops (the ILT sum is not a matrix product there)
+            "nl_repfunc_kernel": roll - 2 * d * S * windows, "nl_dehoog_chain_kernel": roll - 2 * d * S * windows}[name]
+    k = kernels[name]
+    sec = k["per_command_ms"] * 1e-3
+    return dict(bound="mfma", kernel=name, launches_per_command=k["launches_per_command"], avg_launch_ms=k["avg_ms"],
+                per_command_ms=k["per_command_ms"], flops_per_command=need, achieved=need / sec / 1e12, peak=FP64_MFMA_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=need / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS)
+
+
+def profiled_pass(planner, step, ab, steps):
+    """`steps` more commands with the library's per-launch hipEvent pairs on: name -> averages.  Returns (kernels, ab)."""
+    planner.ctx.profile_reset()
+    planner.ctx.profile(True)
+    for _ in range(steps):
+        ab = step(ab)
+    torch.cuda.synchronize()
+    planner.ctx.profile(False)
+    prof = planner.ctx.profile_read()
+    return {k: dict(avg_ms=v["total_ms"] / max(v["launches"], 1), launches=v["launches"], launches_per_command=v["launches"] / max(steps, 1),
+                    per_command_ms=v["total_ms"] / max(steps, 1)) for k, v in prof.items()}, ab
+
+
 def other_configs_section(nlc, local, steps=12, warmup=3, keys=("0", "2", "3", "4", "d4"), planner_options=None):
     """Planning steps/s of BASELINE configs[0], [2], [3], [4] and north_star's literal state_dim = 4 shape, each at its WHOLE
     population on this one GPU (configs[2] / [3] are worded for 2 / 8 GPUs: `--config k --gpus N` shards them): `warmup` + `steps`
-    fenced commands after a time-boxed pre-heat (the de Hoog planner measures its chain forms during its first half second)."""
+    fenced commands after a time-boxed pre-heat (the de Hoog planner measures its chain forms during its first half second).
+    Like the headline -- and like the reference, which always keeps them (planners/mppi_delay.py:300-301) -- every planner here
+    STORES its (K, T, nx) states and (K, T, nu) actions (configs[3]: 1 GB per command); each entry says so, names its dominant
+    kernel's roofline fraction (a second, profiled pass of the same steps) and what the first command costs (`first_command_ms`:
+    planner construction -> first action on the host, i.e. model upload, configuration, workspace and any auto-tuning)."""
     out = {}
     for key in keys:
         cfg = CONFIGS[key]
         env_name, T, B, algo, S, K = cfg["env"], cfg["T"], cfg["B"], cfg["algo"], cfg["S"], cfg["K"]
         d, nu, A, _ = ENV_SHAPES[env_name]
         model = synthetic_state_dict(d, nu, S, env=env_name, algo=algo).to(f"cuda:{local}")
+        torch.cuda.synchronize()
+        t_first = time.perf_counter()
         planner = nlc.MPPIDelay(
             nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
             compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
-            seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False, planner_options=planner_options)
+            seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=True, planner_options=planner_options)
         state = nlc.initial_state(env_name, torch.Generator().manual_seed(0))
         ab = torch.zeros(B, nu, dtype=torch.float64)
 
@@ -827,8 +879,9 @@ def other_configs_section(nlc, local, steps=12, warmup=3, keys=("0", "2", "3", "
             ab[-1] = a.cpu()
             return ab
 
+        ab = step(ab)  # (the action is on the host when command() returns: device="cpu")
+        first_ms = (time.perf_counter() - t_first) * 1e3
         t_end = time.perf_counter() + (0.8 if algo == "dehoog" else 0.1)
-        ab = step(ab)
         while time.perf_counter() < t_end:
             ab = step(ab)
         for _ in range(warmup):
@@ -841,10 +894,14 @@ def other_configs_section(nlc, local, steps=12, warmup=3, keys=("0", "2", "3", "
         el = time.perf_counter() - t0
         windows = K * T
         flops = (flops_gru_needed_per_window(HIDDEN // 2, nu, B) + flops_rollout_needed_per_sample_step(HIDDEN, d, S)) * windows
+        kern, ab = profiled_pass(planner, step, ab, steps)
         out[key] = dict(name=cfg["name"], workload=f"{env_name} (nx={d}, nu={nu}), K={K}, H={T}, action_buffer_size={B}, h={HIDDEN} S={S} {algo}",
                         value=steps / el, unit="planning steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
-                        rollout_body=planner.rollout_body, gpus_the_config_is_worded_for=cfg["gpus"],
-                        roofline_step_frac=flops / (el / steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS)
+                        store_rollouts=True, rollout_body=planner.rollout_body, gpus_the_config_is_worded_for=cfg["gpus"],
+                        first_command_ms=first_ms,
+                        roofline_step_frac=flops / (el / steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                        roofline=dominant_kernel_roofline(kern, d, nu, B, S, int(planner.ctx.get_stat("model_nt3")), windows),
+                        kernels_per_command_ms={k: v["per_command_ms"] for k, v in kern.items()})
         del planner, model
         torch.cuda.empty_cache()
     return out
@@ -857,13 +914,24 @@ def sliced_encoder_child(args, local, timeout_s=240):
     env = dict(os.environ, LOCAL_RANK=str(local))
     for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        return dict(error=f"the section's process did not finish within {timeout_s} s")
-    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
-    if res.returncode != 0 or not lines:
-        return dict(error=f"the section's process exited with {res.returncode}", stderr_tail=res.stderr.decode()[-400:])
+    # polled, with a progress marker every few seconds: under a launcher this worker is itself watched (bench_supervisor.
+    # run_watched allows ~100 s between markers) -- a slow or hung child must cost this section, not the headline line
+    with tempfile.TemporaryFile() as out_f, tempfile.TemporaryFile() as err_f:
+        proc = subprocess.Popen(cmd, stdout=out_f, stderr=err_f, env=env, start_new_session=True)
+        t0 = time.time()
+        while proc.poll() is None and time.time() - t0 < timeout_s:
+            time.sleep(0.5)
+            if int(time.time() - t0) % 5 == 0:
+                mark("sliced_encoder_running")
+        if proc.poll() is None:
+            kill_group(proc)
+            return dict(error=f"the section's process did not finish within {timeout_s} s")
+        out_f.seek(0)
+        err_f.seek(0)
+        stdout, stderr, rc = out_f.read().decode(), err_f.read().decode(errors="replace"), proc.returncode
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    if rc != 0 or not lines:
+        return dict(error=f"the section's process exited with {rc}", stderr_tail=stderr[-400:])
     return json.loads(lines[-1])
 
 
@@ -879,7 +947,7 @@ def sliced_encoder_section(nlc, local, steps, warmup):
     planner = nlc.MPPIDelay(
         nlc.NLDynamics(model, 0.05), nlc.EnvCost(env_name), d, nlc.noise_sigma(nu), num_samples=K, horizon=T, device="cpu",
         compute_device=f"cuda:{local}", lambda_=1.0, u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, noise_rng="philox",
-        seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=False, planner_options={"gru_gemm": 1})
+        seed=0, U_init=torch.zeros(T, nu, dtype=torch.float64), store_rollouts=True, planner_options={"gru_gemm": 1})
     state = nlc.initial_state(env_name, torch.Generator().manual_seed(0))
     ab = torch.zeros(B, nu, dtype=torch.float64)
 

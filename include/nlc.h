@@ -188,6 +188,8 @@ int nlc_set_option(nlc_ctx* ctx, const char* name, double value);
  *   "fused_blocks_per_cu"  resident workgroups per CU the occupancy query returned for the fused kernel (-1 = not queried yet)
  *   "fused_spin_limit"     the option's current value
  *   "gru_gemm"             1 when encode launches run the int8-sliced kernel (option "gru_gemm" = 1 and a hidden_units = 128 model)
+ *   "gru_i8_launches"      launches of the int8-sliced encoder kernel in this PROCESS so far (any ctx): the option alone does not say
+ *                          that a launch took it -- cooperative and fused launches keep their FP64 encoder
  *   "model_nt3"            16-wide output tiles of the representation MLP's last layer as packed by nlc_set_model (the bench's
  *                          issued-flop count needs it), 0 = no model
  * Unknown names: NLC_ERR_BAD_ARG. */

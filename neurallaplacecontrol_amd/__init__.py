@@ -11,6 +11,7 @@ All arithmetic runs in hand-written HIP kernels behind the C ABI of ``libnlc_hip
 (``include/nlc.h``); importing the package does not touch the GPU.  There is no CPU fallback.
 """
 
+from ._lib import set_default_options  # noqa: F401
 from .envs import EnvCost, NLDynamics, OracleDynamics, initial_state, noise_sigma  # noqa: F401
 from .env_loop import BatchedEnv  # noqa: F401
 from .laplace import ilt_reconstruct, laplace_reconstruct, rep_func_inputs  # noqa: F401
@@ -38,4 +39,5 @@ __all__ = [
     "EnvCost",
     "noise_sigma",
     "initial_state",
+    "set_default_options",
 ]

@@ -255,6 +255,22 @@ class NlcError(RuntimeError):
         self.code = code
 
 
+# Options every ctx created from now on starts with (``nlc_set_option`` names; a planner's own ``planner_options`` are applied
+# after them and win).  Set programmatically -- ``neurallaplacecontrol_amd.set_default_options({"gru_gemm": 1})`` turns the
+# int8-sliced encoder on for every planner and model of the process; no environment variable is read.  The GPU suite's
+# ``--nlc-planner-opt`` and its ``encoder_mode`` fixture go through here (tests/conftest.py).
+_DEFAULT_OPTIONS = {}
+
+
+def set_default_options(options=None):
+    """Replace the process-wide default options of new ctxs; returns the previous ones.  ``None`` / ``{}`` clears them."""
+    old = dict(_DEFAULT_OPTIONS)
+    _DEFAULT_OPTIONS.clear()
+    for k, v in (options or {}).items():
+        _DEFAULT_OPTIONS[str(k)] = float(v)
+    return old
+
+
 class Ctx:
     """One ``nlc_ctx`` (= one process x one GPU).  Not thread-safe."""
 
@@ -266,6 +282,8 @@ class Ctx:
             raise NlcError(rc, (self.lib.nlc_last_error(None) or b"").decode())
         self.h = h
         self.device_index = int(device_index)
+        for name, value in _DEFAULT_OPTIONS.items():
+            self.set_option(name, value)
 
     def check(self, rc):
         if rc != 0:

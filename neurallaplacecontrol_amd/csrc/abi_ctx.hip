@@ -100,6 +100,7 @@ extern "C" void nlc_destroy(nlc_ctx* c) {
   nlc_comm_destroy(c);
   prof_flush(c);
   if (c->arena.base) hipFree(c->arena.base);
+  if (c->dbg_scratch) hipFree(c->dbg_scratch);
   if (c->rnn_base) hipFree(c->rnn_base);
   if (c->node_base) hipFree(c->node_base);
   if (c->slot_dev) hipFree(c->slot_dev);
@@ -211,6 +212,12 @@ extern "C" int nlc_set_option(nlc_ctx* c, const char* name, double value) {
     if (value != 0 && value != 1) return fail(c, NLC_ERR_BAD_ARG, "gru_gemm must be 0 (FP64 MFMA) or 1 (int8-sliced)");
     c->opt_gru_gemm = (int)value;
     if (c->has_model) c->gru.use_i8 = (c->gru.i8_stream != nullptr && value == 1) ? 1 : 0;
+  } else if (n == "dbg_gap_us") {
+    if (value < 0 || value > 1.0e5) return fail(c, NLC_ERR_BAD_ARG, "dbg_gap_us must be in 0 .. 1e5");
+    c->opt_dbg_gap_us = value;
+  } else if (n == "dbg_l2_mb") {
+    if (value < 0 || value > 4096) return fail(c, NLC_ERR_BAD_ARG, "dbg_l2_mb must be in 0 .. 4096");
+    c->opt_dbg_l2_mb = value;
   } else if (n == "fused_max_samples") {
     if (value < 0) return fail(c, NLC_ERR_BAD_ARG, "fused_max_samples must be >= 0");
     c->opt_fused_max_samples = (int64_t)value;
@@ -236,6 +243,7 @@ extern "C" int nlc_get_stat(nlc_ctx* c, const char* name, double* out) {
   else if (n == "fused_spin_limit") *out = (double)c->opt_fused_spin_limit;
   else if (n == "model_nt3") *out = c->has_model ? (double)c->net.nt3 : 0.0;
   else if (n == "gru_gemm") *out = (c->has_model && c->gru.use_i8) ? 1.0 : 0.0;  // 1: the encoder launches run kernels_gru_i8.hip
+  else if (n == "gru_i8_launches") *out = (double)nlc::gru_i8_launch_count();  // process-wide
   else return fail(c, NLC_ERR_BAD_ARG, "unknown stat: " + n);
   return NLC_OK;
 }

@@ -8,6 +8,32 @@ using namespace nlc::host;
 
 namespace {
 
+// tools only (options "dbg_gap_us" / "dbg_l2_mb", tools/rollout_giveback.py): what sits between the encoder launch and the rollout
+// launch when the question is what the SECOND kernel inherits from the first -- clocks, cache contents
+__global__ void dbg_spin_kernel(unsigned long long ticks_100mhz) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void dbg_touch_kernel(const double* __restrict__ p, size_t n, double* __restrict__ sink) {
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
+  if (acc == 12345.678) *sink = acc;
+}
+int dbg_between(nlc_ctx* c) {
+  if (c->opt_dbg_gap_us > 0.0) hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, c->stream, (unsigned long long)(c->opt_dbg_gap_us * 100.0));
+  if (c->opt_dbg_l2_mb > 0.0) {
+    const size_t bytes = (size_t)(c->opt_dbg_l2_mb * 1048576.0);
+    if (c->dbg_scratch_bytes < bytes + 8) {
+      if (c->dbg_scratch) hipFree(c->dbg_scratch);
+      NLC_HIP(c, hipMalloc(&c->dbg_scratch, bytes + 8));
+      NLC_HIP(c, hipMemsetAsync(c->dbg_scratch, 0, bytes + 8, c->stream));
+      c->dbg_scratch_bytes = bytes + 8;
+    }
+    hipLaunchKernelGGL(dbg_touch_kernel, dim3(2048), dim3(256), 0, c->stream, c->dbg_scratch, bytes / 8, c->dbg_scratch + bytes / 8);
+  }
+  return NLC_OK;
+}
+
 inline double now_s() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -438,6 +464,8 @@ int rollout_nl_two_launch(nlc_ctx* c, RolloutCall& call, GruArgs& g, RolloutArgs
       ProfScope ps(c, "gru_encode_kernel");
       NLC_HIP(c, launch_gru_encode(g, c->g, c->stream, gru_use_coop(c, g.N)));
     }
+    if (c->opt_dbg_gap_us > 0.0 || c->opt_dbg_l2_mb > 0.0)
+      if (int rc3 = dbg_between(c)) return rc3;
     r.t_begin = 0;
     r.t_end = d.T;
     ProfScope ps(c, "nl_rollout_kernel");

@@ -11,6 +11,8 @@
 // built in registers chunk by chunk as the gates produce it.  The layer-0 input GEMM (K = 4) and linear_out stay FP64 MFMAs.
 // Results differ from the FP64 kernel's at the level of either path's own rounding (tools/i8gemm_check.hip: both within 5 x 2^-53
 // of the row's sum of |w h| of the exact product); tests/test_gpu_i8_gemm.py holds the latents to 1e-12.
+#include <atomic>
+
 #include "nlc_device.h"
 #include "nlc_gru_tile.h"
 #include "nlc_i8gemm.h"
@@ -111,6 +113,10 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
   }
   // digits of the two layers' states, dig[i][c] = digit i of the lane's entries 4 c .. 4 c + 3
   i8::v4i S0[i8::kDigits], S1[i8::kDigits];
+  // Fixed point has no NaN / infinity (i8::fixq yields finite garbage digits): a window with a non-finite entry is remembered
+  // here and its latents leave as NaN -- what the FP64 kernel's arithmetic gives such a window (NaN propagates through every gate)
+  // and what the planner's cost handling expects to see
+  bool bad_input = false;
   auto window_input = [&](int s) {
     // reversed time: GRU step s consumes window element B-1-s  (torch.flip, w_nl.py:27)
     const int j_win = a.B - 1 - s;
@@ -128,6 +134,7 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
           raw = (double)(a.B - 1 - j_win);
       }
       xin = (raw - in_mean) / in_std;
+      bad_input = bad_input || !(xin - xin == 0.0);
     } else if (q == 3) {
       xin = 1.0;
     }
@@ -292,7 +299,12 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
   v4d o[1];
   o[0] = splat(0.0);
   gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return H1[ks * 64 + lane]; });
-  return o[0][0] + a.bo[q < 2 ? q : 0];
+  // the window is column lane & 15; its input dims live in the four lanes q = lane >> 4
+  int bad = bad_input ? 1 : 0;
+  bad |= __shfl_xor(bad, 16);
+  bad |= __shfl_xor(bad, 32);
+  const double res = o[0][0] + a.bo[q < 2 ? q : 0];
+  return bad ? __builtin_nan("") : res;
 }
 
 #ifndef NLC_I8_WAVES  // tools only: 1 = one wavefront per SIMD (512 registers, one workgroup per CU)
@@ -326,8 +338,14 @@ __global__ __launch_bounds__(256, NLC_I8_WAVES) void gru_encode_i8_kernel(const 
   }
 }
 
+// launches of the sliced kernel in this process (nlc_get_stat "gru_i8_launches": the GPU suite checks that a test in the fast mode
+// really ran it -- the option alone does not say so, a cooperative or fused launch keeps its FP64 encoder)
+static std::atomic<unsigned long long> g_i8_launches{0};
+unsigned long long gru_i8_launch_count() { return g_i8_launches.load(); }
+
 hipError_t launch_gru_encode_i8(const GruArgs& a, hipStream_t s) {
   if (a.N <= 0) return hipSuccess;
+  g_i8_launches.fetch_add(1);
   const unsigned grid = (unsigned)((a.N + 63) / 64);
   hipLaunchKernelGGL(gru_encode_i8_kernel, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();

@@ -126,6 +126,11 @@ struct nlc_ctx {
   int64_t commands = 0;                 // nlc_mppi_rollout calls since nlc_create
   int64_t last_giveup_command = -1;     // value of `commands` (0-based) at the last give-up seen by this ctx, -1 = none
   int last_body = 0;                    // body phase 1 of the last command ran on (nlc_get_stat "rollout_body")
+  // tools only (tools/rollout_giveback.py): something BETWEEN the encoder launch and the rollout launch of the two-launch body
+  double opt_dbg_gap_us = 0.0;          // one wavefront spinning on the constant 100 MHz counter for this long (an idle GPU)
+  double opt_dbg_l2_mb = 0.0;           // a read sweep over this many MB of scratch (evicts the L2s)
+  double* dbg_scratch = nullptr;
+  size_t dbg_scratch_bytes = 0;
   int opt_gru_gemm = 0;                 // 1: encoder hidden-state GEMMs on the INT8 matrix pipe (kernels_gru_i8.hip), g == 64 only
   int opt_horizon_chunks = 1;           // Fourier planner, wave-per-tile body (K > 8192): GRU encode of later horizon chunks beside the rollout of earlier ones
   int opt_dehoog_gru_chunks = 0;        // staged de Hoog planner: GRU encode in this many horizon chunks beside the step chain (0 / 1: one launch up front)

@@ -158,6 +158,7 @@ struct GruArgs {
 };
 hipError_t launch_gru_encode(const GruArgs& a, int g, hipStream_t s, bool coop = false, unsigned lds_pad_bytes = 0);
 hipError_t launch_gru_encode_i8(const GruArgs& a, hipStream_t s);
+unsigned long long gru_i8_launch_count();  // process-wide
 
 // ------------------------------------------------------------------ Delta-t RNN baseline (train_utils.py:589-631)
 // One-layer forward GRU over the action window (hidden H) + the hidden part of linear_out: q = W_out[:, :H] h_last.

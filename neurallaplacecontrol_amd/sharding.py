@@ -33,6 +33,16 @@ def gather_partials(partials, gathered, group):
     return gathered
 
 
+def merge_partials_torch(gathered, lambda_):
+    """The shard merge of SURVEY 8e as tensor ops (the planners the HIP kernels are not built for, MPPIDelay._torch_command;
+    merge_kernel does the same on the HIP path): rows (beta_r, eta_r, S_r[t, j]) of every rank -> beta = min beta_r,
+    scale_r = exp(-(beta_r - beta) / lambda), eta = sum scale_r eta_r, S = sum scale_r S_r.  Returns (beta, eta, S)."""
+    beta_r, eta_r, S_r = gathered[:, 0], gathered[:, 1], gathered[:, 2:]
+    beta = beta_r.min()
+    scale = torch.exp(-(beta_r - beta) / lambda_)
+    return beta, (scale * eta_r).sum(), (scale.view(-1, 1) * S_r).sum(dim=0)
+
+
 def slice_noise(raw, k_offset, k_local):
     """Every rank draws the SAME (K, T, nu) tensor from the same seed and keeps its slice, so the sharded
     run consumes the torch generator exactly like the single-GPU / reference run."""

@@ -121,7 +121,7 @@ def test_bench_weights_equal_oracle_synthetic_weights():
 WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from neurallaplacecontrol_amd.sharding import (shard_range, gather_partials, slice_noise, partial_width,
+from neurallaplacecontrol_amd.sharding import (shard_range, gather_partials, slice_noise, partial_width, merge_partials_torch,
                                                replicate_from_rank0, check_same_on_all_ranks, share_bytes_from_rank0)
 from oracle import envs as oenvs, mppi as omppi
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -156,6 +156,10 @@ partials = omppi.shard_partials(out["cost_total"], out["noise"])
 assert partials.numel() == partial_width(T, nu)
 gathered = gather_partials(partials, torch.empty(world, partials.numel(), dtype=torch.float64), dist.group.WORLD)
 beta, eta, dU = omppi.merge_partials(gathered)
+# the product's tensor-op merge (planners the HIP kernels are not built for: MPPIDelay._torch_command) against the oracle's
+b2, e2, S2 = merge_partials_torch(gathered, 1.0)
+assert float(b2) == float(beta) and abs(float(e2) - float(eta)) <= 1e-14 * float(eta)
+assert torch.allclose(S2 / e2, dU, rtol=1e-13, atol=1e-15)
 Ush = torch.roll(U, -1, 0); Ush[-1] = 0
 U_new = Ush + dU.view(T, nu)
 torch.save(dict(U=U_new, beta=beta, eta=eta), os.path.join(sys.argv[2], f"r{rank}.pt"))

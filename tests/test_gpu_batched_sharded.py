@@ -559,6 +559,92 @@ def test_bench_ranks_rehearsed_on_one_gpu(ranks, samples):
     assert rec["config"]["commit"] and rec["config"]["library_build"]["csrc_sha"]
 
 
+def _bench_line(args, timeout=900):
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_config3_shards_rehearsed_on_one_gpu():
+    """BASELINE configs[3] as it is worded -- acrobot, nu = 2, T = 60, 32 768 samples per rank, 122 doubles per
+    rank in the all-gather -- through bench.py's own N > 1 flow.  The GPU pool's process guard allows four ranks on one card (at
+    most six processes beside this one and the launcher), so four of the eight 32 768-sample shards run (`--samples 131072`: the
+    shard SIZE, body and payload of the 8-GPU run); the eight-shard merge itself is test_config3_eight_shards_merge_equals_the_
+    whole_population below.  Same command count on both runs (no time-boxed pre-heat), device Philox noise (G-invariant):
+    the sharded run's action equals the one-GPU whole-population action."""
+    common = ["--config", "3", "--samples", "131072", "--steps", "3", "--warmup", "1", "--preheat-ms", "0", "--no-ilt", "--no-cpu-baseline"]
+    rec = _bench_line(["--gpus", "4", "--rehearse-on-one-gpu"] + common)
+    assert rec["n_gpus"] == 4 and rec["steps"] == 3 and rec["value"] > 0 and rec["config"]["samples_per_gpu"] == 32768
+    assert "acrobot" in rec["config"]["workload"] and "H=60" in rec["config"]["workload"] and rec["config"]["baseline_config"] == "3"
+    seen = rec["config"]["ranks_seen"]
+    assert seen["torch_world"] == 4 and sorted(r["rank"] for r in seen["per_rank"]) == [0, 1, 2, 3]
+    for r in seen["per_rank"]:
+        assert r["rollout_body"] == "wave-per-tile" and r["collective_timing"]["doubles_per_rank"] == 2 + 60 * 2, r
+    one = _bench_line(["--gpus", "1"] + common)
+    assert one["n_gpus"] == 1 and one["config"]["samples_per_gpu"] == 131072
+    np.testing.assert_allclose(rec["config"]["last_action"], one["config"]["last_action"], rtol=0, atol=1e-10)
+
+
+def test_config3_eight_shards_merge_equals_the_whole_population(nlc):
+    """BASELINE configs[3]'s sharding at its own numbers on one GPU, in one process: eight planners each own 32 768 of the
+    262 144 acrobot samples (nu = 2, T = 60, NL dynamics, device Philox noise keyed by the GLOBAL sample index), their eight
+    (beta_r, eta_r, S_r) rows -- 122 doubles each, what the RCCL all-gather carries -- go through nlc_mppi_finish(G = 8) on every
+    shard: action and U equal the one-GPU whole-population planner's to 1e-10 (planners/mppi_delay.py:210-216)."""
+    import ctypes as C
+
+    from neurallaplacecontrol_amd import _lib
+    from oracle import nl_model as onl
+
+    env, K, T, G = "oderl-acrobot", 262144, 60, 8
+    st = onl.ENV_STATS[env]
+    d, nu, A = st["d"], st["nu"], st["act_high"]
+    sd = onl.make_synthetic_state_dict(0, d, nu, 128, 17, st["state_std"], [A / 2], tame=True)
+    model = build_model(nlc, sd)
+    g = torch.Generator().manual_seed(3)
+    U0 = torch.randn(T, nu, dtype=torch.float64, generator=g) * 0.2
+    state = nlc.initial_state(env)
+    ab = (torch.rand(4, nu, dtype=torch.float64, generator=g) * 2 - 1) * A
+
+    def planner():
+        return nlc.MPPIDelay(nlc.NLDynamics(model, 0.05), nlc.EnvCost(env), d, nlc.noise_sigma(nu), K, T, "cpu", lambda_=1.0,
+                             u_min=torch.tensor(-A), u_max=torch.tensor(A), u_scale=A, U_init=U0.clone(), noise_rng="philox", seed=5,
+                             store_rollouts=False)
+
+    full = planner()
+    a_full = full.command(state, ab)
+    U_full, omega_full = full.U.clone(), full.omega.cpu()
+    del full
+    torch.cuda.empty_cache()
+    shards = []
+    for r in range(G):
+        p = planner()
+        p.K_local, p.k_offset = K // G, r * (K // G)  # phase 1 of rank r stand-alone (G = 1 inside); merged by hand below
+        p.command(state, ab)
+        assert p._partials.numel() == 2 + T * nu == 122 and p.rollout_body == "wave-per-tile"
+        shards.append(p)
+    gathered = torch.stack([s._partials for s in shards]).contiguous()
+    U_shift = torch.roll(U0, -1, 0)
+    U_shift[-1] = 0
+    for r, p in enumerate(shards):
+        p.U = U_shift
+        act = torch.empty(nu, dtype=torch.float64)
+        p.ctx.check(p.ctx.lib.nlc_mppi_finish(p.ctx.h, _lib.ptr(gathered), G, r, C.byref(p._buf), _lib.ptr(act)))
+        np.testing.assert_allclose(act.numpy(), a_full.numpy(), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(p.U.numpy(), U_full.numpy(), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(p.omega.cpu().numpy(), omega_full[r * (K // G) : (r + 1) * (K // G)].numpy(), rtol=1e-9, atol=1e-18)
+    del shards
+    torch.cuda.empty_cache()
+
+
 def _independent_planner(idx, K, T, commands, barrier, q, opts):
     """One of the reference's evaluation workers (run_exp_multi.py:145-165): its own process, its own planner, cuda:0."""
     import torch

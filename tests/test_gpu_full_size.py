@@ -15,7 +15,7 @@ from gpu_common import GOLD, TOL, T64, load_sd, build_model
 pytestmark = pytest.mark.gpu
 
 
-def test_full_size_cfg2_properties(nlc):
+def test_full_size_cfg2_properties(nlc, encoder_mode):
     """K=16384, T=40 cartpole, NL dynamics: a sample subset against the oracle + size-independent properties."""
     from oracle import envs as oenvs
     from oracle import mppi as omppi
@@ -56,35 +56,35 @@ def test_full_size_cfg2_properties(nlc):
     np.testing.assert_allclose(action.cpu().numpy(), (U_after[0] * A).numpy(), rtol=1e-10, atol=1e-13)
 
 
-def test_cfg1_cartpole_1024x20(nlc):
+def test_cfg1_cartpole_1024x20(nlc, encoder_mode):
     """BASELINE configs[0] shape: K=1024, H=20 (latency-split rollout kernel)."""
     _subset_check(nlc, "oderl-cartpole", 1024, 20, 4, n_check=128)
 
 
-def test_cfg3_pendulum_shard_32768x40_window5(nlc):
+def test_cfg3_pendulum_shard_32768x40_window5(nlc, encoder_mode):
     """BASELINE configs[2] per-GPU shard: pendulum, 65536/2 samples, H=40, action_buffer_size=5 (delay 4)."""
     _subset_check(nlc, "oderl-pendulum", 32768, 40, 5)
 
 
-def test_cfg4_acrobot_shard_32768x60(nlc):
+def test_cfg4_acrobot_shard_32768x60(nlc, encoder_mode):
     """BASELINE configs[3] per-GPU shard: acrobot (nx=6, nu=2), 262144/8 samples, H=60."""
     _subset_check(nlc, "oderl-acrobot", 32768, 60, 4)
 
 
-def test_cfg4_acrobot_whole_population_262144x60(nlc):
+def test_cfg4_acrobot_whole_population_262144x60(nlc, encoder_mode):
     """BASELINE configs[3] at its WHOLE size on one GPU (the largest population any config names): acrobot, K = 262144,
     H = 60, nu = 2 -- 64 strided samples through the oracle, weights / U / action over all 262144."""
     _subset_check(nlc, "oderl-acrobot", 262144, 60, 4)
     torch.cuda.empty_cache()
 
 
-def test_cfg3_pendulum_whole_population_65536x40(nlc):
+def test_cfg3_pendulum_whole_population_65536x40(nlc, encoder_mode):
     """BASELINE configs[2] at its whole size on one GPU: pendulum, K = 65536, H = 40, 5-row action buffer."""
     _subset_check(nlc, "oderl-pendulum", 65536, 40, 5)
     torch.cuda.empty_cache()
 
 
-def test_full_size_cfg5_dehoog(nlc):
+def test_full_size_cfg5_dehoog(nlc, encoder_mode):
     """BASELINE configs[4] at its own size: cartpole, de Hoog ILT with 33 terms, K = 16384, T = 40, on the staged
     all-HIP path.  64 strided samples through the oracle (mpmath's de Hoog recurrences with IEEE divisions; the kernel
     divides by a refined reciprocal inside the QD table): states after 40 sequential steps and costs must meet the
@@ -287,7 +287,7 @@ def test_tiny_and_ragged_planner_shapes_vs_oracle(nlc, env, K, T, B):
         assert p.U.shape == (T, nu) and p.actions.shape == (K, T, nu)
 
 
-def test_full_size_cfg2_vs_reference_golden_seed_replay(nlc):
+def test_full_size_cfg2_vs_reference_golden_seed_replay(nlc, encoder_mode):
     """G6: BASELINE configs[1] at full size (K=16384, T=40) against the REAL reference MPPIDelay + NeuralLaplaceModel,
     two consecutive commands.  device="cpu" + torch.manual_seed replays the reference's generator stream (ctor U
     draw, one (K, T) draw per command), so the fixture needs no noise tensor."""
@@ -317,7 +317,7 @@ def test_full_size_cfg2_vs_reference_golden_seed_replay(nlc):
 
 
 @pytest.mark.parametrize("tag,env", [("cfg1", "oderl-cartpole"), ("cfg3", "oderl-pendulum"), ("cfg4", "oderl-acrobot")])
-def test_full_size_cfg1_cfg3_cfg4_vs_reference_golden_seed_replay(nlc, tag, env):
+def test_full_size_cfg1_cfg3_cfg4_vs_reference_golden_seed_replay(nlc, tag, env, encoder_mode):
     """G7: BASELINE configs[0] (cartpole, K=1024, T=20), configs[2] (pendulum, K=65536, T=40, 5-row buffer) and configs[3] (acrobot, K=262144, T=60) at
     their FULL population on one GPU against the real reference (seed replay, see G6); cost/omega/states on a strided
     subset plus the population aggregates beta = min cost, eta = sum of weights, sum of costs."""

@@ -153,3 +153,57 @@ def test_sliced_encoder_with_time_channel_vs_reference_golden(nlc, env):
 
         check_command_steps(nlc, g, make)
         assert planners[0].ctx.get_stat("gru_gemm") == 1 and planners[0].rollout_body != "fused"
+
+
+def test_sliced_gemm_adversarial_rows_against_exact_rational_arithmetic(tmp_path):
+    """12 288 outputs of sliced tiles on rows built to break a fixed-point product -- cancelling sums, a 2^+-40
+    spread inside a row (large weights on small states), h = +-1 exactly with |w| on the row scale, every |h| < 2^-54, tiny states
+    among ordinary ones -- against python `fractions` (exact).  The guarantee is absolute: |err| <= 2^-54 (sum |w| + s_m sum |h|) +
+    5 x 2^-53 sum |w h| everywhere, never above 2^-48 of the row scale; for ordinary state magnitudes the FP64 chain's relative
+    bound (5 x 2^-53 sum |w h|) holds too.  (A NaN / infinite window entry is the encoder's business: next test.)"""
+    import sys
+
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import i8_adversarial as adv
+
+    dump = str(tmp_path / "adv.bin")
+    adv.run_dump(dump)
+    table = adv.check(adv.read_dump(dump))
+    assert sum(r["outputs"] for r in table) >= 10000
+    for fam, row in enumerate(table):
+        assert row["outputs"] > 0, row
+        assert row["max_of_bound"] <= 1.0, row
+        assert row["max_abs_err_over_scale"] <= 2.0**-48, row
+        if fam in adv.RELATIVE_FAMILIES:
+            assert row["max_rel_units"] <= 5.0, row
+
+
+def test_sliced_encoder_gives_nan_latents_for_a_non_finite_window(nlc):
+    """fixed point has no NaN / infinity -- a window with a non-finite action must not come back as finite garbage.
+    The sliced encoder marks such a window and returns NaN for both of its latents (what the FP64 kernel's arithmetic yields for
+    a NaN entry); every other window of the launch is untouched."""
+    import oracle.nl_model as onl
+
+    sd = onl.make_synthetic_state_dict(3, 5, 1, 128, 17)
+    model = build_model(nlc, sd)
+    ctx = model.hip_ctx(torch.device("cuda:0"))
+    g = torch.Generator().manual_seed(5)
+    N, B = 4096 + 37, 4
+    win = (torch.rand(N, B, 1, dtype=torch.float64, generator=g) * 2 - 1) * 3.0
+    clean = win.clone()
+    bad = {7: float("nan"), 64: float("inf"), 1000: float("-inf"), N - 1: float("nan")}
+    for i, (w, v) in enumerate(bad.items()):
+        win[w, i % B, 0] = v
+    with torch.no_grad():
+        ctx.set_option("gru_coop", 0)
+        ctx.set_option("gru_gemm", 0)
+        f64 = model.encode_actions(win.cuda()).cpu()
+        ctx.set_option("gru_gemm", 1)
+        i8 = model.encode_actions(win.cuda()).cpu()
+        i8_clean = model.encode_actions(clean.cuda()).cpu()
+    rows = torch.tensor(sorted(bad))
+    assert torch.isnan(i8[rows]).all(), i8[rows]
+    assert torch.isnan(f64[[7, N - 1]]).all(), "the FP64 kernel propagates a NaN entry"
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[rows] = False
+    assert torch.equal(i8[keep], i8_clean[keep]) and torch.isfinite(i8[keep]).all()

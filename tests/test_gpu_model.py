@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
-def test_gru_encoder_vs_reference_golden(nlc, env):
+def test_gru_encoder_vs_reference_golden(nlc, env, encoder_mode):
     """G2: HIP GRU encoder vs the REAL reference ReverseGRUEncoder (nn.GRU) outputs."""
     g = np.load(f"{GOLD}/g2_stages_{env}.npz")
     sd = load_sd(g)
@@ -49,7 +49,7 @@ def test_repfunc_kernel_vs_reference_golden(nlc, env):
 
 
 @pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
-def test_model_forward_vs_golden(nlc, env):
+def test_model_forward_vs_golden(nlc, env, encoder_mode):
     """G3: fused HIP NeuralLaplaceModel.forward vs the reference model (ILT body = build's restatement)."""
     g = np.load(f"{GOLD}/g3_nl_{env}.npz")
     model = build_model(nlc, load_sd(g))
@@ -222,8 +222,9 @@ def test_other_hidden_widths_forward_and_planner(nlc, h, S, algo):
         np.testing.assert_allclose(act.numpy(), ref["action"].numpy(), rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.no_sliced_instance
 @pytest.mark.parametrize("name", ["h64_pendulum", "h256_acrobot"])
-def test_other_hidden_widths_vs_reference_golden(nlc, name):
+def test_other_hidden_widths_vs_reference_golden(nlc, name, encoder_mode):
     """G14: hidden_units 64 (class default with its 33 terms) and 256 against the REAL reference classes: HIP GRU encoder
     (g = 32 / 128) vs nn.GRU, the representation kernel vs the module, model.forward, and two commands of the reference
     planner on every rollout body of the width."""
@@ -346,7 +347,7 @@ def test_model_forward_constant_time_path(nlc):
 
 
 @pytest.mark.parametrize("env", ["cartpole", "pendulum"])
-def test_nl_model_with_time_channel_vs_reference_golden(nlc, env):
+def test_nl_model_with_time_channel_vs_reference_golden(nlc, env, encoder_mode):
     """G5b: encode_obs_time NL model (GRU input nu+1).  forward() on explicit (N, B, nu+1) windows, and the planner with
     the harness closure's constant time channel B-1..0 (mppi_with_model.py:110-119): fused kernel and generic path."""
     g = np.load(f"{GOLD}/g5_nl_obs_time_{env}.npz")

@@ -33,7 +33,7 @@ def test_mppi_oracle_dynamics_vs_reference_golden(nlc, path):
 
 
 @pytest.mark.parametrize("env", ["cartpole", "pendulum", "acrobot"])
-def test_mppi_nl_dynamics_vs_reference_golden(nlc, env):
+def test_mppi_nl_dynamics_vs_reference_golden(nlc, env, encoder_mode):
     """G3: command() with Neural-Laplace dynamics vs reference MPPIDelay + reference model."""
     g = np.load(f"{GOLD}/g3_nl_{env}.npz")
     model = build_model(nlc, load_sd(g))
@@ -616,3 +616,54 @@ def test_refresh_model_picks_up_a_write_through_data(nlc):
     a_new = p.command(state, ab).clone()
     fresh = make().command(state, ab)
     assert torch.equal(a_new, fresh) and not torch.equal(a_new, a0)
+
+
+def _toy_dynamics_and_cost(nx, nu, dtype):
+    """A smooth nonlinear system with nu action dims and a delay window (the reference's contract: dynamics(state, window),
+    running_cost(state, u), planners/mppi_delay.py:271-296) -- plain tensor ops, the same code for the oracle and the planner."""
+    g = torch.Generator().manual_seed(5)
+    Wx = (torch.randn(nx, nx, generator=g, dtype=torch.float64) * 0.3).to(dtype)
+    Wu = (torch.randn(nu, nx, generator=g, dtype=torch.float64) * 0.5).to(dtype)
+
+    def dynamics(state, window):
+        u = 0.7 * window[:, -1, :] + 0.3 * window[:, 0, :]
+        return state + 0.05 * (torch.tanh(state @ Wx.to(state.device)) + u @ Wu.to(state.device))
+
+    def cost(state, u):
+        return (state**2).sum(dim=1) + 0.01 * (u**2).sum(dim=1)
+
+    return dynamics, cost
+
+
+@pytest.mark.parametrize("dtype,nu,tol", [(torch.float64, 3, 1e-9), (torch.float64, 5, 1e-9), (torch.float32, 1, 1e-4), (torch.float32, 3, 1e-4)])
+def test_planner_limits_are_paths_nu_above_two_and_float32(nlc, dtype, nu, tol):
+    """the reference class takes any nu and dtype (planners/mppi_delay.py:115-135); the drop-in constructor
+    must not throw where the HIP planner kernels are not built (nu > 2, a float32 noise_sigma): it plans with tensor ops on the
+    GPU and says so once.  Seeded like the reference (ctor draw, command draws), against the oracle class."""
+    from oracle import mppi as omppi
+
+    nx, K, T, B, A = 4, 256, 12, 4, 2.0
+    dyn, cost = _toy_dynamics_and_cost(nx, nu, dtype)
+    sig = nlc.noise_sigma(nu).to(dtype) if nu > 1 else torch.tensor(1.0, dtype=dtype)
+    state = torch.linspace(-0.5, 0.5, nx, dtype=dtype)
+    ab = (torch.arange(B * nu, dtype=dtype).view(B, nu) * 0.05) - 0.1
+    torch.manual_seed(11)
+    ref = omppi.MPPIOracle(dyn, cost, nx, sig, K, T, 1.0, torch.tensor(-A, dtype=dtype), torch.tensor(A, dtype=dtype), A)
+    ref_actions = [ref.command(state, ab).clone() for _ in range(3)]
+    torch.manual_seed(11)
+    with pytest.warns(UserWarning, match="PyTorch-ROCm tensor ops"):
+        mine = nlc.MPPIDelay(dyn, cost, nx, sig, K, T, "cpu", lambda_=1.0, u_min=torch.tensor(-A, dtype=dtype),
+                             u_max=torch.tensor(A, dtype=dtype), u_scale=A)
+    assert mine.torch_path and mine.rollout_body is None
+    for a_ref in ref_actions:
+        a = mine.command(state, ab)
+        assert a.dtype == dtype and a.shape == (nu,)
+        np.testing.assert_allclose(a.double().numpy(), a_ref.double().numpy(), rtol=tol, atol=tol)
+    assert mine.rollout_body == "callables-torch" and mine._states.is_cuda
+    last = ref.last
+    np.testing.assert_allclose(mine.cost_total.double().numpy(), last["cost_total"].double().numpy(), rtol=tol * 10, atol=tol * 10)
+    np.testing.assert_allclose(mine.states.double().numpy(), last["states"].double().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(mine.omega.double().numpy(), last["omega"].double().numpy(), rtol=tol * 10, atol=tol)
+    np.testing.assert_allclose(mine.U.double().numpy(), ref.U.double().numpy(), rtol=tol, atol=tol)
+    mine.reset()
+    assert mine.U.shape == (T, nu) and mine.U.dtype == dtype

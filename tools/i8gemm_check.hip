@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -73,7 +74,97 @@ __global__ void k_gemm(const signed char* wfrag, const double* rowfac /*16, tile
     }                                                                          \
   } while (0)
 
-int main() {
+// ---------------------------------------------------------------------------------------------------------------------------
+// --adversarial FILE: sliced GEMM tiles on rows built to break a fixed-point product, dumped for tests/test_gpu_i8_gemm.py, which
+// checks every output against EXACT rational arithmetic (python fractions).  Record per tile: int32 family, 16 x 64 W (rows of the
+// tile), 16 row scales s_m = 2^e, 64 x 16 h ([k][column]), 16 x 16 outputs with merged levels, 16 x 16 level by level (row-major
+// [row][column]).  Families:
+//   0 cancelling rows (sum w h ~ 0, sum |w h| large)      1 a 2^+-40 spread of |w| and of |h| inside a row, large against small
+//   2 h = +-1 exactly, |w| up to the row scale exactly     3 every |h| < 2^-54 (quantised to zero)   4 a few tiny h among ordinary ones
+//   5 ordinary random draws (the control)
+static int run_adversarial(const char* path) {
+  std::mt19937_64 rng(2026);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  const int G = 64, per_family = 8, families = 6;
+  FILE* f = fopen(path, "wb");
+  if (!f) return 2;
+  const int n_tiles = per_family * families;
+  fwrite(&n_tiles, 4, 1, f);
+  signed char* dw;
+  double *drf, *dh, *dout;
+  CK(hipMalloc(&dw, 7 * 64 * 16));
+  CK(hipMalloc(&drf, 16 * 8));
+  CK(hipMalloc(&dh, 64 * 16 * 8));
+  CK(hipMalloc(&dout, 64 * 4 * 8));
+  for (int fam = 0; fam < families; ++fam)
+    for (int t = 0; t < per_family; ++t) {
+      std::vector<double> W((size_t)3 * G * G), h(64 * 16);
+      for (auto& v : W) v = U(rng);
+      for (auto& v : h) v = U(rng);
+      const double span = std::ldexp(1.0, (int)(rng() % 7) - 3);  // row scales 2^-3 .. 2^3
+      for (int row = 0; row < 16; ++row)
+        for (int k = 0; k < G; ++k) W[(size_t)row * G + k] *= span;
+      if (fam == 0) {
+        // pairs (2 i, 2 i + 1) whose products cancel to the last bits: h_(2i+1) = -(w_2i h_2i) / w_(2i+1), for ONE row per column
+        for (int n = 0; n < 16; ++n) {
+          const int row = n;
+          for (int i = 0; i < G / 2; ++i) {
+            double &w0 = W[(size_t)row * G + 2 * i], &w1 = W[(size_t)row * G + 2 * i + 1];
+            if (std::fabs(w1) < std::fabs(w0)) std::swap(w0, w1);
+            if (w1 == 0.0) w1 = span;
+            h[(2 * i + 1) * 16 + n] = -(w0 * h[(2 * i) * 16 + n]) / w1;
+          }
+        }
+      } else if (fam == 1) {
+        for (int row = 0; row < 16; ++row)
+          for (int k = 0; k < G; ++k) {
+            const bool big = ((k + row) % 2) == 0;
+            W[(size_t)row * G + k] = std::ldexp(W[(size_t)row * G + k], big ? 0 : -40 + (int)(rng() % 9));
+          }
+        for (int k = 0; k < G; ++k)
+          for (int n = 0; n < 16; ++n) {
+            const bool big_w = ((k + n) % 2) == 0;  // row n: large weights meet small states and the other way round
+            h[k * 16 + n] = std::ldexp(h[k * 16 + n], big_w ? -40 + (int)(rng() % 9) : 0);
+          }
+      } else if (fam == 2) {
+        for (auto& v : h) v = (rng() & 1) ? 1.0 : -1.0;
+        for (int row = 0; row < 16; ++row)
+          for (int k = 0; k < G; k += 5) W[(size_t)row * G + k] = ((rng() & 1) ? 1.0 : -1.0) * span;  // |w| = 2^e exactly
+      } else if (fam == 3) {
+        for (auto& v : h) v = std::ldexp(v, -55 - (int)(rng() % 40));
+        if (t == 0) h[5] = 0x1p-1074;
+      } else if (fam == 4) {
+        for (size_t i = 0; i < h.size(); i += 3) h[i] = std::ldexp(h[i], -55 - (int)(rng() % 900));
+      }
+      const auto rexp = i8_row_exponents(W.data(), 3 * G, G);
+      const auto frag = pack_gru_i8(W.data(), G, rexp);
+      const auto rf = i8_row_factors(rexp);
+      CK(hipMemcpy(dw, frag.data(), 7 * 64 * 16, hipMemcpyHostToDevice));
+      CK(hipMemcpy(drf, rf.data(), 16 * 8, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dh, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+      fwrite(&fam, 4, 1, f);
+      fwrite(W.data(), 8, 16 * G, f);
+      double scale[16];
+      for (int r = 0; r < 16; ++r) scale[r] = std::ldexp(1.0, rexp[r]);
+      fwrite(scale, 8, 16, f);
+      fwrite(h.data(), 8, h.size(), f);
+      for (int merge = 1; merge >= 0; --merge) {
+        if (merge) hipLaunchKernelGGL(k_gemm<true>, dim3(1), dim3(64), 0, 0, dw, drf, dh, dout);
+        else hipLaunchKernelGGL(k_gemm<false>, dim3(1), dim3(64), 0, 0, dw, drf, dh, dout);
+        std::vector<double> out(64 * 4), tile(256);
+        CK(hipMemcpy(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost));
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) tile[(4 * r + (lane >> 4)) * 16 + (lane & 15)] = out[lane * 4 + r];
+        fwrite(tile.data(), 8, 256, f);
+      }
+    }
+  fclose(f);
+  printf("adversarial tiles: %d written to %s\n", n_tiles, path);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 2 && std::strcmp(argv[1], "--adversarial") == 0) return run_adversarial(argv[2]);
   std::mt19937_64 rng(7);
   std::uniform_real_distribution<double> U(-1.0, 1.0);
   int bad = 0;
