@@ -114,8 +114,7 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
   // digits of the two layers' states, dig[i][c] = digit i of the lane's entries 4 c .. 4 c + 3
   i8::v4i S0[i8::kDigits], S1[i8::kDigits];
   // Fixed point has no NaN / infinity (i8::fixq yields finite garbage digits): a window with a non-finite entry is remembered
-  // here and its latents leave as NaN -- what the FP64 kernel's arithmetic gives such a window (NaN propagates through every gate)
-  // and what the planner's cost handling expects to see
+  // here and its latents leave as NaN -- as in the FP64 kernels (nlc_gru_tile.h) and as nn.GRU gives it
   bool bad_input = false;
   auto window_input = [&](int s) {
     // reversed time: GRU step s consumes window element B-1-s  (torch.flip, w_nl.py:27)
@@ -299,12 +298,7 @@ __device__ __forceinline__ double gru_encode_tile_i8(const GruArgs& a, WeightStr
   v4d o[1];
   o[0] = splat(0.0);
   gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return H1[ks * 64 + lane]; });
-  // the window is column lane & 15; its input dims live in the four lanes q = lane >> 4
-  int bad = bad_input ? 1 : 0;
-  bad |= __shfl_xor(bad, 16);
-  bad |= __shfl_xor(bad, 32);
-  const double res = o[0][0] + a.bo[q < 2 ? q : 0];
-  return bad ? __builtin_nan("") : res;
+  return nan_if_bad_window(bad_input, o[0][0] + a.bo[q < 2 ? q : 0]);
 }
 
 #ifndef NLC_I8_WAVES  // tools only: 1 = one wavefront per SIMD (512 registers, one workgroup per CU)

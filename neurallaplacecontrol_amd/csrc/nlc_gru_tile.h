@@ -119,6 +119,14 @@ __device__ __forceinline__ v2d tanh2(v2d x) {
   return __builtin_elementwise_copysign(t, x);
 }
 
+// the window is column lane & 15 of the tile; its input dims live in the four lanes q = lane >> 4
+__device__ __forceinline__ double nan_if_bad_window(bool bad_input, double value) {
+  int bad = bad_input ? 1 : 0;
+  bad |= __shfl_xor(bad, 16);
+  bad |= __shfl_xor(bad, 32);
+  return bad ? __builtin_nan("") : value;
+}
+
 __device__ __forceinline__ v4d gru_gates(const v4d& ar, const v4d& az, const v4d& ain, const v4d& ahn, const v4d& hold) {
   v4d hnew;
 #pragma unroll
@@ -160,6 +168,9 @@ __device__ __forceinline__ double gru_encode_tile(const GruArgs& a, int lane, in
     H1[ks * 64 + lane] = 0.0;
   }
   v4d hn[GT];
+  // A non-finite window entry must leave as NaN latents, as nn.GRU's arithmetic gives it (the reference, w_nl.py:14-29): the
+  // gate math here clamps with v_min / v_max, which swallow a NaN -- so the window is remembered and its outputs are replaced
+  bool bad_input = false;
 
   for (int s = 0; s < a.B; ++s) {
     // reversed time: GRU step s consumes window element B-1-s  (torch.flip, w_nl.py:27)
@@ -178,6 +189,7 @@ __device__ __forceinline__ double gru_encode_tile(const GruArgs& a, int lane, in
           raw = (double)(a.B - 1 - j_win);  // encode_obs_time model: the harness's constant time channel
       }
       xin = (raw - in_mean) / in_std;
+      bad_input = bad_input || !(xin - xin == 0.0);
     } else if (q == 3) {
       xin = 1.0;  // bias column of the packed W_ih0
     }
@@ -220,7 +232,7 @@ __device__ __forceinline__ double gru_encode_tile(const GruArgs& a, int lane, in
   v4d o[1];
   o[0] = splat(0.0);
   gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return H1[ks * 64 + lane]; });
-  return o[0][0] + a.bo[q < 2 ? q : 0];
+  return nan_if_bad_window(bad_input, o[0][0] + a.bo[q < 2 ? q : 0]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -279,6 +291,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
     }
   }
   __syncthreads();
+  bool bad_input = false;  // (see gru_encode_tile)
   for (int s = 0; s < a.B; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
     double* H0c = Hc + cur * IMG;
@@ -290,6 +303,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
     if (q < a.nin) {
       const double raw = xs.raw(a, wc, kk, tt, j_win, q, lane & 15, ab_off);
       xin = (raw - in_mean) / in_std;
+      bad_input = bad_input || !(xin - xin == 0.0);
     } else if (q == 3) {
       xin = 1.0;
     }
@@ -342,7 +356,7 @@ __device__ __forceinline__ double gru_encode_tile_coop(const GruArgs& a, int lan
     gemm_acc<1, KS>(o, a.Wop, lane, [&](int ks) { return Hl[ks * 64 + lane]; });
     out = o[0][0] + a.bo[q < 2 ? q : 0];
   }
-  return out;
+  return nan_if_bad_window(bad_input, out);  // (every wave sees the same window inputs; wave 0's value is the one stored)
 }
 
 }  // namespace nlc

@@ -179,9 +179,10 @@ def test_sliced_gemm_adversarial_rows_against_exact_rational_arithmetic(tmp_path
 
 
 def test_sliced_encoder_gives_nan_latents_for_a_non_finite_window(nlc):
-    """fixed point has no NaN / infinity -- a window with a non-finite action must not come back as finite garbage.
-    The sliced encoder marks such a window and returns NaN for both of its latents (what the FP64 kernel's arithmetic yields for
-    a NaN entry); every other window of the launch is untouched."""
+    """fixed point has no NaN / infinity -- a window with a non-finite action must not come back as finite garbage (and
+    the FP64 kernels' v_min / v_max clamps used to swallow a NaN too).  Every encoder form -- sliced, FP64 wave-sized, FP64
+    cooperative -- marks such a window and returns NaN for both of its latents, as nn.GRU does for a NaN entry (w_nl.py:14-29);
+    every other window of the launch is untouched."""
     import oracle.nl_model as onl
 
     sd = onl.make_synthetic_state_dict(3, 5, 1, 128, 17)
@@ -198,12 +199,18 @@ def test_sliced_encoder_gives_nan_latents_for_a_non_finite_window(nlc):
         ctx.set_option("gru_coop", 0)
         ctx.set_option("gru_gemm", 0)
         f64 = model.encode_actions(win.cuda()).cpu()
+        f64_clean = model.encode_actions(clean.cuda()).cpu()
+        ctx.set_option("gru_coop", 1)
+        coop = model.encode_actions(win.cuda()).cpu()
+        ctx.set_option("gru_coop", 0)
         ctx.set_option("gru_gemm", 1)
         i8 = model.encode_actions(win.cuda()).cpu()
         i8_clean = model.encode_actions(clean.cuda()).cpu()
     rows = torch.tensor(sorted(bad))
-    assert torch.isnan(i8[rows]).all(), i8[rows]
-    assert torch.isnan(f64[[7, N - 1]]).all(), "the FP64 kernel propagates a NaN entry"
     keep = torch.ones(N, dtype=torch.bool)
     keep[rows] = False
-    assert torch.equal(i8[keep], i8_clean[keep]) and torch.isfinite(i8[keep]).all()
+    for got, ref in ((i8, i8_clean), (f64, f64_clean), (coop, f64_clean)):
+        assert torch.isnan(got[rows]).all(), got[rows]
+        assert torch.equal(got[keep], ref[keep]) and torch.isfinite(got[keep]).all()
+    want = onl.gru_encoder(sd, (win[rows] - sd["action_mean"]) / sd["action_std"])  # the torch modules (= the reference's op sequence)
+    assert torch.isnan(want[[0, 3]]).all(), "nn.GRU propagates a NaN entry"
