@@ -9,6 +9,7 @@
 //   ilt_dehoog_kernel   same map, de Hoog-Knight-Stokes quotient-difference acceleration
 //                       (mpmath inverselaplace.py:476-531); O(M^2) complex ops per (point, dim) -> FP64
 //                       VALU bound, not HBM bound.
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 
@@ -411,11 +412,270 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
   }
 }
 
+// ------------------------------------------------------------------ Fourier series, one LANE per row (round 6)
+// The kernel above gives a lane ONE term of a row and pays for it: a value parked in LDS per term, two workgroup barriers and a
+// row-sum phase per tile, 64-bit address arithmetic per load, per-lane phase constants -- 57 + 5 FP64 / integer instructions per
+// 16-byte (theta, phi) pair, and its arithmetic-only time (0.17 ms at N = 655 360) sits ABOVE its memory-only time (0.154 ms).
+// Here a lane owns a whole ROW (one (point, dim): S terms) and a wavefront a tile of 64 consecutive rows = 64 S consecutive doubles
+// of theta and of phi.  The tile lands in the wavefront's private LDS region by DIRECT global -> LDS loads
+// (global_load_lds_dwordx4: 16 B per lane, 1 KB per instruction, no VGPR, no address arithmetic beyond the tile base), is read
+// back row-wise (stride S doubles, S odd: conflict-free ds_read_b64) and summed in a register: no barrier of any kind (a
+// wavefront only waits for its own loads), no LDS writes by the ALU, the term index -- so the quarter turn i^k of the phase and
+// the sign of the weight -- a compile-time constant, the tangent as one rational (m::tan_parts_rat): ~38 instructions per pair.
+// Eight wavefronts per CU (2 x 34 KB regions per workgroup of four at S = 17), each with a whole tile in flight while its SIMD
+// partner computes.  Instances: S = 17 and S = 33 (the reference's default and its de Hoog ablation's term count) with scale = 2
+// (torchlaplace's default: e^{i pi k t / T} = i^k); anything else -- other term counts, another scale, the linear algorithms,
+// unaligned inputs -- keeps ilt_fourier_kernel.
+template <int S, class LD>
+__device__ __forceinline__ double ilt_row_sum(const m::IltRowK& K, LD ld) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < S; ++k) {
+    double th, ph;
+    ld(k, &th, &ph);
+    // tan(phi/2 + pi/4): the argument rounded as the reference rounds it (w_nl.py: tan of the SUM), then a = x - pi/4
+    const double x = fma(ph, 0.5, kPi / 4.0);
+    const double a = (x - K.pio4_hi) - K.pio4_lo;
+    double num, den;
+    m::tan_parts_rat(K, a, &num, &den);
+    // Re(F_k i^k) = |F_k| cos(theta + k pi/2): k & 1 picks the polynomial, ((k + 1) >> 1) & 1 the sign; w_0 = 1/2
+    const double cs = (k & 1) ? m::cos_or_sin_reduced<1>(K, th) : m::cos_or_sin_reduced<0>(K, th);
+    const bool neg = (((k + 1) >> 1) & 1) != 0;
+    const double nc = (k == 0 ? 0.5 * num : num) * cs;
+    const double r = m::rcp_refined(den);
+    acc = fma(neg ? -nc : nc, r, acc);
+  }
+  return acc;
+}
+__device__ __forceinline__ m::IltRowK ilt_row_k_sgpr() {
+  m::IltRowK K = m::ilt_row_k();
+#define NLC_PIN(x) asm volatile("" : "+s"(x))
+#define NLC_PINV(x) asm volatile("" : "+v"(x))
+  // (an FP64 VALU instruction reads at most one scalar operand: the leading coefficient of a Horner chain meets a second
+  // constant in its first step and stays in a VGPR)
+  NLC_PINV(K.pn[0]);
+  NLC_PINV(K.c2[0]);
+  NLC_PINV(K.s2[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) NLC_PIN(K.qn[i]);
+#pragma unroll
+  for (int i = 1; i < 3; ++i) NLC_PIN(K.pn[i]);
+#pragma unroll
+  for (int i = 1; i < 8; ++i) NLC_PIN(K.c2[i]);
+#pragma unroll
+  for (int i = 1; i < 8; ++i) NLC_PIN(K.s2[i]);
+  NLC_PIN(K.pio4_hi);
+  NLC_PIN(K.pio4_lo);
+  NLC_PIN(K.pi_hi);
+  NLC_PIN(K.pi_lo);
+  NLC_PIN(K.inv_pi);
+  NLC_PIN(K.round_shift);
+#undef NLC_PIN
+#undef NLC_PINV
+  return K;
+}
+
+// The tile loads and the counted waits are written out: the loop keeps BOTH arrays' next tiles in flight while it computes
+// (theta of tile n + 1 is requested the moment theta of tile n has been read out of LDS, phi likewise), which needs
+// s_waitcnt vmcnt(N) with N = the loads issued behind the awaited ones -- the compiler's own bookkeeping answers an LDS read
+// behind an LDS-DMA load with vmcnt(0).  Nothing else in the loop is a vector-memory load the compiler counts (the row's t
+// rides in the same hand-counted queue); the store of x needs no wait.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void ilt_lds_load16(const void* g, unsigned lds_addr) {  // 64 lanes x 16 B -> LDS [lds_addr, + 1 KB)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int TILE>
+__device__ __forceinline__ void ilt_lds_load_tile(const char* g_lane, unsigned lds_addr, int lane) {
+  constexpr int NLD = TILE / 1024, REM = TILE % 1024;  // whole-wave 16-byte loads + the lanes of the last one
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) ilt_lds_load16(g_lane + i * 1024, lds_addr + i * 1024);
+  if (REM != 0) {
+    // (every lane issues: the lanes past the tile re-read its last 16 bytes into the pad behind it -- a masked load would sit in
+    // a divergent region and change the number of outstanding loads per lane group)
+    const char* g = (lane < REM / 16) ? g_lane + NLD * 1024 : g_lane + NLD * 1024 - (lane - (REM / 16 - 1)) * 16;
+    ilt_lds_load16(g, lds_addr + NLD * 1024);
+  }
+}
+
+// DBG (tools build only): 1 = loads + the plain sum of what they brought (memory only), 2 = arithmetic on run-time values, no loads
+template <int S, int DBG>
+__global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(const IltArgs a) {
+  static_assert(S % 2 == 1, "row stride S doubles must be odd: conflict-free row-wise reads, 16-byte tile sizes");
+  extern __shared__ __attribute__((aligned(16))) char rows_lds[];
+  constexpr int TILE = 64 * S * 8;                          // bytes of one array's tile
+  constexpr int SLOT = (TILE + 1023) / 1024 * 1024;        // its LDS slot: the last (half) load writes a full KB
+  constexpr int LPT = SLOT / 1024;                          // loads per tile and array
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: scalar loop, scalar M0)
+  char* lt = rows_lds + wave * (2 * SLOT);
+  char* lp = lt + SLOT;
+  const unsigned lt_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lt;
+  const unsigned lp_addr = lt_addr + SLOT;
+  const double* lrow_t = (const double*)lt + lane * S;
+  const double* lrow_p = (const double*)lp + lane * S;
+  const m::IltRowK K = ilt_row_k_sgpr();
+  const int64_t rows_total = a.N * a.d;
+  const int64_t nfull = rows_total / 64;
+  const int64_t W = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+  // the row's point index n = row / d, kept incrementally: row advances by 64 W per tile
+  const unsigned d = (unsigned)a.d;
+  const int64_t step = 64 * W;
+  const int64_t step_n = step / d;
+  const unsigned step_r = (unsigned)(step - step_n * d);
+  int64_t row = w0 * 64 + lane;
+  int64_t n = row / d;
+  unsigned rem = (unsigned)(row - n * d);
+  double t_prev = __builtin_nan(""), sc = 0.0;  // the row scale e^{gamma t}/T is rebuilt only when the row's t changes
+
+  if (DBG == 2) {
+    for (int64_t tile = w0; tile < nfull; tile += W) {
+      const double acc = ilt_row_sum<S>(K, [&](int k, double* th, double* ph) {
+        *th = a.alpha * (double)(lane + k) + (double)tile * 1e-7;
+        *ph = a.alpha * (double)(lane + 3 * k);
+      });
+      __builtin_nontemporal_store(ilt_row_scale(a, 0.125) * acc, a.x + row);
+      row += step;
+    }
+  } else if (w0 < nfull) {
+    // queue of this wavefront's vector-memory loads, oldest first, at the head of iteration n:
+    //   theta_n (LPT)  phi_n (LPT)            [+ the store of x_(n-1), which no wait below depends on]
+    // The row's t is requested at the head of the iteration that uses it and consumed behind a wait of its own: its register must
+    // not travel through a loop-carried copy -- the compiler does not know the load is asynchronous and would copy a register
+    // the data has not reached yet.
+    auto req_theta = [&](int64_t tile, bool real) {
+      const char* g = real ? (const char*)(a.theta + tile * (64 * S)) + lane * 16 : (const char*)a.theta;  // no successor: ONE line
+      ilt_lds_load_tile<TILE>(g, lt_addr, real ? lane : 0);
+    };
+    auto req_phi = [&](int64_t tile, bool real) {
+      const char* g = real ? (const char*)(a.phi + tile * (64 * S)) + lane * 16 : (const char*)a.phi;
+      ilt_lds_load_tile<TILE>(g, lp_addr, real ? lane : 0);
+    };
+    auto req_t = [&](int64_t nn) {
+      double v;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(a.t + nn) : "memory");
+      return v;
+    };
+    req_theta(w0, true);
+    req_phi(w0, true);
+    for (int64_t tile = w0; tile < nfull; tile += W) {
+      double t_row = req_t(n);                        // queue: theta_n, phi_n, t_n
+      const int64_t nxt = tile + W;
+      const bool has_next = nxt < nfull;
+      // the next tile's point index
+      int64_t n_next = n + step_n;
+      unsigned rem_next = rem + step_r;
+      if (rem_next >= d) {
+        rem_next -= d;
+        n_next += 1;
+      }
+      // ---- theta_n has landed when at most the phi_n + t_n loads behind it are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + 1) : "memory");
+      double th[S], ph[S];
+#pragma unroll
+      for (int k = 0; k < S; ++k) th[k] = lrow_t[k];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      req_theta(nxt, has_next);                       // queue: phi_n, t_n, theta_(n+1)
+      // ---- phi_n has landed when at most t_n + theta_(n+1) are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + 1) : "memory");
+#pragma unroll
+      for (int k = 0; k < S; ++k) ph[k] = lrow_p[k];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      req_phi(nxt, has_next);                         // queue: t_n, theta_(n+1), phi_(n+1)
+      double acc;
+      if (DBG == 1) {
+        acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) acc += th[k] + ph[k];
+      } else {
+        acc = ilt_row_sum<S>(K, [&](int k, double* t_o, double* p_o) {
+          *t_o = th[k];
+          *p_o = ph[k];
+        });
+      }
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t_row) : "n"(2 * LPT) : "memory");  // t_n: the next tile's loads are behind it
+      if (t_row != t_prev) {  // (planning and training batches share one t: skipped after the first tile)
+        sc = ilt_row_scale(a, t_row);
+        t_prev = t_row;
+      }
+      __builtin_nontemporal_store(sc * acc, a.x + row);
+      row += step;
+      n = n_next;
+      rem = rem_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last iteration's stand-in loads
+  }
+  // the ragged last tile (fewer than 64 rows): the wavefront whose turn it would be reads its rows straight from memory
+  if (DBG != 2 && nfull * 64 < rows_total && nfull % W == w0) {
+    const int64_t r = nfull * 64 + lane;
+    if (r < rows_total) {
+      const double* rt = a.theta + r * S;
+      const double* rp = a.phi + r * S;
+      const double acc = ilt_row_sum<S>(K, [&](int k, double* th, double* ph) {
+        *th = rt[k];
+        *ph = rp[k];
+      });
+      a.x[r] = ilt_row_scale(a, a.t[r / a.d]) * acc;
+    }
+  }
+}
+
+// true when the row-per-lane kernel takes the launch
+static bool launch_ilt_fourier_rows(const IltArgs& a, hipStream_t s, hipError_t* err) {
+  if (a.lin_wr != nullptr || a.scale != 2.0 || (a.S != 17 && a.S != 33)) return false;
+  if ((((uintptr_t)a.theta) | ((uintptr_t)a.phi)) & 15) return false;  // 16-byte loads
+  const int64_t rows_total = a.N * a.d;
+  const int64_t tiles = (rows_total + 63) / 64;
+  const int per_cu = a.S == 17 ? 2 : 1;  // workgroups of four wavefronts per CU (LDS: 2 x 64 S x 8 B per wavefront)
+  int64_t grid = (tiles + 3) / 4;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  const size_t shmem = (size_t)4 * 2 * ((64 * a.S * 8 + 1023) / 1024 * 1024);  // per wavefront: theta and phi slots of whole KB
+  int dbg = 0;
+#if NLC_ILT_EXPERIMENTS
+  static const int dbg_env = [] {
+    const char* ev = std::getenv("NLC_ILT_DBG");
+    return ev ? std::atoi(ev) : 0;
+  }();
+  static const int rows_env = [] {
+    const char* ev = std::getenv("NLC_ILT_ROWS");
+    return ev ? std::atoi(ev) : 1;
+  }();
+  if (!rows_env) return false;
+  dbg = dbg_env;
+#endif
+  // (more than 64 KB of dynamic LDS per workgroup needs the attribute, once per instance)
+#define NLC_ROWS_LAUNCH(SS, D)                                                                                                       \
+  do {                                                                                                                               \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)ilt_fourier_rows_kernel<SS, D>,                                  \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * ((64 * SS * 8 + 1023) / 1024 * 1024));             \
+    if (attr != hipSuccess) return false;                                                                                            \
+    hipLaunchKernelGGL((ilt_fourier_rows_kernel<SS, D>), dim3((unsigned)grid), dim3(256), shmem, s, a);                              \
+  } while (0)
+  if (a.S == 17) {
+#if NLC_ILT_EXPERIMENTS
+    if (dbg == 1) NLC_ROWS_LAUNCH(17, 1);
+    else if (dbg == 2) NLC_ROWS_LAUNCH(17, 2);
+    else
+#endif
+      NLC_ROWS_LAUNCH(17, 0);
+  } else {
+    NLC_ROWS_LAUNCH(33, 0);
+  }
+#undef NLC_ROWS_LAUNCH
+  (void)dbg;
+  *err = hipGetLastError();
+  return true;
+}
+
 hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
   IltArgs a = a_in;
   const int64_t rows_total = a.N * a.d;
   if (rows_total <= 0) return hipSuccess;
   if (a.S > 256) return hipErrorInvalidValue;
+  {
+    hipError_t e2 = hipSuccess;
+    if (launch_ilt_fourier_rows(a, s, &e2)) return e2;
+  }
 #if NLC_ILT_EXPERIMENTS
   if (a.lin_wr != nullptr && std::getenv("NLC_ILT_LINEAR_ROWS")) return hipErrorInvalidValue;  // time the one-thread-per-row kernel
 #endif

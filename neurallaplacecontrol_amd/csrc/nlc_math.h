@@ -348,5 +348,72 @@ NLC_HD void tan_parts_short(const IltTrigK& K, double x, double* num, double* de
   *den = fmax(ca - sa, K.den_min);
 }
 
+// ---- round 6: forms of the row-per-lane Fourier ILT kernel (kernels_ilt.hip: ilt_fourier_rows_kernel), where the term index --
+// hence the quarter turn of its phase -- is a compile-time constant and the instruction count is what bounds the stream.
+//   tan(pi/4 + a) = (1 + tan a)/(1 - tan a) with tan a = a (Q + z P)/Q, z = a^2, |a| <= pi/4: the rational form of Cephes' tan.c
+//   (P of degree 2, monic Q of degree 4; relative error 3e-16), written for num/den directly and with both polynomials negated
+//   so that num, den > 0:  num = Qn + a (Qn + z Pn), den = Qn - a (Qn + z Pn).  Twelve instructions against the eighteen of the
+//   sin / cos pair (tan_parts_short).
+//   cos(x + m pi/2), m known: ONE reduction by pi (q = rint(x / pi) rides in a single FMA with the 1.5 2^52 shift), then the cosine
+//   (m = 0) or the sine (m = 1: cos(x + pi/2) = -sin x) polynomial on [-pi/2, pi/2]; the caller folds the constant sign.
+struct IltRowK {
+  double qn[4];   // Qn(z) = -(z^4 + Q0 z^3 + Q1 z^2 + Q2 z + Q3): the four lower coefficients, negated
+  double pn[3];   // Pn(z) = -(P0 z^2 + P1 z + P2)
+  double c2[8];   // cos(y) = 1 + z C(z), |y| <= pi/2 (IltTrigK::c2)
+  double s2[8];   // sin(y) = y + y z S(z), |y| <= pi/2, degree 7 in z (sincos_plus_mpio2)
+  double pio4_hi, pio4_lo, pi_hi, pi_lo, inv_pi, round_shift, den_min;
+};
+NLC_HD IltRowK ilt_row_k() {
+  const IltTrigK T = ilt_trig_k();
+  IltRowK K = {
+      {-1.36812963470692954678e4, 1.32089234440210967447e6, -2.50083801823357915839e7, 5.38695755929454629881e7},
+      {1.30936939181383777646e4, -1.15351664838587416140e6, 1.79565251976484877988e7},
+      {T.c2[0], T.c2[1], T.c2[2], T.c2[3], T.c2[4], T.c2[5], T.c2[6], T.c2[7]},
+      {0x1.89a3f16388edcp-49, -0x1.ae513415aadccp-41, 0x1.6124014cbe2fcp-33, -0x1.ae6455a1a9e7ep-26, 0x1.71de3a54562a8p-19,
+       -0x1.a01a01a018aa6p-13, 0x1.1111111111107p-7, -0x1.5555555555555p-3},
+      T.pio4_hi, T.pio4_lo, 2.0 * kPio2Hi, 2.0 * kPio2Lo, T.inv_pi, T.round_shift,
+      // num / den at a = pi/4 must be the reference's saturated |F| = tan(double nearest pi/2) = 1.633e16 (IltTrigK::den_min):
+      // num there is 2 Qn((pi/4)^2) = 7.7885e7
+      7.788508645242503e7 / 1.633123935319537e16};
+  return K;
+}
+NLC_HD void tan_parts_rat(const IltRowK& K, double a, double* num, double* den) {
+  const double z = a * a;
+  double q = K.qn[0] - z;
+  q = fma(q, z, K.qn[1]);
+  q = fma(q, z, K.qn[2]);
+  q = fma(q, z, K.qn[3]);
+  double p = fma(K.pn[0], z, K.pn[1]);
+  p = fma(p, z, K.pn[2]);
+  const double xt = a * fma(z, p, q);
+  *num = q + xt;
+  *den = fmax(q - xt, K.den_min);
+}
+// (-1)^q cos(y) for ODD = 0, (-1)^q sin(y) for ODD = 1, where x = q pi + y: the caller's term is +this (ODD = 0) or -this (ODD = 1)
+template <int ODD>
+NLC_HD double cos_or_sin_reduced(const IltRowK& K, double x) {
+  const double sh = fma(x, K.inv_pi, K.round_shift);
+  const double q = sh - K.round_shift;
+  double y = fma(-q, K.pi_hi, x);
+  y = fma(-q, K.pi_lo, y);
+  const double z = y * y;
+  double r;
+  if (ODD) {
+    double u = fma(K.s2[0], z, K.s2[1]);
+    for (int i = 2; i < 8; ++i) u = fma(u, z, K.s2[i]);
+    r = fma(y * z, u, y);
+  } else {
+    double c = fma(K.c2[0], z, K.c2[1]);
+    for (int i = 2; i < 8; ++i) c = fma(c, z, K.c2[i]);
+    r = fma(c, z, 1.0);
+  }
+  uint64_t sb, rb;
+  __builtin_memcpy(&sb, &sh, sizeof(sb));
+  __builtin_memcpy(&rb, &r, sizeof(rb));
+  rb ^= sb << 63;
+  __builtin_memcpy(&r, &rb, sizeof(r));
+  return r;
+}
+
 }  // namespace m
 }  // namespace nlc

@@ -49,3 +49,17 @@ void nlc_t_tanh_pair_fast(const double* x, double* y, long n) {
   if (n & 1) { double t; nlc::m::tanh_pair_fast(x[n - 1], 0.0, &y[n - 1], &t); }
 }
 }
+extern "C" {
+// round 6: the row-per-lane Fourier ILT kernel's forms -- tan(pi/4 + a) as num/den (Cephes rational), cos(x + m pi/2) with m = i & 1
+void nlc_t_tan_rat(const double* a, double* y, long n) {
+  for (long i = 0; i < n; ++i) {
+    double num, den;
+    nlc::m::tan_parts_rat(nlc::m::ilt_row_k(), a[i], &num, &den);
+    y[i] = num / den;
+  }
+}
+void nlc_t_cos_kpio2(const double* x, double* y, long n) {
+  for (long i = 0; i < n; ++i)
+    y[i] = (i & 1) ? -nlc::m::cos_or_sin_reduced<1>(nlc::m::ilt_row_k(), x[i]) : nlc::m::cos_or_sin_reduced<0>(nlc::m::ilt_row_k(), x[i]);
+}
+}

@@ -135,3 +135,22 @@ def test_ilt_short_forms(lib):
     # relative error bounded by a few ulp plus the pole's conditioning: d tan / tan = dx (1 + tan^2)/tan
     cond = (1 + ref_t ** 2) / np.maximum(ref_t, 1e-300) * 2.3e-16
     assert np.all(np.abs(t - ref_t) <= (6e-16 + cond) * np.maximum(np.abs(ref_t), 1.0))
+
+
+def test_ilt_row_forms(lib):
+    """Round 6, the row-per-lane Fourier ILT kernel: tan(pi/4 + a) = num/den from the Cephes rational (|a| <= pi/4) within a few
+    ulp away from the pole and tracking the argument's own conditioning next to it; cos(x + m pi/2) by one reduction by pi with
+    the cosine (m = 0) or sine (m = 1) polynomial: absolute accuracy ~2e-16."""
+    a = np.linspace(-np.pi / 4, np.pi / 4, 400001)[1:-1]
+    t = call(lib, "nlc_t_tan_rat", a)
+    al = a.astype(np.longdouble)
+    ref = np.tan(al + np.longdouble(np.pi) / 4 + np.longdouble(6.123233995736766e-17) / 2).astype(np.float64)  # (pi/4 to ~1e-33)
+    cond = (1 + ref ** 2) / np.maximum(ref, 1e-300) * 1.2e-16  # the rounding of a itself
+    assert np.all(np.abs(t - ref) <= (6e-16 + cond) * np.maximum(np.abs(ref), 1.0))
+    x = np.concatenate([np.linspace(-7.0, 7.0, 800001), np.linspace(-1e3, 1e3, 20001), [0.0, np.pi, -np.pi]])
+    mm = (np.arange(x.size) & 1).astype(np.float64)
+    y = call(lib, "nlc_t_cos_kpio2", x)
+    xl = x.astype(np.longdouble)
+    want = np.where(mm == 0, np.cos(xl), -np.sin(xl)).astype(np.float64)
+    bound = 3e-16 + 1.2e-16 * np.abs(x) / np.pi
+    assert np.all(np.abs(y - want) <= bound)
