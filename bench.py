@@ -969,13 +969,8 @@ def sliced_encoder_section(nlc, local, steps, warmup):
         ab = step(ab)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    planner.ctx.profile_reset()
-    planner.ctx.profile(True)
-    for _ in range(max(steps // 2, 2)):
-        ab = step(ab)
-    torch.cuda.synchronize()
-    planner.ctx.profile(False)
-    kern = {k: v["total_ms"] / max(v["launches"], 1) for k, v in planner.ctx.profile_read().items()}
+    kern_full, ab = profiled_pass(planner, step, ab, max(steps // 2, 2))
+    kern = {k: v["avg_ms"] for k, v in kern_full.items()}
     uses = planner.ctx.get_stat("gru_gemm")
     g = torch.Generator().manual_seed(11)
     win = ((torch.rand(65536, B, nu, dtype=torch.float64, generator=g) * 2 - 1) * A).to(f"cuda:{local}")
@@ -987,14 +982,39 @@ def sliced_encoder_section(nlc, local, steps, warmup):
         lat_i8 = model.encode_actions(win)
         mctx.set_option("gru_gemm", 0)
     gru_flops = flops_gru_needed_per_window(HIDDEN // 2, nu, B) * K * T
+    enc_s = kern.get("gru_encode_kernel", float("nan")) * 1e-3
+    # the sliced encoder's own roofline: what it ISSUES.  Per 16-window tile: 12 gate tiles of layer 1's input side in GRU step 0,
+    # 36 in every later step (W_hh0, W_ih1, W_hh1), 34 v_mfma_i32_16x16x64_i8 each (digit pairs of level >= 5 of 7 x 7); the layer-0
+    # input GEMM (3 g/16 per step) and linear_out (g/4) stay v_mfma_f64_16x16x4.  One i8 MFMA = 16 x 16 x 64 x 2 integer ops.
+    g_h = HIDDEN // 2
+    tiles = K * T / 16.0
+    i8_mfma = tiles * (12 + 36 * (B - 1)) * 34
+    f64_mfma = tiles * (B * 3 * g_h // 16 + g_h // 4)
+    info = planner.ctx.device_info()
+    simds = info["num_cus"] * 4
+    clk = info["clock_mhz"] * 1e6
+    i8_roofline = dict(
+        bound="int8 mfma issue + fp64 valu (see note)", kernel="gru_encode_i8_kernel", avg_launch_ms=enc_s * 1e3,
+        i8_mfma_per_launch=i8_mfma, f64_mfma_per_launch=f64_mfma, int8_tops_issued=i8_mfma * 32768 / enc_s / 1e12,
+        # one i8 16x16x64 MFMA occupies a SIMD's matrix pipe for 8 clocks at two wavefronts per SIMD (tools/ubench_i8emu.hip:
+        # 9.0 measured), an FP64 16x16x4 for 64
+        matrix_pipe_busy_frac=(i8_mfma * 8 + f64_mfma * 64) / simds / (enc_s * clk),
+        fp64_equivalent_tflops=gru_flops / enc_s / 1e12, frac_of_fp64_mfma_peak=gru_flops / enc_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        note="fp64_equivalent_tflops counts the algorithm's FP64 flops (SURVEY 8d) over the launch's time and may pass the FP64-MFMA "
+             "peak: the products run on the INT8 pipe.  The kernel is bound by FP64 VALU issue beside the MFMAs (recombination, gate "
+             "math, digit cut: ~4 500 VALU per tile-step against 1 224 MFMAs; profiles/r5_i8_gemm.md), clock from nlc_device_info")
     out = dict(planner_option="gru_gemm=1", encoder_kernel="gru_encode_i8_kernel" if uses else "gru_encode_kernel (option not taken)",
-               value=steps / el, unit="planning steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup,
-               kernels_avg_ms=kern, latents_max_abs_diff_vs_fp64_encoder=float((lat_i8 - lat_f64).abs().max()),
+               dtype="int8x7-sliced 54-bit fixed point (hidden-state GEMMs), FP64 elsewhere; FP64-equivalent error bound",
+               value=steps / el, unit="planning steps/s", ms_per_step=el / steps * 1e3, steps=steps, warmup=warmup, store_rollouts=True,
+               kernels_avg_ms=kern, roofline=i8_roofline if uses else None,
+               latents_max_abs_diff_vs_fp64_encoder=float((lat_i8 - lat_f64).abs().max()),
                latents_max_abs=float(lat_f64.abs().max()),
-               encoder_fp64_equivalent_tflops=gru_flops / (kern.get("gru_encode_kernel", float("nan")) * 1e-3) / 1e12,
+               encoder_fp64_equivalent_tflops=gru_flops / enc_s / 1e12,
                note="EXPERIMENTAL and not the headline: `value` above is measured with the FP64-MFMA encoder.  Operands: GRU states and "
                     "row-scaled weights as 54-bit fixed point; error against the exact product within 5 x 2^-53 of the row's sum of "
-                    "|w h|, as the FP64 MFMA chain's (tools/i8gemm_check.hip, profiles/r5_i8gemm_check.txt)")
+                    "|w h| for ordinary state magnitudes, as the FP64 MFMA chain's, and never above 2^-48 of the row scale "
+                    "(tools/i8gemm_check.hip, tools/i8_adversarial.py: profiles/r6_i8_adversarial.json).  The rollout launch behind this "
+                    "encoder runs at a ~5 % lower clock than behind the FP64 one (power management, profiles/r6_rollout_giveback.md)")
     del planner, model
     torch.cuda.empty_cache()
     # the option on two more BASELINE configs (short fenced loops as in other_configs): configs[4] (de Hoog, S = 33: the encoder is

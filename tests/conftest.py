@@ -12,8 +12,23 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fp64_bit_identity: pins bits between planner bodies / encoder forms of the default FP64 path; skipped "
+                                       "when the suite runs with --nlc-planner-opt gru_gemm=1")
     config.addinivalue_line("markers", "no_sliced_instance: an encoder_mode test whose models have no int8-sliced encoder instance "
                                        "(hidden_units other than 128): the option must be harmless, no sliced launch is expected")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`--nlc-planner-opt gru_gemm=1` runs the whole GPU suite in the sliced mode.  The tests marked `fp64_bit_identity` pin
+    BITS between bodies that then run different encoders -- the two-launch bodies the int8-sliced kernel, the fused one-launch
+    body and the cooperative form the FP64 one (include/nlc.h, "gru_gemm") -- or assert that a default planner does not take the
+    option: they are skipped in that mode, with this reason, and run in the default one."""
+    opts = _parse_opts(config.getoption("--nlc-planner-opt"))
+    if opts.get("gru_gemm") == 1.0:
+        skip = pytest.mark.skip(reason="pins bit-identity between bodies that run different encoders under gru_gemm = 1")
+        for item in items:
+            if item.get_closest_marker("fp64_bit_identity"):
+                item.add_marker(skip)
 
 
 def pytest_addoption(parser):

@@ -95,6 +95,7 @@ def test_batched_planner_oracle_options_and_per_sample_state(nlc):
 
 @pytest.mark.parametrize("algo,S,K", [("fourier", 17, 100), ("fourier", 17, 8200), ("dehoog", 17, 72), ("fixed_tablot", 17, 72),
                                       ("stehfest", 8, 100)])
+@pytest.mark.fp64_bit_identity
 def test_batched_planner_nl_dynamics_equals_single_planners(nlc, algo, S, K):
     """NL dynamics: K = 100 makes the 16-sample MFMA tiles straddle episodes; 8200 takes the wave-per-tile kernel."""
     from oracle import nl_model as onl

@@ -69,6 +69,7 @@ def test_sliced_encoder_agrees_with_fp64_encoder(nlc, nu, B, N):
     np.testing.assert_allclose(i8[:512].numpy(), ref.numpy(), **TOL)
 
 
+@pytest.mark.fp64_bit_identity
 def test_planner_with_sliced_encoder(nlc):
     """The two-launch planner (K = 8192: GRU launch + split rollout) with either encoder: the same actions to 1e-9 over three
     commands; the option reaches the launch (stat), the FP64 planner is untouched by it."""

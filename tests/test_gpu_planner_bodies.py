@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("env,K,T,h", [("oderl-cartpole", 1024, 20, 128), ("oderl-acrobot", 4096, 12, 128),
                                         ("oderl-pendulum", 16400, 6, 128), ("oderl-cartpole", 2048, 40, 64),
                                         ("oderl-pendulum", 1000, 40, 256), ("oderl-acrobot", 600, 9, 64)])
+@pytest.mark.fp64_bit_identity
 def test_rollout_kernel_variants_agree(nlc, env, K, T, h):
     """Wave-per-tile (1), latency-split (2: 4 waves per 16-sample tile, LDS exchange) and fused one-launch (3: GRU encode
     and split rollout as roles of one persistent grid, latents handed over inside the launch) rollout bodies: same
@@ -76,6 +77,7 @@ def test_horizon_chunks_pipeline_bit_identical(nlc):
 @pytest.mark.parametrize("K,cap,sched", [(2048, 0, None), (2048, 40, None), (1000, 0, None), (4096, 0, None), (600, 7, None),
                                          (16, 0, None), (2048, 200, None), (2048, 0, (0, -1)), (2048, 0, (2, 1)),
                                          (2048, 40, (3, 0)), (1000, 0, (1, 2)), (600, 7, (1, 0)), (4096, 0, (0, 1))])
+@pytest.mark.fp64_bit_identity
 def test_fused_plan_handoff_repeated_commands(nlc, K, cap, sched):
     """The fused body hands every 16-sample tile's GRU latents from an encoder wavefront to a rollout workgroup INSIDE
     the launch (write-through stores + flag, sc1 loads behind a barrier).  A stale or early read would show up as a
@@ -116,6 +118,7 @@ def test_fused_plan_handoff_repeated_commands(nlc, K, cap, sched):
 
 @pytest.mark.parametrize("K,env,sample_null", [(2048, "oderl-cartpole", False), (1000, "oderl-acrobot", True),
                                                (4096, "oderl-pendulum", False), (48, "oderl-cartpole", True)])
+@pytest.mark.fp64_bit_identity
 def test_fused_inline_sampling_and_weights_bit_identical(nlc, K, env, sample_null):
     """Round 3: with device noise the fused body also samples / bounds the actions (encoder role) and reduces the importance
     weights (after the last rollout tile) INSIDE its launch -- command() = that launch + merge_kernel.  Everything the
@@ -382,6 +385,7 @@ def test_repfunc_split_kernel_agrees_with_wave_per_tile_planner(nlc):
             np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-10, err_msg=f"{env} S={S}")
 
 
+@pytest.mark.fp64_bit_identity
 def test_gru_cooperative_kernel_bit_identical(nlc):
     """gru_encode_coop_kernel (one 16-window tile per workgroup, one gate chunk per wavefront; what small launches and the
     fused body's encoders run) against the wave-per-tile kernel: same chunk GEMMs in the same k order and the same gate
