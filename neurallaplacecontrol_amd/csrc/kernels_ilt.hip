@@ -426,8 +426,12 @@ __global__ __launch_bounds__(256, (ITERS == 8 || ITERS == 16) ? 4 : 3) void ilt_
 // partner computes.  Instances: S = 17 and S = 33 (the reference's default and its de Hoog ablation's term count) with scale = 2
 // (torchlaplace's default: e^{i pi k t / T} = i^k); anything else -- other term counts, another scale, the linear algorithms,
 // unaligned inputs -- keeps ilt_fourier_kernel.
-template <int S, class LD>
-__device__ __forceinline__ double ilt_row_sum(const m::IltRowK& K, LD ld) {
+// GEN = false: scale == 2, the phase of term k is i^k (compile-time quarter turn and sign, w_0 = 1/2).
+// GEN = true: a per-term phase psi_k and weight w_k from a small table in LDS (`tab`: psi_0, w_0, psi_1, w_1, ...; every lane
+// reads the same address: a broadcast) -- the Fourier series at another scale (psi_k = pi k / scale) and the linear algorithms
+// (fixed Talbot / Stehfest: w_re Re F - w_im Im F = |w| R cos(theta + arg w), kernels above).
+template <int S, bool GEN, class LD>
+__device__ __forceinline__ double ilt_row_sum(const m::IltRowK& K, const double* tab, LD ld) {
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < S; ++k) {
@@ -438,12 +442,17 @@ __device__ __forceinline__ double ilt_row_sum(const m::IltRowK& K, LD ld) {
     const double a = (x - K.pio4_hi) - K.pio4_lo;
     double num, den;
     m::tan_parts_rat(K, a, &num, &den);
-    // Re(F_k i^k) = |F_k| cos(theta + k pi/2): k & 1 picks the polynomial, ((k + 1) >> 1) & 1 the sign; w_0 = 1/2
-    const double cs = (k & 1) ? m::cos_or_sin_reduced<1>(K, th) : m::cos_or_sin_reduced<0>(K, th);
-    const bool neg = (((k + 1) >> 1) & 1) != 0;
-    const double nc = (k == 0 ? 0.5 * num : num) * cs;
     const double r = m::rcp_refined(den);
-    acc = fma(neg ? -nc : nc, r, acc);
+    if (GEN) {
+      const double cs = m::cos_or_sin_reduced<0>(K, th + tab[2 * k]);
+      acc = fma((tab[2 * k + 1] * num) * cs, r, acc);
+    } else {
+      // Re(F_k i^k) = |F_k| cos(theta + k pi/2): k & 1 picks the polynomial, ((k + 1) >> 1) & 1 the sign; w_0 = 1/2
+      const double cs = (k & 1) ? m::cos_or_sin_reduced<1>(K, th) : m::cos_or_sin_reduced<0>(K, th);
+      const bool neg = (((k + 1) >> 1) & 1) != 0;
+      const double nc = (k == 0 ? 0.5 * num : num) * cs;
+      acc = fma(neg ? -nc : nc, r, acc);
+    }
   }
   return acc;
 }
@@ -500,7 +509,7 @@ __device__ __forceinline__ void ilt_lds_load_tile(const char* g_lane, unsigned l
 }
 
 // DBG (tools build only): 1 = loads + the plain sum of what they brought (memory only), 2 = arithmetic on run-time values, no loads
-template <int S, int DBG>
+template <int S, bool GEN, int DBG>
 __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(const IltArgs a) {
   static_assert(S % 2 == 1, "row stride S doubles must be odd: conflict-free row-wise reads, 16-byte tile sizes");
   extern __shared__ __attribute__((aligned(16))) char rows_lds[];
@@ -518,6 +527,22 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
   const int64_t rows_total = a.N * a.d;
   const int64_t nfull = rows_total / 64;
   const int64_t W = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+  // GEN: the per-term (phase, weight) table behind the four wavefronts' slots -- the launch's only barrier
+  const double* tab = (const double*)(rows_lds + 4 * (2 * SLOT));
+  const bool lin = a.lin_wr != nullptr;
+  if (GEN) {
+    if ((int)threadIdx.x < S) {
+      const int k = threadIdx.x;
+      const IltLane L = lin ? ilt_lane_linear(a.lin_wr[k], a.lin_wi[k]) : ilt_lane(k, a.scale);
+      // (ilt_lane at scale == 2 describes the quarter turns by dm / a signed weight: spell them out as a phase)
+      double* tw = (double*)(rows_lds + 4 * (2 * SLOT));
+      tw[2 * k] = L.psi + L.dm * (kPi / 2.0);
+      tw[2 * k + 1] = L.wk;
+    }
+    __syncthreads();
+  }
+  // the row scale: e^{gamma t} / T of the Fourier series, 1 / t (times the model's time normalisation) of the linear algorithms
+  auto row_scale = [&](double t) { return (GEN && lin) ? m::div_fast(a.t_div, t) : ilt_row_scale(a, t); };
   // the row's point index n = row / d, kept incrementally: row advances by 64 W per tile
   const unsigned d = (unsigned)a.d;
   const int64_t step = 64 * W;
@@ -530,11 +555,11 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
 
   if (DBG == 2) {
     for (int64_t tile = w0; tile < nfull; tile += W) {
-      const double acc = ilt_row_sum<S>(K, [&](int k, double* th, double* ph) {
+      const double acc = ilt_row_sum<S, GEN>(K, tab, [&](int k, double* th, double* ph) {
         *th = a.alpha * (double)(lane + k) + (double)tile * 1e-7;
         *ph = a.alpha * (double)(lane + 3 * k);
       });
-      __builtin_nontemporal_store(ilt_row_scale(a, 0.125) * acc, a.x + row);
+      __builtin_nontemporal_store(row_scale(0.125) * acc, a.x + row);
       row += step;
     }
   } else if (w0 < nfull) {
@@ -588,14 +613,14 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
 #pragma unroll
         for (int k = 0; k < S; ++k) acc += th[k] + ph[k];
       } else {
-        acc = ilt_row_sum<S>(K, [&](int k, double* t_o, double* p_o) {
+        acc = ilt_row_sum<S, GEN>(K, tab, [&](int k, double* t_o, double* p_o) {
           *t_o = th[k];
           *p_o = ph[k];
         });
       }
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t_row) : "n"(2 * LPT) : "memory");  // t_n: the next tile's loads are behind it
       if (t_row != t_prev) {  // (planning and training batches share one t: skipped after the first tile)
-        sc = ilt_row_scale(a, t_row);
+        sc = row_scale(t_row);
         t_prev = t_row;
       }
       __builtin_nontemporal_store(sc * acc, a.x + row);
@@ -611,26 +636,38 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
     if (r < rows_total) {
       const double* rt = a.theta + r * S;
       const double* rp = a.phi + r * S;
-      const double acc = ilt_row_sum<S>(K, [&](int k, double* th, double* ph) {
+      const double acc = ilt_row_sum<S, GEN>(K, tab, [&](int k, double* th, double* ph) {
         *th = rt[k];
         *ph = rp[k];
       });
-      a.x[r] = ilt_row_scale(a, a.t[r / a.d]) * acc;
+      a.x[r] = row_scale(a.t[r / a.d]) * acc;
     }
   }
 }
 
-// true when the row-per-lane kernel takes the launch
-static bool launch_ilt_fourier_rows(const IltArgs& a, hipStream_t s, hipError_t* err) {
-  if (a.lin_wr != nullptr || a.scale != 2.0 || (a.S != 17 && a.S != 33)) return false;
-  if ((((uintptr_t)a.theta) | ((uintptr_t)a.phi)) & 15) return false;  // 16-byte loads
-  const int64_t rows_total = a.N * a.d;
-  const int64_t tiles = (rows_total + 63) / 64;
-  const int per_cu = a.S == 17 ? 2 : 1;  // workgroups of four wavefronts per CU (LDS: 2 x 64 S x 8 B per wavefront)
+// true when the row-per-lane kernel takes the launch: an odd term count 3 .. 33 (row-wise LDS reads are conflict-free for an
+// odd stride; the reference's default 17, its de Hoog ablation's 33, fixed Talbot's 17) and 16-byte aligned inputs
+template <int S, bool GEN, int DBG>
+static bool launch_rows_instance(const IltArgs& a, hipStream_t s, hipError_t* err) {
+  constexpr int SLOT = (64 * S * 8 + 1023) / 1024 * 1024;
+  constexpr size_t shmem = (size_t)4 * 2 * SLOT + 2 * S * 8;  // four wavefronts' theta / phi slots + the (phase, weight) table
+  // (more than 64 KB of dynamic LDS per workgroup needs the attribute, once per instance)
+  static const hipError_t attr =
+      hipFuncSetAttribute((const void*)ilt_fourier_rows_kernel<S, GEN, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (attr != hipSuccess) return false;
+  const int64_t tiles = (a.N * a.d + 63) / 64;
+  const int per_cu = S <= 17 ? 2 : 1;  // workgroups of four wavefronts per CU (launch bounds, LDS)
   int64_t grid = (tiles + 3) / 4;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
-  const size_t shmem = (size_t)4 * 2 * ((64 * a.S * 8 + 1023) / 1024 * 1024);  // per wavefront: theta and phi slots of whole KB
-  int dbg = 0;
+  hipLaunchKernelGGL((ilt_fourier_rows_kernel<S, GEN, DBG>), dim3((unsigned)grid), dim3(256), shmem, s, a);
+  *err = hipGetLastError();
+  return true;
+}
+static bool launch_ilt_fourier_rows(const IltArgs& a, hipStream_t s, hipError_t* err) {
+  if (a.S < 3 || a.S > 33 || (a.S & 1) == 0) return false;
+  if (a.lin_wr != nullptr && a.lin_wi == nullptr) return false;
+  if ((((uintptr_t)a.theta) | ((uintptr_t)a.phi)) & 15) return false;  // 16-byte loads
+  const bool gen = a.lin_wr != nullptr || a.scale != 2.0;
 #if NLC_ILT_EXPERIMENTS
   static const int dbg_env = [] {
     const char* ev = std::getenv("NLC_ILT_DBG");
@@ -641,30 +678,19 @@ static bool launch_ilt_fourier_rows(const IltArgs& a, hipStream_t s, hipError_t*
     return ev ? std::atoi(ev) : 1;
   }();
   if (!rows_env) return false;
-  dbg = dbg_env;
+  if (a.S == 17 && !gen && dbg_env == 1) return launch_rows_instance<17, false, 1>(a, s, err);
+  if (a.S == 17 && !gen && dbg_env == 2) return launch_rows_instance<17, false, 2>(a, s, err);
 #endif
-  // (more than 64 KB of dynamic LDS per workgroup needs the attribute, once per instance)
-#define NLC_ROWS_LAUNCH(SS, D)                                                                                                       \
-  do {                                                                                                                               \
-    static const hipError_t attr = hipFuncSetAttribute((const void*)ilt_fourier_rows_kernel<SS, D>,                                  \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * ((64 * SS * 8 + 1023) / 1024 * 1024));             \
-    if (attr != hipSuccess) return false;                                                                                            \
-    hipLaunchKernelGGL((ilt_fourier_rows_kernel<SS, D>), dim3((unsigned)grid), dim3(256), shmem, s, a);                              \
-  } while (0)
-  if (a.S == 17) {
-#if NLC_ILT_EXPERIMENTS
-    if (dbg == 1) NLC_ROWS_LAUNCH(17, 1);
-    else if (dbg == 2) NLC_ROWS_LAUNCH(17, 2);
-    else
-#endif
-      NLC_ROWS_LAUNCH(17, 0);
-  } else {
-    NLC_ROWS_LAUNCH(33, 0);
+  switch (a.S) {
+#define NLC_ROWS_CASE(SS) \
+  case SS:                \
+    return gen ? launch_rows_instance<SS, true, 0>(a, s, err) : launch_rows_instance<SS, false, 0>(a, s, err);
+    NLC_ROWS_CASE(3) NLC_ROWS_CASE(5) NLC_ROWS_CASE(7) NLC_ROWS_CASE(9) NLC_ROWS_CASE(11) NLC_ROWS_CASE(13) NLC_ROWS_CASE(15)
+    NLC_ROWS_CASE(17) NLC_ROWS_CASE(19) NLC_ROWS_CASE(21) NLC_ROWS_CASE(23) NLC_ROWS_CASE(25) NLC_ROWS_CASE(27) NLC_ROWS_CASE(29)
+    NLC_ROWS_CASE(31) NLC_ROWS_CASE(33)
+#undef NLC_ROWS_CASE
   }
-#undef NLC_ROWS_LAUNCH
-  (void)dbg;
-  *err = hipGetLastError();
-  return true;
+  return false;
 }
 
 hipError_t launch_ilt_fourier(const IltArgs& a_in, hipStream_t s) {
