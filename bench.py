@@ -52,7 +52,7 @@ ENV, K_SAMPLES, HORIZON, ABUF, S_TERMS, HIDDEN, A_HIGH = "oderl-cartpole", 16384
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= FP64 vector) dense peak, AMD datasheet; the guide lists no f64 row
 # newest committed PMC summary (separate rocprofv3 --pmc passes: tools/collect_profiles.sh + tools/pmc_summarize.py)
-PMC_CANDIDATES = ("r5_pmc_kernels.json", "r4_pmc_kernels.json", "r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
+PMC_CANDIDATES = ("r6_pmc_kernels.json", "r5_pmc_kernels.json", "r4_pmc_kernels.json", "r3_pmc_kernels.json", "r2_pmc_kernels.json", "r1k_pmc_kernels.json")
 # library kernel (nlc_profile_read name) -> key of the PMC summary; the summary's "_meta.kernel_names" must list a
 # rocprof kernel name containing the library name, or the traffic figure belongs to some other build
 PMC_KEYS = {"gru_encode_kernel": "gru_encode", "nl_rollout_kernel": "nl_rollout", "ilt_fourier_kernel": "ilt_fourier",
@@ -116,7 +116,11 @@ def pmc_traffic(pmc_name, pj, lib_kernel):
     meta = pj.get("_meta")
     if meta is not None:
         names = meta.get("kernel_names", {}).get(key, [])
-        if not any(lib_kernel in n for n in names):
+        # (the stand-alone Fourier ILT launches run the row-per-lane kernels since round 6; the library still times them under
+        # the launcher's name)
+        accepted = {"ilt_fourier_kernel": ("ilt_fourier_kernel", "ilt_fourier_rows_kernel"),
+                    "ilt_fourier_bwd_kernel": ("ilt_fourier_bwd_kernel", "ilt_fourier_bwd_rows_kernel")}.get(lib_kernel, (lib_kernel,))
+        if not any(a in n for a in accepted for n in names):
             raise RuntimeError(f"profiles/{pmc_name}: entry {key!r} was collected from kernels {names}, none of which is "
                                f"the library's {lib_kernel!r} -- stale PMC summary, re-run tools/collect_profiles.sh")
         bi = build_info()

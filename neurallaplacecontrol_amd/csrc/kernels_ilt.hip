@@ -839,11 +839,184 @@ __global__ __launch_bounds__(256) void ilt_fourier_bwd_kernel(const IltBwdArgs a
   }
 }
 
+// ------------------------------------------------------------------ Fourier series, backward, one LANE per row (round 6)
+// The forward row kernel's shape for the gradient: a wavefront's tile of 64 rows lands in its LDS region by direct global -> LDS
+// loads, a lane reads its row's S (theta, phi) pairs, writes the 2 S gradients back over them (its own row: no hazard), and the
+// wavefront stores the region -- 16 B per lane, whole lines -- to gtheta / gphi.  No per-element address arithmetic, no barrier,
+// the quarter turn i^k of every term a compile-time constant (sin x and cos x from ONE reduction, m::sincos_reduced), the
+// tangent as one rational:  F_k = w_k R c_k(theta),  R = tan(phi/2 + pi/4),  R' = (1 + R^2) / 2,
+//   c_k = cos, -sin, -cos, sin and c_k' = -sin, -cos, sin, cos for k mod 4 = 0 .. 3  (scale = 2: e^{i pi k t / T} = i^k);
+//   d x / d theta_k = G w_k R c_k'(theta_k),   d x / d phi_k = G w_k R' c_k(theta_k),   G = gx e^{gamma t} / T.
+// Odd term counts 3 .. 33 with scale = 2 and 16-byte aligned arrays; everything else keeps ilt_fourier_bwd_kernel.
+template <int S>
+__global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_bwd_rows_kernel(const IltBwdArgs a) {
+  static_assert(S % 2 == 1, "row stride S doubles must be odd");
+  extern __shared__ __attribute__((aligned(16))) char rows_lds[];
+  constexpr int TILE = 64 * S * 8;
+  constexpr int SLOT = (TILE + 1023) / 1024 * 1024;
+  constexpr int NLD = TILE / 1024, REM = TILE % 1024;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* lt = rows_lds + wave * (2 * SLOT);
+  char* lp = lt + SLOT;
+  const unsigned lt_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lt;
+  const unsigned lp_addr = lt_addr + SLOT;
+  double* lrow_t = (double*)lt + lane * S;
+  double* lrow_p = (double*)lp + lane * S;
+  const m::IltRowK K = ilt_row_k_sgpr();
+  const int64_t rows_total = a.N * a.d;
+  const int64_t nfull = rows_total / 64;
+  const int64_t W = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+  IltArgs sc_args{};  // the row scale only reads these
+  sc_args.alpha = a.alpha;
+  sc_args.log_tol = a.log_tol;
+  sc_args.scale = a.scale;
+  const unsigned d = (unsigned)a.d;
+  const int64_t step = 64 * W;
+  const int64_t step_n = step / d;
+  const unsigned step_r = (unsigned)(step - step_n * d);
+  int64_t row = w0 * 64 + lane;
+  int64_t n = row / d;
+  unsigned rem = (unsigned)(row - n * d);
+  double t_prev = __builtin_nan(""), sc = 0.0;
+  // gradients of one row from its (theta, phi) pairs; G = gx * row scale
+  auto row_grads = [&](double G, auto ld, auto st) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      double th, ph;
+      ld(k, &th, &ph);
+      const double x = fma(ph, 0.5, kPi / 4.0);
+      const double aa = (x - K.pio4_hi) - K.pio4_lo;
+      double num, den;
+      m::tan_parts_rat(K, aa, &num, &den);
+      const double R = num * m::rcp_refined(den);
+      const double Rp = 0.5 * fma(R, R, 1.0);
+      double sn, cs;
+      m::sincos_reduced(K, th, &sn, &cs);
+      const double Gw = k == 0 ? 0.5 * G : G;
+      // k mod 4:          0      1      2      3
+      const double c = (k & 1) ? sn : cs;        //  cos   -sin   -cos    sin
+      const double cd = (k & 1) ? cs : sn;       // -sin   -cos    sin    cos
+      const bool neg_c = (((k + 1) >> 1) & 1) != 0;
+      const bool neg_cd = ((k >> 1) & 1) == 0;
+      const double gt = (Gw * R) * cd, gp = (Gw * Rp) * c;
+      st(k, neg_cd ? -gt : gt, neg_c ? -gp : gp);
+    }
+  };
+  for (int64_t tile = w0; tile < nfull; tile += W) {
+    ilt_lds_load_tile<TILE>((const char*)(a.theta + tile * (64 * S)) + lane * 16, lt_addr, lane);
+    ilt_lds_load_tile<TILE>((const char*)(a.phi + tile * (64 * S)) + lane * 16, lp_addr, lane);
+    double t_row, gx_row;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t_row) : "v"(a.t + n) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(gx_row) : "v"(a.gx + row) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_row), "+v"(gx_row)::"memory");
+    if (t_row != t_prev) {
+      sc = ilt_row_scale(sc_args, t_row);
+      t_prev = t_row;
+    }
+    row_grads(
+        gx_row * sc,
+        [&](int k, double* th, double* ph) {
+          *th = lrow_t[k];
+          *ph = lrow_p[k];
+        },
+        [&](int k, double gt, double gp) {
+          lrow_t[k] = gt;
+          lrow_p[k] = gp;
+        });
+    // the region leaves as it came: 16 B per lane, 1 KB per instruction (LDS operations of one wavefront execute in order: the
+    // reads below see every lane's writes above)
+    char* gtp = (char*)(a.gtheta + tile * (64 * S)) + lane * 16;
+    char* gpp = (char*)(a.gphi + tile * (64 * S)) + lane * 16;
+    typedef double v2dd __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const v2dd vt = *(const v2dd*)(lt + i * 1024 + lane * 16);
+      const v2dd vp = *(const v2dd*)(lp + i * 1024 + lane * 16);
+      __builtin_nontemporal_store(vt, (v2dd*)(gtp + i * 1024));
+      __builtin_nontemporal_store(vp, (v2dd*)(gpp + i * 1024));
+    }
+    if (REM != 0 && lane < REM / 16) {
+      const v2dd vt = *(const v2dd*)(lt + NLD * 1024 + lane * 16);
+      const v2dd vp = *(const v2dd*)(lp + NLD * 1024 + lane * 16);
+      __builtin_nontemporal_store(vt, (v2dd*)(gtp + NLD * 1024));
+      __builtin_nontemporal_store(vp, (v2dd*)(gpp + NLD * 1024));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the region has been read out before the next tile lands in it
+    row += step;
+    n += step_n;
+    rem += step_r;
+    if (rem >= d) {
+      rem -= d;
+      n += 1;
+    }
+  }
+  // the ragged last tile: the wavefront whose turn it would be works straight on memory
+  if (nfull * 64 < rows_total && nfull % W == w0) {
+    const int64_t r = nfull * 64 + lane;
+    if (r < rows_total) {
+      const double* rt = a.theta + r * S;
+      const double* rp = a.phi + r * S;
+      double* ot = a.gtheta + r * S;
+      double* op = a.gphi + r * S;
+      row_grads(
+          a.gx[r] * ilt_row_scale(sc_args, a.t[r / a.d]),
+          [&](int k, double* th, double* ph) {
+            *th = rt[k];
+            *ph = rp[k];
+          },
+          [&](int k, double gt, double gp) {
+            ot[k] = gt;
+            op[k] = gp;
+          });
+    }
+  }
+}
+template <int S>
+static bool launch_bwd_rows_instance(const IltBwdArgs& a, hipStream_t s, hipError_t* err) {
+  constexpr int SLOT = (64 * S * 8 + 1023) / 1024 * 1024;
+  constexpr size_t shmem = (size_t)4 * 2 * SLOT;
+  static const hipError_t attr =
+      hipFuncSetAttribute((const void*)ilt_fourier_bwd_rows_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (attr != hipSuccess) return false;
+  const int64_t tiles = (a.N * a.d + 63) / 64;
+  const int per_cu = S <= 17 ? 2 : 1;
+  int64_t grid = (tiles + 3) / 4;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  hipLaunchKernelGGL((ilt_fourier_bwd_rows_kernel<S>), dim3((unsigned)grid), dim3(256), shmem, s, a);
+  *err = hipGetLastError();
+  return true;
+}
+static bool launch_ilt_fourier_bwd_rows(const IltBwdArgs& a, hipStream_t s, hipError_t* err) {
+  if (a.S < 3 || a.S > 33 || (a.S & 1) == 0 || a.scale != 2.0) return false;
+  if ((((uintptr_t)a.theta) | ((uintptr_t)a.phi) | ((uintptr_t)a.gtheta) | ((uintptr_t)a.gphi)) & 15) return false;
+#if NLC_ILT_EXPERIMENTS
+  static const int rows_env = [] {
+    const char* ev = std::getenv("NLC_ILT_ROWS");
+    return ev ? std::atoi(ev) : 1;
+  }();
+  if (!rows_env) return false;
+#endif
+  switch (a.S) {
+#define NLC_ROWS_CASE(SS) \
+  case SS:                \
+    return launch_bwd_rows_instance<SS>(a, s, err);
+    NLC_ROWS_CASE(3) NLC_ROWS_CASE(5) NLC_ROWS_CASE(7) NLC_ROWS_CASE(9) NLC_ROWS_CASE(11) NLC_ROWS_CASE(13) NLC_ROWS_CASE(15)
+    NLC_ROWS_CASE(17) NLC_ROWS_CASE(19) NLC_ROWS_CASE(21) NLC_ROWS_CASE(23) NLC_ROWS_CASE(25) NLC_ROWS_CASE(27) NLC_ROWS_CASE(29)
+    NLC_ROWS_CASE(31) NLC_ROWS_CASE(33)
+#undef NLC_ROWS_CASE
+  }
+  return false;
+}
+
 hipError_t launch_ilt_fourier_bwd(const IltBwdArgs& a_in, hipStream_t s) {
   IltBwdArgs a = a_in;
   const int64_t rows_total = a.N * a.d;
   if (rows_total <= 0) return hipSuccess;
   if (a.S > 256) return hipErrorInvalidValue;
+  {
+    hipError_t e2 = hipSuccess;
+    if (launch_ilt_fourier_bwd_rows(a, s, &e2)) return e2;
+  }
   a.rpp = 256 / a.S;
   if (a.rpp > 32) a.rpp = 32;
   a.iters = 256 / a.rpp / 8 * 8;  // rows = rpp * iters <= 256: one thread per row stages the row's gradient

@@ -415,5 +415,29 @@ NLC_HD double cos_or_sin_reduced(const IltRowK& K, double x) {
   return r;
 }
 
+// (-1)^q sin(y) and (-1)^q cos(y), x = q pi + y: sin x and cos x by the one reduction of cos_or_sin_reduced (the backward of
+// the row-per-lane Fourier ILT kernel needs both of every term)
+NLC_HD void sincos_reduced(const IltRowK& K, double x, double* sn, double* cs) {
+  const double sh = fma(x, K.inv_pi, K.round_shift);
+  const double q = sh - K.round_shift;
+  double y = fma(-q, K.pi_hi, x);
+  y = fma(-q, K.pi_lo, y);
+  const double z = y * y;
+  double u = fma(K.s2[0], z, K.s2[1]);
+  for (int i = 2; i < 8; ++i) u = fma(u, z, K.s2[i]);
+  double sv = fma(y * z, u, y);
+  double c = fma(K.c2[0], z, K.c2[1]);
+  for (int i = 2; i < 8; ++i) c = fma(c, z, K.c2[i]);
+  double cv = fma(c, z, 1.0);
+  uint64_t sb, vb, cb;
+  __builtin_memcpy(&sb, &sh, sizeof(sb));
+  __builtin_memcpy(&vb, &sv, sizeof(vb));
+  __builtin_memcpy(&cb, &cv, sizeof(cb));
+  vb ^= sb << 63;
+  cb ^= sb << 63;
+  __builtin_memcpy(sn, &vb, sizeof(vb));
+  __builtin_memcpy(cs, &cb, sizeof(cb));
+}
+
 }  // namespace m
 }  // namespace nlc

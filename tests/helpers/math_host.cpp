@@ -63,3 +63,8 @@ void nlc_t_cos_kpio2(const double* x, double* y, long n) {
     y[i] = (i & 1) ? -nlc::m::cos_or_sin_reduced<1>(nlc::m::ilt_row_k(), x[i]) : nlc::m::cos_or_sin_reduced<0>(nlc::m::ilt_row_k(), x[i]);
 }
 }
+extern "C" {
+void nlc_t_sincos_reduced(const double* x, double* sn, double* cs, long n) {
+  for (long i = 0; i < n; ++i) nlc::m::sincos_reduced(nlc::m::ilt_row_k(), x[i], &sn[i], &cs[i]);
+}
+}

@@ -22,6 +22,10 @@ KEYS = ("gru_encode", "nl_plan_fused", "nl_rollout", "nl_repfunc", "nl_dehoog_ch
 def short(name):
     if "ilt_fourier_kernel" in name and "true>" in name:
         return "ilt_linear_stream"  # the Fourier kernel's LIN instance (fixed Talbot / Stehfest)
+    if "ilt_fourier_bwd_rows_kernel" in name:
+        return "ilt_fourier_bwd"  # round 6: the row-per-lane kernels (direct global -> LDS tile loads)
+    if "ilt_fourier_rows_kernel" in name:
+        return "ilt_linear_stream" if ", true," in name else "ilt_fourier"
     for k in KEYS:
         if k in name:
             return k
