@@ -509,33 +509,33 @@ __device__ __forceinline__ void ilt_lds_load_tile(const char* g_lane, unsigned l
 }
 
 // DBG (tools build only): 1 = loads + the plain sum of what they brought (memory only), 2 = arithmetic on run-time values, no loads
-template <int S, bool GEN, int DBG>
-__global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(const IltArgs a) {
+// DEPTH: (theta, phi) region pairs per wavefront = tiles it keeps in flight.  1: eight wavefronts per CU, each requesting the next
+// tile's arrays as it reads the current ones out; 2 (S <= 17): four wavefronts per CU with two region pairs each -- a landed tile
+// no longer waits for its wavefront to finish the tile before it, at half the FP64 issue rate (one wavefront per SIMD), which
+// this kernel can afford (arithmetic-only 0.043 ms of 0.16).
+template <int S, bool GEN, int DBG, int DEPTH>
+__global__ __launch_bounds__(256, (S <= 17 && DEPTH == 1) ? 2 : 1) void ilt_fourier_rows_kernel(const IltArgs a) {
   static_assert(S % 2 == 1, "row stride S doubles must be odd: conflict-free row-wise reads, 16-byte tile sizes");
   extern __shared__ __attribute__((aligned(16))) char rows_lds[];
   constexpr int TILE = 64 * S * 8;                          // bytes of one array's tile
   constexpr int SLOT = (TILE + 1023) / 1024 * 1024;        // its LDS slot: the last (half) load writes a full KB
   constexpr int LPT = SLOT / 1024;                          // loads per tile and array
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: scalar loop, scalar M0)
-  char* lt = rows_lds + wave * (2 * SLOT);
-  char* lp = lt + SLOT;
-  const unsigned lt_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lt;
-  const unsigned lp_addr = lt_addr + SLOT;
-  const double* lrow_t = (const double*)lt + lane * S;
-  const double* lrow_p = (const double*)lp + lane * S;
+  char* lt0 = rows_lds + wave * (DEPTH * 2 * SLOT);
+  const unsigned lt_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lt0;
   const m::IltRowK K = ilt_row_k_sgpr();
   const int64_t rows_total = a.N * a.d;
   const int64_t nfull = rows_total / 64;
   const int64_t W = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
   // GEN: the per-term (phase, weight) table behind the four wavefronts' slots -- the launch's only barrier
-  const double* tab = (const double*)(rows_lds + 4 * (2 * SLOT));
+  const double* tab = (const double*)(rows_lds + 4 * (DEPTH * 2 * SLOT));
   const bool lin = a.lin_wr != nullptr;
   if (GEN) {
     if ((int)threadIdx.x < S) {
       const int k = threadIdx.x;
       const IltLane L = lin ? ilt_lane_linear(a.lin_wr[k], a.lin_wi[k]) : ilt_lane(k, a.scale);
       // (ilt_lane at scale == 2 describes the quarter turns by dm / a signed weight: spell them out as a phase)
-      double* tw = (double*)(rows_lds + 4 * (2 * SLOT));
+      double* tw = (double*)(rows_lds + 4 * (DEPTH * 2 * SLOT));
       tw[2 * k] = L.psi + L.dm * (kPi / 2.0);
       tw[2 * k + 1] = L.wk;
     }
@@ -568,25 +568,32 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
     // The row's t is requested at the head of the iteration that uses it and consumed behind a wait of its own: its register must
     // not travel through a loop-carried copy -- the compiler does not know the load is asynchronous and would copy a register
     // the data has not reached yet.
-    auto req_theta = [&](int64_t tile, bool real) {
-      const char* g = real ? (const char*)(a.theta + tile * (64 * S)) + lane * 16 : (const char*)a.theta;  // no successor: ONE line
-      ilt_lds_load_tile<TILE>(g, lt_addr, real ? lane : 0);
+    auto req_theta = [&](int64_t tile, bool real, int par) {
+      const char* g = real ? (const char*)(a.theta + tile * (64 * S)) + lane * 16 : (const char*)a.theta;  // no successor: the array's head
+      ilt_lds_load_tile<TILE>(g, lt_addr0 + par * (2 * SLOT), real ? lane : 0);
     };
-    auto req_phi = [&](int64_t tile, bool real) {
+    auto req_phi = [&](int64_t tile, bool real, int par) {
       const char* g = real ? (const char*)(a.phi + tile * (64 * S)) + lane * 16 : (const char*)a.phi;
-      ilt_lds_load_tile<TILE>(g, lp_addr, real ? lane : 0);
+      ilt_lds_load_tile<TILE>(g, lt_addr0 + par * (2 * SLOT) + SLOT, real ? lane : 0);
     };
     auto req_t = [&](int64_t nn) {
       double v;
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(a.t + nn) : "memory");
       return v;
     };
-    req_theta(w0, true);
-    req_phi(w0, true);
+    req_theta(w0, true, 0);
+    req_phi(w0, true, 0);
+    if (DEPTH == 2) {
+      req_theta(w0 + W, w0 + W < nfull, 1);
+      req_phi(w0 + W, w0 + W < nfull, 1);
+    }
+    int par = 0;  // the region pair of the current tile (DEPTH = 2: alternating)
     for (int64_t tile = w0; tile < nfull; tile += W) {
-      double t_row = req_t(n);                        // queue: theta_n, phi_n, t_n
-      const int64_t nxt = tile + W;
+      double t_row = req_t(n);                        // queue: theta_n, phi_n, [theta_(n+1), phi_(n+1),] t_n
+      const int64_t nxt = tile + DEPTH * W;
       const bool has_next = nxt < nfull;
+      const double* lrow_t = (const double*)(lt0 + par * (2 * SLOT)) + lane * S;
+      const double* lrow_p = (const double*)(lt0 + par * (2 * SLOT) + SLOT) + lane * S;
       // the next tile's point index
       int64_t n_next = n + step_n;
       unsigned rem_next = rem + step_r;
@@ -594,19 +601,19 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
         rem_next -= d;
         n_next += 1;
       }
-      // ---- theta_n has landed when at most the phi_n + t_n loads behind it are outstanding
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + 1) : "memory");
+      // ---- theta_n has landed when at most the loads behind it are outstanding: phi_n, [the next tile's two arrays,] t_n
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((2 * DEPTH - 1) * LPT + 1) : "memory");
       double th[S], ph[S];
 #pragma unroll
       for (int k = 0; k < S; ++k) th[k] = lrow_t[k];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      req_theta(nxt, has_next);                       // queue: phi_n, t_n, theta_(n+1)
-      // ---- phi_n has landed when at most t_n + theta_(n+1) are outstanding
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + 1) : "memory");
+      req_theta(nxt, has_next, par);                  // queue: phi_n, [..,] t_n, theta_(n+DEPTH)
+      // ---- phi_n has landed when at most [the next tile's two arrays,] t_n and theta_(n+DEPTH) are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((2 * DEPTH - 1) * LPT + 1) : "memory");
 #pragma unroll
       for (int k = 0; k < S; ++k) ph[k] = lrow_p[k];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      req_phi(nxt, has_next);                         // queue: t_n, theta_(n+1), phi_(n+1)
+      req_phi(nxt, has_next, par);                    // queue: [..,] t_n, theta_(n+DEPTH), phi_(n+DEPTH)
       double acc;
       if (DBG == 1) {
         acc = 0.0;
@@ -627,6 +634,7 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
       row += step;
       n = n_next;
       rem = rem_next;
+      if (DEPTH == 2) par ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last iteration's stand-in loads
   }
@@ -647,19 +655,19 @@ __global__ __launch_bounds__(256, S <= 17 ? 2 : 1) void ilt_fourier_rows_kernel(
 
 // true when the row-per-lane kernel takes the launch: an odd term count 3 .. 33 (row-wise LDS reads are conflict-free for an
 // odd stride; the reference's default 17, its de Hoog ablation's 33, fixed Talbot's 17) and 16-byte aligned inputs
-template <int S, bool GEN, int DBG>
+template <int S, bool GEN, int DBG, int DEPTH = 1>
 static bool launch_rows_instance(const IltArgs& a, hipStream_t s, hipError_t* err) {
   constexpr int SLOT = (64 * S * 8 + 1023) / 1024 * 1024;
-  constexpr size_t shmem = (size_t)4 * 2 * SLOT + 2 * S * 8;  // four wavefronts' theta / phi slots + the (phase, weight) table
+  constexpr size_t shmem = (size_t)4 * DEPTH * 2 * SLOT + 2 * S * 8;  // four wavefronts' theta / phi slots + the (phase, weight) table
   // (more than 64 KB of dynamic LDS per workgroup needs the attribute, once per instance)
-  static const hipError_t attr =
-      hipFuncSetAttribute((const void*)ilt_fourier_rows_kernel<S, GEN, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)ilt_fourier_rows_kernel<S, GEN, DBG, DEPTH>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (attr != hipSuccess) return false;
   const int64_t tiles = (a.N * a.d + 63) / 64;
-  const int per_cu = S <= 17 ? 2 : 1;  // workgroups of four wavefronts per CU (launch bounds, LDS)
+  const int per_cu = (S <= 17 && DEPTH == 1) ? 2 : 1;  // workgroups of four wavefronts per CU (launch bounds, LDS)
   int64_t grid = (tiles + 3) / 4;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
-  hipLaunchKernelGGL((ilt_fourier_rows_kernel<S, GEN, DBG>), dim3((unsigned)grid), dim3(256), shmem, s, a);
+  hipLaunchKernelGGL((ilt_fourier_rows_kernel<S, GEN, DBG, DEPTH>), dim3((unsigned)grid), dim3(256), shmem, s, a);
   *err = hipGetLastError();
   return true;
 }
@@ -678,13 +686,24 @@ static bool launch_ilt_fourier_rows(const IltArgs& a, hipStream_t s, hipError_t*
     return ev ? std::atoi(ev) : 1;
   }();
   if (!rows_env) return false;
-  if (a.S == 17 && !gen && dbg_env == 1) return launch_rows_instance<17, false, 1>(a, s, err);
-  if (a.S == 17 && !gen && dbg_env == 2) return launch_rows_instance<17, false, 2>(a, s, err);
+  static const int depth_env = [] {
+    const char* ev = std::getenv("NLC_ILT_DEPTH");
+    return ev ? std::atoi(ev) : 2;
+  }();
+  if (a.S == 17 && !gen && depth_env == 1) {
+    if (dbg_env == 1) return launch_rows_instance<17, false, 1, 1>(a, s, err);
+    if (dbg_env == 2) return launch_rows_instance<17, false, 2, 1>(a, s, err);
+    return launch_rows_instance<17, false, 0, 1>(a, s, err);
+  }
+  if (a.S == 17 && !gen && dbg_env == 1) return launch_rows_instance<17, false, 1, 2>(a, s, err);
+  if (a.S == 17 && !gen && dbg_env == 2) return launch_rows_instance<17, false, 2, 2>(a, s, err);
 #endif
   switch (a.S) {
-#define NLC_ROWS_CASE(SS) \
-  case SS:                \
-    return gen ? launch_rows_instance<SS, true, 0>(a, s, err) : launch_rows_instance<SS, false, 0>(a, s, err);
+  // two tiles in flight per wavefront where two region pairs fit four wavefronts' LDS (S <= 17): 0.160 -> 0.154 ms at S = 17
+#define NLC_ROWS_CASE(SS)                                                                                    \
+  case SS:                                                                                                   \
+    return gen ? launch_rows_instance<SS, true, 0, (SS <= 17 ? 2 : 1)>(a, s, err)                            \
+               : launch_rows_instance<SS, false, 0, (SS <= 17 ? 2 : 1)>(a, s, err);
     NLC_ROWS_CASE(3) NLC_ROWS_CASE(5) NLC_ROWS_CASE(7) NLC_ROWS_CASE(9) NLC_ROWS_CASE(11) NLC_ROWS_CASE(13) NLC_ROWS_CASE(15)
     NLC_ROWS_CASE(17) NLC_ROWS_CASE(19) NLC_ROWS_CASE(21) NLC_ROWS_CASE(23) NLC_ROWS_CASE(25) NLC_ROWS_CASE(27) NLC_ROWS_CASE(29)
     NLC_ROWS_CASE(31) NLC_ROWS_CASE(33)
