@@ -1099,11 +1099,14 @@ def standalone_ilt_section(nlc, local, pmc_name, pj):
     theta = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi).requires_grad_()
     phi = ((torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * (np.pi / 2) * 0.99).requires_grad_()
     gx = torch.randn(N, d, dtype=torch.float64, device="cuda", generator=g)
+    # ONE forward, then the backward launches alone (retain_graph): a forward launch per iteration would mix 13 launches on other
+    # inputs into the rocprofv3 average of the forward kernel above, which has to agree with `avg_launch_ms`
+    xb = nlc.ilt_reconstruct(theta, phi, tt)
     for it in range(13):
         if it == 3:
             ictx.profile_reset()
             ictx.profile(True)
-        torch.autograd.grad(nlc.ilt_reconstruct(theta, phi, tt), (theta, phi), gx)
+        torch.autograd.grad(xb, (theta, phi), gx, retain_graph=True)
     torch.cuda.synchronize()
     ictx.profile(False)
     p = ictx.profile_read()["ilt_fourier_bwd_kernel"]
