@@ -376,3 +376,56 @@ def test_ilt_single_point_wide(nlc):
         else:
             # random (non-smooth) F makes the QD table ill-conditioned: both sides are finite and agree loosely
             assert torch.isfinite(got).all() == torch.isfinite(ref).all()
+
+
+@pytest.mark.parametrize("S", list(range(3, 34, 2)))
+def test_ilt_fourier_row_kernels_every_odd_term_count(nlc, S):
+    """Round 6: the row-per-lane Fourier ILT kernels (direct global -> LDS tile loads, one instance per odd term count 3 .. 33;
+    two tiles in flight per wavefront for S <= 17, one above).  Forward at scale 2 (compile-time quarter turns) and at another
+    scale (the per-term phase / weight table), and the backward, on a population that gives every wavefront several tiles AND a
+    ragged last tile, with a per-row t -- against the oracle and autograd through it."""
+    from oracle import ilt as oilt
+
+    d, N = 3, 64 * 2048 // 3 + 29  # rows = N d: more tiles than the grid has wavefronts at S <= 17, not a multiple of 64
+    g = torch.Generator().manual_seed(S)
+    theta = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi
+    phi = (torch.rand(N, d, S, dtype=torch.float64, generator=g) * 2 - 1) * np.pi / 2 * 0.999
+    t = torch.rand(N, dtype=torch.float64, generator=g) * 2 + 0.05
+    for opts in (None, dict(scale=3.0, alpha=1e-2)):
+        ref = oilt.ilt_from_sphere(theta, phi, t, "fourier", opts)
+        got = nlc.ilt_reconstruct(theta.cuda(), phi.cuda(), t.cuda(), "fourier", opts).cpu()
+        scale = ref.abs().max()
+        np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
+    # backward on a slice (autograd through the CPU oracle is the slow side)
+    n = 64 * 40 // d + 7
+    th = theta[:n].clone().requires_grad_()
+    ph = (phi[:n] * 0.99).clone().requires_grad_()
+    gx = torch.randn(n, d, dtype=torch.float64, generator=g)
+    ref_gt, ref_gp = torch.autograd.grad(oilt.ilt_from_sphere(th, ph, t[:n], "fourier", None), (th, ph), gx)
+    thc, phc = th.detach().cuda().requires_grad_(), ph.detach().cuda().requires_grad_()
+    got_gt, got_gp = torch.autograd.grad(nlc.ilt_reconstruct(thc, phc, t[:n].cuda(), "fourier", None), (thc, phc), gx.cuda())
+    for got_g, ref_g in ((got_gt, ref_gt), (got_gp, ref_gp)):
+        sc = float(ref_g.abs().max())
+        np.testing.assert_allclose(got_g.cpu().numpy() / sc, ref_g.numpy() / sc, rtol=1e-9, atol=1e-11)
+
+
+def test_ilt_fourier_unaligned_and_even_inputs_keep_the_stream_kernel(nlc):
+    """The row kernels need 16-byte aligned arrays and an odd term count; a view that starts 8 bytes into an allocation and an
+    even term count take the term-per-lane stream instead -- same results either way."""
+    from oracle import ilt as oilt
+
+    d, S, N = 5, 17, 4099
+    g = torch.Generator().manual_seed(3)
+    flat_t = (torch.rand(N * d * S + 1, dtype=torch.float64, generator=g) * 2 - 1) * np.pi
+    flat_p = (torch.rand(N * d * S + 1, dtype=torch.float64, generator=g) * 2 - 1) * np.pi / 2 * 0.999
+    t = torch.rand(N, dtype=torch.float64, generator=g) * 2 + 0.05
+    ft, fp = flat_t.cuda(), flat_p.cuda()
+    theta_u, phi_u = ft[1:].view(N, d, S), fp[1:].view(N, d, S)  # data_ptr % 16 == 8
+    assert theta_u.data_ptr() % 16 == 8 and theta_u.is_contiguous()
+    ref = oilt.ilt_from_sphere(flat_t[1:].view(N, d, S), flat_p[1:].view(N, d, S), t, "fourier", None)
+    got_u = nlc.ilt_reconstruct(theta_u, phi_u, t.cuda(), "fourier", None).cpu()
+    got_a = nlc.ilt_reconstruct(theta_u.clone(), phi_u.clone(), t.cuda(), "fourier", None).cpu()  # fresh allocations: aligned
+    scale = ref.abs().max()
+    np.testing.assert_allclose(got_u.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(got_a.numpy() / scale, ref.numpy() / scale, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(got_a.numpy(), got_u.numpy(), rtol=1e-12, atol=1e-13 * float(scale))
