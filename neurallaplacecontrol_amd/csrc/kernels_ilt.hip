@@ -9,6 +9,7 @@
 //   ilt_dehoog_kernel   same map, de Hoog-Knight-Stokes quotient-difference acceleration
 //                       (mpmath inverselaplace.py:476-531); O(M^2) complex ops per (point, dim) -> FP64
 //                       VALU bound, not HBM bound.
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -653,16 +654,27 @@ __global__ __launch_bounds__(256, (S <= 17 && DEPTH == 1) ? 2 : 1) void ilt_four
   }
 }
 
+
+// More than 64 KB of dynamic LDS per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, per function AND per device:
+// remembered per (kernel instance, device) so that a process that plans on several GPUs sets it on each.
+template <class F>
+static bool lds_attr_once(F* fn, size_t shmem, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const unsigned long long bit = 1ull << dev;
+  if (done.load(std::memory_order_acquire) & bit) return true;
+  if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) return false;
+  done.fetch_or(bit, std::memory_order_release);
+  return true;
+}
 // true when the row-per-lane kernel takes the launch: an odd term count 3 .. 33 (row-wise LDS reads are conflict-free for an
 // odd stride; the reference's default 17, its de Hoog ablation's 33, fixed Talbot's 17) and 16-byte aligned inputs
 template <int S, bool GEN, int DBG, int DEPTH = 1>
 static bool launch_rows_instance(const IltArgs& a, hipStream_t s, hipError_t* err) {
   constexpr int SLOT = (64 * S * 8 + 1023) / 1024 * 1024;
   constexpr size_t shmem = (size_t)4 * DEPTH * 2 * SLOT + 2 * S * 8;  // four wavefronts' theta / phi slots + the (phase, weight) table
-  // (more than 64 KB of dynamic LDS per workgroup needs the attribute, once per instance)
-  static const hipError_t attr = hipFuncSetAttribute((const void*)ilt_fourier_rows_kernel<S, GEN, DBG, DEPTH>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (attr != hipSuccess) return false;
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!lds_attr_once(ilt_fourier_rows_kernel<S, GEN, DBG, DEPTH>, shmem, attr_done)) return false;
   const int64_t tiles = (a.N * a.d + 63) / 64;
   const int per_cu = (S <= 17 && DEPTH == 1) ? 2 : 1;  // workgroups of four wavefronts per CU (launch bounds, LDS)
   int64_t grid = (tiles + 3) / 4;
@@ -994,9 +1006,8 @@ template <int S>
 static bool launch_bwd_rows_instance(const IltBwdArgs& a, hipStream_t s, hipError_t* err) {
   constexpr int SLOT = (64 * S * 8 + 1023) / 1024 * 1024;
   constexpr size_t shmem = (size_t)4 * 2 * SLOT;
-  static const hipError_t attr =
-      hipFuncSetAttribute((const void*)ilt_fourier_bwd_rows_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (attr != hipSuccess) return false;
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!lds_attr_once(ilt_fourier_bwd_rows_kernel<S>, shmem, attr_done)) return false;
   const int64_t tiles = (a.N * a.d + 63) / 64;
   const int per_cu = S <= 17 ? 2 : 1;
   int64_t grid = (tiles + 3) / 4;
