@@ -3,6 +3,9 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neurallaplacecontrol_amd as nlc
+if len(sys.argv) > 2:  # an alternative library build (-DNLC_ILT_EXPERIMENTS=1: NLC_ILT_ROWS / NLC_ILT_DEPTH), before the first ctx exists
+    from neurallaplacecontrol_amd import _lib
+    _lib.use_library(sys.argv[2])
 from neurallaplacecontrol_amd.laplace import default_ctx
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 655360
 d, S = 5, 17
