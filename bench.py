@@ -1086,6 +1086,19 @@ def standalone_ilt_section(nlc, local, pmc_name, pj):
     ilt["dehoog33"] = dict(bound="fp64-valu", kernel="ilt_dehoog_kernel", avg_launch_ms=ms2, points=N,
                            algorithmic_bytes=nb2, achieved=nb2 / (ms2 * 1e-3) / 1e9, unit="GB/s",
                            frac_hbm=nb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=tr2, traffic_source=tr2_src)
+    # ... and the ablation's other side at the same term count: the Fourier series with 33 terms (the row kernel with ONE tile in
+    # flight per wavefront: two region pairs of 64 x 33 doubles do not fit four wavefronts' LDS)
+    heat(lambda: nlc.ilt_reconstruct(theta, phi, tt))
+    ictx.profile_reset()
+    ictx.profile(True)
+    for _ in range(10):
+        nlc.ilt_reconstruct(theta, phi, tt)
+    torch.cuda.synchronize()
+    ictx.profile(False)
+    p = ictx.profile_read()["ilt_fourier_kernel"]
+    ms5 = p["total_ms"] / p["launches"]
+    ilt["fourier33"] = dict(bound="hbm", kernel="ilt_fourier_kernel (rows, S = 33)", avg_launch_ms=ms5, points=N, algorithmic_bytes=nb2,
+                            achieved=nb2 / (ms5 * 1e-3) / 1e9, unit="GB/s", frac=nb2 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
     del theta, phi
     # fixed Talbot at the Fourier kernel's shape: the same coalesced stream with the algorithm's per-term phase / weight
     theta = (torch.rand(N, d, S_TERMS, dtype=torch.float64, device="cuda", generator=g) * 2 - 1) * np.pi

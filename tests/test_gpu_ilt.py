@@ -378,10 +378,10 @@ def test_ilt_single_point_wide(nlc):
             assert torch.isfinite(got).all() == torch.isfinite(ref).all()
 
 
-@pytest.mark.parametrize("S", list(range(3, 34, 2)))
-def test_ilt_fourier_row_kernels_every_odd_term_count(nlc, S):
-    """Round 6: the row-per-lane Fourier ILT kernels (direct global -> LDS tile loads, one instance per odd term count 3 .. 33;
-    two tiles in flight per wavefront for S <= 17, one above).  Forward at scale 2 (compile-time quarter turns) and at another
+@pytest.mark.parametrize("S", list(range(3, 34)))
+def test_ilt_fourier_row_kernels_every_term_count(nlc, S):
+    """Round 6: the row-per-lane kernels of the Fourier ILT (direct global -> LDS tile loads; odd S <= 17: two tiles in flight per
+    wavefront, odd S > 17: one; even S keeps the term-per-lane stream -- a 64-row tile's row-wise reads would conflict).  Forward at scale 2 (compile-time quarter turns) and at another
     scale (the per-term phase / weight table), and the backward, on a population that gives every wavefront several tiles AND a
     ragged last tile, with a per-row t -- against the oracle and autograd through it."""
     from oracle import ilt as oilt
