@@ -204,6 +204,11 @@ class MPPIDelay:
             self._cost_total = self._cost_nz = self._omega = None
             self._U_t = None
             if self.pg is not None and self.G > 1:
+                if self.M > 1 and self.rollout_var_cost != 0:
+                    # (the variance of the running cost is a statistic of the WHOLE population: the HIP path all-reduces it,
+                    # this path would silently use each rank's own samples)
+                    raise NotImplementedError("rollout_samples > 1 with rollout_var_cost on a K-sharded planner that plans with "
+                                              f"tensor ops ({self.torch_path})")
                 check_same_on_all_ranks((self.K, self.T, self.nu), self.pg, "num_samples / horizon / nu", self.cd)
             self.U = U_init if U_init is not None else self.noise_dist.sample((self.T,))
             return
