@@ -233,6 +233,21 @@ p = n.MPPIDelay(n.OracleDynamics("oderl-cartpole", 0.05, 1), n.EnvCost("oderl-ca
 with torch.no_grad():
     a = p.command(state, ab).cpu()
 out["varcost"] = dict(acts=a, cost=p.cost_total.cpu())
+# a planner the HIP kernels are not built for (nu = 3): tensor ops on the GPU, the same (beta, eta, S) partials and ONE all-gather
+import warnings
+gen = torch.Generator().manual_seed(5)
+Wx3, Wu3 = torch.randn(4, 4, generator=gen, dtype=torch.float64) * 0.3, torch.randn(3, 4, generator=gen, dtype=torch.float64) * 0.5
+dyn3 = lambda s, w: s + 0.05 * (torch.tanh(s @ Wx3.to(s.device)) + (0.7 * w[:, -1, :] + 0.3 * w[:, 0, :]) @ Wu3.to(s.device))
+cost3 = lambda s, u: (s ** 2).sum(dim=1) + 0.01 * (u ** 2).sum(dim=1)
+torch.manual_seed(77)                      # the same global draw on every rank; each keeps its slice
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    p = n.MPPIDelay(dyn3, cost3, 4, n.noise_sigma(3), 512, 6, "cpu", lambda_=1.0, u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0),
+                    u_scale=2.0, U_init=torch.zeros(6, 3, dtype=torch.float64), process_group=dist.group.WORLD)
+assert p.torch_path and p.K_local == 256
+st3, ab3 = torch.linspace(-0.5, 0.5, 4, dtype=torch.float64), torch.zeros(4, 3, dtype=torch.float64)
+acts3 = torch.stack([p.command(st3, ab3).cpu() for _ in range(3)])
+out["torch_path"] = dict(acts=acts3, U=p.U.cpu(), omega=p.omega.cpu())
 torch.save(out, os.path.join(sys.argv[2], f"r{rank}.pt"))
 dist.destroy_process_group()
 """
@@ -367,6 +382,22 @@ def test_two_process_sharded_planner_end_to_end(nlc, tmp_path):
     plain.command(state, ab)
     shift = p.cost_total - plain.cost_total
     assert float(shift.min()) > 1e-6 and float(shift.max() - shift.min()) < 1e-9  # one constant, as in the reference
+    # the tensor-op planner (nu = 3) sharded over the two ranks == the same planner alone, under the same seed
+    gen = torch.Generator().manual_seed(5)
+    Wx3, Wu3 = torch.randn(4, 4, generator=gen, dtype=torch.float64) * 0.3, torch.randn(3, 4, generator=gen, dtype=torch.float64) * 0.5
+    dyn3 = lambda s, w: s + 0.05 * (torch.tanh(s @ Wx3.to(s.device)) + (0.7 * w[:, -1, :] + 0.3 * w[:, 0, :]) @ Wu3.to(s.device))  # noqa: E731
+    cost3 = lambda s, u: (s ** 2).sum(dim=1) + 0.01 * (u ** 2).sum(dim=1)  # noqa: E731
+    torch.manual_seed(77)
+    with pytest.warns(UserWarning, match="PyTorch-ROCm tensor ops"):
+        p3 = nlc.MPPIDelay(dyn3, cost3, 4, nlc.noise_sigma(3), 512, 6, "cpu", lambda_=1.0, u_min=torch.tensor(-2.0),
+                           u_max=torch.tensor(2.0), u_scale=2.0, U_init=torch.zeros(6, 3, dtype=torch.float64))
+    st3, ab3 = torch.linspace(-0.5, 0.5, 4, dtype=torch.float64), torch.zeros(4, 3, dtype=torch.float64)
+    acts3 = torch.stack([p3.command(st3, ab3) for _ in range(3)])
+    assert torch.equal(r0["torch_path"]["acts"], r1["torch_path"]["acts"]) and torch.equal(r0["torch_path"]["U"], r1["torch_path"]["U"])
+    np.testing.assert_allclose(r0["torch_path"]["acts"].numpy(), acts3.numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r0["torch_path"]["U"].numpy(), p3.U.numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(torch.cat((r0["torch_path"]["omega"], r1["torch_path"]["omega"])).numpy(), p3.omega.numpy(),
+                               rtol=1e-9, atol=1e-15)
 
 
 _TIMEOUT_RANK_WORKER = r"""
